@@ -1,0 +1,167 @@
+/*
+ * leann_mi355x.h -- C ABI of libleann_mi355x.so, the MI355X (gfx950) native replacement for the
+ * query-time selective-recompute beam search of LEANN.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the LEANN tree,
+ * packages/...).  The reference reaches its native code through SWIG (faiss fork) and pybind11
+ * (DiskANN fork); both forks are un-vendored submodules, so the binding surface is taken from the
+ * Python call sites.  Plain C: pointers + sizes, no torch / C++ types.  All functions return 0 on
+ * success or a negative LM_E* code; lm_last_error() gives the thread-local message.  Nothing throws
+ * across this boundary.  Pointer arguments named d_* are DEVICE (HBM) pointers, everything else is
+ * host memory.  A handle is not re-entrant: one search at a time per lm_index.
+ */
+#ifndef LEANN_MI355X_H
+#define LEANN_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_OK 0
+#define LM_EINVAL (-1)   /* bad argument                 -> Python ValueError      */
+#define LM_ENOENT (-2)   /* file missing                 -> FileNotFoundError      */
+#define LM_EFORMAT (-3)  /* malformed index file         -> ValueError             */
+#define LM_EHIP (-4)     /* HIP runtime failure / no GPU -> RuntimeError           */
+#define LM_ESTATE (-5)   /* e.g. recompute requested but no provider attached -> RuntimeError */
+#define LM_EPROVIDER (-6)/* embedding provider callback failed                     */
+
+#define LM_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT: "mips", "cosine" (hnsw_backend.py:25-29) */
+#define LM_METRIC_L2 1            /* faiss.METRIC_L2 */
+
+#define LM_DTYPE_F32 0
+#define LM_DTYPE_F16 1
+
+typedef struct lm_index lm_index;     /* HBM-resident compact-CSR graph + search workspace */
+typedef struct lm_tokens lm_tokens;   /* HBM-resident pre-tokenised passage store           */
+typedef struct lm_pq_index lm_pq_index; /* HBM-resident PQ codes + graph (DiskANN-style path) */
+
+/* ---- errors / device ------------------------------------------------------------------- */
+const char *lm_last_error(void);
+int lm_device_count(void);           /* 0 when no HIP device is visible */
+const char *lm_version(void);
+
+/* ---- index lifetime ---------------------------------------------------------------------
+ * Replaces faiss.read_index(str(index_file), faiss.IO_FLAG_MMAP, HNSWIndexConfig{is_compact,
+ * is_recompute})                                   leann_backend_hnsw/hnsw_backend.py:145-151.
+ * Parses the compact-CSR file written by convert_to_csr.py:182-237 (or the original IHNf layout,
+ * :264-301,439-479) and uploads level_ptr / node_offsets / neighbors / levels to HBM.  If the file
+ * carries flat embedding storage it is attached as the stored-embedding table. */
+int lm_index_read(const char *path, int device, lm_index **out);
+
+/* Same, from arrays already in host memory (layout of convert_to_csr.py:494-548). */
+int lm_index_create_from_csr(int64_t ntotal, int32_t d, int32_t metric,
+                             const uint64_t *node_offsets /* ntotal+1 */,
+                             const uint64_t *level_ptr, int64_t n_level_ptr,
+                             const int32_t *neighbors, int64_t n_neighbors,
+                             const int32_t *levels /* ntotal */,
+                             int32_t entry_point, int32_t max_level, int device, lm_index **out);
+void lm_index_free(lm_index *idx);
+
+typedef struct {
+    int64_t ntotal;
+    int32_t d;
+    int32_t d_padded;       /* row stride of embeddings handed to the kernels (multiple of 64) */
+    int32_t metric;
+    int32_t entry_point;
+    int32_t max_level;
+    int32_t max_degree0;    /* largest level-0 neighbour list */
+    int32_t max_degree_up;  /* largest upper-level neighbour list */
+    int64_t n_neighbors;
+    int32_t has_table;      /* stored embeddings attached (non-pruned index) */
+    int32_t has_provider;
+    int32_t device;
+} lm_index_info_t;
+int lm_index_info(const lm_index *idx, lm_index_info_t *out);
+
+/* ---- embedding sources --------------------------------------------------------------------
+ * Stored embeddings (recompute_embeddings=False on a non-pruned index, hnsw_backend.py:189-193):
+ * rows of `table` are gathered straight from HBM by the distance kernel.
+ * location 0: host pointer, copied (and zero-padded to d_padded) into library-owned HBM;
+ * location 1: device pointer with row stride d_padded, borrowed (caller keeps it alive). */
+int lm_index_attach_table(lm_index *idx, const void *table, int32_t dtype, int64_t ntotal, int32_t d,
+                          int32_t location);
+
+/* Recompute provider: replaces the per-hop ZMQ REQ of the faiss fork to the embedding server
+ * ([[ids],[query]] -> distances / [ids] -> embeddings, hnsw_embedding_server.py:148-284).
+ * Called once per search round, on the index's stream, with the SORTED, DE-DUPLICATED node ids
+ * of that round in device memory.  The callback must enqueue (on `stream`) work that produces
+ * fp32 embeddings [n][d_padded] (zero padded) in device memory and store that buffer's address
+ * in *d_out; the buffer must stay valid until the next callback or the end of the search.
+ * Return 0 on success; any other value aborts the search with LM_EPROVIDER. */
+typedef int (*lm_provider_fn)(void *user, const int32_t *d_ids, int32_t n, void **d_out, void *stream);
+int lm_index_set_provider(lm_index *idx, lm_provider_fn fn, void *user);
+
+/* hipStream_t all kernels of this index are enqueued on (default: the null stream). */
+int lm_index_set_stream(lm_index *idx, void *hip_stream);
+
+/* ---- search ---------------------------------------------------------------------------------
+ * Mirrors faiss.SearchParametersHNSW as filled in hnsw_backend.py:203-234. */
+typedef struct {
+    int32_t efSearch;                /* complexity                               :206 */
+    int32_t beam_size;               /* beam_width: pops per query per round     :207 */
+    int32_t check_relative_distance; /* 0 for OpenAI-cosine models               :209-217 */
+    float pq_pruning_ratio;          /* prune_ratio (two-level search; 0 = off)  :220 */
+    int32_t local_prune;             /* pruning_strategy == "local"              :223-225 */
+    float send_neigh_times_ratio;    /* pruning_strategy == "proportional"       :226-228 */
+    int32_t batch_size;              /* accepted, unused: rounds batch across queries :234 */
+    int32_t zmq_port;                /* accepted, unused: the encoder is in-process   :205 */
+    int32_t recompute;               /* 1: use the provider, 0: use the attached table */
+    int32_t max_batch;               /* queries in flight per pass (0 = default 4096) */
+} lm_search_params;
+void lm_search_params_default(lm_search_params *p);
+
+/* Replaces index.search(n, swig_ptr(x), k, swig_ptr(D), swig_ptr(I), params)
+ *                                                           hnsw_backend.py:241-248.
+ * x: n x d fp32 queries (host).  distances: n x k fp32, labels: n x k int64, caller-allocated
+ * (hnsw_backend.py:236-238).  l2: squared L2 ascending; inner product: +IP descending.
+ * Unfilled slots: label -1, distance +inf (l2) / -inf (ip). */
+int lm_index_search(lm_index *idx, int64_t n, const float *x, int32_t k, float *distances,
+                    int64_t *labels, const lm_search_params *params);
+/* Same with queries and results resident in HBM (no PCIe in the timed region). */
+int lm_index_search_device(lm_index *idx, int64_t n, const float *d_x, int32_t k, float *d_distances,
+                           int64_t *d_labels, const lm_search_params *params);
+
+typedef struct {
+    int64_t ndis;         /* (query,node) distance evaluations of the last search            */
+    int64_t nunique;      /* embeddings requested from the provider (after cross-query dedup) */
+    int64_t nrounds;      /* lock-step rounds                                                 */
+    int64_t nexpand;      /* level-0 expansions                                               */
+    int64_t update_launches; /* launches of the fused distance+beam-update kernel            */
+    double update_ms;     /* summed HIP-event time of those launches (profiling on)          */
+    double expand_ms;     /* summed HIP-event time of the expand(+uniq) kernels              */
+    double provider_ms;   /* summed HIP-event time spent in provider work                    */
+} lm_search_stats;
+int lm_index_get_stats(const lm_index *idx, lm_search_stats *out);
+int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around kernels */
+
+/* ---- stand-alone kernels (parity tests, shard merge) ----------------------------------------
+ * Distances of query row qidx[i] against embedding row ids[i] with the canonical reduction of
+ * oracle/lm_oracle.c:orc_dist.  d_table rows have stride d_padded; d_q is nq x d_padded. */
+int lm_dist_gather(const void *d_table, int32_t dtype, int32_t d_padded, int32_t metric,
+                   const float *d_q, const int32_t *d_qidx, const int32_t *d_ids, int64_t npairs,
+                   float *d_out, void *stream);
+/* Per-query merge of S per-shard top-k lists (60M-chunk config; ids already global, -1 = empty):
+ * in: S x B x k, out: B x k, ordered by (internal distance, id). */
+int lm_topk_merge(const int64_t *d_in_ids, const float *d_in_dist, int32_t S, int32_t B, int32_t k,
+                  int32_t metric, int64_t *d_out_ids, float *d_out_dist, void *stream);
+
+/* ---- token store ---------------------------------------------------------------------------
+ * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
+ * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised
+ * once at load and kept packed in HBM (u16 ids, vocab < 65536). */
+int lm_tokens_create(const uint16_t *tokens, const uint64_t *offsets /* n+1 */, int64_t n, int device,
+                     lm_tokens **out);
+void lm_tokens_free(lm_tokens *t);
+/* d_out_ids: n x T int32 (pad_id beyond the chunk length, chunks truncated to T);
+ * d_out_len: n int32. */
+int lm_tokens_gather(const lm_tokens *t, const int32_t *d_ids, int32_t n, int32_t T, int32_t pad_id,
+                     int32_t *d_out_ids, int32_t *d_out_len, void *stream);
+int64_t lm_tokens_count(const lm_tokens *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEANN_MI355X_H */

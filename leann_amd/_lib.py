@@ -1,0 +1,133 @@
+"""ctypes binding of libleann_mi355x.so (the C ABI declared in include/leann_mi355x.h).
+
+The library is built in-tree by ``leann_amd.build.build_all()`` (hipcc, gfx950).  There is no CPU
+fallback: if the shared object is missing or no HIP device is visible, every compute entry point
+raises -- loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libleann_mi355x.so"
+BUILD_LIB_PATH = _PKG / "lib" / "libleann_hnswbuild.so"
+
+LM_OK, LM_EINVAL, LM_ENOENT, LM_EFORMAT, LM_EHIP, LM_ESTATE, LM_EPROVIDER = 0, -1, -2, -3, -4, -5, -6
+METRIC_INNER_PRODUCT, METRIC_L2 = 0, 1
+DTYPE_F32, DTYPE_F16 = 0, 1
+
+
+class LeannMi355xError(RuntimeError):
+    pass
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("ntotal", C.c_int64), ("d", C.c_int32), ("d_padded", C.c_int32), ("metric", C.c_int32),
+        ("entry_point", C.c_int32), ("max_level", C.c_int32), ("max_degree0", C.c_int32),
+        ("max_degree_up", C.c_int32), ("n_neighbors", C.c_int64), ("has_table", C.c_int32),
+        ("has_provider", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class SearchParams(C.Structure):
+    """Mirror of lm_search_params == faiss.SearchParametersHNSW as filled in hnsw_backend.py:203-234."""
+
+    _fields_ = [
+        ("efSearch", C.c_int32), ("beam_size", C.c_int32), ("check_relative_distance", C.c_int32),
+        ("pq_pruning_ratio", C.c_float), ("local_prune", C.c_int32), ("send_neigh_times_ratio", C.c_float),
+        ("batch_size", C.c_int32), ("zmq_port", C.c_int32), ("recompute", C.c_int32), ("max_batch", C.c_int32),
+    ]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [
+        ("ndis", C.c_int64), ("nunique", C.c_int64), ("nrounds", C.c_int64), ("nexpand", C.c_int64),
+        ("update_launches", C.c_int64), ("update_ms", C.c_double), ("expand_ms", C.c_double),
+        ("provider_ms", C.c_double),
+    ]
+
+
+PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p)
+
+# every symbol include/leann_mi355x.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "lm_last_error", "lm_device_count", "lm_version",
+    "lm_index_read", "lm_index_create_from_csr", "lm_index_free", "lm_index_info",
+    "lm_index_attach_table", "lm_index_set_provider", "lm_index_set_stream",
+    "lm_search_params_default", "lm_index_search", "lm_index_search_device",
+    "lm_index_get_stats", "lm_index_set_profiling",
+    "lm_dist_gather", "lm_topk_merge",
+    "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise LeannMi355xError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C leann_amd/csrc`. leann-backend-mi355x has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    lib.lm_last_error.restype = C.c_char_p
+    lib.lm_version.restype = C.c_char_p
+    lib.lm_device_count.restype = C.c_int
+    lib.lm_index_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.lm_index_create_from_csr.argtypes = [i64, i32, i32, vp, vp, i64, vp, i64, vp, i32, i32, C.c_int, C.POINTER(vp)]
+    lib.lm_index_free.argtypes = [vp]
+    lib.lm_index_free.restype = None
+    lib.lm_index_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    lib.lm_index_attach_table.argtypes = [vp, vp, i32, i64, i32, i32]
+    lib.lm_index_set_provider.argtypes = [vp, PROVIDER_FN, vp]
+    lib.lm_index_set_stream.argtypes = [vp, vp]
+    lib.lm_search_params_default.argtypes = [C.POINTER(SearchParams)]
+    lib.lm_search_params_default.restype = None
+    lib.lm_index_search.argtypes = [vp, i64, f32p, i32, vp, vp, C.POINTER(SearchParams)]
+    lib.lm_index_search_device.argtypes = [vp, i64, vp, i32, vp, vp, C.POINTER(SearchParams)]
+    lib.lm_index_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
+    lib.lm_index_set_profiling.argtypes = [vp, i32]
+    lib.lm_dist_gather.argtypes = [vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]
+    lib.lm_topk_merge.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.lm_tokens_create.argtypes = [vp, vp, i64, C.c_int, C.POINTER(vp)]
+    lib.lm_tokens_free.argtypes = [vp]
+    lib.lm_tokens_free.restype = None
+    lib.lm_tokens_gather.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.lm_tokens_count.argtypes = [vp]
+    lib.lm_tokens_count.restype = i64
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().lm_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map LM_E* codes onto the exceptions the reference raises at the same places
+    (hnsw_backend.py:134,143,189-196; searcher_base.py:54)."""
+    if rc == LM_OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc == LM_EINVAL or rc == LM_EFORMAT:
+        raise ValueError(msg)
+    if rc == LM_ENOENT:
+        raise FileNotFoundError(msg)
+    raise LeannMi355xError(msg)
+
+
+def device_count() -> int:
+    return int(load().lm_device_count())
+
+
+def require_gpu() -> None:
+    if device_count() <= 0:
+        raise LeannMi355xError("no HIP device visible: leann-backend-mi355x needs an MI355X (gfx950) GPU and has no CPU fallback")

@@ -1,0 +1,67 @@
+// lm_internal.h -- shared internals of libleann_mi355x (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/leann_mi355x.h"
+
+namespace lm {
+
+void set_error(const std::string& msg);
+
+#define LM_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            lm::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+            return LM_EHIP;                                                                \
+        }                                                                                  \
+    } while (0)
+
+#define LM_FAIL(code, msg)        \
+    do {                          \
+        lm::set_error(msg);       \
+        return (code);            \
+    } while (0)
+
+// ---- query phases (same state machine as oracle/lm_oracle.c) ----
+enum : int32_t { PH_SEED = 0, PH_UPPER = 1, PH_BEAM = 2, PH_DONE = 3 };
+
+constexpr uint64_t KEY_NONE = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint64_t KEY_EXPANDED = 1ull;
+
+// total-order key (dist, id): NaN -> +inf, -0 -> +0; bit 0 = expanded flag
+__host__ __device__ inline uint64_t make_key(float d, int32_t id) {
+    if (d != d) d = __builtin_inff();
+    if (d == 0.0f) d = 0.0f;
+    uint32_t u = __builtin_bit_cast(uint32_t, d);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((uint64_t)u << 32) | ((uint64_t)(uint32_t)id << 1);
+}
+__host__ __device__ inline float key_dist(uint64_t key) {
+    uint32_t u = (uint32_t)(key >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ inline int32_t key_id(uint64_t key) { return (int32_t)((uint32_t)key >> 1); }
+
+// Parsed compact-CSR file (lm_csr_reader.cpp)
+struct HostCsr {
+    int64_t ntotal = 0;
+    int32_t d = 0;
+    int32_t metric = 0;
+    int32_t entry_point = -1;
+    int32_t max_level = -1;
+    std::vector<int32_t> levels;
+    std::vector<uint64_t> level_ptr;
+    std::vector<uint64_t> node_offsets;
+    std::vector<int32_t> neighbors;
+    std::vector<float> storage;  // ntotal*d when the file carries flat embeddings
+};
+int read_csr_file(const char* path, HostCsr& out);  // returns LM_* code
+
+}  // namespace lm

@@ -1,0 +1,1064 @@
+// lm_search.hip -- HBM-resident compact-CSR graph + lock-step selective-recompute beam search
+// for MI355X (gfx950).  Kernels:
+//   k_init        reset per-query state
+//   k_expand      one wave per query: pop list -> CSR neighbour gather -> visited test-and-set
+//                 (per-query bitmap) -> per-query new-list; sets the round's dedup bitmap
+//   k_uniq_count / k_uniq_emit   round bitmap -> SORTED unique node list + per-word ranks
+//   k_update<..>  one workgroup per query: LDS/regs-staged query, 16-lane row dot products with the
+//                 canonical reduction (bit-exact with oracle/lm_oracle.c:orc_dist), bitonic merge
+//                 into the ef-pool, next pops, phase transitions
+//   k_finalize    pool -> (labels, distances)
+// Algorithm contract: oracle/lm_oracle.c header (set semantics under the (dist,id) total order).
+// Reference call site replaced: index.search(...) leann_backend_hnsw/hnsw_backend.py:241-248.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include <hip/hip_fp16.h>
+
+#include "lm_internal.h"
+
+namespace lm {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ---------------------------------------------------------------------------------------------
+// device-side views
+// ---------------------------------------------------------------------------------------------
+struct GraphDev {
+    int64_t N;
+    int32_t entry_point, max_level;
+    const uint64_t* node_offsets;
+    const uint64_t* level_ptr;
+    const int32_t* neighbors;
+};
+
+struct WsDev {
+    int32_t B, ef, W, maxnew;
+    int64_t nw;  // visited words per query
+    int32_t* phase;
+    int32_t* level;
+    uint64_t* cur_key;
+    int32_t* nsteps;
+    int32_t* npool;
+    int32_t* npop;
+    int32_t* nnew;
+    int32_t* pop;     // B x W
+    int32_t* newid;   // B x maxnew
+    uint64_t* pool;   // B x ef
+    uint32_t* visited;  // B x nw
+    // round dedup (recompute mode)
+    uint32_t* rbm;        // nw  (accumulated by k_expand, cleared by k_uniq_emit)
+    uint32_t* rbm_snap;   // nw  (this round's bitmap for rank lookups)
+    int32_t* word_rank;   // nw
+    int32_t* tile_sum;    // ntiles
+    int32_t* uniq;        // ucap
+    // counters: [0]=live queries this round [1]=n_uniq [2..] stats
+    unsigned long long* counters;
+};
+enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_NCOUNTERS = 8 };
+
+constexpr int UNIQ_TILE = 4096;  // words per block in the uniq scan
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init(WsDev ws, int32_t max_level) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ws.B) return;
+    ws.phase[q] = PH_SEED;
+    ws.level[q] = max_level;
+    ws.cur_key[q] = KEY_NONE;
+    ws.nsteps[q] = 0;
+    ws.npool[q] = 0;
+    ws.npop[q] = 0;
+    ws.nnew[q] = 0;
+}
+
+__device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32_t level, uint64_t& b, uint32_t& cnt) {
+    // convert_to_csr.py:507-548  p = node_offsets[i] + l ; data[level_ptr[p] : level_ptr[p+1]]
+    uint64_t p = g.node_offsets[node] + (uint64_t)level;
+    b = g.level_ptr[p];
+    cnt = (uint32_t)(g.level_ptr[p + 1] - b);
+}
+
+// one wave (64 lanes) per query
+__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int ph = ws.phase[q];
+    if (ph == PH_DONE) {
+        if (lane == 0) ws.nnew[q] = 0;
+        return;
+    }
+    int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
+    int total = 0;
+    if (ph == PH_SEED) {
+        if (lane == 0) {
+            newid[0] = g.entry_point;
+            if (use_rbm) atomicOr(&ws.rbm[g.entry_point >> 5], 1u << (g.entry_point & 31));
+        }
+        total = 1;
+    } else if (ph == PH_UPPER) {
+        uint64_t b;
+        uint32_t cnt;
+        nbr_range(g, key_id(ws.cur_key[q]), ws.level[q], b, cnt);
+        for (uint32_t j = lane; j < cnt; j += 64) {
+            int32_t v = g.neighbors[b + j];
+            newid[j] = v;
+            if (use_rbm) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+        }
+        total = (int)cnt;
+    } else {
+        uint32_t* vis = ws.visited + (size_t)q * ws.nw;
+        const int npop = ws.npop[q];
+        for (int pi = 0; pi < npop; ++pi) {
+            uint64_t b;
+            uint32_t cnt;
+            nbr_range(g, ws.pop[(size_t)q * ws.W + pi], 0, b, cnt);
+            for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
+                uint32_t j = j0 + lane;
+                bool fresh = false;
+                int32_t v = -1;
+                if (j < cnt) {
+                    v = g.neighbors[b + j];
+                    uint32_t bit = 1u << (v & 31);
+                    uint32_t old = atomicOr(&vis[v >> 5], bit);
+                    fresh = !(old & bit);
+                }
+                unsigned long long m = __ballot(fresh);
+                if (fresh) {
+                    int r = __popcll(m & ((1ull << lane) - 1ull));
+                    newid[total + r] = v;
+                    if (use_rbm) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+                }
+                total += __popcll(m);
+            }
+        }
+    }
+    if (lane == 0) {
+        ws.nnew[q] = total;
+        atomicAdd(&ws.counters[C_LIVE], 1ull);
+        atomicAdd(&ws.counters[C_NDIS], (unsigned long long)total);
+    }
+}
+
+// round bitmap -> per-tile popcounts
+__global__ __launch_bounds__(256) void k_uniq_count(WsDev ws) {
+    __shared__ int red[4];
+    const int64_t base = (int64_t)blockIdx.x * UNIQ_TILE;
+    int s = 0;
+    for (int i = threadIdx.x; i < UNIQ_TILE; i += 256) {
+        int64_t w = base + i;
+        if (w < ws.nw) s += __popc(ws.rbm[w]);
+    }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws.tile_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// per tile: exclusive ranks, sorted unique ids, snapshot + clear of the round bitmap
+__global__ __launch_bounds__(256) void k_uniq_emit(WsDev ws, int ntiles) {
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // tile base = sum of previous tiles
+    int part = 0;
+    for (int t = tid; t < (int)blockIdx.x; t += 256) part += ws.tile_sum[t];
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
+    if (lane == 0) wsum[wv] = part;
+    __syncthreads();
+    int run = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * UNIQ_TILE;
+    for (int r = 0; r < UNIQ_TILE; r += 256) {
+        int64_t w = base + r + tid;
+        uint32_t bits = 0;
+        if (w < ws.nw) {
+            bits = ws.rbm[w];
+            ws.rbm_snap[w] = bits;
+            if (bits) ws.rbm[w] = 0;
+        }
+        int c = __popc(bits);
+        // inclusive wave scan
+        int x = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int i = 0; i < wv; ++i) woff += wsum[i];
+        int rowtot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        int excl = run + woff + x - c;
+        if (w < ws.nw) {
+            ws.word_rank[w] = excl;
+            while (bits) {
+                int bpos = __ffs(bits) - 1;
+                bits &= bits - 1;
+                ws.uniq[excl++] = (int32_t)(w * 32 + bpos);
+            }
+        }
+        run += rowtot;
+        __syncthreads();
+    }
+    if (blockIdx.x == (unsigned)ntiles - 1 && tid == 0) ws.counters[C_NUNIQ] = (unsigned long long)run;
+}
+
+// ---- canonical distance: 16 lanes per row, lane t owns float4 chunks t, t+16, ... -------------
+template <int NCH, bool L2>
+__device__ __forceinline__ float row_reduce(const float4 (&e)[NCH], const float4 (&qv)[NCH]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (L2) {
+            float d0 = e[i].x - qv[i].x, d1 = e[i].y - qv[i].y, d2 = e[i].z - qv[i].z, d3 = e[i].w - qv[i].w;
+            a0 = __builtin_fmaf(d0, d0, a0);
+            a1 = __builtin_fmaf(d1, d1, a1);
+            a2 = __builtin_fmaf(d2, d2, a2);
+            a3 = __builtin_fmaf(d3, d3, a3);
+        } else {
+            a0 = __builtin_fmaf(e[i].x, qv[i].x, a0);
+            a1 = __builtin_fmaf(e[i].y, qv[i].y, a1);
+            a2 = __builtin_fmaf(e[i].z, qv[i].z, a2);
+            a3 = __builtin_fmaf(e[i].w, qv[i].w, a3);
+        }
+    }
+    float s = (a0 + a1) + (a2 + a3);
+    s += __shfl_xor(s, 8, 16);
+    s += __shfl_xor(s, 4, 16);
+    s += __shfl_xor(s, 2, 16);
+    s += __shfl_xor(s, 1, 16);
+    return L2 ? s : -s;
+}
+
+template <int NCH, bool F16>
+__device__ __forceinline__ void load_row(const void* table, int64_t slot, int lane16, float4 (&e)[NCH]) {
+    if (F16) {
+        const uint2* row = (const uint2*)table + slot * (int64_t)(NCH * 16);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            uint2 h = row[lane16 + 16 * i];
+            __half2 h0 = __builtin_bit_cast(__half2, h.x), h1 = __builtin_bit_cast(__half2, h.y);
+            float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+            e[i] = make_float4(f0.x, f0.y, f1.x, f1.y);
+        }
+    } else {
+        const float4* row = (const float4*)table + slot * (int64_t)(NCH * 16);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) e[i] = row[lane16 + 16 * i];
+    }
+}
+
+struct UpdateArgs {
+    const float* Q;       // B x Dp
+    const void* E;        // embeddings: table (row = node id) or provider output (row = rank)
+    int32_t by_rank;      // 1: row index = rank of node in this round's unique list
+    int32_t check_rel;
+    int32_t max_level;
+    int32_t P2;           // pow2 >= ef + maxnew
+};
+
+template <int NCH, bool L2, bool F16>
+__global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;  // P2
+    __shared__ unsigned long long s_best;
+
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ph = ws.phase[q];
+    if (ph == PH_DONE) return;
+    const int n = ws.nnew[q];
+    const int npool0 = (ph == PH_BEAM) ? ws.npool[q] : 0;
+    const int ef = ws.ef;
+    uint64_t* pool = ws.pool + (size_t)q * ef;
+
+    // stage: existing pool | new keys (filled below) | padding
+    for (int i = tid; i < a.P2; i += 256) keys[i] = (i < npool0) ? pool[i] : KEY_NONE;
+    if (tid == 0) s_best = KEY_NONE;
+
+    // query slice in registers: lane t of every 16-lane group holds chunks t, t+16, ...
+    const int lane16 = tid & 15, sg = tid >> 4;
+    float4 qv[NCH];
+    {
+        const float4* qrow = (const float4*)(a.Q + (size_t)q * (NCH * 64));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
+    }
+    __syncthreads();
+
+    const int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
+    // two rows in flight per 16-lane group
+    for (int i = sg; i < n; i += 32) {
+        const int i2 = i + 16;
+        const bool has2 = i2 < n;
+        int32_t v0 = newid[i];
+        int32_t v1 = has2 ? newid[i2] : v0;
+        int64_t s0 = v0, s1 = v1;
+        if (a.by_rank) {
+            s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
+            s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
+        }
+        float4 e0[NCH], e1[NCH];
+        load_row<NCH, F16>(a.E, s0, lane16, e0);
+        load_row<NCH, F16>(a.E, s1, lane16, e1);
+        float d0 = row_reduce<NCH, L2>(e0, qv);
+        float d1 = row_reduce<NCH, L2>(e1, qv);
+        if (lane16 == 0) {
+            keys[npool0 + i] = make_key(d0, v0);
+            if (has2) keys[npool0 + i2] = make_key(d1, v1);
+        }
+    }
+    __syncthreads();
+
+    if (ph != PH_BEAM) {
+        // greedy descent (faiss greedy_update_nearest): best (dist,id) among the neighbours
+        for (int i = tid; i < n; i += 256) atomicMin(&s_best, (unsigned long long)keys[i]);
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t best = s_best;
+            int level = ws.level[q];
+            int phase = ph;
+            uint64_t cur = ws.cur_key[q];
+            if (ph == PH_SEED) {
+                cur = best;
+                phase = PH_UPPER;
+                level = a.max_level;
+            } else {
+                if (best != KEY_NONE && best < cur) cur = best;
+                else level--;
+            }
+            if (level <= 0) {
+                // faiss HNSW::search: candidates.push(nearest); search_from_candidates(level 0)
+                phase = PH_BEAM;
+                int32_t c = key_id(cur);
+                atomicOr(&ws.visited[(size_t)q * ws.nw + (c >> 5)], 1u << (c & 31));
+                pool[0] = cur | KEY_EXPANDED;
+                ws.npool[q] = 1;
+                ws.pop[(size_t)q * ws.W] = c;
+                ws.npop[q] = 1;
+                ws.nsteps[q] = 1;
+                atomicAdd(&ws.counters[C_NEXPAND], 1ull);
+            }
+            ws.cur_key[q] = cur;
+            ws.level[q] = level;
+            ws.phase[q] = phase;
+        }
+        return;
+    }
+
+    // ---- level-0 beam: merge the new keys into the pool (keep the ef smallest) ----
+    if (n > 0) {
+        for (unsigned k2 = 2; k2 <= (unsigned)a.P2; k2 <<= 1) {
+            for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+                for (unsigned i = tid; i < (unsigned)a.P2; i += 256) {
+                    unsigned ixj = i ^ j;
+                    if (ixj > i) {
+                        uint64_t x = keys[i], y = keys[ixj];
+                        bool up = (i & k2) == 0;
+                        if ((x > y) == up) {
+                            keys[i] = y;
+                            keys[ixj] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const int npool1 = min(ef, npool0 + n);
+    // ---- next pops: the W smallest unexpanded entries (wave 0) ----
+    if (tid < 64) {
+        const int nsteps = ws.nsteps[q];
+        int allowed = ws.W;
+        if (!a.check_rel) allowed = min(allowed, max(0, ef + 1 - nsteps));  // faiss: nstep > efSearch -> break
+        int found = 0;
+        for (int base = 0; base < npool1 && found < allowed; base += 64) {
+            int i = base + tid;
+            bool un = i < npool1 && !(keys[i] & KEY_EXPANDED);
+            unsigned long long m = __ballot(un);
+            int r = found + __popcll(m & ((1ull << tid) - 1ull));
+            if (un && r < allowed) {
+                keys[i] |= KEY_EXPANDED;
+                ws.pop[(size_t)q * ws.W + r] = key_id(keys[i]);
+            }
+            found += __popcll(m);
+        }
+        found = min(found, allowed);
+        if (tid == 0) {
+            ws.npop[q] = found;
+            ws.nsteps[q] = nsteps + found;
+            ws.npool[q] = npool1;
+            if (found == 0) ws.phase[q] = PH_DONE;
+            else atomicAdd(&ws.counters[C_NEXPAND], (unsigned long long)found);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npool1; i += 256) pool[i] = keys[i];
+}
+
+__global__ void k_finalize(WsDev ws, int32_t k, int32_t metric, int64_t* labels, float* dist) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ws.B * k) return;
+    int q = t / k, i = t % k;
+    if (i < ws.npool[q]) {
+        uint64_t key = ws.pool[(size_t)q * ws.ef + i];
+        float d = key_dist(key);
+        labels[t] = key_id(key);
+        dist[t] = metric == LM_METRIC_L2 ? d : -d;
+    } else {
+        labels[t] = -1;
+        dist[t] = metric == LM_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+    }
+}
+
+__global__ void k_fill_empty(int64_t n, int32_t metric, int64_t* labels, float* dist) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    labels[t] = -1;
+    dist[t] = metric == LM_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+}
+
+// pad queries [n][D] -> [n][Dp]
+__global__ void k_pad_rows(const float* x, int64_t n, int32_t D, int32_t Dp, float* out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * Dp) return;
+    int64_t r = t / Dp;
+    int32_t c = (int32_t)(t % Dp);
+    out[t] = c < D ? x[r * D + c] : 0.0f;
+}
+
+__global__ void k_pad_rows_f16(const __half* x, int64_t n, int32_t D, int32_t Dp, __half* out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * Dp) return;
+    int64_t r = t / Dp;
+    int32_t c = (int32_t)(t % Dp);
+    out[t] = c < D ? x[r * D + c] : __float2half(0.0f);
+}
+
+// stand-alone pair distances (parity tests)
+template <int NCH, bool L2, bool F16>
+__global__ __launch_bounds__(256) void k_dist_pairs(const void* table, const float* Q, const int32_t* qidx,
+                                                    const int32_t* ids, int64_t npairs, float* out) {
+    const int lane16 = threadIdx.x & 15;
+    int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= npairs) return;
+    float4 qv[NCH], e[NCH];
+    const float4* qrow = (const float4*)(Q + (size_t)qidx[p] * (NCH * 64));
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
+    load_row<NCH, F16>(table, ids[p], lane16, e);
+    float d = row_reduce<NCH, L2>(e, qv);
+    if (lane16 == 0) out[p] = d;
+}
+
+// per-query merge of S shard lists (one 64-lane block per query, LDS bitonic)
+__global__ __launch_bounds__(64) void k_topk_merge(const int64_t* in_ids, const float* in_dist, int S, int B, int k,
+                                                   int metric, int P2, int64_t* out_ids, float* out_dist) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;          // P2 : (dist, slot)
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int tot = S * k;
+    // key = (internal dist, id) cannot hold 63-bit ids: sort by (dist, id) with a 2-word compare
+    int64_t* ids = (int64_t*)(keys + P2);       // P2
+    for (int i = tid; i < P2; i += 64) {
+        if (i < tot) {
+            int s = i / k, j = i % k;
+            size_t src = ((size_t)s * B + q) * k + j;
+            int64_t id = in_ids[src];
+            float d = metric == LM_METRIC_L2 ? in_dist[src] : -in_dist[src];
+            if (id < 0) {
+                keys[i] = KEY_NONE;
+                ids[i] = INT64_MAX;
+            } else {
+                keys[i] = make_key(d, 0) >> 32;  // ordered 32-bit distance
+                ids[i] = id;
+            }
+        } else {
+            keys[i] = KEY_NONE;
+            ids[i] = INT64_MAX;
+        }
+    }
+    __syncthreads();
+    for (unsigned k2 = 2; k2 <= (unsigned)P2; k2 <<= 1)
+        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+            for (unsigned i = tid; i < (unsigned)P2; i += 64) {
+                unsigned ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t x = keys[i], y = keys[ixj];
+                    int64_t xi = ids[i], yi = ids[ixj];
+                    bool gt = x > y || (x == y && xi > yi);
+                    bool up = (i & k2) == 0;
+                    if (gt == up) {
+                        keys[i] = y; keys[ixj] = x;
+                        ids[i] = yi; ids[ixj] = xi;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += 64) {
+        size_t dst = (size_t)q * k + i;
+        if (keys[i] == KEY_NONE) {
+            out_ids[dst] = -1;
+            out_dist[dst] = metric == LM_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+        } else {
+            float d = key_dist(keys[i] << 32);
+            out_ids[dst] = ids[i];
+            out_dist[dst] = metric == LM_METRIC_L2 ? d : -d;
+        }
+    }
+}
+
+}  // namespace lm
+
+// =============================================================================================
+// host side
+// =============================================================================================
+using namespace lm;
+
+struct lm_index {
+    int device = 0;
+    int64_t N = 0;
+    int32_t D = 0, Dp = 0, metric = 0, entry_point = -1, max_level = -1;
+    int32_t maxdeg0 = 0, maxdeg_up = 0;
+    int64_t n_neighbors = 0, n_level_ptr = 0;
+    uint64_t* d_node_offsets = nullptr;
+    uint64_t* d_level_ptr = nullptr;
+    int32_t* d_neighbors = nullptr;
+    // stored embeddings
+    void* d_table = nullptr;
+    bool table_owned = false;
+    int32_t table_dtype = LM_DTYPE_F32;
+    // provider
+    lm_provider_fn provider = nullptr;
+    void* provider_user = nullptr;
+    hipStream_t stream = nullptr;
+    // workspace
+    WsDev ws{};
+    int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0;
+    int64_t ws_ucap = 0;
+    std::vector<void*> ws_allocs;
+    float* d_qpad = nullptr;
+    int64_t qpad_cap = 0;
+    unsigned long long* h_counters = nullptr;  // pinned
+    // stats / profiling
+    lm_search_stats stats{};
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_expand, ev_provider;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static int free_ws(lm_index* ix) {
+    for (void* p : ix->ws_allocs) (void)hipFree(p);
+    ix->ws_allocs.clear();
+    ix->ws_B = ix->ws_ef = ix->ws_W = ix->ws_maxnew = 0;
+    ix->ws_ucap = 0;
+    return 0;
+}
+
+template <typename T>
+static int ws_alloc(lm_index* ix, T** p, size_t count) {
+    void* v = nullptr;
+    LM_HIP(hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T)));
+    ix->ws_allocs.push_back(v);
+    *p = (T*)v;
+    return LM_OK;
+}
+
+static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W) {
+    int32_t maxnew = std::max({W * ix->maxdeg0, ix->maxdeg_up, 1});
+    if (B <= ix->ws_B && ef == ix->ws_ef && W == ix->ws_W && maxnew == ix->ws_maxnew) {
+        ix->ws.B = B;
+        return LM_OK;
+    }
+    free_ws(ix);
+    WsDev& w = ix->ws;
+    w.B = B; w.ef = ef; w.W = W; w.maxnew = maxnew;
+    w.nw = (ix->N + 31) / 32;
+    int rc;
+#define A(ptr, cnt) if ((rc = ws_alloc(ix, &w.ptr, (cnt))) != LM_OK) return rc
+    A(phase, B); A(level, B); A(cur_key, B); A(nsteps, B); A(npool, B); A(npop, B); A(nnew, B);
+    A(pop, (size_t)B * W); A(newid, (size_t)B * maxnew); A(pool, (size_t)B * ef);
+    A(visited, (size_t)B * w.nw);
+    A(rbm, w.nw); A(rbm_snap, w.nw); A(word_rank, w.nw);
+    int ntiles = (int)((w.nw + UNIQ_TILE - 1) / UNIQ_TILE);
+    A(tile_sum, std::max(ntiles, 1));
+    ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * maxnew);
+    A(uniq, ix->ws_ucap);
+    A(counters, C_NCOUNTERS);
+#undef A
+    LM_HIP(hipMemsetAsync(w.rbm, 0, w.nw * 4, ix->stream));
+    ix->ws_B = B; ix->ws_ef = ef; ix->ws_W = W; ix->ws_maxnew = maxnew;
+    return LM_OK;
+}
+
+static hipEvent_t get_event(lm_index* ix) {
+    hipEvent_t e;
+    if (!ix->ev_pool.empty()) {
+        e = ix->ev_pool.back();
+        ix->ev_pool.pop_back();
+        return e;
+    }
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static double drain_events(lm_index* ix, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+    double ms = 0;
+    for (auto& p : v) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+        ix->ev_pool.push_back(p.first);
+        ix->ev_pool.push_back(p.second);
+    }
+    v.clear();
+    return ms;
+}
+
+struct EvScope {
+    lm_index* ix;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* v;
+    hipEvent_t a{}, b{};
+    EvScope(lm_index* i, std::vector<std::pair<hipEvent_t, hipEvent_t>>* vec) : ix(i), v(vec) {
+        if (ix->profiling) {
+            a = get_event(ix);
+            b = get_event(ix);
+            (void)hipEventRecord(a, ix->stream);
+        }
+    }
+    ~EvScope() {
+        if (ix->profiling) {
+            (void)hipEventRecord(b, ix->stream);
+            v->push_back({a, b});
+        }
+    }
+};
+
+template <bool L2, bool F16>
+static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
+    dim3 grid(ix->ws.B), block(256);
+    switch (ix->Dp / 64) {
+#define CASE(n) case n: hipLaunchKernelGGL((k_update<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); break
+        CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(12); CASE(16);
+#undef CASE
+        default: LM_FAIL(LM_EINVAL, "unsupported padded dimension (supported: 64..384, 512, 768, 1024)");
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+static int launch_update(lm_index* ix, const UpdateArgs& a, bool f16) {
+    size_t shmem = (size_t)a.P2 * sizeof(uint64_t);
+    bool l2 = ix->metric == LM_METRIC_L2;
+    if (l2) return f16 ? launch_update_nch<true, true>(ix, a, shmem) : launch_update_nch<true, false>(ix, a, shmem);
+    return f16 ? launch_update_nch<false, true>(ix, a, shmem) : launch_update_nch<false, false>(ix, a, shmem);
+}
+
+static int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// one pass over <= max_batch queries; d_q: B x Dp (padded)
+static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, const lm_search_params& prm,
+                       float* d_dist, int64_t* d_labels) {
+    const int32_t ef = std::max(prm.efSearch, k);  // faiss: max(efSearch, k)
+    const int32_t W = std::max(prm.beam_size, 1);
+    int rc = ensure_ws(ix, B, ef, W);
+    if (rc) return rc;
+    WsDev& ws = ix->ws;
+    hipStream_t st = ix->stream;
+    const bool recompute = prm.recompute != 0;
+    GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors};
+
+    LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
+    LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, ws, ix->max_level);
+
+    UpdateArgs ua{};
+    ua.Q = d_q;
+    ua.check_rel = prm.check_relative_distance;
+    ua.max_level = ix->max_level;
+    ua.P2 = next_pow2(ef + ws.maxnew);
+    if ((size_t)ua.P2 * 8 > 64 * 1024) LM_FAIL(LM_EINVAL, "efSearch * beam too large for the LDS pool (ef + beam*degree <= 8192)");
+    const int ntiles = (int)((ws.nw + UNIQ_TILE - 1) / UNIQ_TILE);
+    const int sync_every = recompute ? 1 : 4;
+    int64_t rounds = 0;
+    unsigned long long* hc = ix->h_counters;
+
+    for (;;) {
+        LM_HIP(hipMemsetAsync(ws.counters + C_LIVE, 0, sizeof(unsigned long long), st));
+        {
+            EvScope es(ix, &ix->ev_expand);
+            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), 0, st, g, ws, recompute ? 1 : 0);
+            if (recompute) {
+                hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
+                hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
+            }
+        }
+        rounds++;
+        bool do_sync = (rounds % sync_every) == 0;
+        if (do_sync) {
+            LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            if (hc[C_LIVE] == 0) {
+                rounds--;
+                break;
+            }
+        }
+        if (recompute) {
+            int32_t nu = (int32_t)hc[C_NUNIQ];
+            void* d_e = nullptr;
+            ix->stats.nunique += nu;
+            if (nu > 0) {
+                EvScope es(ix, &ix->ev_provider);
+                int prc = ix->provider(ix->provider_user, ws.uniq, nu, &d_e, (void*)st);
+                if (prc != 0 || !d_e) LM_FAIL(LM_EPROVIDER, "embedding provider failed (rc=" + std::to_string(prc) + ")");
+            }
+            ua.E = d_e;
+            ua.by_rank = 1;
+            EvScope es(ix, &ix->ev_update);
+            rc = launch_update(ix, ua, false);
+        } else {
+            ua.E = ix->d_table;
+            ua.by_rank = 0;
+            EvScope es(ix, &ix->ev_update);
+            rc = launch_update(ix, ua, ix->table_dtype == LM_DTYPE_F16);
+        }
+        if (rc) return rc;
+        ix->stats.update_launches++;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((B * k + 255) / 256), dim3(256), 0, st, ws, k, ix->metric, d_labels, d_dist);
+    LM_HIP(hipGetLastError());
+    ix->stats.nrounds += rounds;
+    ix->stats.ndis += (int64_t)hc[C_NDIS];
+    ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
+    return LM_OK;
+}
+
+static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k, float* d_dist, int64_t* d_labels,
+                            const lm_search_params* params) {
+    if (!ix || !params || n < 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad search arguments");
+    lm_search_params prm = *params;
+    if (prm.efSearch <= 0) LM_FAIL(LM_EINVAL, "efSearch must be positive");
+    LM_HIP(hipSetDevice(ix->device));
+    ix->stats = lm_search_stats{};
+    if (n == 0) return LM_OK;
+    hipStream_t st = ix->stream;
+    if (ix->N == 0 || ix->entry_point < 0) {
+        hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, n * (int64_t)k,
+                           ix->metric, d_labels, d_dist);
+        LM_HIP(hipStreamSynchronize(st));
+        return LM_OK;
+    }
+    if (prm.recompute) {
+        if (!ix->provider) LM_FAIL(LM_ESTATE, "recompute requested but no embedding provider is attached");
+    } else if (!ix->d_table) {
+        LM_FAIL(LM_ESTATE, "index stores no embeddings (pruned): recompute is required");
+    }
+    // pad queries to Dp if needed
+    const float* d_q = d_x;
+    if (ix->D != ix->Dp) {
+        if (n > ix->qpad_cap) {
+            if (ix->d_qpad) (void)hipFree(ix->d_qpad);
+            LM_HIP(hipMalloc((void**)&ix->d_qpad, (size_t)n * ix->Dp * sizeof(float)));
+            ix->qpad_cap = n;
+        }
+        int64_t tot = n * ix->Dp;
+        hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_x, n, ix->D, ix->Dp, ix->d_qpad);
+        d_q = ix->d_qpad;
+    }
+    int64_t maxb = prm.max_batch > 0 ? prm.max_batch : 4096;
+    // bound the visited bitmaps to 8 GiB
+    int64_t nwbytes = ((ix->N + 31) / 32) * 4;
+    maxb = std::max<int64_t>(1, std::min<int64_t>(maxb, (8ll << 30) / std::max<int64_t>(nwbytes, 1)));
+    lm_search_stats total{};
+    for (int64_t off = 0; off < n; off += maxb) {
+        int32_t B = (int32_t)std::min<int64_t>(maxb, n - off);
+        lm_search_stats keep = ix->stats;
+        int rc = search_pass(ix, B, d_q + (size_t)off * ix->Dp, k, prm, d_dist + (size_t)off * k, d_labels + (size_t)off * k);
+        (void)keep;
+        if (rc) return rc;
+    }
+    LM_HIP(hipStreamSynchronize(st));
+    if (ix->profiling) {
+        ix->stats.update_ms = drain_events(ix, ix->ev_update);
+        ix->stats.expand_ms = drain_events(ix, ix->ev_expand);
+        ix->stats.provider_ms = drain_events(ix, ix->ev_provider);
+    }
+    (void)total;
+    return LM_OK;
+}
+
+static void compute_degrees(lm_index* ix, const uint64_t* node_offsets, const uint64_t* level_ptr) {
+    int32_t m0 = 0, mu = 0;
+    for (int64_t i = 0; i < ix->N; ++i) {
+        uint64_t p0 = node_offsets[i], p1 = node_offsets[i + 1];
+        for (uint64_t p = p0; p + 1 < p1; ++p) {
+            int32_t deg = (int32_t)(level_ptr[p + 1] - level_ptr[p]);
+            if (p == p0) m0 = std::max(m0, deg);
+            else mu = std::max(mu, deg);
+        }
+    }
+    ix->maxdeg0 = m0;
+    ix->maxdeg_up = mu;
+}
+
+extern "C" {
+
+const char* lm_last_error(void) { return g_err.c_str(); }
+const char* lm_version(void) { return "leann-mi355x 0.1 (gfx950)"; }
+
+int lm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void lm_search_params_default(lm_search_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->efSearch = 64;
+    p->beam_size = 1;
+    p->check_relative_distance = 1;
+    p->recompute = 1;
+    p->max_batch = 0;
+}
+
+int lm_index_create_from_csr(int64_t ntotal, int32_t d, int32_t metric, const uint64_t* node_offsets,
+                             const uint64_t* level_ptr, int64_t n_level_ptr, const int32_t* neighbors,
+                             int64_t n_neighbors, const int32_t* levels, int32_t entry_point, int32_t max_level,
+                             int device, lm_index** out) {
+    if (!out) LM_FAIL(LM_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (ntotal < 0 || d <= 0 || (metric != LM_METRIC_L2 && metric != LM_METRIC_INNER_PRODUCT))
+        LM_FAIL(LM_EINVAL, "bad ntotal / d / metric");
+    if (ntotal > 0 && (!node_offsets || !level_ptr || !levels)) LM_FAIL(LM_EINVAL, "NULL CSR array");
+    if (ntotal > 0x7fffffff) LM_FAIL(LM_EINVAL, "ntotal exceeds int32 node ids");
+    if (ntotal > 0) {
+        if ((int64_t)node_offsets[ntotal] != n_level_ptr) LM_FAIL(LM_EFORMAT, "node_offsets[ntotal] != len(level_ptr)");
+        if (entry_point < 0 || entry_point >= ntotal) LM_FAIL(LM_EFORMAT, "entry_point out of range");
+        if (levels[entry_point] != max_level + 1) LM_FAIL(LM_EFORMAT, "levels[entry_point] != max_level + 1");
+        for (int64_t i = 0; i < ntotal; ++i)
+            if ((int64_t)(node_offsets[i + 1] - node_offsets[i]) != (int64_t)levels[i] + 1)
+                LM_FAIL(LM_EFORMAT, "node_offsets[i+1]-node_offsets[i] != levels[i]+1");
+        for (int64_t p = 0; p + 1 < n_level_ptr; ++p)
+            if (level_ptr[p + 1] < level_ptr[p]) LM_FAIL(LM_EFORMAT, "level_ptr not monotone");
+        if (n_level_ptr > 0 && (int64_t)level_ptr[n_level_ptr - 1] > n_neighbors) LM_FAIL(LM_EFORMAT, "level_ptr past neighbors");
+        for (int64_t e = 0; e < n_neighbors; ++e)
+            if (neighbors[e] < 0 || neighbors[e] >= ntotal) LM_FAIL(LM_EFORMAT, "neighbor id out of range");
+    }
+    int ndev = lm_device_count();
+    if (ndev <= 0) LM_FAIL(LM_EHIP, "no HIP device visible: libleann_mi355x requires an MI355X (gfx950) GPU");
+    if (device < 0 || device >= ndev) LM_FAIL(LM_EINVAL, "device index out of range");
+    LM_HIP(hipSetDevice(device));
+    lm_index* ix = new lm_index();
+    ix->device = device;
+    ix->N = ntotal; ix->D = d; ix->Dp = (d + 63) / 64 * 64; ix->metric = metric;
+    ix->entry_point = ntotal > 0 ? entry_point : -1;
+    ix->max_level = max_level;
+    ix->n_neighbors = n_neighbors; ix->n_level_ptr = n_level_ptr;
+    if (ntotal > 0) {
+        compute_degrees(ix, node_offsets, level_ptr);
+        hipError_t e;
+        if ((e = hipMalloc((void**)&ix->d_node_offsets, (size_t)(ntotal + 1) * 8)) != hipSuccess ||
+            (e = hipMalloc((void**)&ix->d_level_ptr, (size_t)std::max<int64_t>(n_level_ptr, 1) * 8)) != hipSuccess ||
+            (e = hipMalloc((void**)&ix->d_neighbors, (size_t)std::max<int64_t>(n_neighbors, 1) * 4)) != hipSuccess ||
+            (e = hipMemcpy(ix->d_node_offsets, node_offsets, (size_t)(ntotal + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(ix->d_level_ptr, level_ptr, (size_t)n_level_ptr * 8, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemcpy(ix->d_neighbors, neighbors, (size_t)n_neighbors * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+            set_error(std::string("graph upload failed: ") + hipGetErrorString(e));
+            lm_index_free(ix);
+            return LM_EHIP;
+        }
+    }
+    if (hipHostMalloc((void**)&ix->h_counters, C_NCOUNTERS * sizeof(unsigned long long)) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        lm_index_free(ix);
+        return LM_EHIP;
+    }
+    std::memset(ix->h_counters, 0, C_NCOUNTERS * sizeof(unsigned long long));
+    *out = ix;
+    return LM_OK;
+}
+
+int lm_index_read(const char* path, int device, lm_index** out) {
+    if (!out || !path) LM_FAIL(LM_EINVAL, "NULL argument");
+    *out = nullptr;
+    HostCsr h;
+    int rc = read_csr_file(path, h);
+    if (rc) return rc;
+    rc = lm_index_create_from_csr(h.ntotal, h.d, h.metric, h.node_offsets.data(), h.level_ptr.data(),
+                                  (int64_t)h.level_ptr.size(), h.neighbors.data(), (int64_t)h.neighbors.size(),
+                                  h.levels.data(), h.entry_point, h.max_level, device, out);
+    if (rc) return rc;
+    if (!h.storage.empty()) {
+        rc = lm_index_attach_table(*out, h.storage.data(), LM_DTYPE_F32, h.ntotal, h.d, 0);
+        if (rc) {
+            lm_index_free(*out);
+            *out = nullptr;
+        }
+    }
+    return rc;
+}
+
+void lm_index_free(lm_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    free_ws(ix);
+    if (ix->d_node_offsets) (void)hipFree(ix->d_node_offsets);
+    if (ix->d_level_ptr) (void)hipFree(ix->d_level_ptr);
+    if (ix->d_neighbors) (void)hipFree(ix->d_neighbors);
+    if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
+    if (ix->d_qpad) (void)hipFree(ix->d_qpad);
+    if (ix->h_counters) (void)hipHostFree(ix->h_counters);
+    for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
+    delete ix;
+}
+
+int lm_index_info(const lm_index* ix, lm_index_info_t* o) {
+    if (!ix || !o) LM_FAIL(LM_EINVAL, "NULL argument");
+    o->ntotal = ix->N; o->d = ix->D; o->d_padded = ix->Dp; o->metric = ix->metric;
+    o->entry_point = ix->entry_point; o->max_level = ix->max_level;
+    o->max_degree0 = ix->maxdeg0; o->max_degree_up = ix->maxdeg_up; o->n_neighbors = ix->n_neighbors;
+    o->has_table = ix->d_table != nullptr; o->has_provider = ix->provider != nullptr; o->device = ix->device;
+    return LM_OK;
+}
+
+int lm_index_attach_table(lm_index* ix, const void* table, int32_t dtype, int64_t ntotal, int32_t d, int32_t location) {
+    if (!ix || !table) LM_FAIL(LM_EINVAL, "NULL argument");
+    if (ntotal != ix->N || d != ix->D) LM_FAIL(LM_EINVAL, "table shape does not match the index");
+    if (dtype != LM_DTYPE_F32 && dtype != LM_DTYPE_F16) LM_FAIL(LM_EINVAL, "dtype must be f32 or f16");
+    LM_HIP(hipSetDevice(ix->device));
+    if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
+    ix->d_table = nullptr;
+    ix->table_owned = false;
+    ix->table_dtype = dtype;
+    if (location == 1) {
+        ix->d_table = const_cast<void*>(table);  // borrowed, stride Dp
+        return LM_OK;
+    }
+    size_t es = dtype == LM_DTYPE_F16 ? 2 : 4;
+    void* dst = nullptr;
+    LM_HIP(hipMalloc(&dst, std::max<size_t>((size_t)ntotal * ix->Dp * es, 16)));
+    ix->d_table = dst;
+    ix->table_owned = true;
+    if (ix->D == ix->Dp) {
+        LM_HIP(hipMemcpy(dst, table, (size_t)ntotal * d * es, hipMemcpyHostToDevice));
+    } else {
+        void* tmp = nullptr;
+        LM_HIP(hipMalloc(&tmp, std::max<size_t>((size_t)ntotal * d * es, 16)));
+        LM_HIP(hipMemcpy(tmp, table, (size_t)ntotal * d * es, hipMemcpyHostToDevice));
+        int64_t tot = ntotal * ix->Dp;
+        if (dtype == LM_DTYPE_F32)
+            hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, (const float*)tmp, ntotal, d, ix->Dp, (float*)dst);
+        else
+            hipLaunchKernelGGL(k_pad_rows_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, (const __half*)tmp, ntotal, d, ix->Dp, (__half*)dst);
+        LM_HIP(hipDeviceSynchronize());
+        (void)hipFree(tmp);
+    }
+    return LM_OK;
+}
+
+int lm_index_set_provider(lm_index* ix, lm_provider_fn fn, void* user) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    ix->provider = fn;
+    ix->provider_user = user;
+    return LM_OK;
+}
+
+int lm_index_set_stream(lm_index* ix, void* s) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    ix->stream = (hipStream_t)s;
+    return LM_OK;
+}
+
+int lm_index_set_profiling(lm_index* ix, int32_t enable) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    ix->profiling = enable != 0;
+    return LM_OK;
+}
+
+int lm_index_get_stats(const lm_index* ix, lm_search_stats* out) {
+    if (!ix || !out) LM_FAIL(LM_EINVAL, "NULL argument");
+    *out = ix->stats;
+    return LM_OK;
+}
+
+int lm_index_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k, float* d_distances, int64_t* d_labels,
+                           const lm_search_params* params) {
+    if (n > 0 && (!d_x || !d_distances || !d_labels)) LM_FAIL(LM_EINVAL, "NULL buffer");
+    return do_search_device(ix, n, d_x, k, d_distances, d_labels, params);
+}
+
+int lm_index_search(lm_index* ix, int64_t n, const float* x, int32_t k, float* distances, int64_t* labels,
+                    const lm_search_params* params) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    if (n < 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad n / k");
+    if (n == 0) return LM_OK;
+    if (!x || !distances || !labels) LM_FAIL(LM_EINVAL, "NULL buffer");
+    LM_HIP(hipSetDevice(ix->device));
+    float* d_x = nullptr;
+    float* d_d = nullptr;
+    int64_t* d_l = nullptr;
+    LM_HIP(hipMalloc((void**)&d_x, (size_t)n * ix->D * 4));
+    LM_HIP(hipMalloc((void**)&d_d, (size_t)n * k * 4));
+    LM_HIP(hipMalloc((void**)&d_l, (size_t)n * k * 8));
+    int rc = LM_OK;
+    if (hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = LM_EHIP;
+    if (!rc) rc = do_search_device(ix, n, d_x, k, d_d, d_l, params);
+    if (!rc && (hipMemcpyAsync(distances, d_d, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                hipMemcpyAsync(labels, d_l, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                hipStreamSynchronize(ix->stream) != hipSuccess)) {
+        set_error("result copy failed");
+        rc = LM_EHIP;
+    }
+    (void)hipFree(d_x);
+    (void)hipFree(d_d);
+    (void)hipFree(d_l);
+    return rc;
+}
+
+int lm_dist_gather(const void* d_table, int32_t dtype, int32_t d_padded, int32_t metric, const float* d_q,
+                   const int32_t* d_qidx, const int32_t* d_ids, int64_t npairs, float* d_out, void* stream) {
+    if (npairs == 0) return LM_OK;
+    if (!d_table || !d_q || !d_qidx || !d_ids || !d_out) LM_FAIL(LM_EINVAL, "NULL buffer");
+    if (d_padded <= 0 || d_padded % 64) LM_FAIL(LM_EINVAL, "d_padded must be a positive multiple of 64");
+    dim3 grid((unsigned)((npairs + 15) / 16)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool l2 = metric == LM_METRIC_L2, f16 = dtype == LM_DTYPE_F16;
+#define GO(n)                                                                                                     \
+    case n:                                                                                                       \
+        if (l2 && f16) hipLaunchKernelGGL((k_dist_pairs<n, true, true>), grid, block, 0, st, d_table, d_q, d_qidx, d_ids, npairs, d_out);        \
+        else if (l2) hipLaunchKernelGGL((k_dist_pairs<n, true, false>), grid, block, 0, st, d_table, d_q, d_qidx, d_ids, npairs, d_out);         \
+        else if (f16) hipLaunchKernelGGL((k_dist_pairs<n, false, true>), grid, block, 0, st, d_table, d_q, d_qidx, d_ids, npairs, d_out);        \
+        else hipLaunchKernelGGL((k_dist_pairs<n, false, false>), grid, block, 0, st, d_table, d_q, d_qidx, d_ids, npairs, d_out);                \
+        break
+    switch (d_padded / 64) {
+        GO(1); GO(2); GO(3); GO(4); GO(5); GO(6); GO(8); GO(12); GO(16);
+        default: LM_FAIL(LM_EINVAL, "unsupported padded dimension");
+    }
+#undef GO
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+int lm_topk_merge(const int64_t* d_in_ids, const float* d_in_dist, int32_t S, int32_t B, int32_t k, int32_t metric,
+                  int64_t* d_out_ids, float* d_out_dist, void* stream) {
+    if (B == 0) return LM_OK;
+    if (!d_in_ids || !d_in_dist || !d_out_ids || !d_out_dist || S <= 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad merge arguments");
+    int P2 = next_pow2(S * k);
+    if (P2 > 2048) LM_FAIL(LM_EINVAL, "S*k too large for the merge kernel (<= 2048)");
+    hipLaunchKernelGGL(k_topk_merge, dim3(B), dim3(64), (size_t)P2 * 16, (hipStream_t)stream, d_in_ids, d_in_dist, S, B, k,
+                       metric, P2, d_out_ids, d_out_dist);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+}  // extern "C"

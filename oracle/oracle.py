@@ -1,0 +1,190 @@
+"""ctypes front-end of the CPU oracle (oracle/lm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, bench.py's ``cpu_baseline`` leg and
+``__graft_entry__.smoke()``.  Nothing under ``leann_amd/`` may import this module.
+Parity status: "parity unpinned" at the faiss boundary (see lm_oracle.c header).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+from typing import Callable, Optional
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "liblm_oracle.so"
+
+METRIC_IP = 0
+METRIC_L2 = 1
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not _LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_HERE)] + (["-B"] if force else []), check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class _Graph(C.Structure):
+    _fields_ = [
+        ("N", C.c_int64),
+        ("D", C.c_int32),
+        ("Dp", C.c_int32),
+        ("max_level", C.c_int32),
+        ("entry_point", C.c_int32),
+        ("metric", C.c_int32),
+        ("node_offsets", C.c_void_p),
+        ("level_ptr", C.c_void_p),
+        ("neighbors", C.c_void_p),
+        ("levels", C.c_void_p),
+    ]
+
+
+class _Params(C.Structure):
+    _fields_ = [("ef", C.c_int32), ("beam", C.c_int32), ("k", C.c_int32), ("check_relative_distance", C.c_int32)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("ndis", C.c_int64), ("nunique", C.c_int64), ("nrounds", C.c_int64), ("nexpand", C.c_int64)]
+
+
+_PROVIDER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_float))
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(_LIB_PATH))
+        _lib.orc_dist.restype = C.c_float
+        _lib.orc_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        _lib.orc_search.restype = C.c_int
+        _lib.orc_search.argtypes = [
+            C.POINTER(_Graph), C.c_void_p, _PROVIDER, C.c_void_p, C.c_void_p, C.c_int32,
+            C.POINTER(_Params), C.c_void_p, C.c_void_p, C.POINTER(_Stats),
+        ]
+        _lib.orc_bruteforce_topk.restype = C.c_int
+        _lib.orc_bruteforce_topk.argtypes = [
+            C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+        ]
+        _lib.orc_merge_topk.restype = C.c_int
+        _lib.orc_merge_topk.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+        ]
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def pad64(x: np.ndarray) -> np.ndarray:
+    """Zero-pad the last dim to a multiple of 64 floats (the canonical row layout)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    d = x.shape[-1]
+    dp = (d + 63) // 64 * 64
+    if dp == d:
+        return x
+    out = np.zeros(x.shape[:-1] + (dp,), dtype=np.float32)
+    out[..., :d] = x
+    return out
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def dist(e: np.ndarray, q: np.ndarray, metric: int) -> float:
+    e, q = pad64(e), pad64(q)
+    return float(lib().orc_dist(_ptr(e), _ptr(q), e.shape[-1], metric))
+
+
+class OracleGraph:
+    """Holds the compact-CSR arrays (convert_to_csr.py:182-237 layout) for the oracle."""
+
+    def __init__(self, node_offsets, level_ptr, neighbors, levels, entry_point, max_level, metric, D):
+        self.node_offsets = np.ascontiguousarray(node_offsets, dtype=np.uint64)
+        self.level_ptr = np.ascontiguousarray(level_ptr, dtype=np.uint64)
+        self.neighbors = np.ascontiguousarray(neighbors, dtype=np.int32)
+        self.levels = np.ascontiguousarray(levels, dtype=np.int32)
+        self.N = int(self.levels.shape[0])
+        self.D = int(D)
+        self.Dp = (self.D + 63) // 64 * 64
+        self.entry_point, self.max_level, self.metric = int(entry_point), int(max_level), int(metric)
+        if self.neighbors.size == 0:  # keep a valid pointer
+            self.neighbors = np.zeros(1, dtype=np.int32)
+
+    def cstruct(self) -> _Graph:
+        return _Graph(self.N, self.D, self.Dp, self.max_level, self.entry_point, self.metric,
+                      _ptr(self.node_offsets), _ptr(self.level_ptr), _ptr(self.neighbors), _ptr(self.levels))
+
+
+def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: int = 1,
+           check_relative_distance: bool = True, table: Optional[np.ndarray] = None,
+           provider: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+    """Run the oracle search.  Exactly one of ``table`` (N x D, stored embeddings) or
+    ``provider`` (callable: sorted unique int32 ids -> (n, D) float32) must be given.
+    Returns (ids int64 (B,k), dist float32 (B,k), stats dict)."""
+    assert (table is None) != (provider is None)
+    q = pad64(np.atleast_2d(queries))
+    B = q.shape[0]
+    assert q.shape[1] == graph.Dp, (q.shape, graph.Dp)
+    ids = np.empty((B, k), dtype=np.int64)
+    dd = np.empty((B, k), dtype=np.float32)
+    st = _Stats()
+    prm = _Params(ef, beam, k, 1 if check_relative_distance else 0)
+    g = graph.cstruct()
+    tab = None
+    err: list = []
+    if table is not None:
+        tab = pad64(table)
+        assert tab.shape == (graph.N, graph.Dp)
+        cb = _PROVIDER()
+    else:
+        Dp = graph.Dp
+
+        def _cb(_user, ids_p, n, out_p):
+            try:
+                idv = np.ctypeslib.as_array(ids_p, shape=(n,)).copy()
+                e = pad64(np.asarray(provider(idv), dtype=np.float32))
+                assert e.shape == (n, Dp), e.shape
+                np.ctypeslib.as_array(out_p, shape=(n, Dp))[:] = e
+                return 0
+            except Exception as ex:  # noqa: BLE001 - surfaced after the C call returns
+                err.append(ex)
+                return 1
+
+        cb = _PROVIDER(_cb)
+    rc = lib().orc_search(C.byref(g), _ptr(tab), cb, None, _ptr(q), B, C.byref(prm), _ptr(ids), _ptr(dd), C.byref(st))
+    if err:
+        raise err[0]
+    if rc:
+        raise RuntimeError(f"orc_search failed rc={rc}")
+    stats = {f: int(getattr(st, f)) for f, _ in _Stats._fields_}
+    return ids, dd, stats
+
+
+def bruteforce_topk(table: np.ndarray, queries: np.ndarray, k: int, metric: int):
+    tab, q = pad64(table), pad64(np.atleast_2d(queries))
+    B = q.shape[0]
+    ids = np.empty((B, k), dtype=np.int64)
+    dd = np.empty((B, k), dtype=np.float32)
+    lib().orc_bruteforce_topk(_ptr(tab), tab.shape[0], tab.shape[1], metric, _ptr(q), B, k, _ptr(ids), _ptr(dd))
+    return ids, dd
+
+
+def merge_topk(ids: np.ndarray, dist_: np.ndarray, metric: int):
+    """ids/dist: (S, B, k) -> (B, k) merged by (internal distance, id)."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    dist_ = np.ascontiguousarray(dist_, dtype=np.float32)
+    S, B, k = ids.shape
+    oi = np.empty((B, k), dtype=np.int64)
+    od = np.empty((B, k), dtype=np.float32)
+    lib().orc_merge_topk(_ptr(ids), _ptr(dist_), S, B, k, metric, _ptr(oi), _ptr(od))
+    return oi, od
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())

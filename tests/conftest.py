@@ -1,0 +1,24 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_libs():
+    """Build the HIP library, the host builder and the oracle once per session (cross-compiles without a GPU)."""
+    import __graft_entry__ as ge
+
+    ge.build()
+    return True

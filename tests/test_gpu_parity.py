@@ -1,0 +1,233 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): top-k ids bit-exact under the (distance, id) tie-break; distances
+bit-exact too, because the kernel implements the oracle's canonical fp32 reduction order (the
+north_star tolerance of 1e-4 is asserted as well, as the contractual bound).
+"""
+import numpy as np
+import pytest
+
+from tests.util import clustered, oracle_graph, queries_near, recall_at_k
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from leann_amd import _lib
+
+    _lib.require_gpu()
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _build(n, d, metric, seed, M=16, efc=80, normalize=True):
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(n, d, seed, normalize=normalize)
+    g = build_hnsw(x, metric, M=M, ef_construction=efc, seed=seed)
+    return x, g
+
+
+def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32):
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    d = x.shape[1]
+    og = oracle_graph(g, d)
+    xt = x.astype(table_dtype)
+    oi, od, ost = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, table=xt.astype(np.float32))
+    idx = Mi355xIndex.from_csr(g, device=0)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if mode == "table":
+        idx.attach_table(xt)
+        prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=False)
+        gd, gi = idx.search(q, k, prm)
+    else:
+        dp = idx.info.d_padded
+        xdev = torch.zeros((x.shape[0], dp), dtype=torch.float32, device="cuda")
+        xdev[:, :d] = torch.from_numpy(xt.astype(np.float32)).cuda()
+        keep = {}
+        seen = []
+
+        def provider(d_ids, n, stream):
+            ids = as_tensor(d_ids, (n,), "int32")
+            seen.append(ids.cpu().numpy().copy())
+            keep["e"] = xdev.index_select(0, ids.long()).contiguous()
+            return keep["e"].data_ptr()
+
+        idx.set_provider(provider)
+        prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=True)
+        gdt, git = idx.search_device(torch.from_numpy(q).cuda(), k, prm)
+        torch.cuda.synchronize()
+        gd, gi = gdt.cpu().numpy(), git.cpu().numpy()
+        # provider contract: sorted unique ids every round
+        for s in seen:
+            assert np.all(np.diff(s) > 0)
+        _, _, pst = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, provider=lambda idv: xt.astype(np.float32)[idv])
+        assert idx.stats()["nunique"] == pst["nunique"]
+    st = idx.stats()
+    assert np.array_equal(gi, oi), f"ids differ: {np.argwhere(gi != oi)[:5]}"
+    assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), "distances not bit-exact"
+    assert np.allclose(gd, od, atol=1e-4, rtol=0)
+    assert st["ndis"] == ost["ndis"] and st["nexpand"] == ost["nexpand"] and st["nrounds"] == ost["nrounds"], (st, ost)
+    idx.close()
+    return gi
+
+
+@pytest.mark.parametrize("metric", ["mips", "l2"])
+@pytest.mark.parametrize("ef,beam", [(16, 1), (64, 1), (64, 4), (200, 2)])
+def test_table_mode_parity(env, metric, ef, beam):
+    x, g = _build(6000, 384, metric, seed=1)
+    q = queries_near(x, 48, seed=2)
+    _check(env, x, g, q, 10, ef, beam, "table")
+
+
+@pytest.mark.parametrize("metric", ["mips", "l2"])
+def test_recompute_mode_parity(env, metric):
+    x, g = _build(5000, 384, metric, seed=3)
+    q = queries_near(x, 40, seed=4)
+    _check(env, x, g, q, 10, 64, 2, "provider")
+
+
+@pytest.mark.parametrize("d", [64, 100, 384, 768, 1024])
+def test_dimensions_and_padding(env, d):
+    x, g = _build(2500, d, "mips", seed=5)
+    q = queries_near(x, 16, seed=6)
+    _check(env, x, g, q, 5, 32, 1, "table")
+    _check(env, x, g, q, 5, 32, 2, "provider")
+
+
+def test_fp16_table(env):
+    x, g = _build(4000, 768, "mips", seed=7)
+    q = queries_near(x, 24, seed=8)
+    _check(env, x, g, q, 10, 64, 1, "table", table_dtype=np.float16)
+
+
+def test_check_relative_distance_off(env):
+    x, g = _build(4000, 128, "mips", seed=9)
+    q = queries_near(x, 24, seed=10)
+    _check(env, x, g, q, 10, 24, 1, "table", check_rel=False)
+    _check(env, x, g, q, 10, 24, 4, "table", check_rel=False)
+
+
+def test_ties_duplicate_vectors(env):
+    """Duplicate vectors -> equal distances -> ordering by id (SURVEY 8c golden case iv)."""
+    x, _ = _build(1500, 64, "l2", seed=11, normalize=False)
+    x[500:1000] = x[:500]  # every vector in [0,500) has an exact duplicate
+    from leann_amd.hnsw_builder import build_hnsw
+
+    g = build_hnsw(x, "l2", M=12, ef_construction=60, seed=11)
+    q = x[:32].copy()
+    gi = _check(env, x, g, q, 4, 48, 2, "table")
+    for i in range(32):
+        assert gi[i, 0] == i and gi[i, 1] == i + 500  # distance 0 twice, smaller id first
+
+
+def test_k_larger_than_reachable_and_tiny_index(env):
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(7, 64, 12)
+    g = build_hnsw(x, "mips", M=4, ef_construction=10)
+    q = queries_near(x, 3, 13)
+    gi = _check(env, x, g, q, 10, 16, 1, "table")
+    assert (gi[:, 7:] == -1).all() and (gi[:, :7] >= 0).all()
+
+
+def test_single_node_and_empty(env):
+    from leann_amd.csr_format import HnswCsr
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+
+    x = clustered(1, 64, 14)
+    g = build_hnsw(x, "l2", M=4, ef_construction=10)
+    _check(env, x, g, x.copy(), 3, 8, 1, "table")
+    ge = build_hnsw(np.zeros((0, 64), np.float32), "l2")
+    assert isinstance(ge, HnswCsr) and ge.ntotal == 0
+    idx = Mi355xIndex.from_csr(ge)
+    d, l = idx.search(np.zeros((2, 64), np.float32), 3, idx.make_params(ef=8, recompute=False))
+    assert (l == -1).all() and np.isinf(d).all()
+
+
+def test_recall_full_size_property(env):
+    """Size-independent property at a larger N: recall vs exact top-k >= 0.9 at ef=64 and
+    monotone in ef; results sorted best-first."""
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x, g = _build(60000, 128, "mips", seed=15, M=16, efc=100)
+    q = queries_near(x, 200, seed=16)
+    gt, _ = orc.bruteforce_topk(x, q, 10, 0)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_table(x)
+    recs = []
+    for ef in (16, 64, 128):
+        d, l = idx.search(q, 10, idx.make_params(ef=ef, beam=2, recompute=False))
+        assert np.all(np.diff(d, axis=1) <= 0)  # +IP descending
+        recs.append(recall_at_k(l, gt))
+    assert recs[1] >= 0.9 and recs[0] <= recs[1] + 1e-9 <= recs[2] + 2e-9, recs
+
+
+def test_dist_gather_kernel(env):
+    """lm_dist_gather == oracle orc_dist bit-for-bit (both metrics, f32/f16 rows)."""
+    import ctypes as C
+
+    torch = env
+    from leann_amd import _lib
+    from oracle import oracle as orc
+
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    n, d, nq, npairs = 3000, 384, 32, 5000
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ids = rng.integers(0, n, npairs).astype(np.int32)
+    qidx = rng.integers(0, nq, npairs).astype(np.int32)
+    for dtype, code in ((np.float32, 0), (np.float16, 1)):
+        xt = x.astype(dtype)
+        tx = torch.from_numpy(xt).cuda()
+        tq = torch.from_numpy(q).cuda()
+        ti, tqi = torch.from_numpy(ids).cuda(), torch.from_numpy(qidx).cuda()
+        out = torch.empty(npairs, dtype=torch.float32, device="cuda")
+        for metric in (0, 1):
+            _lib.check(lib.lm_dist_gather(C.c_void_p(tx.data_ptr()), code, d, metric, C.c_void_p(tq.data_ptr()),
+                                          C.c_void_p(tqi.data_ptr()), C.c_void_p(ti.data_ptr()), npairs,
+                                          C.c_void_p(out.data_ptr()), None))
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            xf = xt.astype(np.float32)
+            exp = np.array([orc.dist(xf[ids[p]], q[qidx[p]], metric) for p in range(0, npairs, 7)], dtype=np.float32)
+            assert np.array_equal(got[::7].view(np.uint32), exp.view(np.uint32))
+            # and within 1e-4 relative of the reference server's numpy formula (hnsw_embedding_server.py:195-200)
+            ref = (np.sum((xf[ids] - q[qidx]) ** 2, axis=1) if metric == 1 else -np.einsum("ij,ij->i", xf[ids], q[qidx]))
+            assert np.allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_topk_merge_kernel(env):
+    import ctypes as C
+
+    torch = env
+    from leann_amd import _lib
+    from oracle import oracle as orc
+
+    lib = _lib.load()
+    rng = np.random.default_rng(18)
+    S, B, k = 8, 37, 10
+    for metric in (0, 1):
+        ids = rng.integers(0, 10**9, (S, B, k)).astype(np.int64)
+        dist = np.sort(rng.standard_normal((S, B, k)).astype(np.float32), axis=2)
+        if metric == 0:
+            dist = dist[:, :, ::-1].copy()
+        ids[3, :, 6:] = -1  # short shard
+        dist[5, 4, :] = dist[2, 4, :]  # ties across shards
+        ti, td = torch.from_numpy(ids).cuda(), torch.from_numpy(dist).cuda()
+        oi = torch.empty((B, k), dtype=torch.int64, device="cuda")
+        od = torch.empty((B, k), dtype=torch.float32, device="cuda")
+        _lib.check(lib.lm_topk_merge(C.c_void_p(ti.data_ptr()), C.c_void_p(td.data_ptr()), S, B, k, metric,
+                                     C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+        torch.cuda.synchronize()
+        ei, ed = orc.merge_topk(ids, dist, metric)
+        assert np.array_equal(oi.cpu().numpy(), ei) and np.array_equal(od.cpu().numpy(), ed)

@@ -1,0 +1,154 @@
+"""CPU tests of the oracle itself (the oracle is test infrastructure; these pin ITS behaviour).
+
+The faiss boundary is "parity unpinned" (no golden ids/distances in the reference), so
+the oracle is pinned by (i) a hand-traced graph, (ii) exact brute force, (iii) the distance
+formulas of hnsw_embedding_server.py:195-200, (iv) tie ordering by id.
+"""
+import numpy as np
+import pytest
+
+from leann_amd.csr_format import METRIC_INNER_PRODUCT, METRIC_L2, csr_from_adjacency
+from oracle import oracle as orc
+from tests.util import clustered, oracle_graph, queries_near, recall_at_k
+
+
+def _line_graph():
+    """8 nodes on a line (1-d coordinates 0..7, embedded in 64-d), level-0 links i<->i+1,
+    node 3 is the entry point with 2 levels; level 1 holds {3, 6} linked to each other."""
+    n, d = 8, 64
+    x = np.zeros((n, d), np.float32)
+    x[:, 0] = np.arange(n)
+    adj = []
+    for i in range(n):
+        l0 = [j for j in (i - 1, i + 1) if 0 <= j < n]
+        lv = [np.array(l0, np.int32)]
+        if i == 3:
+            lv.append(np.array([6], np.int32))
+        if i == 6:
+            lv.append(np.array([3], np.int32))
+        adj.append(lv)
+    g = csr_from_adjacency(adj, d, METRIC_L2, entry_point=3, M=2)
+    return x, g
+
+
+def test_hand_traced_line_graph():
+    x, g = _line_graph()
+    g.validate()
+    og = oracle_graph(g, 64)
+    q = np.zeros((1, 64), np.float32)
+    q[0, 0] = 6.4
+    # hand trace, ef=2,k=2,W=1: seed d(3)=11.56; level1: nbr 6 d=0.16 -> move; level1 again: nbr 3 worse -> level 0.
+    # level0: pool={6}; pop 6 -> new {5(1.96),7(0.36)}; pool={6*,7}; pop 7 -> new {} (6 visited); pool {6*,7*} -> done.
+    ids, dist, st = orc.search(og, q, 2, ef=2, beam=1, table=x)
+    assert ids.tolist() == [[6, 7]]
+    np.testing.assert_allclose(dist[0], [0.16, 0.36], rtol=1e-5)
+    assert st["nrounds"] == 5 and st["ndis"] == 1 + 1 + 1 + 2 + 0 and st["nexpand"] == 2
+    # ef=1 keeps only the best: pops 6 only, 5 and 7 evaluated, none enters the 1-pool
+    ids, dist, st = orc.search(og, q, 1, ef=1, beam=1, table=x)
+    assert ids.tolist() == [[6]] and st["nexpand"] == 1
+    # ef=4: walks further left
+    ids, _, _ = orc.search(og, q, 4, ef=4, beam=1, table=x)
+    assert ids.tolist() == [[6, 7, 5, 4]]
+    # beam 2 gives the same answer here
+    ids2, _, _ = orc.search(og, q, 4, ef=4, beam=2, table=x)
+    assert ids2.tolist() == [[6, 7, 5, 4]]
+
+
+def test_distance_formulas_match_reference_server():
+    rng = np.random.default_rng(0)
+    for d in (64, 100, 384, 768):
+        e, q = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
+        # hnsw_embedding_server.py:195-200
+        l2 = float(np.sum(np.square(e.astype(np.float64) - q)))
+        ip = float(-np.dot(e.astype(np.float64), q))
+        assert abs(orc.dist(e, q, METRIC_L2) - l2) <= 1e-4 * max(1.0, abs(l2))
+        assert abs(orc.dist(e, q, METRIC_INNER_PRODUCT) - ip) <= 1e-4 * max(1.0, abs(ip))
+
+
+@pytest.mark.parametrize("metric,mt", [("mips", METRIC_INNER_PRODUCT), ("l2", METRIC_L2)])
+def test_recall_against_bruteforce(built_libs, metric, mt):
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(8000, 64, 1)
+    q = queries_near(x, 100, 2)
+    g = build_hnsw(x, metric, M=16, ef_construction=100)
+    g.validate()
+    og = oracle_graph(g, 64)
+    gt, gd = orc.bruteforce_topk(x, q, 10, mt)
+    # brute force agrees with numpy
+    ref = np.argsort(-(q @ x.T) if mt == 0 else ((q[:, None, :] - x[None, :, :]) ** 2).sum(-1), axis=1, kind="stable")[:, :10]
+    assert recall_at_k(gt, ref) > 0.999
+    prev = 0.0
+    for ef in (10, 40, 160):
+        ids, dist, _ = orc.search(og, q, 10, ef=ef, beam=1, table=x)
+        r = recall_at_k(ids, gt)
+        assert r >= prev - 1e-9
+        prev = r
+        # best-first ordering of the contract (tests/test_diskann_partition.py:216-220 in the reference)
+        assert np.all(np.diff(dist, axis=1) <= 0) if mt == 0 else np.all(np.diff(dist, axis=1) >= 0)
+    assert prev >= 0.97
+
+
+def test_provider_mode_equals_table_mode(built_libs):
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(3000, 100, 3)  # D not a multiple of 64 -> padding path
+    q = queries_near(x, 30, 4)
+    g = build_hnsw(x, "mips", M=12, ef_construction=60)
+    og = oracle_graph(g, 100)
+    calls = []
+
+    def provider(ids):
+        assert np.all(np.diff(ids) > 0), "provider must receive sorted unique ids"
+        calls.append(len(ids))
+        return x[ids]
+
+    a = orc.search(og, q, 10, ef=48, beam=3, table=x)
+    b = orc.search(og, q, 10, ef=48, beam=3, provider=provider)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert b[2]["nunique"] == sum(calls) <= b[2]["ndis"]
+
+
+def test_ties_order_by_id(built_libs):
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(600, 64, 5, normalize=False)
+    x[300:] = x[:300]
+    g = build_hnsw(x, "l2", M=8, ef_construction=40)
+    og = oracle_graph(g, 64)
+    ids, dist, _ = orc.search(og, x[:20].copy(), 2, ef=32, beam=1, table=x)
+    for i in range(20):
+        assert ids[i].tolist() == [i, i + 300] and dist[i, 0] == 0.0 and dist[i, 1] == 0.0
+
+
+def test_empty_small_and_unfilled():
+    x, g = _line_graph()
+    og = oracle_graph(g, 64)
+    ids, dist, _ = orc.search(og, x[:2], 12, ef=16, beam=1, table=x)
+    assert (ids[:, 8:] == -1).all() and np.isinf(dist[:, 8:]).all() and (ids[:, :8] >= 0).all()
+    e = csr_from_adjacency([], 64, METRIC_INNER_PRODUCT, entry_point=-1)
+    oe = orc.OracleGraph(e.node_offsets, e.level_ptr, e.neighbors, e.levels, -1, -1, 0, 64)
+    ids, dist, _ = orc.search(oe, x[:2], 3, ef=4, table=np.zeros((0, 64), np.float32))
+    assert (ids == -1).all() and (dist == -np.inf).all()
+
+
+def test_check_relative_distance_off_caps_expansions(built_libs):
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(3000, 64, 6)
+    q = queries_near(x, 10, 7)
+    g = build_hnsw(x, "mips", M=12, ef_construction=60)
+    og = oracle_graph(g, 64)
+    _, _, st = orc.search(og, q, 5, ef=8, beam=1, check_relative_distance=False, table=x)
+    assert st["nexpand"] <= 10 * (8 + 1)
+
+
+def test_merge_topk():
+    rng = np.random.default_rng(8)
+    S, B, k = 4, 9, 5
+    ids = rng.integers(0, 1000, (S, B, k)).astype(np.int64)
+    d = np.sort(rng.standard_normal((S, B, k)).astype(np.float32), axis=2)
+    oi, od = orc.merge_topk(ids, d, METRIC_L2)
+    for b in range(B):
+        allp = sorted(zip(d[:, b].ravel().tolist(), ids[:, b].ravel().tolist()))[:k]
+        assert [p[1] for p in allp] == oi[b].tolist()
