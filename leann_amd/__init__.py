@@ -1,0 +1,11 @@
+"""leann_amd -- MI355X (gfx950) native selective-recompute beam search for LEANN.
+
+Importing the package registers the ``"mi355x"`` backend in LEANN's ``BACKEND_REGISTRY``
+(packages/leann-core/src/leann/registry.py:16-27).  Compute lives in libleann_mi355x.so (HIP);
+there is no CPU fallback.
+"""
+
+from .backend import Mi355xBackend, Mi355xBuilder, Mi355xSearcher  # noqa: F401  (registers the backend)
+
+__version__ = "0.1.0"
+__all__ = ["Mi355xBackend", "Mi355xBuilder", "Mi355xSearcher"]

@@ -1,0 +1,336 @@
+"""``leann-backend-mi355x``: the LEANN backend plugin for MI355X.
+
+Host-side mirror of the reference's HNSW backend (packages/leann-backend-hnsw/leann_backend_hnsw/
+hnsw_backend.py): same factory / builder / searcher classes, the same ``search`` signature,
+argument meaning, return value and error behaviour -- but the native search
+(``faiss.IndexHNSW.search`` + per-hop ZMQ round trips to the embedding server) is replaced by
+libleann_mi355x.so: graph in HBM, lock-step selective-recompute beam search, in-process encoder.
+"""
+
+from __future__ import annotations
+
+import json
+import logging
+import pickle
+import time
+from pathlib import Path
+from typing import Any, Literal, Optional
+
+import numpy as np
+
+from . import _lib
+from ._compat import (
+    LeannBackendBuilderInterface,
+    LeannBackendFactoryInterface,
+    LeannBackendSearcherInterface,
+    register_backend,
+)
+from .csr_format import METRIC_INNER_PRODUCT, METRIC_L2, read_index, write_index
+
+logger = logging.getLogger(__name__)
+
+METRIC_MAP = {"mips": METRIC_INNER_PRODUCT, "l2": METRIC_L2, "cosine": METRIC_INNER_PRODUCT}  # hnsw_backend.py:22-29
+
+
+def normalize_l2(data: np.ndarray) -> np.ndarray:
+    """hnsw_backend.py:32-35 (zero vectors stay zero)."""
+    norms = np.linalg.norm(data, axis=1, keepdims=True)
+    norms[norms == 0] = 1
+    return data / norms
+
+
+@register_backend("mi355x")
+class Mi355xBackend(LeannBackendFactoryInterface):
+    @staticmethod
+    def builder(**kwargs) -> LeannBackendBuilderInterface:
+        return Mi355xBuilder(**kwargs)
+
+    @staticmethod
+    def searcher(index_path: str, **kwargs) -> LeannBackendSearcherInterface:
+        return Mi355xSearcher(index_path, **kwargs)
+
+
+class Mi355xBuilder(LeannBackendBuilderInterface):
+    """Mirror of HNSWBuilder (hnsw_backend.py:49-117): same kwargs and defaults, writes the same
+    compact-CSR ``<stem>.index`` file (pruned when ``is_recompute``)."""
+
+    def __init__(self, **kwargs):
+        self.build_params = kwargs.copy()
+        self.is_compact = self.build_params.setdefault("is_compact", True)
+        self.is_recompute = self.build_params.setdefault("is_recompute", True)
+        self.M = self.build_params.setdefault("M", 32)
+        self.efConstruction = self.build_params.setdefault("efConstruction", 200)
+        self.distance_metric = self.build_params.setdefault("distance_metric", "mips")
+        self.dimensions = self.build_params.get("dimensions")
+        if not self.is_recompute and self.is_compact:
+            logger.warning("is_recompute=False requires non-compact HNSW. Forcing is_compact=False.")
+            self.is_compact = False
+            self.build_params["is_compact"] = False
+
+    def build(self, data: np.ndarray, ids: list, index_path: str, **kwargs) -> None:
+        from .hnsw_builder import build_hnsw
+
+        path = Path(index_path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        if data.dtype != np.float32:
+            logger.warning(f"Converting data to float32, shape: {data.shape}")
+            data = data.astype(np.float32)
+        metric = self.distance_metric.lower()
+        if metric not in METRIC_MAP:
+            raise ValueError(f"Unsupported distance_metric '{self.distance_metric}'.")
+        if metric == "cosine":
+            data = normalize_l2(data)
+        g = build_hnsw(data, metric, M=self.M, ef_construction=self.efConstruction)
+        g.storage = np.ascontiguousarray(data, dtype=np.float32)
+        # the file always uses the CSR layout; "non-compact" in the reference == embeddings kept
+        write_index(path.parent / f"{path.stem}.index", g, prune_embeddings=bool(self.is_recompute))
+
+
+class _NoServer:
+    """Stands in for EmbeddingServerManager (leann/api.py:798-806 calls .stop_server())."""
+
+    server_port = None
+
+    def stop_server(self) -> None:
+        return None
+
+
+class Mi355xSearcher(LeannBackendSearcherInterface):
+    """Mirror of HNSWSearcher (hnsw_backend.py:120-253) on top of the C ABI."""
+
+    def __init__(self, index_path: str, **kwargs):
+        self.index_path = Path(index_path)
+        self.index_dir = self.index_path.parent
+        self.meta = kwargs.get("meta") or self._load_meta()
+        if not self.meta:
+            raise ValueError("Searcher requires metadata from .meta.json.")
+        self.dimensions = self.meta.get("dimensions")
+        if not self.dimensions:
+            raise ValueError("Dimensions not found in Leann metadata.")
+        self.embedding_model = self.meta.get("embedding_model")
+        self.embedding_mode = self.meta.get("embedding_mode", "sentence-transformers")
+        self.embedding_server_manager = _NoServer()
+        bk = self.meta.get("backend_kwargs", {})
+        self.distance_metric = (kwargs.get("distance_metric") or bk.get("distance_metric", "mips")).lower()
+        if self.distance_metric not in METRIC_MAP:
+            raise ValueError(f"Unsupported distance_metric '{self.distance_metric}'.")
+        # leann/api.py:472-479 writes these two flags only for backend_name == "hnsw"; derive them from
+        # the persisted build kwargs otherwise
+        self.is_compact = self.meta.get("is_compact", bk.get("is_compact", True))
+        self.is_pruned = self.meta.get("is_pruned", bool(self.is_compact and bk.get("is_recompute", True)))
+        self.index_file = self.index_dir / f"{self.index_path.stem}.index"
+        if not self.index_file.exists():
+            raise FileNotFoundError(f"HNSW index file not found at {self.index_file}")
+        self.device = int(kwargs.get("device", 0))
+        self.encoder_batch = int(kwargs.get("encoder_batch", 2048))
+        self.encoder_dtype = kwargs.get("encoder_dtype", "float16")
+        self._index = None
+        self._provider = None
+        self._encoder = None
+        self._tokenizer = None
+        self._tokens = None
+        if kwargs.get("enable_warmup"):
+            self._ensure_index_loaded()
+
+    # ---- loading ---------------------------------------------------------------------------
+    def _load_meta(self) -> dict:
+        meta_path = self.index_dir / f"{self.index_path.name}.meta.json"
+        if not meta_path.exists():
+            raise FileNotFoundError(f"Leann metadata file not found at {meta_path}")
+        with open(meta_path, encoding="utf-8") as f:
+            return json.load(f)
+
+    def _ensure_index_loaded(self):
+        """Graph -> HBM.  Equivalent of faiss.read_index(...MMAP, HNSWIndexConfig) (hnsw_backend.py:145-151);
+        there is no CPU fallback: without a HIP device this raises."""
+        if self._index is None:
+            from .index import Mi355xIndex
+
+            _lib.require_gpu()
+            self._index = Mi355xIndex.read(str(self.index_file), device=self.device)
+            if self._index.info.d != int(self.dimensions):
+                raise ValueError(f"index dimension {self._index.info.d} != meta dimensions {self.dimensions}")
+        return self._index
+
+    def _torch_device(self):
+        import torch
+
+        return torch.device("cuda", self.device)
+
+    def _ensure_encoder(self):
+        if self._encoder is None:
+            import torch
+
+            from .encoder import BertEncoder
+
+            if not self.embedding_model:
+                raise ValueError("Cannot use recompute mode without 'embedding_model' in meta.json.")
+            _lib.require_gpu()
+            enc = BertEncoder.load(self.embedding_model)
+            dt = torch.float16 if self.encoder_dtype == "float16" else torch.float32
+            self._encoder = enc.to(self._torch_device(), dtype=dt).eval()
+        return self._encoder
+
+    def _passages_file(self, passages_source_file: Optional[str]) -> Path:
+        """Resolve the JSONL of passages (meta.json 'passage_sources', leann/api.py:144-192)."""
+        cands = []
+        for src in self.meta.get("passage_sources", []):
+            if src.get("path_relative"):
+                cands.append(self.index_dir / src["path_relative"])
+            if src.get("path"):
+                p = Path(src["path"])
+                cands.append(p if p.is_absolute() else self.index_dir / p)
+                cands.append(p)
+        cands.append(Path(str(self.index_path) + ".passages.jsonl"))
+        for c in cands:
+            if c.exists():
+                return c
+        raise FileNotFoundError(f"passages file not found (tried {[str(c) for c in cands]})")
+
+    def _read_passage_texts(self, path: Path) -> list[str]:
+        """Node i <-> i-th passage (HNSW labels are insertion indices, hnsw_backend.py:89,251)."""
+        texts = []
+        with open(path, encoding="utf-8") as f:
+            for line in f:
+                if line.strip():
+                    texts.append(json.loads(line).get("text", ""))
+        return texts
+
+    def attach_token_store(self, tokens, tokenizer=None) -> None:
+        """Use an already tokenised corpus (synthetic benchmarks; skips the JSONL pass)."""
+        self._tokens = tokens
+        self._tokenizer = tokenizer
+        self._provider = None
+
+    def attach_encoder(self, encoder) -> None:
+        self._encoder = encoder
+        self._provider = None
+
+    def _ensure_server_running(self, passages_source_file: str, port: Optional[int], **kwargs) -> int:
+        """The reference spawns the embedding-server subprocess here (searcher_base.py:58-84,
+        embedding_server_manager.py:76-104).  Ours: make the in-process encoder + HBM token store
+        ready and return the port unchanged (nothing listens on it)."""
+        idx = self._ensure_index_loaded()
+        enc = self._ensure_encoder()
+        if self._tokens is None:
+            from .token_store import TokenStore
+            from .tokenizer import load_tokenizer
+
+            t0 = time.time()
+            texts = self._read_passage_texts(self._passages_file(passages_source_file))
+            if len(texts) != idx.info.ntotal:
+                raise ValueError(f"{len(texts)} passages but the index holds {idx.info.ntotal} nodes")
+            max_len = min(enc.cfg.max_seq_length, enc.cfg.max_pos)
+            self._tokenizer = load_tokenizer(self.embedding_model, max_len, str(self.index_path), texts, enc.cfg.vocab_size)
+            seqs = self._tokenizer.encode_batch(texts)
+            self._tokens = TokenStore.from_lists(seqs, device=self.device)
+            logger.info(f"token store ready: {len(texts)} passages in {time.time() - t0:.2f}s ({self._tokenizer.kind})")
+        if self._provider is None:
+            from .recompute import RecomputeProvider
+
+            self._provider = RecomputeProvider(enc, self._tokens, idx.info.d_padded, self._torch_device(),
+                                               batch_size=self.encoder_batch)
+            idx.set_provider(self._provider)
+        return int(port) if port is not None else 0
+
+    def compute_query_embedding(self, query: str, use_server_if_available: bool = True,
+                                zmq_port: Optional[int] = None) -> np.ndarray:
+        """(1, D) float32 embedding of a query string with the same in-process encoder
+        (searcher_base.py:86-128 goes through the server / falls back to a local model)."""
+        import torch
+
+        enc = self._ensure_encoder()
+        if self._tokenizer is None:
+            from .tokenizer import load_tokenizer
+
+            self._tokenizer = load_tokenizer(self.embedding_model, min(enc.cfg.max_seq_length, enc.cfg.max_pos),
+                                             str(self.index_path), None, enc.cfg.vocab_size)
+        ids = self._tokenizer.encode_batch([query])[0]
+        dev = self._torch_device()
+        t = torch.tensor([ids], dtype=torch.int32, device=dev)
+        lens = torch.tensor([len(ids)], dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            e = enc(t, lens)
+        return e.float().cpu().numpy()
+
+    # ---- search ----------------------------------------------------------------------------
+    def search(self, query: np.ndarray, top_k: int, zmq_port: Optional[int] = None, complexity: int = 64,
+               beam_width: int = 1, prune_ratio: float = 0.0, recompute_embeddings: bool = True,
+               pruning_strategy: Literal["global", "local", "proportional"] = "global", batch_size: int = 0,
+               **kwargs) -> dict[str, Any]:
+        """Same contract as HNSWSearcher.search (hnsw_backend.py:153-253):
+        returns {"labels": list[list[str]] (B x k), "distances": np.ndarray (B, k) float32}."""
+        if not recompute_embeddings and self.is_pruned:
+            raise RuntimeError(
+                "Recompute is required for pruned/compact HNSW index. "
+                "Re-run search with --recompute, or rebuild with --no-recompute and --no-compact.")
+        if recompute_embeddings and zmq_port is None:
+            raise ValueError("zmq_port must be provided if recompute_embeddings is True")
+        query = np.atleast_2d(np.asarray(query))
+        if query.dtype != np.float32:
+            query = query.astype(np.float32)
+        if self.distance_metric == "cosine":
+            query = normalize_l2(query)
+        idx = self._ensure_index_loaded()
+        if recompute_embeddings and self._provider is None:
+            self._ensure_server_running(str(self.index_dir / f"{self.index_path.name}.meta.json"), zmq_port)
+        # hnsw_backend.py:209-217: OpenAI cosine models disable the relative distance check
+        model = (self.meta.get("embedding_model") or "").lower()
+        check_rel = not (self.distance_metric == "cosine" and any(m in model for m in ["text-embedding", "openai"]))
+        params = idx.make_params(
+            ef=int(complexity), beam=int(beam_width), check_relative_distance=check_rel, recompute=bool(recompute_embeddings),
+            prune_ratio=float(prune_ratio), local_prune=(pruning_strategy == "local"),
+            send_neigh_times_ratio=(1.0 if pruning_strategy == "proportional" else 0.0),
+            batch_size=int(batch_size), zmq_port=int(zmq_port or 0), max_batch=int(kwargs.get("max_batch", 0)))
+        if recompute_embeddings:
+            import torch
+
+            idx.set_stream(torch.cuda.current_stream(self._torch_device()).cuda_stream)
+        t0 = time.time()
+        distances, labels = idx.search(np.ascontiguousarray(query), int(top_k), params)
+        logger.info(f"  Search time in Mi355xSearcher.search() backend: {time.time() - t0} seconds")
+        string_labels = [[str(int(l)) for l in row] for row in labels]
+        return {"labels": string_labels, "distances": distances}
+
+    def last_stats(self) -> dict:
+        return self._index.stats() if self._index is not None else {}
+
+    def cleanup(self) -> None:
+        if self._index is not None:
+            self._index.close()
+            self._index = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def write_leann_bundle(index_path: str, texts: list[str], embeddings: np.ndarray, embedding_model: str,
+                       backend_name: str = "mi355x", **backend_kwargs) -> None:
+    """Write the LEANN index bundle the way LeannBuilder.build_index does (leann/api.py:409-481):
+    ``<index_path>.passages.jsonl`` + ``.passages.idx`` (pickle {id: byte offset}) +
+    ``<index_path>.meta.json`` + the backend's ``<stem>.index``.  Lets the backend be used (and
+    tested) end to end without importing leann-core."""
+    path = Path(index_path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    pj = Path(str(path) + ".passages.jsonl")
+    offsets = {}
+    with open(pj, "w", encoding="utf-8") as f:
+        for i, t in enumerate(texts):
+            offsets[str(i)] = f.tell()
+            f.write(json.dumps({"id": str(i), "text": t, "metadata": {}}, ensure_ascii=False) + "\n")
+    with open(str(path) + ".passages.idx", "wb") as f:
+        pickle.dump(offsets, f)
+    b = Mi355xBuilder(dimensions=int(embeddings.shape[1]), **backend_kwargs)
+    b.build(embeddings, [str(i) for i in range(len(texts))], str(path))
+    meta = {
+        "version": "1.0", "backend_name": backend_name, "embedding_model": embedding_model,
+        "dimensions": int(embeddings.shape[1]), "backend_kwargs": b.build_params, "embedding_mode": "sentence-transformers",
+        "passage_sources": [{"type": "jsonl", "path": pj.name, "index_path": path.name + ".passages.idx",
+                             "path_relative": pj.name, "index_path_relative": path.name + ".passages.idx"}],
+        "is_compact": bool(b.is_compact), "is_pruned": bool(b.is_compact and b.is_recompute),
+    }
+    with open(str(path) + ".meta.json", "w", encoding="utf-8") as f:
+        json.dump(meta, f, indent=2)

@@ -58,7 +58,7 @@ struct WsDev {
     // counters: [0]=live queries this round [1]=n_uniq [2..] stats
     unsigned long long* counters;
 };
-enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_NCOUNTERS = 8 };
+enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NCOUNTERS = 8 };
 
 constexpr int UNIQ_TILE = 4096;  // words per block in the uniq scan
 
@@ -85,7 +85,7 @@ __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32
 }
 
 // one wave (64 lanes) per query
-__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm) {
+__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
     const int ph = ws.phase[q];
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
         ws.nnew[q] = total;
         atomicAdd(&ws.counters[C_LIVE], 1ull);
         atomicAdd(&ws.counters[C_NDIS], (unsigned long long)total);
+        atomicMax(&ws.counters[C_ROUNDS], (unsigned long long)round_no);
     }
 }
 
@@ -696,7 +697,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         LM_HIP(hipMemsetAsync(ws.counters + C_LIVE, 0, sizeof(unsigned long long), st));
         {
             EvScope es(ix, &ix->ev_expand);
-            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), 0, st, g, ws, recompute ? 1 : 0);
+            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), 0, st, g, ws, recompute ? 1 : 0, (int)(rounds + 1));
             if (recompute) {
                 hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
                 hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
@@ -707,10 +708,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         if (do_sync) {
             LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             LM_HIP(hipStreamSynchronize(st));
-            if (hc[C_LIVE] == 0) {
-                rounds--;
-                break;
-            }
+            if (hc[C_LIVE] == 0) break;
         }
         if (recompute) {
             int32_t nu = (int32_t)hc[C_NUNIQ];
@@ -736,7 +734,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     }
     hipLaunchKernelGGL(k_finalize, dim3((B * k + 255) / 256), dim3(256), 0, st, ws, k, ix->metric, d_labels, d_dist);
     LM_HIP(hipGetLastError());
-    ix->stats.nrounds += rounds;
+    ix->stats.nrounds += (int64_t)hc[C_ROUNDS];
     ix->stats.ndis += (int64_t)hc[C_NDIS];
     ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
     return LM_OK;

@@ -1,0 +1,226 @@
+"""In-process sentence-embedding encoder (BERT family) on PyTorch-ROCm.
+
+Replaces the embedding-recompute server of the reference for the search path:
+``compute_embeddings_sentence_transformers`` (packages/leann-core/src/leann/embedding_compute.py:71-353:
+fp16 on GPU :157-162,199-204, model.encode :229-239, manual mean-pool path :323-334) running
+inside ``hnsw_embedding_server.py``.  Same arithmetic as sentence-transformers' Transformer ->
+Pooling(mean|cls) -> optional Normalize stack; weights are loaded from a Hugging Face BERT
+checkpoint when one is available locally, otherwise seeded random weights of the identical
+architecture (throughput-identical; there is no network in the build/bench environment).
+
+MFMA is used only here (hipBLASLt GEMMs + fused attention through torch SDPA); the traversal,
+distance and beam-update kernels are the hand-written HIP in csrc/.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, replace
+from pathlib import Path
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    vocab_size: int = 30522
+    hidden: int = 384
+    layers: int = 6
+    heads: int = 12
+    ffn: int = 1536
+    max_pos: int = 512
+    type_vocab: int = 2
+    ln_eps: float = 1e-12
+    pooling: str = "mean"  # "mean" | "cls"
+    normalize: bool = True
+    max_seq_length: int = 256
+    pad_id: int = 0
+
+    @property
+    def dim(self) -> int:
+        return self.hidden
+
+    def flops_per_chunk(self, T: int) -> float:
+        """2*P_enc*T + 4*L*T^2*H."""
+        p_layer = 4 * self.hidden * self.hidden + 2 * self.hidden * self.ffn
+        return 2.0 * self.layers * p_layer * T + 4.0 * self.layers * T * T * self.hidden
+
+
+# architecture presets for the models BASELINE.json names
+PRESETS = {
+    "all-minilm-l6-v2": EncoderConfig(hidden=384, layers=6, heads=12, ffn=1536, pooling="mean", normalize=True, max_seq_length=256),
+    "bge-small-en-v1.5": EncoderConfig(hidden=384, layers=12, heads=12, ffn=1536, pooling="cls", normalize=True, max_seq_length=512),
+    "bge-base-en-v1.5": EncoderConfig(hidden=768, layers=12, heads=12, ffn=3072, pooling="cls", normalize=True, max_seq_length=512),
+    "contriever": EncoderConfig(hidden=768, layers=12, heads=12, ffn=3072, pooling="mean", normalize=False, max_seq_length=512),
+    "all-mpnet-base-v2": EncoderConfig(hidden=768, layers=12, heads=12, ffn=3072, pooling="mean", normalize=True, max_seq_length=384),
+}
+
+
+def config_for(model_name: str) -> EncoderConfig:
+    key = (model_name or "").lower()
+    for k, v in PRESETS.items():
+        if k in key:
+            return v
+    return PRESETS["all-minilm-l6-v2"]
+
+
+class _Layer(nn.Module):
+    def __init__(self, c: EncoderConfig):
+        super().__init__()
+        self.qkv = nn.Linear(c.hidden, 3 * c.hidden)
+        self.out = nn.Linear(c.hidden, c.hidden)
+        self.ln1 = nn.LayerNorm(c.hidden, eps=c.ln_eps)
+        self.fc1 = nn.Linear(c.hidden, c.ffn)
+        self.fc2 = nn.Linear(c.ffn, c.hidden)
+        self.ln2 = nn.LayerNorm(c.hidden, eps=c.ln_eps)
+        self.heads = c.heads
+
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
+        n, t, h = x.shape
+        qkv = self.qkv(x).view(n, t, 3, self.heads, h // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
+        a = a.transpose(1, 2).reshape(n, t, h)
+        x = self.ln1(x + self.out(a))
+        x = self.ln2(x + self.fc2(F.gelu(self.fc1(x))))
+        return x
+
+
+class BertEncoder(nn.Module):
+    """BERT encoder + sentence pooling.  ``forward(input_ids[n,T], lengths[n]) -> [n, hidden] fp32``."""
+
+    def __init__(self, cfg: EncoderConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.word = nn.Embedding(cfg.vocab_size, cfg.hidden)
+        self.pos = nn.Embedding(cfg.max_pos, cfg.hidden)
+        self.tok_type = nn.Embedding(cfg.type_vocab, cfg.hidden)
+        self.ln = nn.LayerNorm(cfg.hidden, eps=cfg.ln_eps)
+        self.layers = nn.ModuleList([_Layer(cfg) for _ in range(cfg.layers)])
+
+    # ---- construction ----------------------------------------------------------------------
+    @classmethod
+    def random_init(cls, cfg: EncoderConfig, seed: int = 0) -> "BertEncoder":
+        """Seeded Hugging Face-style init (normal(0, 0.02) weights, zero biases, unit LayerNorm),
+        generated on the CPU so that every device gets identical bits."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        m = cls(cfg)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, (nn.Linear, nn.Embedding)):
+                    mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * 0.02)
+                    if isinstance(mod, nn.Linear):
+                        mod.bias.zero_()
+                elif isinstance(mod, nn.LayerNorm):
+                    mod.weight.fill_(1.0)
+                    mod.bias.zero_()
+        return m.eval()
+
+    @classmethod
+    def from_hf_state_dict(cls, cfg: EncoderConfig, sd: dict) -> "BertEncoder":
+        """Load a Hugging Face ``BertModel`` state dict (the module sentence-transformers wraps)."""
+        sd = {k[len("bert."):] if k.startswith("bert.") else k: v for k, v in sd.items()}
+        m = cls(cfg)
+        with torch.no_grad():
+            m.word.weight.copy_(sd["embeddings.word_embeddings.weight"])
+            m.pos.weight.copy_(sd["embeddings.position_embeddings.weight"])
+            m.tok_type.weight.copy_(sd["embeddings.token_type_embeddings.weight"])
+            m.ln.weight.copy_(sd["embeddings.LayerNorm.weight"])
+            m.ln.bias.copy_(sd["embeddings.LayerNorm.bias"])
+            for i, L in enumerate(m.layers):
+                p = f"encoder.layer.{i}."
+                L.qkv.weight.copy_(torch.cat([sd[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0))
+                L.qkv.bias.copy_(torch.cat([sd[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0))
+                L.out.weight.copy_(sd[p + "attention.output.dense.weight"])
+                L.out.bias.copy_(sd[p + "attention.output.dense.bias"])
+                L.ln1.weight.copy_(sd[p + "attention.output.LayerNorm.weight"])
+                L.ln1.bias.copy_(sd[p + "attention.output.LayerNorm.bias"])
+                L.fc1.weight.copy_(sd[p + "intermediate.dense.weight"])
+                L.fc1.bias.copy_(sd[p + "intermediate.dense.bias"])
+                L.fc2.weight.copy_(sd[p + "output.dense.weight"])
+                L.fc2.bias.copy_(sd[p + "output.dense.bias"])
+                L.ln2.weight.copy_(sd[p + "output.LayerNorm.weight"])
+                L.ln2.bias.copy_(sd[p + "output.LayerNorm.bias"])
+        return m.eval()
+
+    @classmethod
+    def load(cls, model_name: str, seed: int = 0) -> "BertEncoder":
+        """Local Hugging Face checkpoint if ``model_name`` is a directory (or in the offline HF
+        cache); otherwise seeded random weights of the preset architecture."""
+        cfg = config_for(model_name)
+        try:
+            from transformers import AutoConfig, AutoModel
+
+            path = model_name if Path(model_name).is_dir() else model_name
+            hc = AutoConfig.from_pretrained(path, local_files_only=True)
+            hf = AutoModel.from_pretrained(path, local_files_only=True)
+            cfg = replace(cfg, vocab_size=hc.vocab_size, hidden=hc.hidden_size, layers=hc.num_hidden_layers,
+                          heads=hc.num_attention_heads, ffn=hc.intermediate_size, max_pos=hc.max_position_embeddings,
+                          type_vocab=hc.type_vocab_size, ln_eps=hc.layer_norm_eps)
+            return cls.from_hf_state_dict(cfg, hf.state_dict())
+        except Exception:  # noqa: BLE001 - offline: no checkpoint available
+            return cls.random_init(cfg, seed)
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, input_ids: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        cfg = self.cfg
+        n, t = input_ids.shape
+        pos = torch.arange(t, device=input_ids.device)
+        x = self.word(input_ids) + self.pos(pos)[None] + self.tok_type.weight[0][None, None]
+        x = self.ln(x)
+        valid = pos[None, :] < lengths[:, None]  # [n, t]
+        mask = None
+        if not bool((lengths == t).all()):
+            mask = valid[:, None, None, :]  # broadcast over heads and query positions
+        for L in self.layers:
+            x = L(x, mask)
+        x = x.float()
+        if cfg.pooling == "cls":
+            e = x[:, 0]
+        else:  # mean over valid tokens (sentence-transformers Pooling / embedding_compute.py:323-334)
+            w = valid.unsqueeze(-1).to(x.dtype)
+            e = (x * w).sum(1) / w.sum(1).clamp(min=1e-9)
+        if cfg.normalize:
+            e = F.normalize(e, p=2, dim=1)
+        return e
+
+    @torch.no_grad()
+    def encode_tokens(self, input_ids: torch.Tensor, lengths: torch.Tensor, batch_size: int = 1024,
+                      bucket: int = 32) -> torch.Tensor:
+        """Length-bucketed batched forward: rows are grouped by ceil(len/bucket) and every group
+        is truncated to its own max length, so padding waste is < bucket tokens per chunk."""
+        n = input_ids.shape[0]
+        out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=input_ids.device)
+        if n == 0:
+            return out
+        order = torch.argsort(lengths, stable=True)
+        sl = lengths[order]
+        # group boundaries where the bucketed length changes or the batch is full
+        bl = ((sl + bucket - 1) // bucket).tolist()
+        start = 0
+        while start < n:
+            end = start + 1
+            while end < n and end - start < batch_size and bl[end] == bl[start]:
+                end += 1
+            idx = order[start:end]
+            tmax = int(sl[end - 1])
+            out[idx] = self.forward(input_ids[idx, :tmax], lengths[idx])
+            start = end
+        return out
+
+
+def hf_reference_embed(hf_model, input_ids: torch.Tensor, lengths: torch.Tensor, pooling: str, normalize: bool):
+    """sentence-transformers semantics on top of a Hugging Face BertModel (used by the parity tests
+    and the golden-vector generator)."""
+    t = input_ids.shape[1]
+    mask = (torch.arange(t)[None, :] < lengths[:, None]).long()
+    with torch.no_grad():
+        h = hf_model(input_ids=input_ids.long(), attention_mask=mask).last_hidden_state.float()
+    if pooling == "cls":
+        e = h[:, 0]
+    else:
+        w = mask.unsqueeze(-1).float()
+        e = (h * w).sum(1) / w.sum(1).clamp(min=1e-9)
+    return F.normalize(e, p=2, dim=1) if normalize else e
