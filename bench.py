@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""bench.py -- queries/sec of the selective-recompute beam search at recall@10 >= 0.9.
+
+Workload (BASELINE.json configs[1]): 1M synthetic text chunks, HNSW graph (M=32), all-MiniLM-L6-v2
+shaped encoder (384-d, seeded random weights -- no checkpoints offline), embeddings recomputed at
+query time, 1 x MI355X.  A "step" is one pass of the hot path over one batch of B queries:
+lm_index_search_device(recompute=1) -> per round: CSR expand / visited / dedup kernels, HBM token
+gather, BERT forward (PyTorch-ROCm fp16), fused distance + beam-update kernel.  Queries, graph,
+token store and results are HBM resident when the timed region starts.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+For N > 1 the driver launches one rank per GPU through torch.distributed.run; the graph and the
+token store are replicated, the query batch is partitioned across ranks, there is no collective on
+the data path (weak scaling: B queries per rank per step).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunks", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=256, help="queries per rank per step")
+    ap.add_argument("--ef", type=int, default=0, help="efSearch; 0 = smallest of the sweep with recall@10 >= 0.9")
+    ap.add_argument("--beam", type=int, default=1)
+    ap.add_argument("--model", default="sentence-transformers/all-MiniLM-L6-v2")
+    ap.add_argument("--M", type=int, default=32)
+    ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table-roofline", action="store_true", help="also time the stored-embedding (HBM gather) mode")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus
+    from leann_amd.token_store import TokenStore
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, W, B = args.steps, args.warmup, args.batch
+    n_q = B * (K + W)
+    t_setup = time.time()
+
+    # ---- corpus -> HBM token store ------------------------------------------------------------
+    spec = CorpusSpec(n_chunks=args.chunks, seed=1234)
+    corpus = SyntheticCorpus(spec)
+    tok, off = corpus.chunks()
+    tokens = TokenStore(tok, off, device=local_rank)
+    log(f"corpus: {args.chunks} chunks, {int(off[-1])} tokens ({time.time() - t_setup:.1f}s)")
+
+    # ---- encoder ------------------------------------------------------------------------------
+    cfg = config_for(args.model)
+    enc = BertEncoder.load(args.model).to(dev, dtype=torch.float16).eval()
+    D = cfg.hidden
+    provider = RecomputeProvider(enc, tokens, (D + 63) // 64 * 64, dev, batch_size=2048)
+
+    # ---- embeddings of every chunk (index build time only) ---------------------------------------
+    t0 = time.time()
+    X = torch.empty((args.chunks, D), dtype=torch.float32, device=dev)
+    step = 32768
+    for b0 in range(0, args.chunks, step):
+        ids = torch.arange(b0, min(args.chunks, b0 + step), dtype=torch.int32, device=dev)
+        X[b0 : b0 + ids.shape[0]] = provider.embed_ids(ids)
+    torch.cuda.synchronize()
+    t_embed = time.time() - t0
+    log(f"embedded corpus in {t_embed:.1f}s ({args.chunks / t_embed:.0f} chunks/s)")
+
+    # ---- graph ----------------------------------------------------------------------------------
+    t0 = time.time()
+    g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc, verbose=(rank == 0 and bool(os.environ.get("BENCH_VERBOSE"))))
+    t_graph = time.time() - t0
+    deg0 = g.level0_degrees()
+    log(f"graph built in {t_graph:.1f}s: max_level={g.max_level} mean level-0 degree={deg0.mean():.1f} edges={g.neighbors.shape[0]}")
+    idx = Mi355xIndex.from_csr(g, device=local_rank)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---- queries + exact ground truth ------------------------------------------------------------
+    qt, qo, _ = corpus.queries(n_q * world, seed=4321)
+    qstore = TokenStore(qt, qo, device=local_rank)
+    Q_all = RecomputeProvider(enc, qstore, provider.dp, dev).embed_ids(torch.arange(n_q * world, dtype=torch.int32, device=dev))
+    Q = Q_all[rank * n_q : (rank + 1) * n_q].contiguous()
+    gt = torch.empty((n_q, 10), dtype=torch.int64, device=dev)
+    for b0 in range(0, n_q, 1024):
+        s = Q[b0 : b0 + 1024] @ X.T
+        gt[b0 : b0 + 1024] = torch.topk(s, 10, dim=1).indices
+    gt_np = gt.cpu().numpy()
+
+    def recall(labels_np, rows):
+        hit = 0
+        for i, r in enumerate(rows):
+            hit += len(set(labels_np[i].tolist()) & set(gt_np[r].tolist()))
+        return hit / (10 * len(rows))
+
+    # ---- ef selection in stored-embedding mode (same traversal, no encoder) -----------------------
+    idx.attach_table(X)
+    sweep = {}
+    nsel = min(n_q, 512)
+    for ef in (16, 32, 64, 128, 256):
+        _, l = idx.search_device(Q[:nsel], 10, idx.make_params(ef=ef, beam=args.beam, recompute=False))
+        st = idx.stats()
+        sweep[ef] = {"recall": recall(l.cpu().numpy(), range(nsel)), "ndis_per_query": st["ndis"] / nsel}
+    log("ef sweep (stored-embedding mode):", json.dumps(sweep))
+    ef = args.ef or next((e for e in sorted(sweep) if sweep[e]["recall"] >= 0.9), 256)
+
+    # optional: HBM-gather roofline of the fused kernel in stored-embedding mode, big batch
+    table_roof = None
+    if args.table_roofline:
+        idx.set_profiling(True)
+        prm = idx.make_params(ef=ef, beam=4, recompute=False, max_batch=16384)
+        Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
+        idx.search_device(Qbig, 10, prm)
+        idx.search_device(Qbig, 10, prm)
+        st = idx.stats()
+        bytes_eval = D * 4 + 4
+        table_roof = {"achieved": st["ndis"] * bytes_eval / (st["update_ms"] * 1e-3) / 1e9, "unit": "GB/s",
+                      "launches": st["update_launches"], "ms_per_launch": st["update_ms"] / max(st["update_launches"], 1),
+                      "queries": 8192, "beam": 4}
+        idx.set_profiling(False)
+
+    # ---- timed region: recompute mode ---------------------------------------------------------------
+    idx.set_provider(provider)
+    prm = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B)
+    idx.set_profiling(True)
+    setup_s = time.time() - t_setup
+    log(f"setup done in {setup_s:.1f}s; ef={ef}; timing {K} steps x {B} queries (+{W} warmup)")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out_labels = []
+    for w in range(W):
+        _, l = idx.search_device(Q[w * B : (w + 1) * B], 10, prm)
+    agg = {"ndis": 0, "nunique": 0, "nrounds": 0, "update_ms": 0.0, "update_launches": 0, "provider_ms": 0.0, "expand_ms": 0.0}
+    provider.chunks = 0
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(K):
+        lo = (W + s) * B
+        _, l = idx.search_device(Q[lo : lo + B], 10, prm)
+        out_labels.append(l)
+        st = idx.stats()
+        for k_ in agg:
+            agg[k_] += st[k_]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    labels_np = torch.cat(out_labels).cpu().numpy() if out_labels else np.zeros((0, 10), np.int64)
+    rec = recall(labels_np, range(W * B, (W + K) * B)) if K else 0.0
+    if world > 1:
+        t = torch.tensor([rec], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rec = float(t.item()) / world
+    qps = world * K * B / elapsed if elapsed > 0 else 0.0
+
+    # ---- roofline of the hand-written distance/beam-update kernel (HIP events, timed region) -------
+    bytes_eval = D * 4 + 4  # D*s_e + 4 (id); the distance never goes back to HBM (fused)
+    upd_s = agg["update_ms"] * 1e-3
+    achieved = agg["ndis"] * bytes_eval / upd_s / 1e9 if upd_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_update (fused gather+distance+beam update)", "achieved": round(achieved, 2),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "bytes_per_eval": bytes_eval, "evals_per_launch": round(agg["ndis"] / max(agg["update_launches"], 1), 1),
+                "us_per_launch": round(1e3 * agg["update_ms"] / max(agg["update_launches"], 1), 2)}
+    # encoder (MFMA bound): flops of the chunks actually recomputed / HIP-event time of the provider
+    lens = np.diff(off.astype(np.int64))
+    mean_flops = float(np.mean([cfg.flops_per_chunk(int(t)) for t in np.random.default_rng(0).choice(lens, 4096)]))
+    enc_tf = agg["nunique"] * mean_flops / (agg["provider_ms"] * 1e-3) / 1e12 if agg["provider_ms"] > 0 else 0.0
+    roofline_encoder = {"bound": "mfma", "achieved": round(enc_tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(enc_tf / 2500.0, 5), "chunks_per_query": round(agg["nunique"] / max(K * B, 1), 1),
+                        "mean_gflop_per_chunk": round(mean_flops / 1e9, 3), "provider_ms_share": round(agg["provider_ms"] / (elapsed * 1e3), 4)}
+
+    result = {
+        "metric": "queries/sec at recall@10>=0.9, 1M-chunk HNSW, MiniLM-L6 recompute",
+        "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 distances/beam (fp16 encoder GEMMs)", "data": "synthetic",
+        "config": {"workload": f"{args.chunks} synthetic chunks (topic model, len~N(180,50)), HNSW M={args.M} GPU-built, "
+                               f"{args.model} shape (random init), ef_search={ef}, beam={args.beam}, top-10, "
+                               f"{B} queries/step/GPU, queries partitioned over {world} GPU(s), graph replicated",
+                   "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
+                   "parallelism": f"queries-dp{world}"},
+        "recall_at_10": round(rec, 4),
+        "roofline": roofline, "roofline_encoder": roofline_encoder,
+        "ef_sweep": sweep,
+        "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),
+                      "rounds_per_step": round(agg["nrounds"] / max(K, 1), 1)},
+        "setup_s": {"total": round(setup_s, 1), "embed_corpus": round(t_embed, 1), "build_graph": round(t_graph, 1)},
+    }
+    if table_roof:
+        result["roofline_table_mode"] = table_roof
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle + fp32 CPU encoder on a bounded sample ---------
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, g, Q, tok, off, cfg, ef, args.beam)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
+    """The reference path on the host cores: oracle traversal (oracle/lm_oracle.c, kind "port") with
+    embeddings recomputed per round by the SAME encoder in fp32 on the CPU
+    (embedding_compute.py:148-154 uses fp32 on CPU).  Bounded to ~cpu_baseline_seconds."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder
+    from leann_amd.synth import pad_batch
+    from oracle import oracle as orc
+
+    ncores = orc.num_threads()
+    torch.set_num_threads(ncores)
+    enc = BertEncoder.load(args.model).float().eval()
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, cfg.hidden)
+    lens_all = np.diff(off.astype(np.int64))
+    T = int(lens_all.max())
+    stat = {"chunks": 0, "enc_s": 0.0}
+
+    def provider(idv):
+        t0 = time.perf_counter()
+        n = idv.shape[0]
+        ids = np.zeros((n, T), np.int32)
+        ln = lens_all[idv].astype(np.int32)
+        for i, v in enumerate(idv):
+            b = int(off[v])
+            ids[i, : ln[i]] = tok[b : b + ln[i]]
+        with torch.no_grad():
+            e = enc.encode_tokens(torch.from_numpy(ids), torch.from_numpy(ln), batch_size=64).numpy()
+        stat["chunks"] += n
+        stat["enc_s"] += time.perf_counter() - t0
+        return e
+
+    q = Q[:64].cpu().numpy()
+    # calibrate on one query, then size the sample
+    t0 = time.perf_counter()
+    orc.search(og, q[:1], 10, ef=ef, beam=beam, provider=provider)
+    one = time.perf_counter() - t0
+    nq = int(max(1, min(63, args.cpu_baseline_seconds // max(one, 1e-3))))
+    stat = {"chunks": 0, "enc_s": 0.0}
+    t0 = time.perf_counter()
+    _, _, st = orc.search(og, q[1 : 1 + nq], 10, ef=ef, beam=beam, provider=provider)
+    el = time.perf_counter() - t0
+    return {"value": round(nq / el, 5), "unit": "queries/s", "cores": ncores, "kind": "port",
+            "sample": f"{nq} queries (batched lock-step, same graph/ef/beam), oracle traversal + fp32 CPU encoder; "
+                      f"{st['nunique']} chunks recomputed in {stat['enc_s']:.1f}s of {el:.1f}s",
+            "chunks_per_s_encoder": round(stat["chunks"] / max(stat["enc_s"], 1e-9), 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,83 +1,75 @@
-"""Bulk HNSW-format graph construction on the GPU (index build time; not the query hot path).
+"""Bulk HNSW graph construction driven by the GPU search kernel (index build time).
 
 The reference inserts points one at a time with faiss (hnsw_backend.py:83-90: M=32,
-efConstruction=200) -- minutes to hours at 1M-60M chunks on CPU.  On an MI355X the whole
-embedding table fits in HBM, so the graph is built in bulk instead:
-  * per level, EXACT k-nearest-neighbour candidates by tiled matmul + top-k (MFMA GEMMs via torch);
-  * the HNSW neighbour-selection heuristic (Malkov & Yashunin Alg. 4: keep a candidate only if it
-    is closer to the base point than to every neighbour already kept) vectorised over nodes;
-  * reverse links, capped at 2M (level 0) / M (upper levels) by similarity;
-  * levels drawn from the HNSW geometric distribution, entry point = a top-level node.
-The output is the same compact-CSR structure (convert_to_csr.py:494-548) the search path reads.
-Works on any torch device (CPU for the small tests).
+efConstruction=200) -- far too slow for 1M-60M chunks without a tuned CPU library.  Here the same
+insertion algorithm (Malkov & Yashunin Alg. 1: search the current graph with ef=efConstruction,
+pick <= M diverse neighbours with the Alg. 4 heuristic, add reverse links, re-prune overflowing
+lists) is run in BATCHES: every batch of new points searches the graph built so far with
+``lm_index_search_device`` (stored-embedding mode: the embedding table is HBM resident at build
+time), and link selection / reverse-link pruning are vectorised torch ops.  Levels are built top
+down; the level-l graph is seeded with the finished level-(l+1) graph (its nodes exist on level l
+too), which hands the lower level its long-range links -- the role early insertions play in
+sequential HNSW.  Output: the compact-CSR arrays of convert_to_csr.py:494-548.
+
+``search_fn`` is injectable so that the CPU tests can drive the builder with the oracle; the
+default is the HIP path (no CPU fallback).
 """
 
 from __future__ import annotations
 
 import math
+from typing import Callable, Optional
 
 import numpy as np
 import torch
 
 from .csr_format import METRIC_INNER_PRODUCT, METRIC_L2, HnswCsr
 
+SearchFn = Callable[[HnswCsr, torch.Tensor, torch.Tensor, int, int], "tuple[torch.Tensor, torch.Tensor]"]
+
+
+# ---------------------------------------------------------------------------------------------
+# similarity helpers (similarity = ip, or -squared-l2: larger is closer)
+# ---------------------------------------------------------------------------------------------
+def _cdtype(x: torch.Tensor):
+    return torch.float16 if x.is_cuda else torch.float32
+
 
 @torch.no_grad()
-def _knn(x: torch.Tensor, sub: torch.Tensor, k: int, metric: int, row_block: int, col_block: int):
-    """Exact kNN among rows ``sub`` of x (similarity = ip or -l2).  Returns (ids [n,k] local indices, sim [n,k])."""
-    xs = x[sub]
+def _bruteforce_knn(xs: torch.Tensor, k: int, metric: int):
     n = xs.shape[0]
     k = min(k, n - 1)
-    cd = torch.float16 if x.is_cuda else torch.float32
-    xh = xs.to(cd)
-    sq = (xs.float() ** 2).sum(1) if metric == METRIC_L2 else None
-    out_i = torch.empty((n, k), dtype=torch.int64, device=x.device)
-    out_s = torch.empty((n, k), dtype=torch.float32, device=x.device)
-    for r0 in range(0, n, row_block):
-        r1 = min(n, r0 + row_block)
-        best_s = torch.full((r1 - r0, k), -float("inf"), device=x.device)
-        best_i = torch.zeros((r1 - r0, k), dtype=torch.int64, device=x.device)
-        for c0 in range(0, n, col_block):
-            c1 = min(n, c0 + col_block)
-            s = (xh[r0:r1] @ xh[c0:c1].T).float()
-            if metric == METRIC_L2:
-                s = 2 * s - sq[r0:r1, None] - sq[None, c0:c1]
-            # mask self
-            lo, hi = max(r0, c0), min(r1, c1)
-            if lo < hi:
-                idx = torch.arange(lo, hi, device=x.device)
-                s[idx - r0, idx - c0] = -float("inf")
-            kk = min(k, c1 - c0)
-            ts, ti = torch.topk(s, kk, dim=1)
-            cs = torch.cat([best_s, ts], 1)
-            ci = torch.cat([best_i, ti + c0], 1)
-            best_s, sel = torch.topk(cs, k, dim=1)
-            best_i = torch.gather(ci, 1, sel)
-        out_i[r0:r1] = best_i
-        out_s[r0:r1] = best_s
-    return out_i, out_s
+    if k <= 0:
+        return torch.zeros((n, 0), dtype=torch.int64, device=xs.device), torch.zeros((n, 0), device=xs.device)
+    s = xs.float() @ xs.float().T
+    if metric == METRIC_L2:
+        sq = (xs.float() ** 2).sum(1)
+        s = 2 * s - sq[:, None] - sq[None, :]
+    s.fill_diagonal_(-float("inf"))
+    ts, ti = torch.topk(s, k, dim=1)
+    return ti, ts
 
 
 @torch.no_grad()
-def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int):
-    """Vectorised HNSW select-neighbours heuristic.  cand/sim: [n,K] sorted best first.
-    Returns keep mask [n,K] with at most m True per row."""
+def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+    """HNSW select-neighbours heuristic, vectorised over rows.  cand [n,K] (-1 = empty), sim [n,K]
+    sorted best first.  Returns keep mask [n,K] with <= m True per row."""
     n, K = cand.shape
     keep = torch.zeros((n, K), dtype=torch.bool, device=xs.device)
-    cd = torch.float16 if xs.is_cuda else torch.float32
+    cd = _cdtype(xs)
     for b0 in range(0, n, block):
         b1 = min(n, b0 + block)
-        cv = xs[cand[b0:b1]].to(cd)  # [b,K,D]
-        cc = torch.bmm(cv, cv.transpose(1, 2)).float()  # ip among candidates
+        cb = cand[b0:b1]
+        valid = cb >= 0
+        cv = xs[cb.clamp(min=0)].to(cd)
+        cc = torch.bmm(cv, cv.transpose(1, 2)).float()
         if metric == METRIC_L2:
             sq = (cv.float() ** 2).sum(-1)
             cc = 2 * cc - sq[:, :, None] - sq[:, None, :]
-        kb = torch.zeros((b1 - b0, K), dtype=torch.bool, device=xs.device)
+        kb = torch.zeros_like(valid)
         cnt = torch.zeros((b1 - b0,), dtype=torch.int32, device=xs.device)
         sb = sim[b0:b1]
-        valid = torch.isfinite(sb)
         for j in range(K):
-            # candidate j is dropped if some kept s is at least as close to it as the base point is
             conflict = ((cc[:, j, :] >= sb[:, j : j + 1]) & kb).any(1)
             ok = (~conflict) & (cnt < m) & valid[:, j]
             kb[:, j] = ok
@@ -86,91 +78,263 @@ def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m
     return keep
 
 
-@torch.no_grad()
-def _level_graph(x: torch.Tensor, sub: torch.Tensor, m_out: int, cap: int, k_cand: int, metric: int,
-                 row_block: int, col_block: int):
-    """Adjacency among ``sub`` (global ids): returns (src_sorted global ids, dst global ids, counts per sub node)."""
-    n = sub.shape[0]
-    if n <= 1:
-        return torch.zeros(0, dtype=torch.int64, device=x.device), torch.zeros(n, dtype=torch.int64, device=x.device)
-    ci, cs = _knn(x, sub, k_cand, metric, row_block, col_block)
-    keep = _select_heuristic(x[sub], ci, cs, m_out, metric, block=max(256, row_block // 4))
-    src = torch.arange(n, device=x.device)[:, None].expand_as(ci)[keep]
-    dst = ci[keep]
-    w = cs[keep]
-    # add reverse links, dedupe, keep the `cap` most similar per source
-    s2 = torch.cat([src, dst])
-    d2 = torch.cat([dst, src])
-    w2 = torch.cat([w, w])
-    key = s2 * n + d2
-    key, perm = torch.sort(key, stable=True)
-    first = torch.ones_like(key, dtype=torch.bool)
-    first[1:] = key[1:] != key[:-1]
-    s2, d2, w2 = s2[perm][first], d2[perm][first], w2[perm][first]
-    # order by (src, -w): sort by w descending first, then stable sort by src
-    o1 = torch.argsort(w2, descending=True, stable=True)
-    s2, d2 = s2[o1], d2[o1]
-    o2 = torch.argsort(s2, stable=True)
-    s2, d2 = s2[o2], d2[o2]
-    counts = torch.bincount(s2, minlength=n)
-    starts = torch.cumsum(counts, 0) - counts
-    rank = torch.arange(s2.shape[0], device=x.device) - starts[s2]
-    ok = rank < cap
-    s2, d2 = s2[ok], d2[ok]
-    counts = torch.bincount(s2, minlength=n)
-    return sub[d2], counts
+class _LevelGraph:
+    """Fixed-capacity adjacency of one level over the node subset ``sub`` (sorted global ids)."""
+
+    def __init__(self, sub: torch.Tensor, cap: int):
+        n = sub.shape[0]
+        self.sub = sub
+        self.cap = cap
+        self.adj = torch.full((n, cap), -1, dtype=torch.int64, device=sub.device)
+        self.sim = torch.full((n, cap), -float("inf"), dtype=torch.float32, device=sub.device)
+        self.deg = torch.zeros((n,), dtype=torch.int64, device=sub.device)
+
+    @torch.no_grad()
+    def add_links(self, xs: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, w: torch.Tensor, metric: int):
+        """Add directed edges src->dst (weights w = similarity); lists that overflow ``cap`` are
+        re-pruned with the heuristic (faiss shrink_neighbor_list)."""
+        if src.numel() == 0:
+            return
+        n, cap = self.adj.shape
+        aff = torch.unique(src)
+        # existing edges of the affected rows
+        ea = self.adj[aff]
+        em = ea >= 0
+        es = aff[:, None].expand_as(ea)[em]
+        s_all = torch.cat([es, src])
+        d_all = torch.cat([ea[em], dst])
+        w_all = torch.cat([self.sim[aff][em], w])
+        # dedupe (src,dst)
+        key = s_all * n + d_all
+        key, perm = torch.sort(key, stable=True)
+        first = torch.ones_like(key, dtype=torch.bool)
+        first[1:] = key[1:] != key[:-1]
+        s_all, d_all, w_all = s_all[perm][first], d_all[perm][first], w_all[perm][first]
+        # order by (src, -w)
+        o1 = torch.argsort(w_all, descending=True, stable=True)
+        s_all, d_all, w_all = s_all[o1], d_all[o1], w_all[o1]
+        o2 = torch.argsort(s_all, stable=True)
+        s_all, d_all, w_all = s_all[o2], d_all[o2], w_all[o2]
+        cnt = torch.bincount(s_all, minlength=n)
+        start = torch.cumsum(cnt, 0) - cnt
+        rank = torch.arange(s_all.shape[0], device=s_all.device) - start[s_all]
+        Kc = 2 * cap
+        okc = rank < Kc
+        s_all, d_all, w_all, rank = s_all[okc], d_all[okc], w_all[okc], rank[okc]
+        # dense candidate rows for the affected nodes
+        row_of = torch.full((n,), -1, dtype=torch.int64, device=s_all.device)
+        row_of[aff] = torch.arange(aff.shape[0], device=s_all.device)
+        cand = torch.full((aff.shape[0], Kc), -1, dtype=torch.int64, device=s_all.device)
+        csim = torch.full((aff.shape[0], Kc), -float("inf"), dtype=torch.float32, device=s_all.device)
+        cand[row_of[s_all], rank] = d_all
+        csim[row_of[s_all], rank] = w_all
+        ccount = (cand >= 0).sum(1)
+        over = ccount > cap
+        new_adj = cand[:, :cap].clone()
+        new_sim = csim[:, :cap].clone()
+        if bool(over.any()):
+            oi = torch.nonzero(over).flatten()
+            keep = _select_heuristic(xs, cand[oi], csim[oi], cap, metric)
+            # compact kept entries to the front (stable)
+            order = torch.argsort((~keep).int(), dim=1, stable=True)
+            kc = torch.gather(cand[oi], 1, order)[:, :cap]
+            ks = torch.gather(csim[oi], 1, order)[:, :cap]
+            kk = torch.gather(keep, 1, order)[:, :cap]
+            kc[~kk] = -1
+            ks[~kk] = -float("inf")
+            new_adj[oi] = kc
+            new_sim[oi] = ks
+        self.adj[aff] = new_adj
+        self.sim[aff] = new_sim
+        self.deg[aff] = (new_adj >= 0).sum(1)
+
+
+def _assemble_csr(levels_top: np.ndarray, graphs: "list[tuple[np.ndarray, np.ndarray]]", base_sub: np.ndarray,
+                  d: int, mt: int, entry_global: int, M: int, efc: int) -> HnswCsr:
+    """CSR over the nodes ``base_sub`` (sorted global ids) from per-level adjacencies.
+    graphs[j] = (sub_global_ids, adj [n_j, cap] LOCAL to that sub, -1 padded) for level base+j.
+    levels_top: top level (relative to base) of every node of base_sub."""
+    n = base_sub.shape[0]
+    nlev = levels_top.astype(np.int64) + 1
+    node_offsets = np.zeros(n + 1, np.uint64)
+    node_offsets[1:] = np.cumsum(nlev + 1)
+    nptr = int(node_offsets[-1])
+    deg = np.zeros(nptr, np.int64)
+    per = []
+    for j, (sub, adj) in enumerate(graphs):
+        loc = np.searchsorted(base_sub, sub)  # sub-local -> base-local
+        m = adj >= 0
+        dj = m.sum(1)
+        deg[node_offsets[loc].astype(np.int64) + j] = dj
+        per.append((loc, adj, m, dj))
+    level_ptr = np.zeros(nptr, np.uint64)
+    if nptr:
+        level_ptr[1:] = np.cumsum(deg)[:-1]
+    neighbors = np.empty(int(deg.sum()), np.int32)
+    for j, (loc, adj, m, dj) in enumerate(per):
+        if not m.any():
+            continue
+        begin = level_ptr[node_offsets[loc].astype(np.int64) + j].astype(np.int64)
+        # entries are left-packed per row (add_links keeps them compact); positions by cumulative count
+        pos = np.cumsum(m, axis=1) - 1
+        rows = np.nonzero(m)
+        neighbors[begin[rows[0]] + pos[rows]] = loc[adj[rows]]
+    max_level = int(levels_top.max()) if n else -1
+    entry = int(np.searchsorted(base_sub, entry_global)) if n else -1
+    cum = np.array([0, 2 * M] + [2 * M + M * (i + 1) for i in range(max(max_level, 0) + 1)], dtype=np.int32)
+    return HnswCsr(d=d, ntotal=n, metric_type=mt, levels=nlev.astype(np.int32), level_ptr=level_ptr,
+                   node_offsets=node_offsets, neighbors=neighbors, entry_point=entry, max_level=max_level,
+                   ef_construction=efc, cum_nneighbor_per_level=cum)
+
+
+def hip_search_fn(device_index: int = 0, beam: int = 2) -> SearchFn:
+    """Default candidate search: the HIP stored-embedding search (lm_index_search_device)."""
+
+    def fn(g: HnswCsr, table: torch.Tensor, queries: torch.Tensor, ef: int, k: int):
+        from .index import Mi355xIndex
+
+        idx = Mi355xIndex.from_csr(g, device=device_index)
+        try:
+            dp = idx.info.d_padded
+            if table.shape[1] != dp:
+                t = torch.zeros((table.shape[0], dp), dtype=torch.float32, device=table.device)
+                t[:, : table.shape[1]] = table
+                table = t
+            idx.set_stream(torch.cuda.current_stream().cuda_stream)
+            idx.attach_table(table.float().contiguous())
+            prm = idx.make_params(ef=ef, beam=beam, recompute=False, max_batch=16384)
+            dist, ids = idx.search_device(queries.float().contiguous(), k, prm)
+            torch.cuda.synchronize()
+            sim = dist if g.metric_type == METRIC_INNER_PRODUCT else -dist
+            return ids, sim
+        finally:
+            idx.close()
+
+    return fn
 
 
 @torch.no_grad()
-def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, k_cand: int = 96, seed: int = 12345,
-                    row_block: int = 8192, col_block: int = 131072) -> HnswCsr:
-    """x: [N, D] float tensor (any device).  Returns the compact-CSR graph on the host."""
+def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, ef_construction: int = 200, seed: int = 12345,
+                    search_fn: Optional[SearchFn] = None, growth: float = 1.5, k_cand: int = 0,
+                    seed_nodes: int = 2048, refine: bool = True, verbose: bool = False) -> HnswCsr:
+    """x: [N, D] float tensor on the build device.  Returns the compact-CSR HNSW graph (host)."""
     metric = metric.lower()
     if metric not in ("mips", "cosine", "l2"):
         raise ValueError(f"Unsupported distance_metric '{metric}'.")
     mt = METRIC_L2 if metric == "l2" else METRIC_INNER_PRODUCT
     n, d = x.shape
     dev = x.device
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    u = torch.rand(n, generator=g, dtype=torch.float64).clamp_min(1e-300)
-    lv = (-(u.log()) / math.log(M)).floor().clamp(max=30).to(torch.int64)  # top level of each node
-    if n > 0 and int(lv.max()) > 0:
-        # keep the hierarchy meaningful for tiny inputs: at least one node on every level below the top
-        pass
-    levels = (lv + 1).to(torch.int32)
-    max_level = int(lv.max()) if n else -1
+    if n == 0:
+        return HnswCsr(d=d, ntotal=0, metric_type=mt, levels=np.zeros(0, np.int32), level_ptr=np.zeros(0, np.uint64),
+                       node_offsets=np.zeros(1, np.uint64), neighbors=np.zeros(0, np.int32), entry_point=-1, max_level=-1)
+    if search_fn is None:
+        search_fn = hip_search_fn(dev.index or 0)
+    k_cand = k_cand or min(ef_construction, 128)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    u = torch.rand(n, generator=gen, dtype=torch.float64).clamp_min(1e-300)
+    lv = (-(u.log()) / math.log(M)).floor().clamp(max=30).to(torch.int64)
+    max_level = int(lv.max())
+    lv_np = lv.numpy()
+    entry_global = int(np.nonzero(lv_np == max_level)[0][0])
     lv_dev = lv.to(dev)
-    per_level = []
-    for l in range(max_level + 1):
-        sub = torch.nonzero(lv_dev >= l, as_tuple=False).flatten()
+    finished: "list[_LevelGraph]" = []  # finished[0] is the level just above the one being built
+
+    for l in range(max_level, -1, -1):
+        sub = torch.nonzero(lv_dev >= l).flatten()
+        nl = sub.shape[0]
+        xs = x[sub]
         cap = 2 * M if l == 0 else M
-        mo = M if l == 0 else max(M // 2, 2)
-        dst, counts = _level_graph(x, sub, mo, cap, k_cand if l == 0 else min(k_cand, 64), mt, row_block, col_block)
-        per_level.append((sub.cpu().numpy(), dst.cpu().numpy().astype(np.int32), counts.cpu().numpy().astype(np.int64)))
-    # assemble CSR: node-major, level-minor (convert_to_csr.py:507-548)
-    levels_np = levels.numpy()
-    node_offsets = np.zeros(n + 1, np.uint64)
-    node_offsets[1:] = np.cumsum(levels_np.astype(np.int64) + 1)
-    nptr = int(node_offsets[-1]) if n else 0
-    deg = np.zeros(nptr, np.int64)  # degree at pointer slot (closing slots stay 0)
-    for l, (sub, dst, counts) in enumerate(per_level):
-        deg[node_offsets[sub].astype(np.int64) + l] = counts
-    level_ptr = np.zeros(nptr, np.uint64)
-    if nptr:
-        level_ptr[1:] = np.cumsum(deg)[:-1]
-    total = int(deg.sum())
-    neighbors = np.empty(total, np.int32)
-    for l, (sub, dst, counts) in enumerate(per_level):
-        if dst.shape[0] == 0:
-            continue
-        begin = level_ptr[node_offsets[sub].astype(np.int64) + l].astype(np.int64)
-        # dst is grouped by source in `sub` order
-        src_rep = np.repeat(np.arange(sub.shape[0]), counts)
-        within = np.arange(dst.shape[0]) - np.repeat(np.cumsum(counts) - counts, counts)
-        neighbors[begin[src_rep] + within] = dst
-    top = np.nonzero(levels_np == max_level + 1)[0]
-    entry = int(top[0]) if n else -1
-    cum = np.array([0, 2 * M] + [2 * M + M * (i + 1) for i in range(max(max_level, 0) + 1)], dtype=np.int32)
-    return HnswCsr(d=d, ntotal=n, metric_type=mt, levels=levels_np, level_ptr=level_ptr, node_offsets=node_offsets,
-                   neighbors=neighbors, entry_point=entry, max_level=max_level, ef_construction=k_cand,
-                   cum_nneighbor_per_level=cum)
+        G = _LevelGraph(sub, cap)
+        inserted = torch.zeros(nl, dtype=torch.bool, device=dev)
+        if finished and finished[0].sub.shape[0] >= 2:
+            # seed with the level above (its nodes are a subset of this level)
+            up = finished[0]
+            loc = torch.searchsorted(sub, up.sub)
+            m = up.adj >= 0
+            a = torch.full((up.adj.shape[0], cap), -1, dtype=torch.int64, device=dev)
+            s = torch.full((up.adj.shape[0], cap), -float("inf"), device=dev)
+            a[:, : up.cap][m] = loc[up.adj[m]]
+            s[:, : up.cap][m] = up.sim[m]
+            G.adj[loc], G.sim[loc] = a, s
+            G.deg[loc] = m.sum(1)
+            inserted[loc] = True
+        else:
+            ns = min(nl, seed_nodes)
+            perm0 = torch.randperm(nl, generator=gen)[:ns].to(dev)
+            if finished:  # keep the upper node(s) inside the seed set
+                perm0 = torch.unique(torch.cat([torch.searchsorted(sub, finished[0].sub), perm0]))
+            ci, cs = _bruteforce_knn(xs[perm0], min(k_cand, perm0.shape[0] - 1), mt)
+            if ci.shape[1] > 0:
+                keep = _select_heuristic(xs[perm0], ci, cs, M, mt)
+                src = perm0[torch.arange(perm0.shape[0], device=dev)[:, None].expand_as(ci)[keep]]
+                dst = perm0[ci[keep]]
+                w = cs[keep]
+                G.add_links(xs, torch.cat([src, dst]), torch.cat([dst, src]), torch.cat([w, w]), mt)
+            inserted[perm0] = True
+        rest = torch.nonzero(~inserted).flatten()
+        rest = rest[torch.randperm(rest.shape[0], generator=gen).to(dev)]
+        # levels (relative to l) of the nodes of this subset, for the temporary search structure
+        rel_top = (lv_np[sub.cpu().numpy()] - l).astype(np.int64)
+        sub_np = sub.cpu().numpy()
+
+        def temp_csr():
+            graphs = [(sub_np, G.adj.cpu().numpy())] + [(f.sub.cpu().numpy(), f.adj.cpu().numpy()) for f in finished]
+            return _assemble_csr(rel_top, graphs, sub_np, d, mt, entry_global, M, ef_construction)
+
+        def insert(batch: torch.Tensor, replace: bool):
+            g = temp_csr()
+            kk = min(k_cand + (1 if replace else 0), max(int(inserted.sum()) - 1, 1))
+            ids, sim = search_fn(g, xs, xs[batch], max(ef_construction, kk), kk)
+            ids = ids.to(dev)
+            sim = sim.to(dev).float()
+            if replace:  # refinement: drop self, merge with current links
+                selfm = ids == batch[:, None]
+                ids = ids.masked_fill(selfm, -1)
+                sim = sim.masked_fill(selfm, -float("inf"))
+                ids = torch.cat([ids, G.adj[batch]], 1)
+                sim = torch.cat([sim, G.sim[batch]], 1)
+                # dedupe within rows: sort by id, blank repeated
+                so = torch.argsort(ids, dim=1, stable=True)
+                ids_s = torch.gather(ids, 1, so)
+                dup = torch.zeros_like(ids_s, dtype=torch.bool)
+                dup[:, 1:] = (ids_s[:, 1:] == ids_s[:, :-1]) & (ids_s[:, 1:] >= 0)
+                dupo = torch.zeros_like(dup)
+                dupo.scatter_(1, so, dup)
+                ids = ids.masked_fill(dupo, -1)
+                sim = sim.masked_fill(dupo, -float("inf"))
+                o = torch.argsort(sim, dim=1, descending=True, stable=True)
+                ids, sim = torch.gather(ids, 1, o), torch.gather(sim, 1, o)
+            ids = ids.masked_fill(~torch.isfinite(sim), -1)
+            keep = _select_heuristic(xs, ids, sim, M, mt)
+            src = batch[:, None].expand_as(ids)[keep]
+            dst = ids[keep]
+            w = sim[keep]
+            if replace:
+                G.adj[batch] = -1
+                G.sim[batch] = -float("inf")
+                G.deg[batch] = 0
+            G.add_links(xs, torch.cat([src, dst]), torch.cat([dst, src]), torch.cat([w, w]), mt)
+            inserted[batch] = True
+
+        pos = 0
+        while pos < rest.shape[0]:
+            have = int(inserted.sum())
+            bs = max(256, int(have * (growth - 1.0)))
+            batch = rest[pos : pos + bs]
+            insert(batch, replace=False)
+            pos += batch.shape[0]
+            if verbose:
+                print(f"[build] level {l}: {int(inserted.sum())}/{nl} nodes, mean degree {float(G.deg[inserted].float().mean()):.1f}")
+        if refine and nl > seed_nodes:
+            allb = torch.arange(nl, device=dev)
+            step = max(4096, nl // 8)
+            for b0 in range(0, nl, step):
+                insert(allb[b0 : b0 + step], replace=True)
+            if verbose:
+                print(f"[build] level {l}: refined, mean degree {float(G.deg.float().mean()):.1f}")
+        finished.insert(0, G)
+
+    # final assembly over all nodes (level 0 subset == everything)
+    graphs = [(f.sub.cpu().numpy(), f.adj.cpu().numpy()) for f in finished]
+    all_ids = np.arange(n, dtype=np.int64)
+    return _assemble_csr(lv_np, graphs, all_ids, d, mt, entry_global, M, ef_construction)

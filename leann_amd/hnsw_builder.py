@@ -36,6 +36,22 @@ def _load():
     return _blib
 
 
+def default_threads(cap: int = 16) -> int:
+    """Usable cores (affinity / cgroup aware), capped: the builder takes per-node spin locks and
+    oversubscribed threads make it crawl."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p_))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, cap))
+
+
 def build_hnsw(data: np.ndarray, metric: str = "mips", M: int = 32, ef_construction: int = 200,
                seed: int = 12345, num_threads: int = 0) -> HnswCsr:
     """Build an HNSW graph over ``data`` (N, D) float32.  ``metric``: "mips" | "cosine" | "l2"
@@ -51,7 +67,7 @@ def build_hnsw(data: np.ndarray, metric: str = "mips", M: int = 32, ef_construct
                        node_offsets=np.zeros(1, np.uint64), neighbors=np.zeros(0, np.int32), entry_point=-1, max_level=-1,
                        ef_construction=ef_construction)
     b = _load()
-    h = b.lm_hnsw_build(x.ctypes.data, n, d, mt, M, ef_construction, seed, num_threads or (os.cpu_count() or 1))
+    h = b.lm_hnsw_build(x.ctypes.data, n, d, mt, M, ef_construction, seed, num_threads or default_threads())
     if not h:
         raise ValueError("lm_hnsw_build rejected its arguments")
     try:

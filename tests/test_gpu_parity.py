@@ -23,12 +23,18 @@ def env():
     return torch
 
 
-def _build(n, d, metric, seed, M=16, efc=80, normalize=True):
+_CACHE = {}
+
+
+def _build(n, d, metric, seed, M=16, efc=60, normalize=True):
     from leann_amd.hnsw_builder import build_hnsw
 
-    x = clustered(n, d, seed, normalize=normalize)
-    g = build_hnsw(x, metric, M=M, ef_construction=efc, seed=seed)
-    return x, g
+    key = (n, d, metric, seed, M, efc, normalize)
+    if key not in _CACHE:
+        x = clustered(n, d, seed, normalize=normalize)
+        _CACHE[key] = (x, build_hnsw(x, metric, M=M, ef_construction=efc, seed=seed))
+    x, g = _CACHE[key]
+    return x.copy(), g
 
 
 def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32):
@@ -81,34 +87,34 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
 @pytest.mark.parametrize("metric", ["mips", "l2"])
 @pytest.mark.parametrize("ef,beam", [(16, 1), (64, 1), (64, 4), (200, 2)])
 def test_table_mode_parity(env, metric, ef, beam):
-    x, g = _build(6000, 384, metric, seed=1)
-    q = queries_near(x, 48, seed=2)
+    x, g = _build(3000, 384, metric, seed=1)
+    q = queries_near(x, 32, seed=2)
     _check(env, x, g, q, 10, ef, beam, "table")
 
 
 @pytest.mark.parametrize("metric", ["mips", "l2"])
 def test_recompute_mode_parity(env, metric):
-    x, g = _build(5000, 384, metric, seed=3)
-    q = queries_near(x, 40, seed=4)
+    x, g = _build(3000, 384, metric, seed=1)
+    q = queries_near(x, 32, seed=4)
     _check(env, x, g, q, 10, 64, 2, "provider")
 
 
 @pytest.mark.parametrize("d", [64, 100, 384, 768, 1024])
 def test_dimensions_and_padding(env, d):
-    x, g = _build(2500, d, "mips", seed=5)
+    x, g = _build(1500, d, "mips", seed=5)
     q = queries_near(x, 16, seed=6)
     _check(env, x, g, q, 5, 32, 1, "table")
     _check(env, x, g, q, 5, 32, 2, "provider")
 
 
 def test_fp16_table(env):
-    x, g = _build(4000, 768, "mips", seed=7)
+    x, g = _build(1500, 768, "mips", seed=5)
     q = queries_near(x, 24, seed=8)
     _check(env, x, g, q, 10, 64, 1, "table", table_dtype=np.float16)
 
 
 def test_check_relative_distance_off(env):
-    x, g = _build(4000, 128, "mips", seed=9)
+    x, g = _build(2000, 128, "mips", seed=9)
     q = queries_near(x, 24, seed=10)
     _check(env, x, g, q, 10, 24, 1, "table", check_rel=False)
     _check(env, x, g, q, 10, 24, 4, "table", check_rel=False)
@@ -158,7 +164,7 @@ def test_recall_full_size_property(env):
     from leann_amd.index import Mi355xIndex
     from oracle import oracle as orc
 
-    x, g = _build(60000, 128, "mips", seed=15, M=16, efc=100)
+    x, g = _build(30000, 128, "mips", seed=15, M=16, efc=80)
     q = queries_near(x, 200, seed=16)
     gt, _ = orc.bruteforce_topk(x, q, 10, 0)
     idx = Mi355xIndex.from_csr(g)
