@@ -246,7 +246,8 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     from leann_amd.synth import pad_batch
     from oracle import oracle as orc
 
-    ncores = orc.num_threads()
+    ncores = orc.usable_cores()  # affinity / cgroup aware (the GPU box exposes 256 threads, 16 usable)
+    orc.set_num_threads(ncores)
     torch.set_num_threads(ncores)
     enc = BertEncoder.load(args.model).float().eval()
     og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, cfg.hidden)

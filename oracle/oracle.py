@@ -77,6 +77,9 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
         ]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_num_threads.argtypes = [C.c_int]
+        _lib.orc_set_num_threads.restype = None
+        _lib.orc_set_num_threads(usable_cores())
     return _lib
 
 
@@ -184,6 +187,27 @@ def merge_topk(ids: np.ndarray, dist_: np.ndarray, metric: int):
     od = np.empty((B, k), dtype=np.float32)
     lib().orc_merge_topk(_ptr(ids), _ptr(dist_), S, B, k, metric, _ptr(oi), _ptr(od))
     return oi, od
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use (affinity mask and cgroup cpu.max aware)."""
+    import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p_))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(int(n))
 
 
 def num_threads() -> int:
