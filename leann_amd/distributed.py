@@ -1,0 +1,113 @@
+"""Multi-GPU host logic: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
+
+Two modes; the reference has no distributed code at all, so this is new design:
+
+* **replicated graph, partitioned queries** (1M / 10M-chunk configs): queries are independent units,
+  every rank searches its slice; no collective on the data path.  `gather_results` optionally
+  concatenates the slices on every rank with one all_gather.
+* **sharded graph** (60M-chunk config): each rank holds a disjoint shard (local node ids +
+  ``id_base``), every rank searches ALL queries on its shard, the per-shard top-k lists
+  ``(B,k) x {f32 dist, i64 id}`` are exchanged with ONE all_gather (30 KB/rank at B=256, k=10 --
+  latency bound, so a single one-shot collective, not a ring pipeline) and merged per query by
+  ``lm_topk_merge`` (order: internal distance, then id).
+
+The local search and the merge are injectable (``search_fn`` / ``merge_fn``) so the world_size-2
+``gloo`` tests can run the host logic on CPU with the oracle as the compute stand-in; the defaults
+are the HIP paths and raise without a GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def partition(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of n items for `rank` (first n % world ranks get one more)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def hip_merge_fn(ids: torch.Tensor, dist_: torch.Tensor, metric: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(S,B,k) device tensors -> (B,k) via the lm_topk_merge kernel."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    S, B, k = ids.shape
+    ids = ids.contiguous()
+    dist_ = dist_.contiguous()
+    oi = torch.empty((B, k), dtype=torch.int64, device=ids.device)
+    od = torch.empty((B, k), dtype=torch.float32, device=ids.device)
+    _lib.check(lib.lm_topk_merge(C.c_void_p(ids.data_ptr()), C.c_void_p(dist_.data_ptr()), S, B, k, metric,
+                                 C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lm_topk_merge")
+    return oi, od
+
+
+class PartitionedSearch:
+    """Replicated index, queries partitioned across ranks."""
+
+    def __init__(self, search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]],
+                 group: Optional[dist.ProcessGroup] = None):
+        self.search_fn = search_fn
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def search(self, queries: torch.Tensor, k: int, gather_results: bool = True):
+        """queries: (B,D) identical on every rank.  Returns (dist (B,k), ids (B,k)) for all B when
+        gather_results, else this rank's slice and its (lo, hi)."""
+        B = queries.shape[0]
+        lo, hi = partition(B, self.world, self.rank)
+        d, i = self.search_fn(queries[lo:hi].contiguous(), k)
+        if not gather_results or self.world == 1:
+            return (d, i) if self.world == 1 else (d, i, (lo, hi))
+        # equal-size all_gather: pad the slices to the largest one
+        m = (B + self.world - 1) // self.world
+        pd = torch.zeros((m, k), dtype=torch.float32, device=d.device)
+        pi = torch.full((m, k), -1, dtype=torch.int64, device=i.device)
+        pd[: hi - lo], pi[: hi - lo] = d, i
+        gd = [torch.empty_like(pd) for _ in range(self.world)]
+        gi = [torch.empty_like(pi) for _ in range(self.world)]
+        dist.all_gather(gd, pd, group=self.group)
+        dist.all_gather(gi, pi, group=self.group)
+        od = torch.cat([gd[r][: partition(B, self.world, r)[1] - partition(B, self.world, r)[0]] for r in range(self.world)])
+        oi = torch.cat([gi[r][: partition(B, self.world, r)[1] - partition(B, self.world, r)[0]] for r in range(self.world)])
+        return od, oi
+
+
+class ShardedSearch:
+    """Graph sharded across ranks: local top-k on every shard, one all_gather, per-query merge."""
+
+    def __init__(self, search_fn: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]], id_base: int,
+                 metric: int, merge_fn: Callable = hip_merge_fn, group: Optional[dist.ProcessGroup] = None):
+        self.search_fn = search_fn
+        self.id_base = int(id_base)
+        self.metric = int(metric)
+        self.merge_fn = merge_fn
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def search(self, queries: torch.Tensor, k: int):
+        """queries: (B,D) identical on every rank -> global (dist (B,k), ids (B,k)), identical on every rank."""
+        d, i = self.search_fn(queries, k)
+        i = torch.where(i >= 0, i + self.id_base, i)
+        if self.world == 1:
+            return self.merge_fn(i[None].contiguous(), d[None].contiguous(), self.metric)[::-1]
+        gd = [torch.empty_like(d) for _ in range(self.world)]
+        gi = [torch.empty_like(i) for _ in range(self.world)]
+        dist.all_gather(gd, d.contiguous(), group=self.group)
+        dist.all_gather(gi, i.contiguous(), group=self.group)
+        oi, od = self.merge_fn(torch.stack(gi), torch.stack(gd), self.metric)
+        return od, oi
+
+
+def shard_bounds(n: int, world: int):
+    """Node ranges of the shards: [(lo, hi)] * world."""
+    return [partition(n, world, r) for r in range(world)]

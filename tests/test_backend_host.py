@@ -1,0 +1,119 @@
+"""Host-side logic of the backend plugin (no GPU): registration, constructor / search validation with
+the reference's error behaviour, builder output, and the real leann-core boundary when the reference
+tree is present."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import clustered
+
+ROOT = Path(__file__).resolve().parent.parent
+REF_CORE = Path("/root/reference/packages/leann-core/src")
+
+
+def _bundle(tmp_path, n=120, d=32, **kw):
+    from leann_amd.backend import write_leann_bundle
+
+    x = clustered(n, d, 1)
+    texts = [f"passage number {i} about topic {i % 7}" for i in range(n)]
+    p = str(tmp_path / "idx.leann")
+    write_leann_bundle(p, texts, x, "sentence-transformers/all-MiniLM-L6-v2", **kw)
+    return p, x, texts
+
+
+def test_registered_and_factory(built_libs):
+    from leann_amd import Mi355xBackend, Mi355xBuilder, Mi355xSearcher
+    from leann_amd._compat import BACKEND_REGISTRY
+
+    assert BACKEND_REGISTRY["mi355x"] is Mi355xBackend
+    assert isinstance(Mi355xBackend.builder(M=8), Mi355xBuilder)
+    import leann_backend_mi355x  # the autodiscovery shim (registry.py:30-47)
+
+    assert leann_backend_mi355x.Mi355xSearcher is Mi355xSearcher
+
+
+def test_builder_writes_reference_layout(tmp_path, built_libs):
+    from leann_amd import csr_format as cf
+
+    p, x, texts = _bundle(tmp_path, distance_metric="cosine", M=8, efConstruction=40)
+    g = cf.read_index(tmp_path / "idx.index")  # <stem>.index next to <name>.leann.* (hnsw_backend.py:141)
+    assert g.ntotal == 120 and g.d == 32 and g.is_pruned and g.metric_type == cf.METRIC_INNER_PRODUCT
+    meta = json.loads(Path(p + ".meta.json").read_text())
+    assert meta["backend_name"] == "mi355x" and meta["dimensions"] == 32
+    assert meta["backend_kwargs"]["M"] == 8 and meta["backend_kwargs"]["is_recompute"] is True
+    assert meta["is_compact"] is True and meta["is_pruned"] is True
+    lines = Path(p + ".passages.jsonl").read_text().splitlines()
+    assert json.loads(lines[5]) == {"id": "5", "text": texts[5], "metadata": {}}
+    # is_recompute=False keeps the embeddings and forces is_compact False (hnsw_backend.py:58-64)
+    from leann_amd.backend import Mi355xBuilder
+
+    b = Mi355xBuilder(is_recompute=False, M=8, efConstruction=40)
+    assert b.is_compact is False and b.build_params["is_compact"] is False
+    b.build(x, [str(i) for i in range(120)], str(tmp_path / "full.leann"))
+    assert np.array_equal(cf.read_index(tmp_path / "full.index").storage, x)
+    with pytest.raises(ValueError, match="Unsupported distance_metric"):
+        Mi355xBuilder(distance_metric="hamming").build(x, [], str(tmp_path / "bad.leann"))
+
+
+def test_searcher_errors_match_reference(tmp_path, built_libs):
+    from leann_amd import Mi355xSearcher, _lib
+
+    with pytest.raises(FileNotFoundError, match="metadata file not found"):  # searcher_base.py:54
+        Mi355xSearcher(str(tmp_path / "nope.leann"))
+    p, x, _ = _bundle(tmp_path, M=8, efConstruction=40)
+    meta = json.loads(Path(p + ".meta.json").read_text())
+    with pytest.raises(ValueError, match="Unsupported distance_metric"):  # hnsw_backend.py:134
+        Mi355xSearcher(p, meta={**meta, "backend_kwargs": {"distance_metric": "hamming"}})
+    with pytest.raises(ValueError, match="Dimensions"):
+        Mi355xSearcher(p, meta={k: v for k, v in meta.items() if k != "dimensions"})
+    os.rename(tmp_path / "idx.index", tmp_path / "idx.index.bak")
+    with pytest.raises(FileNotFoundError, match="HNSW index file not found"):  # hnsw_backend.py:143
+        Mi355xSearcher(p)
+    os.rename(tmp_path / "idx.index.bak", tmp_path / "idx.index")
+    s = Mi355xSearcher(p)
+    assert s.is_pruned and s.distance_metric == "mips" and s.embedding_server_manager.stop_server() is None
+    with pytest.raises(RuntimeError, match="Recompute is required"):  # hnsw_backend.py:189-193
+        s.search(x[:1], 3, recompute_embeddings=False)
+    with pytest.raises(ValueError, match="zmq_port must be provided"):  # hnsw_backend.py:194-196
+        s.search(x[:1], 3, recompute_embeddings=True, zmq_port=None)
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.LeannMi355xError, match="no HIP device"):  # no CPU fallback
+            s.search(x[:1], 3, recompute_embeddings=True, zmq_port=5557)
+        with pytest.raises(_lib.LeannMi355xError):
+            s._ensure_server_running(p + ".meta.json", 5557)
+
+
+@pytest.mark.skipif(not REF_CORE.exists(), reason="reference tree not present (GPU box)")
+def test_real_leann_core_boundary(tmp_path, built_libs):
+    """With the reference's leann-core on sys.path the backend registers in ITS registry, derives
+    from ITS ABCs, and `LeannSearcher(index)` instantiates our searcher from meta.json."""
+    p, _, _ = _bundle(tmp_path, M=8, efConstruction=40)
+    code = f"""
+import sys
+sys.path.insert(0, {str(REF_CORE)!r}); sys.path.insert(0, {str(ROOT)!r})
+import leann_backend_mi355x
+from leann.registry import BACKEND_REGISTRY
+from leann.interface import LeannBackendSearcherInterface, LeannBackendFactoryInterface
+from leann_amd import Mi355xBackend, Mi355xSearcher, _compat, _lib
+assert _compat.HAVE_LEANN_CORE
+assert BACKEND_REGISTRY["mi355x"] is Mi355xBackend and issubclass(Mi355xBackend, LeannBackendFactoryInterface)
+assert issubclass(Mi355xSearcher, LeannBackendSearcherInterface)
+from leann.api import LeannSearcher
+s = LeannSearcher({p!r})
+assert isinstance(s.backend_impl, Mi355xSearcher), type(s.backend_impl)
+assert len(s.passage_manager) == 120 if hasattr(s.passage_manager, "__len__") else True
+try:
+    s.search("passage about topic 3", top_k=3)
+except _lib.LeannMi355xError as e:
+    assert "no HIP device" in str(e); print("LOUD-FAIL-OK")
+else:
+    print("SEARCH-RAN")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LOUD-FAIL-OK" in r.stdout or "SEARCH-RAN" in r.stdout

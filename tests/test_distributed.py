@@ -1,0 +1,90 @@
+"""world_size-2 `gloo` tests of the multi-GPU host logic on CPU.  The local search /
+merge are injected with the ORACLE as compute stand-in (test infrastructure); on a GPU box the same
+classes run with the HIP defaults."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from leann_amd.distributed import PartitionedSearch, ShardedSearch, partition, shard_bounds
+from tests.util import clustered, oracle_graph, queries_near
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_partition_covers_everything():
+    for n in (0, 1, 7, 256, 1000):
+        for w in (1, 2, 3, 8):
+            sl = [partition(n, w, r) for r in range(w)]
+            assert sl[0][0] == 0 and sl[-1][1] == n
+            assert all(sl[i][1] == sl[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in sl) - min(h - l for l, h in sl) <= 1
+
+
+def _oracle_merge(ids, dist_, metric):
+    from oracle import oracle as orc
+
+    oi, od = orc.merge_topk(ids.numpy(), dist_.numpy(), metric)
+    return torch.from_numpy(oi), torch.from_numpy(od)
+
+
+def _worker(rank, world, port, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from leann_amd.hnsw_builder import build_hnsw
+    from oracle import oracle as orc
+
+    torch.set_num_threads(1)
+    x = clustered(3000, 64, 5)
+    q = torch.from_numpy(queries_near(x, 33, 6))
+    if mode == "partitioned":
+        g = build_hnsw(x, "mips", M=8, ef_construction=40, num_threads=1)
+        og = oracle_graph(g, 64)
+
+        def search_fn(qq, k):
+            i, d, _ = orc.search(og, qq.numpy(), k, ef=32, table=x)
+            return torch.from_numpy(d), torch.from_numpy(i)
+
+        d, i = PartitionedSearch(search_fn).search(q, 5)
+        ei, ed, _ = orc.search(og, q.numpy(), 5, ef=32, table=x)
+        ok = np.array_equal(i.numpy(), ei) and np.array_equal(d.numpy(), ed)
+    else:
+        lo, hi = shard_bounds(3000, world)[rank]
+        xs = x[lo:hi]
+        g = build_hnsw(xs, "mips", M=8, ef_construction=40, num_threads=1)
+        og = oracle_graph(g, 64)
+
+        def search_fn(qq, k):
+            i, d, _ = orc.search(og, qq.numpy(), k, ef=64, table=xs)
+            return torch.from_numpy(d), torch.from_numpy(i)
+
+        d, i = ShardedSearch(search_fn, id_base=lo, metric=0, merge_fn=_oracle_merge).search(q, 5)
+        # every rank holds the same merged answer; it must be close to the exact global top-5
+        gt, _ = orc.bruteforce_topk(x, q.numpy(), 5, 0)
+        rec = np.mean([len(set(i[r].tolist()) & set(gt[r].tolist())) / 5 for r in range(q.shape[0])])
+        ok = rec > 0.95 and bool(np.all(np.diff(d.numpy(), axis=1) <= 0)) and int(i.max()) < 3000
+        gi = [torch.empty_like(i) for _ in range(world)]
+        dist.all_gather(gi, i)
+        ok = ok and all(torch.equal(gi[0], t) for t in gi)
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["partitioned", "sharded"])
+def test_two_rank_gloo(mode, built_libs):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
