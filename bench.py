@@ -140,15 +140,21 @@ def main():
     table_roof = None
     if args.table_roofline:
         idx.set_profiling(True)
-        prm = idx.make_params(ef=ef, beam=4, recompute=False, max_batch=16384)
         Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
-        idx.search_device(Qbig, 10, prm)
-        idx.search_device(Qbig, 10, prm)
-        st = idx.stats()
         bytes_eval = D * 4 + 4
-        table_roof = {"achieved": st["ndis"] * bytes_eval / (st["update_ms"] * 1e-3) / 1e9, "unit": "GB/s",
-                      "launches": st["update_launches"], "ms_per_launch": st["update_ms"] / max(st["update_launches"], 1),
-                      "queries": 8192, "beam": 4}
+        table_roof = {}
+        for variant in (1, 0, 1, 0):  # interleaved A/B: 1 = full bitonic sort, 0 = sort-new + rank merge (default)
+            for beam_t, ef_t in ((4, ef), (1, 64)):
+                idx.set_option("update_variant", variant)
+                prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=16384)
+                idx.search_device(Qbig, 10, prm)
+                st = idx.stats()
+                key = f"v{variant}_beam{beam_t}_ef{ef_t}"
+                r = {"GBps": round(st["ndis"] * bytes_eval / (st["update_ms"] * 1e-3) / 1e9, 1), "launches": st["update_launches"],
+                     "us_per_launch": round(1e3 * st["update_ms"] / max(st["update_launches"], 1), 2),
+                     "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
+                table_roof.setdefault(key, []).append(r)
+        idx.set_option("update_variant", 0)
         idx.set_profiling(False)
 
     # ---- timed region: recompute mode ---------------------------------------------------------------

@@ -27,12 +27,19 @@ void set_error(const std::string& msg) { g_err = msg; }
 // ---------------------------------------------------------------------------------------------
 // device-side views
 // ---------------------------------------------------------------------------------------------
+struct L0Range {  // derived at load from node_offsets/level_ptr: level-0 list of node i
+    uint64_t begin;
+    uint32_t count;
+    uint32_t pad;
+};
+
 struct GraphDev {
     int64_t N;
     int32_t entry_point, max_level;
     const uint64_t* node_offsets;
     const uint64_t* level_ptr;
     const int32_t* neighbors;
+    const L0Range* l0;
 };
 
 struct WsDev {
@@ -45,6 +52,7 @@ struct WsDev {
     int32_t* npool;
     int32_t* npop;
     int32_t* nnew;
+    unsigned long long* ndis_q;  // per-query distance evaluations (no same-address atomics in the round kernels)
     int32_t* pop;     // B x W
     int32_t* newid;   // B x maxnew
     uint64_t* pool;   // B x ef
@@ -55,10 +63,15 @@ struct WsDev {
     int32_t* word_rank;   // nw
     int32_t* tile_sum;    // ntiles
     int32_t* uniq;        // ucap
+    // flat (query,node) pair list of the round (split variant): segments allocated by atomicAdd
+    int32_t* seg_start;   // B
+    int32_t* pair_q;      // B x maxnew
+    int32_t* pair_v;      // B x maxnew
+    uint64_t* pair_key;   // B x maxnew
     // counters: [0]=live queries this round [1]=n_uniq [2..] stats
     unsigned long long* counters;
 };
-enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NCOUNTERS = 8 };
+enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NPAIRS = 5, C_NCOUNTERS = 8 };
 
 constexpr int UNIQ_TILE = 4096;  // words per block in the uniq scan
 
@@ -75,6 +88,7 @@ __global__ void k_init(WsDev ws, int32_t max_level) {
     ws.npool[q] = 0;
     ws.npop[q] = 0;
     ws.nnew[q] = 0;
+    ws.ndis_q[q] = 0;
 }
 
 __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32_t level, uint64_t& b, uint32_t& cnt) {
@@ -84,8 +98,13 @@ __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32
     cnt = (uint32_t)(g.level_ptr[p + 1] - b);
 }
 
-// one wave (64 lanes) per query
-__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no) {
+// one wave (64 lanes) per query.  Level-0 expansion is FLATTENED over (pop, neighbour) so that the
+// dependent chain is pop -> l0 range -> neighbour ids -> visited atomic, once per 64 neighbours
+// instead of once per popped node.  Dynamic LDS: maxnew ints (staging of the new-list).
+__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int flat) {
+    extern __shared__ int32_t s_new[];
+    __shared__ uint32_t s_off[65];
+    __shared__ uint64_t s_b[64];
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
     const int ph = ws.phase[q];
@@ -93,56 +112,83 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
         if (lane == 0) ws.nnew[q] = 0;
         return;
     }
-    int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
     int total = 0;
     if (ph == PH_SEED) {
-        if (lane == 0) {
-            newid[0] = g.entry_point;
-            if (use_rbm) atomicOr(&ws.rbm[g.entry_point >> 5], 1u << (g.entry_point & 31));
-        }
+        if (lane == 0) s_new[0] = g.entry_point;
         total = 1;
     } else if (ph == PH_UPPER) {
         uint64_t b;
         uint32_t cnt;
         nbr_range(g, key_id(ws.cur_key[q]), ws.level[q], b, cnt);
-        for (uint32_t j = lane; j < cnt; j += 64) {
-            int32_t v = g.neighbors[b + j];
-            newid[j] = v;
-            if (use_rbm) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
-        }
+        for (uint32_t j = lane; j < cnt; j += 64) s_new[j] = g.neighbors[b + j];
         total = (int)cnt;
     } else {
         uint32_t* vis = ws.visited + (size_t)q * ws.nw;
         const int npop = ws.npop[q];
-        for (int pi = 0; pi < npop; ++pi) {
-            uint64_t b;
-            uint32_t cnt;
-            nbr_range(g, ws.pop[(size_t)q * ws.W + pi], 0, b, cnt);
-            for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
-                uint32_t j = j0 + lane;
+        for (int p0 = 0; p0 < npop; p0 += 64) {
+            const int np = min(64, npop - p0);
+            uint32_t cnt = 0;
+            if (lane < np) {
+                L0Range r = g.l0[ws.pop[(size_t)q * ws.W + p0 + lane]];
+                s_b[lane] = r.begin;
+                cnt = r.count;
+            }
+            uint32_t x = cnt;  // inclusive scan
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (lane == 0) s_off[0] = 0;
+            if (lane < np) s_off[lane + 1] = x;
+            const uint32_t totalc = __shfl(x, np - 1);
+            __syncthreads();
+            for (uint32_t f0 = 0; f0 < totalc; f0 += 64) {
+                const uint32_t f = f0 + lane;
                 bool fresh = false;
                 int32_t v = -1;
-                if (j < cnt) {
-                    v = g.neighbors[b + j];
+                if (f < totalc) {
+                    int lo = 0, hi = np - 1;  // largest pi with s_off[pi] <= f
+                    while (lo < hi) {
+                        int mid = (lo + hi + 1) >> 1;
+                        if (s_off[mid] <= f) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    v = g.neighbors[s_b[lo] + (f - s_off[lo])];
                     uint32_t bit = 1u << (v & 31);
                     uint32_t old = atomicOr(&vis[v >> 5], bit);
                     fresh = !(old & bit);
                 }
                 unsigned long long m = __ballot(fresh);
-                if (fresh) {
-                    int r = __popcll(m & ((1ull << lane) - 1ull));
-                    newid[total + r] = v;
-                    if (use_rbm) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
-                }
+                if (fresh) s_new[total + __popcll(m & ((1ull << lane) - 1ull))] = v;
                 total += __popcll(m);
             }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
+    int start = 0;
+    if (flat) {
+        if (lane == 0) start = (int)atomicAdd(&ws.counters[C_NPAIRS], (unsigned long long)total);
+        start = __shfl(start, 0);
+    }
+    for (int i = lane; i < total; i += 64) {
+        const int32_t v = s_new[i];
+        newid[i] = v;
+        if (use_rbm) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+        if (flat) {
+            ws.pair_q[start + i] = q;
+            ws.pair_v[start + i] = v;
         }
     }
     if (lane == 0) {
         ws.nnew[q] = total;
-        atomicAdd(&ws.counters[C_LIVE], 1ull);
-        atomicAdd(&ws.counters[C_NDIS], (unsigned long long)total);
-        atomicMax(&ws.counters[C_ROUNDS], (unsigned long long)round_no);
+        if (flat) ws.seg_start[q] = start;
+        ws.ndis_q[q] += (unsigned long long)total;
+        // plain stores of identical values (benign): a contended same-address atomic costs ~12 ns per
+        // workgroup and serialises the launch tail (MI355X_MICROARCH.md, price list row "fanin")
+        ws.counters[C_LIVE] = 1ull;
+        ws.counters[C_ROUNDS] = (unsigned long long)round_no;
     }
 }
 
@@ -264,7 +310,7 @@ struct UpdateArgs {
 };
 
 template <int NCH, bool L2, bool F16>
-__global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
+__global__ __launch_bounds__(256) void k_update_sort(WsDev ws, UpdateArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* keys = (uint64_t*)smem;  // P2
     __shared__ unsigned long long s_best;
@@ -343,7 +389,6 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
                 ws.pop[(size_t)q * ws.W] = c;
                 ws.npop[q] = 1;
                 ws.nsteps[q] = 1;
-                atomicAdd(&ws.counters[C_NEXPAND], 1ull);
             }
             ws.cur_key[q] = cur;
             ws.level[q] = level;
@@ -395,11 +440,336 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
             ws.nsteps[q] = nsteps + found;
             ws.npool[q] = npool1;
             if (found == 0) ws.phase[q] = PH_DONE;
-            else atomicAdd(&ws.counters[C_NEXPAND], (unsigned long long)found);
         }
     }
     __syncthreads();
     for (int i = tid; i < npool1; i += 256) pool[i] = keys[i];
+}
+
+
+// ---- variant 0 (default): sort only the NEW keys, then merge with the (already sorted) pool by rank ----
+// LDS: pool[ef] | newk[Pn] | out[ef]   (a.P2 carries ef_lds = ef rounded up to 2, Pn is per block)
+template <int NCH, bool L2, bool F16>
+__global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned long long s_best;
+
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ph = ws.phase[q];
+    if (ph == PH_DONE) return;
+    const int n = ws.nnew[q];
+    const int ef = ws.ef;
+    const int npool0 = (ph == PH_BEAM) ? ws.npool[q] : 0;
+    uint64_t* pool = ws.pool + (size_t)q * ef;
+    uint64_t* lpool = (uint64_t*)smem;      // ef
+    uint64_t* out = lpool + ef;             // ef
+    uint64_t* newk = out + ef;              // maxnew rounded up to pow2
+    int Pn = 1;
+    while (Pn < n) Pn <<= 1;
+
+    for (int i = tid; i < npool0; i += 256) lpool[i] = pool[i];
+    for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+    if (tid == 0) s_best = KEY_NONE;
+
+    const int lane16 = tid & 15, sg = tid >> 4;
+    float4 qv[NCH];
+    {
+        const float4* qrow = (const float4*)(a.Q + (size_t)q * (NCH * 64));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
+    }
+    const int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
+    for (int i = sg; i < n; i += 32) {
+        const int i2 = i + 16;
+        const bool has2 = i2 < n;
+        int32_t v0 = newid[i];
+        int32_t v1 = has2 ? newid[i2] : v0;
+        int64_t s0 = v0, s1 = v1;
+        if (a.by_rank) {
+            s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
+            s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
+        }
+        float4 e0[NCH], e1[NCH];
+        load_row<NCH, F16>(a.E, s0, lane16, e0);
+        load_row<NCH, F16>(a.E, s1, lane16, e1);
+        float d0 = row_reduce<NCH, L2>(e0, qv);
+        float d1 = row_reduce<NCH, L2>(e1, qv);
+        if (lane16 == 0) {
+            newk[i] = make_key(d0, v0);
+            if (has2) newk[i2] = make_key(d1, v1);
+        }
+    }
+    __syncthreads();
+
+    if (ph != PH_BEAM) {
+        for (int i = tid; i < n; i += 256) atomicMin(&s_best, (unsigned long long)newk[i]);
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t best = s_best;
+            int level = ws.level[q];
+            int phase = ph;
+            uint64_t cur = ws.cur_key[q];
+            if (ph == PH_SEED) {
+                cur = best;
+                phase = PH_UPPER;
+                level = a.max_level;
+            } else {
+                if (best != KEY_NONE && best < cur) cur = best;
+                else level--;
+            }
+            if (level <= 0) {
+                phase = PH_BEAM;
+                int32_t c = key_id(cur);
+                atomicOr(&ws.visited[(size_t)q * ws.nw + (c >> 5)], 1u << (c & 31));
+                pool[0] = cur | KEY_EXPANDED;
+                ws.npool[q] = 1;
+                ws.pop[(size_t)q * ws.W] = c;
+                ws.npop[q] = 1;
+                ws.nsteps[q] = 1;
+            }
+            ws.cur_key[q] = cur;
+            ws.level[q] = level;
+            ws.phase[q] = phase;
+        }
+        return;
+    }
+
+    const int npool1 = min(ef, npool0 + n);
+    uint64_t* fin = lpool;  // where the merged pool lives
+    if (n > 0) {
+        // bitonic sort of the new keys only
+        for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
+            for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+                for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
+                    unsigned ixj = i ^ j;
+                    if (ixj > i) {
+                        uint64_t x = newk[i], y = newk[ixj];
+                        bool up = (i & k2) == 0;
+                        if ((x > y) == up) {
+                            newk[i] = y;
+                            newk[ixj] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // merge by rank: (dist,id) pairs are unique across pool U new, compare without the flag bit
+        for (int i = tid; i < npool0; i += 256) {
+            uint64_t key = lpool[i];
+            uint64_t kk = key >> 1;
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((newk[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+            int r = i + lo;
+            if (r < ef) out[r] = key;
+        }
+        for (int j = tid; j < n; j += 256) {
+            uint64_t key = newk[j];
+            uint64_t kk = key >> 1;
+            int lo = 0, hi = npool0;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((lpool[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+            int r = j + lo;
+            if (r < ef) out[r] = key;
+        }
+        __syncthreads();
+        fin = out;
+    }
+    if (tid < 64) {
+        const int nsteps = ws.nsteps[q];
+        int allowed = ws.W;
+        if (!a.check_rel) allowed = min(allowed, max(0, ef + 1 - nsteps));
+        int found = 0;
+        for (int base = 0; base < npool1 && found < allowed; base += 64) {
+            int i = base + tid;
+            bool un = i < npool1 && !(fin[i] & KEY_EXPANDED);
+            unsigned long long m = __ballot(un);
+            int r = found + __popcll(m & ((1ull << tid) - 1ull));
+            if (un && r < allowed) {
+                fin[i] |= KEY_EXPANDED;
+                ws.pop[(size_t)q * ws.W + r] = key_id(fin[i]);
+            }
+            found += __popcll(m);
+        }
+        found = min(found, allowed);
+        if (tid == 0) {
+            ws.npop[q] = found;
+            ws.nsteps[q] = nsteps + found;
+            ws.npool[q] = npool1;
+            if (found == 0) ws.phase[q] = PH_DONE;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npool1; i += 256) pool[i] = fin[i];
+}
+
+// ---- variant 2 (split): flat, perfectly balanced distance kernel over the round's pair list ----------
+template <int NCH, bool L2, bool F16>
+__global__ __launch_bounds__(256) void k_dist_flat(WsDev ws, UpdateArgs a) {
+    const int total = (int)ws.counters[C_NPAIRS];
+    const int lane16 = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    for (int base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
+        const int p0 = base + sg, p1 = p0 + 16;
+        if (p0 >= total) continue;
+        const bool has2 = p1 < total;
+        const int32_t v0 = ws.pair_v[p0], q0 = ws.pair_q[p0];
+        const int32_t v1 = has2 ? ws.pair_v[p1] : v0, q1 = has2 ? ws.pair_q[p1] : q0;
+        int64_t s0 = v0, s1 = v1;
+        if (a.by_rank) {
+            s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
+            s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
+        }
+        float4 e0[NCH], e1[NCH], qa[NCH], qb[NCH];
+        load_row<NCH, F16>(a.E, s0, lane16, e0);
+        load_row<NCH, F16>(a.E, s1, lane16, e1);
+        const float4* qr0 = (const float4*)(a.Q + (size_t)q0 * (NCH * 64));
+        const float4* qr1 = (const float4*)(a.Q + (size_t)q1 * (NCH * 64));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            qa[i] = qr0[lane16 + 16 * i];
+            qb[i] = qr1[lane16 + 16 * i];
+        }
+        const float d0 = row_reduce<NCH, L2>(e0, qa);
+        const float d1 = row_reduce<NCH, L2>(e1, qb);
+        if (lane16 == 0) {
+            ws.pair_key[p0] = make_key(d0, v0);
+            if (has2) ws.pair_key[p1] = make_key(d1, v1);
+        }
+    }
+}
+
+// per-query state update from the keys of k_dist_flat (one 64-lane wave per query)
+__global__ __launch_bounds__(64) void k_merge(WsDev ws, UpdateArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned long long s_best;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ph = ws.phase[q];
+    if (ph == PH_DONE) return;
+    const int n = ws.nnew[q];
+    const int ef = ws.ef;
+    const int npool0 = (ph == PH_BEAM) ? ws.npool[q] : 0;
+    uint64_t* pool = ws.pool + (size_t)q * ef;
+    uint64_t* lpool = (uint64_t*)smem;
+    uint64_t* out = lpool + ef;
+    uint64_t* newk = out + ef;
+    const uint64_t* src = ws.pair_key + ws.seg_start[q];
+    int Pn = 1;
+    while (Pn < n) Pn <<= 1;
+    for (int i = tid; i < npool0; i += 64) lpool[i] = pool[i];
+    for (int i = tid; i < Pn; i += 64) newk[i] = i < n ? src[i] : KEY_NONE;
+    if (tid == 0) s_best = KEY_NONE;
+    __syncthreads();
+    if (ph != PH_BEAM) {
+        for (int i = tid; i < n; i += 64) atomicMin(&s_best, (unsigned long long)newk[i]);
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t best = s_best;
+            int level = ws.level[q];
+            int phase = ph;
+            uint64_t cur = ws.cur_key[q];
+            if (ph == PH_SEED) {
+                cur = best;
+                phase = PH_UPPER;
+                level = a.max_level;
+            } else {
+                if (best != KEY_NONE && best < cur) cur = best;
+                else level--;
+            }
+            if (level <= 0) {
+                phase = PH_BEAM;
+                int32_t c = key_id(cur);
+                atomicOr(&ws.visited[(size_t)q * ws.nw + (c >> 5)], 1u << (c & 31));
+                pool[0] = cur | KEY_EXPANDED;
+                ws.npool[q] = 1;
+                ws.pop[(size_t)q * ws.W] = c;
+                ws.npop[q] = 1;
+                ws.nsteps[q] = 1;
+            }
+            ws.cur_key[q] = cur;
+            ws.level[q] = level;
+            ws.phase[q] = phase;
+        }
+        return;
+    }
+    const int npool1 = min(ef, npool0 + n);
+    uint64_t* fin = lpool;
+    if (n > 0) {
+        for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
+            for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+                for (unsigned i = tid; i < (unsigned)Pn; i += 64) {
+                    unsigned ixj = i ^ j;
+                    if (ixj > i) {
+                        uint64_t x = newk[i], y = newk[ixj];
+                        bool up = (i & k2) == 0;
+                        if ((x > y) == up) {
+                            newk[i] = y;
+                            newk[ixj] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < npool0; i += 64) {
+            uint64_t key = lpool[i];
+            uint64_t kk = key >> 1;
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((newk[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+            if (i + lo < ef) out[i + lo] = key;
+        }
+        for (int j = tid; j < n; j += 64) {
+            uint64_t key = newk[j];
+            uint64_t kk = key >> 1;
+            int lo = 0, hi = npool0;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((lpool[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+            if (j + lo < ef) out[j + lo] = key;
+        }
+        __syncthreads();
+        fin = out;
+    }
+    {
+        const int nsteps = ws.nsteps[q];
+        int allowed = ws.W;
+        if (!a.check_rel) allowed = min(allowed, max(0, ef + 1 - nsteps));
+        int found = 0;
+        for (int base = 0; base < npool1 && found < allowed; base += 64) {
+            int i = base + tid;
+            bool un = i < npool1 && !(fin[i] & KEY_EXPANDED);
+            unsigned long long m = __ballot(un);
+            int r = found + __popcll(m & ((1ull << tid) - 1ull));
+            if (un && r < allowed) {
+                fin[i] |= KEY_EXPANDED;
+                ws.pop[(size_t)q * ws.W + r] = key_id(fin[i]);
+            }
+            found += __popcll(m);
+        }
+        found = min(found, allowed);
+        if (tid == 0) {
+            ws.npop[q] = found;
+            ws.nsteps[q] = nsteps + found;
+            ws.npool[q] = npool1;
+            if (found == 0) ws.phase[q] = PH_DONE;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < npool1; i += 64) pool[i] = fin[i];
 }
 
 __global__ void k_finalize(WsDev ws, int32_t k, int32_t metric, int64_t* labels, float* dist) {
@@ -414,6 +784,29 @@ __global__ void k_finalize(WsDev ws, int32_t k, int32_t metric, int64_t* labels,
     } else {
         labels[t] = -1;
         dist[t] = metric == LM_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+    }
+}
+
+// end-of-search totals: nexpand = sum of per-query pops (nsteps), ndis = sum of per-query evaluations
+__global__ __launch_bounds__(256) void k_stats(WsDev ws) {
+    __shared__ unsigned long long red[2][4];
+    unsigned long long a = 0, b = 0;
+    for (int q = threadIdx.x; q < ws.B; q += 256) {
+        a += ws.ndis_q[q];
+        b += (unsigned long long)ws.nsteps[q];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m);
+        b += __shfl_xor(b, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws.counters[C_NDIS] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        ws.counters[C_NEXPAND] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -531,6 +924,7 @@ struct lm_index {
     uint64_t* d_node_offsets = nullptr;
     uint64_t* d_level_ptr = nullptr;
     int32_t* d_neighbors = nullptr;
+    L0Range* d_l0 = nullptr;
     // stored embeddings
     void* d_table = nullptr;
     bool table_owned = false;
@@ -550,6 +944,7 @@ struct lm_index {
     // stats / profiling
     lm_search_stats stats{};
     bool profiling = false;
+    int update_variant = 0;  // 0: sort-new + rank merge (default), 1: full bitonic sort (A/B reference)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_expand, ev_provider;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -583,7 +978,7 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W) {
     w.nw = (ix->N + 31) / 32;
     int rc;
 #define A(ptr, cnt) if ((rc = ws_alloc(ix, &w.ptr, (cnt))) != LM_OK) return rc
-    A(phase, B); A(level, B); A(cur_key, B); A(nsteps, B); A(npool, B); A(npop, B); A(nnew, B);
+    A(phase, B); A(level, B); A(cur_key, B); A(nsteps, B); A(npool, B); A(npop, B); A(nnew, B); A(ndis_q, B);
     A(pop, (size_t)B * W); A(newid, (size_t)B * maxnew); A(pool, (size_t)B * ef);
     A(visited, (size_t)B * w.nw);
     A(rbm, w.nw); A(rbm_snap, w.nw); A(word_rank, w.nw);
@@ -591,6 +986,7 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W) {
     A(tile_sum, std::max(ntiles, 1));
     ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * maxnew);
     A(uniq, ix->ws_ucap);
+    A(seg_start, B); A(pair_q, (size_t)B * maxnew); A(pair_v, (size_t)B * maxnew); A(pair_key, (size_t)B * maxnew);
     A(counters, C_NCOUNTERS);
 #undef A
     LM_HIP(hipMemsetAsync(w.rbm, 0, w.nw * 4, ix->stream));
@@ -640,11 +1036,36 @@ struct EvScope {
     }
 };
 
+static int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
 template <bool L2, bool F16>
 static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
     dim3 grid(ix->ws.B), block(256);
+    const bool sortv = ix->update_variant == 1;
+    if (ix->update_variant == 2) {
+        // split: flat distance kernel (grid-stride over the pair list) + one-wave-per-query merge
+        long cap = (long)ix->ws.B * ix->ws.maxnew;
+        dim3 fg((unsigned)std::max<long>(1, std::min<long>((cap + 31) / 32, 256L * 20)));
+        switch (ix->Dp / 64) {
+#define CASEF(n) case n: hipLaunchKernelGGL((k_dist_flat<n, L2, F16>), fg, block, 0, ix->stream, ix->ws, a); break
+            CASEF(1); CASEF(2); CASEF(3); CASEF(4); CASEF(5); CASEF(6); CASEF(8); CASEF(12); CASEF(16);
+#undef CASEF
+            default: LM_FAIL(LM_EINVAL, "unsupported padded dimension (supported: 64..384, 512, 768, 1024)");
+        }
+        hipLaunchKernelGGL(k_merge, grid, dim3(64), shmem, ix->stream, ix->ws, a);
+        LM_HIP(hipGetLastError());
+        return LM_OK;
+    }
     switch (ix->Dp / 64) {
-#define CASE(n) case n: hipLaunchKernelGGL((k_update<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); break
+#define CASE(n)                                                                                              \
+    case n:                                                                                                  \
+        if (sortv) hipLaunchKernelGGL((k_update_sort<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); \
+        else hipLaunchKernelGGL((k_update<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a);          \
+        break
         CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(12); CASE(16);
 #undef CASE
         default: LM_FAIL(LM_EINVAL, "unsupported padded dimension (supported: 64..384, 512, 768, 1024)");
@@ -654,16 +1075,11 @@ static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
 }
 
 static int launch_update(lm_index* ix, const UpdateArgs& a, bool f16) {
-    size_t shmem = (size_t)a.P2 * sizeof(uint64_t);
+    size_t shmem = ix->update_variant == 1 ? (size_t)a.P2 * sizeof(uint64_t)
+                                           : (size_t)(2 * ix->ws.ef + next_pow2(ix->ws.maxnew)) * sizeof(uint64_t);
     bool l2 = ix->metric == LM_METRIC_L2;
     if (l2) return f16 ? launch_update_nch<true, true>(ix, a, shmem) : launch_update_nch<true, false>(ix, a, shmem);
     return f16 ? launch_update_nch<false, true>(ix, a, shmem) : launch_update_nch<false, false>(ix, a, shmem);
-}
-
-static int next_pow2(int x) {
-    int p = 1;
-    while (p < x) p <<= 1;
-    return p;
 }
 
 // one pass over <= max_batch queries; d_q: B x Dp (padded)
@@ -676,7 +1092,8 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     WsDev& ws = ix->ws;
     hipStream_t st = ix->stream;
     const bool recompute = prm.recompute != 0;
-    GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors};
+    GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
+    const int flat = ix->update_variant == 2 ? 1 : 0;
 
     LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
     LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
@@ -695,9 +1112,11 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
 
     for (;;) {
         LM_HIP(hipMemsetAsync(ws.counters + C_LIVE, 0, sizeof(unsigned long long), st));
+        if (flat) LM_HIP(hipMemsetAsync(ws.counters + C_NPAIRS, 0, sizeof(unsigned long long), st));
         {
             EvScope es(ix, &ix->ev_expand);
-            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), 0, st, g, ws, recompute ? 1 : 0, (int)(rounds + 1));
+            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, recompute ? 1 : 0,
+                               (int)(rounds + 1), flat);
             if (recompute) {
                 hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
                 hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
@@ -733,7 +1152,10 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         ix->stats.update_launches++;
     }
     hipLaunchKernelGGL(k_finalize, dim3((B * k + 255) / 256), dim3(256), 0, st, ws, k, ix->metric, d_labels, d_dist);
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, st, ws);
     LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
     ix->stats.nrounds += (int64_t)hc[C_ROUNDS];
     ix->stats.ndis += (int64_t)hc[C_NDIS];
     ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
@@ -794,10 +1216,12 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     return LM_OK;
 }
 
-static void compute_degrees(lm_index* ix, const uint64_t* node_offsets, const uint64_t* level_ptr) {
+static void compute_degrees(lm_index* ix, const uint64_t* node_offsets, const uint64_t* level_ptr, std::vector<L0Range>& l0) {
     int32_t m0 = 0, mu = 0;
+    l0.resize((size_t)ix->N);
     for (int64_t i = 0; i < ix->N; ++i) {
         uint64_t p0 = node_offsets[i], p1 = node_offsets[i + 1];
+        l0[i] = L0Range{p1 > p0 + 1 ? level_ptr[p0] : 0, p1 > p0 + 1 ? (uint32_t)(level_ptr[p0 + 1] - level_ptr[p0]) : 0u, 0u};
         for (uint64_t p = p0; p + 1 < p1; ++p) {
             int32_t deg = (int32_t)(level_ptr[p + 1] - level_ptr[p]);
             if (p == p0) m0 = std::max(m0, deg);
@@ -863,9 +1287,12 @@ int lm_index_create_from_csr(int64_t ntotal, int32_t d, int32_t metric, const ui
     ix->max_level = max_level;
     ix->n_neighbors = n_neighbors; ix->n_level_ptr = n_level_ptr;
     if (ntotal > 0) {
-        compute_degrees(ix, node_offsets, level_ptr);
+        std::vector<L0Range> l0;
+        compute_degrees(ix, node_offsets, level_ptr, l0);
         hipError_t e;
-        if ((e = hipMalloc((void**)&ix->d_node_offsets, (size_t)(ntotal + 1) * 8)) != hipSuccess ||
+        if ((e = hipMalloc((void**)&ix->d_l0, (size_t)ntotal * sizeof(L0Range))) != hipSuccess ||
+            (e = hipMemcpy(ix->d_l0, l0.data(), (size_t)ntotal * sizeof(L0Range), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMalloc((void**)&ix->d_node_offsets, (size_t)(ntotal + 1) * 8)) != hipSuccess ||
             (e = hipMalloc((void**)&ix->d_level_ptr, (size_t)std::max<int64_t>(n_level_ptr, 1) * 8)) != hipSuccess ||
             (e = hipMalloc((void**)&ix->d_neighbors, (size_t)std::max<int64_t>(n_neighbors, 1) * 4)) != hipSuccess ||
             (e = hipMemcpy(ix->d_node_offsets, node_offsets, (size_t)(ntotal + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -913,6 +1340,7 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_node_offsets) (void)hipFree(ix->d_node_offsets);
     if (ix->d_level_ptr) (void)hipFree(ix->d_level_ptr);
     if (ix->d_neighbors) (void)hipFree(ix->d_neighbors);
+    if (ix->d_l0) (void)hipFree(ix->d_l0);
     if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
     if (ix->d_qpad) (void)hipFree(ix->d_qpad);
     if (ix->h_counters) (void)hipHostFree(ix->h_counters);
@@ -981,6 +1409,16 @@ int lm_index_set_profiling(lm_index* ix, int32_t enable) {
     if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
     ix->profiling = enable != 0;
     return LM_OK;
+}
+
+int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
+    if (!ix || !name) LM_FAIL(LM_EINVAL, "NULL argument");
+    if (!std::strcmp(name, "update_variant")) {
+        if (value < 0 || value > 2) LM_FAIL(LM_EINVAL, "update_variant must be 0, 1 or 2");
+        ix->update_variant = (int)value;
+        return LM_OK;
+    }
+    LM_FAIL(LM_EINVAL, std::string("unknown option: ") + name);
 }
 
 int lm_index_get_stats(const lm_index* ix, lm_search_stats* out) {

@@ -115,6 +115,9 @@ class Mi355xIndex:
     def set_stream(self, stream_ptr: int) -> None:
         check(self._lib.lm_index_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def set_option(self, name: str, value: int) -> None:
+        check(self._lib.lm_index_set_option(self._h, name.encode(), int(value)), "lm_index_set_option")
+
     def set_profiling(self, on: bool) -> None:
         check(self._lib.lm_index_set_profiling(self._h, 1 if on else 0))
 

@@ -37,7 +37,7 @@ def _build(n, d, metric, seed, M=16, efc=60, normalize=True):
     return x.copy(), g
 
 
-def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32):
+def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32, variant=0):
     from leann_amd.devmem import as_tensor
     from leann_amd.index import Mi355xIndex
     from oracle import oracle as orc
@@ -48,6 +48,7 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
     oi, od, ost = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, table=xt.astype(np.float32))
     idx = Mi355xIndex.from_csr(g, device=0)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_option("update_variant", variant)
     if mode == "table":
         idx.attach_table(xt)
         prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=False)
@@ -105,6 +106,20 @@ def test_dimensions_and_padding(env, d):
     q = queries_near(x, 16, seed=6)
     _check(env, x, g, q, 5, 32, 1, "table")
     _check(env, x, g, q, 5, 32, 2, "provider")
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_update_kernel_variants_parity(env, variant):
+    """The A/B variants of the update step (1: fused + full bitonic sort, 2: split flat-distance +
+    merge kernels) obey the same contract as the default."""
+    for metric in ("mips", "l2"):
+        x, g = _build(3000, 384, metric, seed=1)
+        q = queries_near(x, 32, seed=2)
+        _check(env, x, g, q, 10, 64, 4, "table", variant=variant)
+        _check(env, x, g, q, 10, 16, 1, "table", variant=variant)
+        _check(env, x, g, q, 10, 64, 2, "provider", variant=variant)
+    x, g = _build(1500, 100, "mips", seed=5)
+    _check(env, x, g, queries_near(x, 16, seed=6), 5, 32, 3, "provider", variant=variant, check_rel=False)
 
 
 def test_fp16_table(env):
