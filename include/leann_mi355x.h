@@ -36,7 +36,6 @@ extern "C" {
 
 typedef struct lm_index lm_index;     /* HBM-resident compact-CSR graph + search workspace */
 typedef struct lm_tokens lm_tokens;   /* HBM-resident pre-tokenised passage store           */
-typedef struct lm_pq_index lm_pq_index; /* HBM-resident PQ codes + graph (DiskANN-style path) */
 
 /* ---- errors / device ------------------------------------------------------------------- */
 const char *lm_last_error(void);
@@ -139,6 +138,37 @@ int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around 
 /* Tuning knobs (A/B measurements): "update_variant" 0 = fused, sort-new + rank-merge (default), 1 = fused, full bitonic sort,
  * 2 = split (flat distance kernel over the pair list + one-wave-per-query merge kernel). */
 int lm_index_set_option(lm_index *idx, const char *name, int64_t value);
+
+/* ---- DiskANN-style path: PQ-ADC traversal + deferred exact rerank ---------------------------------
+ * Replaces _diskannpy.StaticDiskFloatIndex(metric, prefix, threads, cache, mechanism, zmq_port,
+ * pq_prefix, partition_prefix)            leann_backend_diskann/diskann_backend.py:371-380
+ * and  .batch_search(query, B, top_k, complexity, beam_width, num_threads, use_deferred_fetch,
+ * skip_search_reorder, recompute_neighbors, dedup_node_dis, prune_ratio, batch_recompute,
+ * use_global_pruning)                                                  diskann_backend.py:453-467.
+ * The graph is the lm_index' level-0 graph entered at entry_point (the medoid for a Vamana graph);
+ * lm_pq_attach adds the product quantiser: m sub-quantisers x 256 centroids x (d/m) floats and the
+ * N x m code bytes (the role of <prefix>_pq_pivots.bin / _pq_compressed.bin).  Traversal uses PQ
+ * distances only; with use_deferred_fetch the final candidate list (<= complexity per query) is
+ * re-ranked with exact distances of embeddings fetched ONCE through the provider (:444-449); without
+ * it, stored embeddings are used when attached, else the PQ order is returned. */
+int lm_pq_attach(lm_index *idx, int32_t m, const float *codebooks, const uint8_t *codes, int64_t ntotal);
+typedef struct {
+    int32_t complexity;          /* L: candidate list size                 :456 */
+    int32_t beam_width;          /* W: nodes expanded per iteration (<=64) :457 */
+    int32_t num_threads;         /* accepted, unused                       :459 */
+    int32_t use_deferred_fetch;  /* = recompute_embeddings                 :450,460 */
+    int32_t skip_search_reorder; /* return PQ order / distances            :461 */
+    int32_t recompute_neighbors; /* accepted, must be 0 (as the reference passes) :451,462 */
+    int32_t dedup_node_dis;      /* accepted, unused                       :463 */
+    float prune_ratio;           /* accepted, unused                       :464 */
+    int32_t batch_recompute;     /* accepted, unused (the rerank IS one batch) :465 */
+    int32_t use_global_pruning;  /* accepted, unused                       :466 */
+} lm_pq_search_params;
+void lm_pq_search_params_default(lm_pq_search_params *p);
+int lm_pq_batch_search(lm_index *idx, int64_t n, const float *x, int32_t k, const lm_pq_search_params *params,
+                       int64_t *labels, float *distances);
+int lm_pq_batch_search_device(lm_index *idx, int64_t n, const float *d_x, int32_t k,
+                              const lm_pq_search_params *params, int64_t *d_labels, float *d_distances);
 
 /* ---- stand-alone kernels (parity tests, shard merge) ----------------------------------------
  * Distances of query row qidx[i] against embedding row ids[i] with the canonical reduction of

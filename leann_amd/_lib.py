@@ -50,6 +50,17 @@ class SearchStats(C.Structure):
     ]
 
 
+class PqSearchParams(C.Structure):
+    """Mirror of lm_pq_search_params == the batch_search argument list of diskann_backend.py:453-467."""
+
+    _fields_ = [
+        ("complexity", C.c_int32), ("beam_width", C.c_int32), ("num_threads", C.c_int32),
+        ("use_deferred_fetch", C.c_int32), ("skip_search_reorder", C.c_int32), ("recompute_neighbors", C.c_int32),
+        ("dedup_node_dis", C.c_int32), ("prune_ratio", C.c_float), ("batch_recompute", C.c_int32),
+        ("use_global_pruning", C.c_int32),
+    ]
+
+
 PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p)
 
 # every symbol include/leann_mi355x.h declares (checked by tests/test_abi.py)
@@ -60,6 +71,7 @@ EXPORTED_SYMBOLS = [
     "lm_search_params_default", "lm_index_search", "lm_index_search_device",
     "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option",
     "lm_dist_gather", "lm_topk_merge",
+    "lm_pq_attach", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
 ]
 
@@ -98,6 +110,11 @@ def load() -> C.CDLL:
     lib.lm_index_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.lm_dist_gather.argtypes = [vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]
     lib.lm_topk_merge.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.lm_pq_attach.argtypes = [vp, i32, vp, vp, i64]
+    lib.lm_pq_search_params_default.argtypes = [C.POINTER(PqSearchParams)]
+    lib.lm_pq_search_params_default.restype = None
+    lib.lm_pq_batch_search.argtypes = [vp, i64, vp, i32, C.POINTER(PqSearchParams), vp, vp]
+    lib.lm_pq_batch_search_device.argtypes = [vp, i64, vp, i32, C.POINTER(PqSearchParams), vp, vp]
     lib.lm_tokens_create.argtypes = [vp, vp, i64, C.c_int, C.POINTER(vp)]
     lib.lm_tokens_free.argtypes = [vp]
     lib.lm_tokens_free.restype = None

@@ -1,0 +1,529 @@
+// lm_pq_impl.h -- DiskANN-style path: PQ-ADC beam search as ONE persistent kernel per batch + a single
+// deferred-fetch exact rerank.  Included at the end of lm_search.hip (shares its kernels and lm_index).
+//
+// Reference surface replaced (fork not in tree): _diskannpy.StaticDiskFloatIndex(...).batch_search(...)
+// packages/leann-backend-diskann/leann_backend_diskann/diskann_backend.py:371-380,453-467; strategy
+// stated at :444-449 (traversal on PQ distances only, one final rerank via deferred embedding fetch,
+// the protobuf NodeEmbeddingRequest of diskann_embedding_server.py:258-334 becomes lm_provider_fn).
+//
+// MI355X design: a PQ lookup table is m*256 floats (48 KB at m=48).  Re-staging it every lock-step
+// round would move more bytes than exact fp32 distances do, so the whole traversal of a query runs
+// inside one workgroup that keeps LUT + candidate list in LDS (160 KB/CU) from start to finish:
+// no host round trips, no inter-workgroup communication; HBM traffic per evaluation is the m-byte
+// code + the neighbour id.  Arithmetic contract: oracle/lm_oracle_pq.c.
+#pragma once
+
+namespace lm {
+
+struct PqDev {
+    int32_t m, dsub;
+    const float* codebooks;  // m x 256 x dsub
+    const uint8_t* codes;    // N x m
+};
+
+struct PqArgs {
+    const float* Q;  // B x Dp
+    int32_t Dp, metric, L, W, maxnew, Pmax;
+    unsigned long long* n_adc_q;  // per-query ADC evaluations
+    int32_t* rounds_q;
+};
+
+// dynamic LDS: lut[m*256] f32 | lpool[L] u64 | out[L] u64 | newk[Pmax] u64 | s_new[maxnew] i32
+__global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev ws, PqArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_off[65];
+    __shared__ uint64_t s_b[64];
+    __shared__ int32_t s_pop[64];
+    __shared__ int s_npop, s_wcnt[4];
+    float* lut = (float*)smem;
+    uint64_t* lpool = (uint64_t*)(lut + pq.m * 256);
+    uint64_t* outp = lpool + a.L;
+    uint64_t* newk = outp + a.L;
+    int32_t* s_new = (int32_t*)(newk + a.Pmax);
+
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* qv = a.Q + (size_t)q * a.Dp;
+    // ---- lookup table (canonical: sequential fmaf over the sub-vector) ----
+    for (int e = tid; e < pq.m * 256; e += 256) {
+        const int j = e >> 8;
+        const float* cb = pq.codebooks + (size_t)e * pq.dsub;
+        const float* qs = qv + j * pq.dsub;
+        float acc = 0.0f;
+        if (a.metric == LM_METRIC_L2) {
+            for (int t = 0; t < pq.dsub; ++t) {
+                float d = qs[t] - cb[t];
+                acc = __builtin_fmaf(d, d, acc);
+            }
+        } else {
+            for (int t = 0; t < pq.dsub; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+            acc = -acc;
+        }
+        lut[e] = acc;
+    }
+    __syncthreads();
+    uint32_t* vis = ws.visited + (size_t)q * ws.nw;
+    const int mw = pq.m >> 2;  // u32 words per code
+    auto adc = [&](int32_t v, int r) -> float {  // partial sum of lane r (j = r, r+4, ...)
+        const uint32_t* cw = (const uint32_t*)(pq.codes + (size_t)v * pq.m);
+        float p = 0.0f;
+        for (int i = 0; i < mw; ++i) {
+            uint32_t w = cw[i];
+            p = p + lut[((4 * i + r) << 8) + ((w >> (8 * r)) & 255u)];
+        }
+        return p;
+    };
+    // ---- seed with the entry point (medoid) ----
+    int npool = 0;
+    if (tid < 4) {
+        const int32_t ep = g.entry_point;
+        float p = adc(ep, tid);
+        float s01 = p + __shfl_xor(p, 1, 4);
+        float tot = s01 + __shfl_xor(s01, 2, 4);
+        if (tid == 0) {
+            atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+            lpool[0] = make_key(tot, ep);
+        }
+    }
+    npool = 1;
+    unsigned long long n_adc = 1;
+    int rounds = 0, nexp = 0;
+    __syncthreads();
+
+    for (;;) {
+        // ---- pops: the W smallest unexpanded (wave 0) ----
+        if (tid < 64) {
+            int found = 0;
+            for (int base = 0; base < npool && found < a.W; base += 64) {
+                int i = base + tid;
+                bool un = i < npool && !(lpool[i] & KEY_EXPANDED);
+                unsigned long long m = __ballot(un);
+                int r = found + __popcll(m & ((1ull << tid) - 1ull));
+                if (un && r < a.W) {
+                    lpool[i] |= KEY_EXPANDED;
+                    s_pop[r] = key_id(lpool[i]);
+                }
+                found += __popcll(m);
+            }
+            found = min(found, a.W);
+            // neighbour ranges of the pops + inclusive scan of their degrees
+            uint32_t cnt = 0;
+            if (tid < found) {
+                L0Range r = g.l0[s_pop[tid]];
+                s_b[tid] = r.begin;
+                cnt = r.count;
+            }
+            uint32_t x = cnt;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t y = __shfl_up(x, d);
+                if (tid >= d) x += y;
+            }
+            if (tid == 0) {
+                s_off[0] = 0;
+                s_npop = found;
+            }
+            if (tid < found) s_off[tid + 1] = x;
+        }
+        __syncthreads();
+        const int np = s_npop;
+        if (np == 0) break;
+        rounds++;
+        nexp += np;
+        const uint32_t totalc = s_off[np];
+        // ---- flattened expansion over 256 threads, visited test-and-set, ordered compaction ----
+        int total = 0;
+        for (uint32_t f0 = 0; f0 < totalc; f0 += 256) {
+            const uint32_t f = f0 + tid;
+            bool fresh = false;
+            int32_t v = -1;
+            if (f < totalc) {
+                int lo = 0, hi = np - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (s_off[mid] <= f) lo = mid;
+                    else hi = mid - 1;
+                }
+                v = g.neighbors[s_b[lo] + (f - s_off[lo])];
+                uint32_t bit = 1u << (v & 31);
+                uint32_t old = atomicOr(&vis[v >> 5], bit);
+                fresh = !(old & bit);
+            }
+            unsigned long long m = __ballot(fresh);
+            if (lane == 0) s_wcnt[wv] = __popcll(m);
+            __syncthreads();
+            int woff = 0;
+            for (int i = 0; i < wv; ++i) woff += s_wcnt[i];
+            if (fresh) s_new[total + woff + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            __syncthreads();
+        }
+        const int n = total;
+        n_adc += (unsigned long long)n;
+        int Pn = 1;
+        while (Pn < n) Pn <<= 1;
+        // ---- ADC distances: 4 lanes per vector ----
+        {
+            const int r = tid & 3, gi = tid >> 2;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + gi;
+                const int32_t v = i < n ? s_new[i] : s_new[0];
+                float p = adc(v, r);
+                float s01 = p + __shfl_xor(p, 1, 4);
+                float tot = s01 + __shfl_xor(s01, 2, 4);
+                if (r == 0 && i < n) newk[i] = make_key(tot, v);
+            }
+            for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+        }
+        __syncthreads();
+        if (n > 0) {
+            for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
+                for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+                    for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
+                        unsigned ixj = i ^ j;
+                        if (ixj > i) {
+                            uint64_t x = newk[i], y = newk[ixj];
+                            bool up = (i & k2) == 0;
+                            if ((x > y) == up) {
+                                newk[i] = y;
+                                newk[ixj] = x;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < npool; i += 256) {
+                uint64_t key = lpool[i];
+                uint64_t kk = key >> 1;
+                int lo = 0, hi = n;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if ((newk[mid] >> 1) < kk) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (i + lo < a.L) outp[i + lo] = key;
+            }
+            for (int j = tid; j < n; j += 256) {
+                uint64_t key = newk[j];
+                uint64_t kk = key >> 1;
+                int lo = 0, hi = npool;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if ((lpool[mid] >> 1) < kk) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (j + lo < a.L) outp[j + lo] = key;
+            }
+            __syncthreads();
+            npool = min(a.L, npool + n);
+            for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
+            __syncthreads();
+        }
+    }
+    // ---- final candidate list -> global pool ----
+    uint64_t* pool = ws.pool + (size_t)q * ws.ef;
+    for (int i = tid; i < npool; i += 256) pool[i] = lpool[i];
+    if (tid == 0) {
+        ws.npool[q] = npool;
+        ws.nsteps[q] = nexp;
+        a.n_adc_q[q] = n_adc;
+        a.rounds_q[q] = rounds + 1;
+    }
+}
+
+// set the dedup bitmap for every candidate of every query
+__global__ void k_pq_mark(WsDev ws) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ws.B * ws.ef) return;
+    int q = t / ws.ef, i = t % ws.ef;
+    if (i < ws.npool[q]) {
+        int32_t v = key_id(ws.pool[(size_t)q * ws.ef + i]);
+        atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+    }
+}
+
+// exact canonical distances of the candidates, then per-query sort (one workgroup per query)
+template <int NCH, bool L2, bool F16>
+__global__ __launch_bounds__(256) void k_pq_rerank(WsDev ws, UpdateArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;  // P2 >= ef
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = ws.npool[q];
+    uint64_t* pool = ws.pool + (size_t)q * ws.ef;
+    for (int i = n + tid; i < a.P2; i += 256) keys[i] = KEY_NONE;
+    const int lane16 = tid & 15, sg = tid >> 4;
+    float4 qv[NCH];
+    {
+        const float4* qrow = (const float4*)(a.Q + (size_t)q * (NCH * 64));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
+    }
+    for (int i = sg; i < n; i += 32) {
+        const int i2 = i + 16;
+        const bool has2 = i2 < n;
+        int32_t v0 = key_id(pool[i]);
+        int32_t v1 = has2 ? key_id(pool[i2]) : v0;
+        int64_t s0 = v0, s1 = v1;
+        if (a.by_rank) {
+            s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
+            s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
+        }
+        float4 e0[NCH], e1[NCH];
+        load_row<NCH, F16>(a.E, s0, lane16, e0);
+        load_row<NCH, F16>(a.E, s1, lane16, e1);
+        float d0 = row_reduce<NCH, L2>(e0, qv);
+        float d1 = row_reduce<NCH, L2>(e1, qv);
+        if (lane16 == 0) {
+            keys[i] = make_key(d0, v0);
+            if (has2) keys[i2] = make_key(d1, v1);
+        }
+    }
+    __syncthreads();
+    for (unsigned k2 = 2; k2 <= (unsigned)a.P2; k2 <<= 1)
+        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+            for (unsigned i = tid; i < (unsigned)a.P2; i += 256) {
+                unsigned ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t x = keys[i], y = keys[ixj];
+                    bool up = (i & k2) == 0;
+                    if ((x > y) == up) {
+                        keys[i] = y;
+                        keys[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 256) pool[i] = keys[i];
+}
+
+__global__ __launch_bounds__(256) void k_pq_stats(WsDev ws, PqArgs a) {
+    __shared__ unsigned long long red[2][4];
+    __shared__ int redr[4];
+    unsigned long long x = 0, y = 0;
+    int r = 0;
+    for (int q = threadIdx.x; q < ws.B; q += 256) {
+        x += a.n_adc_q[q];
+        y += (unsigned long long)ws.nsteps[q];
+        r = max(r, a.rounds_q[q]);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        x += __shfl_xor(x, m);
+        y += __shfl_xor(y, m);
+        r = max(r, __shfl_xor(r, m));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = x;
+        red[1][threadIdx.x >> 6] = y;
+        redr[threadIdx.x >> 6] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws.counters[C_NDIS] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        ws.counters[C_NEXPAND] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        ws.counters[C_ROUNDS] = (unsigned long long)max(max(redr[0], redr[1]), max(redr[2], redr[3]));
+    }
+}
+
+}  // namespace lm
+
+template <bool L2, bool F16>
+static int launch_rerank_nch(lm_index* ix, const UpdateArgs& a) {
+    dim3 grid(ix->ws.B), block(256);
+    size_t shmem = (size_t)a.P2 * 8;
+    switch (ix->Dp / 64) {
+#define CASER(n) case n: hipLaunchKernelGGL((k_pq_rerank<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); break
+        CASER(1); CASER(2); CASER(3); CASER(4); CASER(5); CASER(6); CASER(8); CASER(12); CASER(16);
+#undef CASER
+        default: LM_FAIL(LM_EINVAL, "unsupported padded dimension");
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, const lm_pq_search_params& prm,
+                          float* d_dist, int64_t* d_labels) {
+    const int32_t L = std::max(prm.complexity, k);
+    const int32_t W = std::max(prm.beam_width, 1);
+    if (W > 64) LM_FAIL(LM_EINVAL, "beam_width > 64 is not supported by the PQ traversal kernel");
+    int rc = ensure_ws(ix, B, L, W);
+    if (rc) return rc;
+    WsDev& ws = ix->ws;
+    hipStream_t st = ix->stream;
+    if ((int64_t)B > ix->pq_cap) {
+        if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
+        if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
+        LM_HIP(hipMalloc((void**)&ix->d_pq_nadc, (size_t)B * 8));
+        LM_HIP(hipMalloc((void**)&ix->d_pq_rounds, (size_t)B * 4));
+        ix->pq_cap = B;
+    }
+    GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
+    PqDev pq{ix->pq_m, ix->D / ix->pq_m, ix->d_pq_codebooks, ix->d_pq_codes};
+    PqArgs pa{};
+    pa.Q = d_q; pa.Dp = ix->Dp; pa.metric = ix->metric; pa.L = L; pa.W = W; pa.maxnew = ws.maxnew;
+    pa.Pmax = next_pow2(ws.maxnew);
+    pa.n_adc_q = ix->d_pq_nadc; pa.rounds_q = ix->d_pq_rounds;
+    size_t shmem = (size_t)ix->pq_m * 256 * 4 + (size_t)2 * L * 8 + (size_t)pa.Pmax * 8 + (size_t)ws.maxnew * 4;
+    if (shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "PQ search state does not fit the 160 KB LDS (reduce m, complexity or beam_width)");
+    LM_HIP(hipFuncSetAttribute((const void*)k_pq_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
+    LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
+    {
+        EvScope es(ix, &ix->ev_update);
+        hipLaunchKernelGGL(k_pq_traverse, dim3(B), dim3(256), shmem, st, g, pq, ws, pa);
+    }
+    LM_HIP(hipGetLastError());
+    ix->stats.update_launches++;
+    hipLaunchKernelGGL(k_pq_stats, dim3(1), dim3(256), 0, st, ws, pa);
+    unsigned long long* hc = ix->h_counters;
+    const bool have_table = ix->d_table != nullptr;
+    const bool rerank = !prm.skip_search_reorder && ((prm.use_deferred_fetch && ix->provider) || have_table);
+    if (rerank) {
+        UpdateArgs ua{};
+        ua.Q = d_q;
+        ua.P2 = next_pow2(L);
+        if (prm.use_deferred_fetch && ix->provider) {
+            // ONE deferred fetch for the union of all candidate lists
+            const int ntiles = (int)((ws.nw + UNIQ_TILE - 1) / UNIQ_TILE);
+            hipLaunchKernelGGL(k_pq_mark, dim3((B * L + 255) / 256), dim3(256), 0, st, ws);
+            hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
+            hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
+            LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            int32_t nu = (int32_t)hc[C_NUNIQ];
+            void* d_e = nullptr;
+            ix->stats.nunique += nu;
+            if (nu > 0) {
+                EvScope es(ix, &ix->ev_provider);
+                int prc = ix->provider(ix->provider_user, ws.uniq, nu, &d_e, (void*)st);
+                if (prc != 0 || !d_e) LM_FAIL(LM_EPROVIDER, "embedding provider failed (rc=" + std::to_string(prc) + ")");
+            }
+            ua.E = d_e;
+            ua.by_rank = 1;
+            rc = ix->metric == LM_METRIC_L2 ? launch_rerank_nch<true, false>(ix, ua) : launch_rerank_nch<false, false>(ix, ua);
+        } else {
+            ua.E = ix->d_table;
+            ua.by_rank = 0;
+            const bool f16 = ix->table_dtype == LM_DTYPE_F16, l2 = ix->metric == LM_METRIC_L2;
+            rc = l2 ? (f16 ? launch_rerank_nch<true, true>(ix, ua) : launch_rerank_nch<true, false>(ix, ua))
+                    : (f16 ? launch_rerank_nch<false, true>(ix, ua) : launch_rerank_nch<false, false>(ix, ua));
+        }
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((B * k + 255) / 256), dim3(256), 0, st, ws, k, ix->metric, d_labels, d_dist);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    LM_HIP(hipStreamSynchronize(st));
+    ix->stats.ndis += (int64_t)hc[C_NDIS];
+    ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
+    ix->stats.nrounds = std::max<int64_t>(ix->stats.nrounds, (int64_t)hc[C_ROUNDS]);
+    return LM_OK;
+}
+
+extern "C" {
+
+int lm_pq_attach(lm_index* ix, int32_t m, const float* codebooks, const uint8_t* codes, int64_t ntotal) {
+    if (!ix || !codebooks || !codes) LM_FAIL(LM_EINVAL, "NULL argument");
+    if (ntotal != ix->N) LM_FAIL(LM_EINVAL, "code count does not match the index");
+    if (m <= 0 || m % 4 || ix->D % m) LM_FAIL(LM_EINVAL, "m must be a multiple of 4 that divides d");
+    LM_HIP(hipSetDevice(ix->device));
+    if (ix->d_pq_codebooks) (void)hipFree(ix->d_pq_codebooks);
+    if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
+    ix->d_pq_codebooks = nullptr;
+    ix->d_pq_codes = nullptr;
+    const size_t cb_bytes = (size_t)256 * ix->D * 4, code_bytes = (size_t)ntotal * m;
+    LM_HIP(hipMalloc((void**)&ix->d_pq_codebooks, cb_bytes));
+    LM_HIP(hipMalloc((void**)&ix->d_pq_codes, std::max<size_t>(code_bytes, 16)));
+    LM_HIP(hipMemcpy(ix->d_pq_codebooks, codebooks, cb_bytes, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(ix->d_pq_codes, codes, code_bytes, hipMemcpyHostToDevice));
+    ix->pq_m = m;
+    return LM_OK;
+}
+
+void lm_pq_search_params_default(lm_pq_search_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->complexity = 64;
+    p->beam_width = 1;
+    p->use_global_pruning = 1;
+    p->num_threads = 8;
+}
+
+static int pq_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k, const lm_pq_search_params* params,
+                            int64_t* d_labels, float* d_dist) {
+    if (!ix || !params || n < 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad search arguments");
+    if (params->complexity <= 0) LM_FAIL(LM_EINVAL, "complexity must be positive");
+    if (!ix->d_pq_codes) LM_FAIL(LM_ESTATE, "no PQ codes attached (lm_pq_attach)");
+    if (params->use_deferred_fetch && !ix->provider && !ix->d_table)
+        LM_FAIL(LM_ESTATE, "deferred fetch requested but neither an embedding provider nor stored embeddings are attached");
+    LM_HIP(hipSetDevice(ix->device));
+    ix->stats = lm_search_stats{};
+    if (n == 0) return LM_OK;
+    hipStream_t st = ix->stream;
+    if (ix->N == 0 || ix->entry_point < 0) {
+        hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, n * (int64_t)k, ix->metric,
+                           d_labels, d_dist);
+        LM_HIP(hipStreamSynchronize(st));
+        return LM_OK;
+    }
+    const float* d_q = d_x;
+    if (ix->D != ix->Dp) {
+        if (n > ix->qpad_cap) {
+            if (ix->d_qpad) (void)hipFree(ix->d_qpad);
+            LM_HIP(hipMalloc((void**)&ix->d_qpad, (size_t)n * ix->Dp * sizeof(float)));
+            ix->qpad_cap = n;
+        }
+        int64_t tot = n * ix->Dp;
+        hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_x, n, ix->D, ix->Dp, ix->d_qpad);
+        d_q = ix->d_qpad;
+    }
+    int64_t maxb = 4096;
+    int64_t nwbytes = ((ix->N + 31) / 32) * 4;
+    maxb = std::max<int64_t>(1, std::min<int64_t>(maxb, (8ll << 30) / std::max<int64_t>(nwbytes, 1)));
+    for (int64_t off = 0; off < n; off += maxb) {
+        int32_t B = (int32_t)std::min<int64_t>(maxb, n - off);
+        int rc = pq_search_pass(ix, B, d_q + (size_t)off * ix->Dp, k, *params, d_dist + (size_t)off * k, d_labels + (size_t)off * k);
+        if (rc) return rc;
+    }
+    LM_HIP(hipStreamSynchronize(st));
+    if (ix->profiling) {
+        ix->stats.update_ms = drain_events(ix, ix->ev_update);
+        ix->stats.provider_ms = drain_events(ix, ix->ev_provider);
+    }
+    return LM_OK;
+}
+
+int lm_pq_batch_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k, const lm_pq_search_params* params,
+                              int64_t* d_labels, float* d_distances) {
+    if (n > 0 && (!d_x || !d_labels || !d_distances)) LM_FAIL(LM_EINVAL, "NULL buffer");
+    return pq_search_device(ix, n, d_x, k, params, d_labels, d_distances);
+}
+
+int lm_pq_batch_search(lm_index* ix, int64_t n, const float* x, int32_t k, const lm_pq_search_params* params, int64_t* labels,
+                       float* distances) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    if (n < 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad n / k");
+    if (n == 0) return LM_OK;
+    if (!x || !labels || !distances) LM_FAIL(LM_EINVAL, "NULL buffer");
+    LM_HIP(hipSetDevice(ix->device));
+    float* d_x = nullptr;
+    float* d_d = nullptr;
+    int64_t* d_l = nullptr;
+    LM_HIP(hipMalloc((void**)&d_x, (size_t)n * ix->D * 4));
+    LM_HIP(hipMalloc((void**)&d_d, (size_t)n * k * 4));
+    LM_HIP(hipMalloc((void**)&d_l, (size_t)n * k * 8));
+    int rc = LM_OK;
+    if (hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = LM_EHIP;
+    if (!rc) rc = pq_search_device(ix, n, d_x, k, params, d_l, d_d);
+    if (!rc && (hipMemcpyAsync(distances, d_d, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                hipMemcpyAsync(labels, d_l, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                hipStreamSynchronize(ix->stream) != hipSuccess)) {
+        set_error("result copy failed");
+        rc = LM_EHIP;
+    }
+    (void)hipFree(d_x);
+    (void)hipFree(d_d);
+    (void)hipFree(d_l);
+    return rc;
+}
+
+}  // extern "C"

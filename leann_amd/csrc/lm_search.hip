@@ -925,6 +925,13 @@ struct lm_index {
     uint64_t* d_level_ptr = nullptr;
     int32_t* d_neighbors = nullptr;
     L0Range* d_l0 = nullptr;
+    // PQ (DiskANN-style path)
+    int32_t pq_m = 0;
+    float* d_pq_codebooks = nullptr;
+    uint8_t* d_pq_codes = nullptr;
+    unsigned long long* d_pq_nadc = nullptr;
+    int32_t* d_pq_rounds = nullptr;
+    int64_t pq_cap = 0;
     // stored embeddings
     void* d_table = nullptr;
     bool table_owned = false;
@@ -984,7 +991,7 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W) {
     A(rbm, w.nw); A(rbm_snap, w.nw); A(word_rank, w.nw);
     int ntiles = (int)((w.nw + UNIQ_TILE - 1) / UNIQ_TILE);
     A(tile_sum, std::max(ntiles, 1));
-    ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * maxnew);
+    ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * std::max(maxnew, ef));
     A(uniq, ix->ws_ucap);
     A(seg_start, B); A(pair_q, (size_t)B * maxnew); A(pair_v, (size_t)B * maxnew); A(pair_key, (size_t)B * maxnew);
     A(counters, C_NCOUNTERS);
@@ -1341,6 +1348,10 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_level_ptr) (void)hipFree(ix->d_level_ptr);
     if (ix->d_neighbors) (void)hipFree(ix->d_neighbors);
     if (ix->d_l0) (void)hipFree(ix->d_l0);
+    if (ix->d_pq_codebooks) (void)hipFree(ix->d_pq_codebooks);
+    if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
+    if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
+    if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
     if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
     if (ix->d_qpad) (void)hipFree(ix->d_qpad);
     if (ix->h_counters) (void)hipHostFree(ix->h_counters);
@@ -1498,3 +1509,5 @@ int lm_topk_merge(const int64_t* d_in_ids, const float* d_in_dist, int32_t S, in
 }
 
 }  // extern "C"
+
+#include "lm_pq_impl.h"

@@ -11,7 +11,7 @@ from typing import Callable, Optional
 import numpy as np
 
 from . import _lib
-from ._lib import SearchParams, SearchStats, check
+from ._lib import PqSearchParams, SearchParams, SearchStats, check
 from .csr_format import HnswCsr
 
 
@@ -160,6 +160,47 @@ class Mi355xIndex:
                                               C.c_void_p(labels.data_ptr()), C.byref(params))
         self._raise_provider(rc, "lm_index_search_device")
         return dist, labels
+
+    # ---- DiskANN-style path -----------------------------------------------------------------
+    def attach_pq(self, codebooks: np.ndarray, codes: np.ndarray) -> None:
+        """codebooks: (m, 256, d/m) float32; codes: (N, m) uint8."""
+        cb = np.ascontiguousarray(codebooks, dtype=np.float32)
+        cd = np.ascontiguousarray(codes, dtype=np.uint8)
+        if cb.ndim != 3 or cb.shape[1] != 256 or cb.shape[0] * cb.shape[2] != self.info.d or cd.shape != (self.info.ntotal, cb.shape[0]):
+            raise ValueError("codebooks must be (m, 256, d/m) and codes (N, m)")
+        check(self._lib.lm_pq_attach(self._h, cb.shape[0], _np_ptr(cb), _np_ptr(cd), cd.shape[0]), "lm_pq_attach")
+
+    @staticmethod
+    def make_pq_params(complexity: int = 64, beam_width: int = 1, use_deferred_fetch: bool = False,
+                       skip_search_reorder: bool = False, num_threads: int = 8, dedup_node_dis: bool = False,
+                       prune_ratio: float = 0.0, batch_recompute: bool = False, use_global_pruning: bool = True) -> PqSearchParams:
+        return PqSearchParams(complexity, beam_width, num_threads, 1 if use_deferred_fetch else 0,
+                              1 if skip_search_reorder else 0, 0, 1 if dedup_node_dis else 0, prune_ratio,
+                              1 if batch_recompute else 0, 1 if use_global_pruning else 0)
+
+    def pq_search(self, queries: np.ndarray, k: int, params: PqSearchParams):
+        """== StaticDiskFloatIndex.batch_search(...) -> (labels, distances) (diskann_backend.py:453-467)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.info.d:
+            raise ValueError(f"query must be (B, {self.info.d}) float32")
+        n = q.shape[0]
+        dist = np.empty((n, k), dtype=np.float32)
+        labels = np.empty((n, k), dtype=np.int64)
+        rc = self._lib.lm_pq_batch_search(self._h, n, _np_ptr(q), k, C.byref(params), _np_ptr(labels), _np_ptr(dist))
+        self._raise_provider(rc, "lm_pq_batch_search")
+        return labels, dist
+
+    def pq_search_device(self, queries, k: int, params: PqSearchParams):
+        import torch
+
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        n = queries.shape[0]
+        dist = torch.empty((n, k), dtype=torch.float32, device=queries.device)
+        labels = torch.empty((n, k), dtype=torch.int64, device=queries.device)
+        rc = self._lib.lm_pq_batch_search_device(self._h, n, C.c_void_p(queries.data_ptr()), k, C.byref(params),
+                                                 C.c_void_p(labels.data_ptr()), C.c_void_p(dist.data_ptr()))
+        self._raise_provider(rc, "lm_pq_batch_search_device")
+        return labels, dist
 
     def stats(self) -> dict:
         st = SearchStats()

@@ -51,6 +51,19 @@ class _Stats(C.Structure):
     _fields_ = [("ndis", C.c_int64), ("nunique", C.c_int64), ("nrounds", C.c_int64), ("nexpand", C.c_int64)]
 
 
+class _Pq(C.Structure):
+    _fields_ = [("m", C.c_int32), ("dsub", C.c_int32), ("codebooks", C.c_void_p), ("codes", C.c_void_p)]
+
+
+class _PqParams(C.Structure):
+    _fields_ = [("L", C.c_int32), ("W", C.c_int32), ("k", C.c_int32), ("use_deferred_fetch", C.c_int32),
+                ("skip_search_reorder", C.c_int32)]
+
+
+class _PqStats(C.Structure):
+    _fields_ = [("n_adc", C.c_int64), ("n_rerank_unique", C.c_int64), ("n_rounds", C.c_int64), ("n_expand", C.c_int64)]
+
+
 _PROVIDER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_float))
 
 _lib = None
@@ -77,6 +90,13 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
         ]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_pq_search.restype = C.c_int
+        _lib.orc_pq_search.argtypes = [C.POINTER(_Graph), C.POINTER(_Pq), C.c_void_p, _PROVIDER, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.POINTER(_PqParams), C.c_void_p, C.c_void_p, C.POINTER(_PqStats)]
+        _lib.orc_pq_lut.restype = None
+        _lib.orc_pq_lut.argtypes = [C.POINTER(_Pq), C.c_void_p, C.c_int32, C.c_void_p]
+        _lib.orc_pq_adc.restype = C.c_float
+        _lib.orc_pq_adc.argtypes = [C.POINTER(_Pq), C.c_void_p, C.c_int64]
         _lib.orc_set_num_threads.argtypes = [C.c_int]
         _lib.orc_set_num_threads.restype = None
         _lib.orc_set_num_threads(usable_cores())
@@ -167,6 +187,62 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
         raise RuntimeError(f"orc_search failed rc={rc}")
     stats = {f: int(getattr(st, f)) for f, _ in _Stats._fields_}
     return ids, dd, stats
+
+
+def _make_provider(provider, Dp, err):
+    def _cb(_user, ids_p, n, out_p):
+        try:
+            idv = np.ctypeslib.as_array(ids_p, shape=(n,)).copy()
+            e = pad64(np.asarray(provider(idv), dtype=np.float32))
+            assert e.shape == (n, Dp), e.shape
+            np.ctypeslib.as_array(out_p, shape=(n, Dp))[:] = e
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            err.append(ex)
+            return 1
+
+    return _PROVIDER(_cb)
+
+
+def pq_search(graph: OracleGraph, codebooks: np.ndarray, codes: np.ndarray, queries: np.ndarray, k: int, L: int = 64,
+              W: int = 1, table: Optional[np.ndarray] = None, provider=None, use_deferred_fetch: bool = False,
+              skip_search_reorder: bool = False):
+    """DiskANN-style oracle: PQ-ADC traversal (+ exact rerank from `table`, or from `provider` when
+    use_deferred_fetch).  Returns (ids, dist, stats)."""
+    cb = np.ascontiguousarray(codebooks, dtype=np.float32)
+    cd = np.ascontiguousarray(codes, dtype=np.uint8)
+    m, _, dsub = cb.shape
+    assert m * dsub == graph.D and cd.shape == (graph.N, m)
+    q = pad64(np.atleast_2d(queries))
+    B = q.shape[0]
+    ids = np.empty((B, k), dtype=np.int64)
+    dd = np.empty((B, k), dtype=np.float32)
+    pq = _Pq(m, dsub, _ptr(cb), _ptr(cd))
+    prm = _PqParams(L, W, k, 1 if use_deferred_fetch else 0, 1 if skip_search_reorder else 0)
+    st = _PqStats()
+    g = graph.cstruct()
+    tab = pad64(table) if table is not None else None
+    err: list = []
+    cbf = _make_provider(provider, graph.Dp, err) if provider is not None else _PROVIDER()
+    rc = lib().orc_pq_search(C.byref(g), C.byref(pq), _ptr(tab), cbf, None, _ptr(q), B, C.byref(prm), _ptr(ids), _ptr(dd),
+                             C.byref(st))
+    if err:
+        raise err[0]
+    if rc:
+        raise RuntimeError(f"orc_pq_search failed rc={rc}")
+    return ids, dd, {f: int(getattr(st, f)) for f, _ in _PqStats._fields_}
+
+
+def pq_lut_adc(codebooks: np.ndarray, codes: np.ndarray, query: np.ndarray, metric: int, ids: np.ndarray):
+    """Canonical LUT + ADC distances of `ids` (for kernel-level tests)."""
+    cb = np.ascontiguousarray(codebooks, dtype=np.float32)
+    cd = np.ascontiguousarray(codes, dtype=np.uint8)
+    m, _, dsub = cb.shape
+    pq = _Pq(m, dsub, _ptr(cb), _ptr(cd))
+    qv = np.ascontiguousarray(query, dtype=np.float32)
+    lut = np.empty((m, 256), np.float32)
+    lib().orc_pq_lut(C.byref(pq), _ptr(qv), metric, _ptr(lut))
+    return lut, np.array([lib().orc_pq_adc(C.byref(pq), _ptr(lut), int(v)) for v in ids], np.float32)
 
 
 def bruteforce_topk(table: np.ndarray, queries: np.ndarray, k: int, metric: int):

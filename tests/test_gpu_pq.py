@@ -1,0 +1,98 @@
+"""DiskANN-style path on the GPU (PQ-ADC persistent traversal kernel + deferred rerank) vs the oracle."""
+import numpy as np
+import pytest
+
+from tests.util import clustered, oracle_graph, queries_near, recall_at_k
+
+pytestmark = pytest.mark.gpu
+_C = {}
+
+
+def _setup(n, d, m, metric, seed):
+    import torch
+
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.pq import encode_pq, flat_graph, train_pq
+
+    key = (n, d, m, metric, seed)
+    if key not in _C:
+        x = clustered(n, d, seed, n_centers=64, sigma=0.5)
+        g = flat_graph(build_hnsw(x, metric, M=12, ef_construction=60, seed=seed), x)
+        cb = train_pq(torch.from_numpy(x), m, iters=8, seed=seed).numpy()
+        codes = encode_pq(torch.from_numpy(x), torch.from_numpy(cb)).numpy()
+        _C[key] = (x, g, cb, codes)
+    return _C[key]
+
+
+@pytest.mark.parametrize("metric", ["l2", "mips"])
+@pytest.mark.parametrize("L,W", [(32, 1), (64, 4), (100, 64)])
+def test_pq_search_parity(metric, L, W):
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    _lib.require_gpu()
+    x, g, cb, codes = _setup(4000, 96, 24, metric, 3)
+    q = queries_near(x, 40, 4)
+    og = oracle_graph(g, 96)
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.attach_pq(cb, codes)
+    # (1) PQ order only
+    oi, od, ost = orc.pq_search(og, cb, codes, q, 10, L=L, W=W, skip_search_reorder=True)
+    gi, gd = idx.pq_search(q, 10, idx.make_pq_params(L, W, skip_search_reorder=True))
+    st = idx.stats()
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    assert st["ndis"] == ost["n_adc"] and st["nexpand"] == ost["n_expand"] and st["nrounds"] == ost["n_rounds"], (st, ost)
+    # (2) deferred fetch through the provider (one call, sorted unique ids)
+    xdev = torch.zeros((x.shape[0], idx.info.d_padded), device="cuda")
+    xdev[:, :96] = torch.from_numpy(x).cuda()
+    calls, keep = [], {}
+
+    def provider(d_ids, n, stream):
+        ids = as_tensor(d_ids, (n,), "int32")
+        calls.append(ids.cpu().numpy().copy())
+        keep["e"] = xdev.index_select(0, ids.long()).contiguous()
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+    oi, od, ost = orc.pq_search(og, cb, codes, q, 10, L=L, W=W, provider=lambda idv: x[idv], use_deferred_fetch=True)
+    gi, gd = idx.pq_search(q, 10, idx.make_pq_params(L, W, use_deferred_fetch=True))
+    assert len(calls) == 1 and np.all(np.diff(calls[0]) > 0) and len(calls[0]) == ost["n_rerank_unique"]
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    assert np.allclose(gd, od, atol=1e-4, rtol=0)
+    # (3) stored embeddings (recompute_embeddings=False on an index that keeps them)
+    idx.set_provider(None)
+    idx.attach_table(x)
+    oi, od, _ = orc.pq_search(og, cb, codes, q, 10, L=L, W=W, table=x)
+    gi, gd = idx.pq_search(q, 10, idx.make_pq_params(L, W))
+    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    gt, _ = orc.bruteforce_topk(x, q, 10, 1 if metric == "l2" else 0)
+    if L >= 64:
+        assert recall_at_k(gi, gt) > 0.9
+    idx.close()
+
+
+def test_pq_errors_and_edge_cases():
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.index import Mi355xIndex
+
+    _lib.require_gpu()
+    x, g, cb, codes = _setup(4000, 96, 24, "l2", 3)
+    idx = Mi355xIndex.from_csr(g)
+    with pytest.raises(RuntimeError):  # no codes attached
+        idx.pq_search(x[:1], 3, idx.make_pq_params(16, 1))
+    with pytest.raises(ValueError):
+        idx.attach_pq(cb[:, :, :3], codes)
+    idx.attach_pq(cb, codes)
+    with pytest.raises(RuntimeError):  # deferred fetch without provider/table
+        idx.pq_search(x[:1], 3, idx.make_pq_params(16, 1, use_deferred_fetch=True))
+    with pytest.raises(ValueError):  # beam > 64
+        idx.pq_search(x[:1], 3, idx.make_pq_params(16, 65, skip_search_reorder=True))
+    l, d = idx.pq_search(x[:2], 5000, idx.make_pq_params(16, 1, skip_search_reorder=True))  # k > N reachable
+    assert (l[:, 4000:] == -1).all()
