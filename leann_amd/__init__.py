@@ -5,7 +5,14 @@ Importing the package registers the ``"mi355x"`` backend in LEANN's ``BACKEND_RE
 there is no CPU fallback.
 """
 
-from .backend import Mi355xBackend, Mi355xBuilder, Mi355xSearcher  # noqa: F401  (registers the backend)
+from .backend import (  # noqa: F401  (registers the backends)
+    Mi355xBackend,
+    Mi355xBuilder,
+    Mi355xDiskannBackend,
+    Mi355xDiskannBuilder,
+    Mi355xDiskannSearcher,
+    Mi355xSearcher,
+)
 
 __version__ = "0.1.0"
-__all__ = ["Mi355xBackend", "Mi355xBuilder", "Mi355xSearcher"]
+__all__ = ["Mi355xBackend", "Mi355xBuilder", "Mi355xSearcher", "Mi355xDiskannBackend", "Mi355xDiskannBuilder", "Mi355xDiskannSearcher"]

@@ -308,7 +308,7 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
 
 
 def write_leann_bundle(index_path: str, texts: list[str], embeddings: np.ndarray, embedding_model: str,
-                       backend_name: str = "mi355x", **backend_kwargs) -> None:
+                       backend_name: str = "mi355x", **backend_kwargs) -> None:  # noqa: C901
     """Write the LEANN index bundle the way LeannBuilder.build_index does (leann/api.py:409-481):
     ``<index_path>.passages.jsonl`` + ``.passages.idx`` (pickle {id: byte offset}) +
     ``<index_path>.meta.json`` + the backend's ``<stem>.index``.  Lets the backend be used (and
@@ -323,7 +323,12 @@ def write_leann_bundle(index_path: str, texts: list[str], embeddings: np.ndarray
             f.write(json.dumps({"id": str(i), "text": t, "metadata": {}}, ensure_ascii=False) + "\n")
     with open(str(path) + ".passages.idx", "wb") as f:
         pickle.dump(offsets, f)
-    b = Mi355xBuilder(dimensions=int(embeddings.shape[1]), **backend_kwargs)
+    if backend_name == "mi355x_diskann":
+        b = Mi355xDiskannBuilder(dimensions=int(embeddings.shape[1]), **backend_kwargs)
+        b.build_params.setdefault("distance_metric", "mips")
+        b.is_compact, b.is_recompute = True, bool(backend_kwargs.get("is_recompute", False))
+    else:
+        b = Mi355xBuilder(dimensions=int(embeddings.shape[1]), **backend_kwargs)
     b.build(embeddings, [str(i) for i in range(len(texts))], str(path))
     meta = {
         "version": "1.0", "backend_name": backend_name, "embedding_model": embedding_model,
@@ -334,3 +339,124 @@ def write_leann_bundle(index_path: str, texts: list[str], embeddings: np.ndarray
     }
     with open(str(path) + ".meta.json", "w", encoding="utf-8") as f:
         json.dump(meta, f, indent=2)
+
+
+# =============================================================================================
+# DiskANN-style backend: PQ traversal + deferred rerank
+# =============================================================================================
+
+
+def pq_bytes_for_budget(num_vectors: int, dim: int, search_memory_gb: float | None = None) -> int:
+    """PQ bytes per vector from DiskANN's memory budget rule: search_memory_maximum defaults to 1/10
+    of the fp32 embedding size (diskann_backend.py:105-111) => ~ dim*4/10 bytes per vector, rounded
+    to a divisor of dim that is a multiple of 4."""
+    budget = (search_memory_gb * (1024**3) / max(num_vectors, 1)) if search_memory_gb else dim * 4 / 10
+    # <= 96 sub-quantisers: the m*256*4-byte lookup table must stay LDS resident (160 KB/CU) next to the
+    # candidate list and a beam_width=64 frontier
+    cands = [m for m in range(4, min(dim, 96) + 1, 4) if dim % m == 0]
+    return min(cands, key=lambda m: (abs(m - budget), m)) if cands else 4
+
+
+@register_backend("mi355x_diskann")
+class Mi355xDiskannBackend(LeannBackendFactoryInterface):
+    @staticmethod
+    def builder(**kwargs) -> LeannBackendBuilderInterface:
+        return Mi355xDiskannBuilder(**kwargs)
+
+    @staticmethod
+    def searcher(index_path: str, **kwargs) -> LeannBackendSearcherInterface:
+        return Mi355xDiskannSearcher(index_path, **kwargs)
+
+
+class Mi355xDiskannBuilder(LeannBackendBuilderInterface):
+    """Mirror of DiskannBuilder (diskann_backend.py:142-297): kwargs ``complexity`` (build list size),
+    ``graph_degree``, ``search_memory_maximum`` (PQ budget), ``distance_metric``, ``num_threads``.
+    Writes ``<stem>.index`` (flat graph in the compact-CSR container, entry = medoid, embeddings kept
+    unless ``is_recompute``) and ``<stem>_pq.npz`` (codebooks + codes: the role of
+    ``_pq_pivots.bin`` / ``_pq_compressed.bin``, whose real layouts live in the absent fork)."""
+
+    def __init__(self, **kwargs):
+        self.build_params = kwargs.copy()
+
+    def build(self, data: np.ndarray, ids: list, index_path: str, **kwargs) -> None:
+        import torch
+
+        from .hnsw_builder import build_hnsw
+        from .pq import encode_pq, flat_graph, train_pq
+
+        path = Path(index_path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        if data.dtype != np.float32:
+            logger.warning(f"Converting data to float32, shape: {data.shape}")
+            data = data.astype(np.float32)
+        bk = {**self.build_params, **kwargs}
+        if "backend_kwargs" in bk:
+            bk.update(bk.pop("backend_kwargs"))
+        metric = bk.get("distance_metric", "mips").lower()
+        if metric not in METRIC_MAP:
+            raise ValueError(f"Unsupported distance_metric '{bk.get('distance_metric', 'unknown')}'.")
+        if metric == "cosine":
+            data = normalize_l2(data)
+        degree = int(bk.get("graph_degree", 32))
+        g = build_hnsw(data, metric, M=max(2, degree // 2), ef_construction=max(int(bk.get("complexity", 64)), degree),
+                       num_threads=int(bk.get("num_threads", 0)))
+        fg = flat_graph(g, data)
+        fg.storage = np.ascontiguousarray(data)
+        write_index(path.parent / f"{path.stem}.index", fg, prune_embeddings=bool(bk.get("is_recompute", False)))
+        m = int(bk.get("pq_bytes") or pq_bytes_for_budget(data.shape[0], data.shape[1], bk.get("search_memory_maximum")))
+        x = torch.from_numpy(data)
+        cb = train_pq(x, m, seed=0)
+        codes = encode_pq(x, cb)
+        np.savez(path.parent / f"{path.stem}_pq.npz", codebooks=cb.numpy(), codes=codes.numpy())
+
+
+class Mi355xDiskannSearcher(Mi355xSearcher):
+    """Mirror of DiskannSearcher (diskann_backend.py:300-471)."""
+
+    def __init__(self, index_path: str, **kwargs):
+        super().__init__(index_path, **kwargs)
+        self.num_threads = kwargs.get("num_threads", 8)
+        self.pq_file = self.index_dir / f"{self.index_path.stem}_pq.npz"
+        if not self.pq_file.exists():
+            raise FileNotFoundError(f"PQ file not found at {self.pq_file}")
+        self._pq_attached = False
+
+    def _ensure_index_loaded(self):
+        idx = super()._ensure_index_loaded()
+        if not self._pq_attached:
+            z = np.load(self.pq_file)
+            idx.attach_pq(z["codebooks"], z["codes"])
+            self._pq_attached = True
+        return idx
+
+    def search(self, query: np.ndarray, top_k: int, complexity: int = 64, beam_width: int = 1, prune_ratio: float = 0.0,
+               recompute_embeddings: bool = False, pruning_strategy: Literal["global", "local", "proportional"] = "global",
+               zmq_port: Optional[int] = None, batch_recompute: bool = False, dedup_node_dis: bool = False,
+               **kwargs) -> dict[str, Any]:
+        """Same contract as DiskannSearcher.search (diskann_backend.py:383-471)."""
+        if recompute_embeddings and zmq_port is None:
+            raise ValueError("zmq_port must be provided if recompute_embeddings is True")
+        if pruning_strategy == "proportional":
+            raise NotImplementedError(
+                "DiskANN backend does not support 'proportional' pruning strategy. Use 'global' or 'local' instead.")
+        query = np.atleast_2d(np.asarray(query))
+        if query.dtype != np.float32:
+            query = query.astype(np.float32)
+        if self.distance_metric == "cosine":
+            query = normalize_l2(query)
+        idx = self._ensure_index_loaded()
+        if recompute_embeddings and self._provider is None:
+            self._ensure_server_running(str(self.index_dir / f"{self.index_path.name}.meta.json"), zmq_port)
+        if recompute_embeddings:
+            import torch
+
+            idx.set_stream(torch.cuda.current_stream(self._torch_device()).cuda_stream)
+        # traversal always on PQ distances; recompute => one final rerank via deferred fetch (:444-450)
+        params = idx.make_pq_params(int(complexity), int(beam_width), use_deferred_fetch=bool(recompute_embeddings),
+                                    skip_search_reorder=bool(kwargs.get("skip_search_reorder", False)),
+                                    num_threads=int(self.num_threads), dedup_node_dis=bool(dedup_node_dis),
+                                    prune_ratio=float(prune_ratio), batch_recompute=bool(batch_recompute),
+                                    use_global_pruning=(pruning_strategy != "local"))
+        labels, distances = idx.pq_search(np.ascontiguousarray(query), int(top_k), params)
+        string_labels = [[str(int(l)) for l in row] for row in labels]
+        return {"labels": string_labels, "distances": distances}

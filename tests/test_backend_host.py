@@ -117,3 +117,35 @@ else:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "LOUD-FAIL-OK" in r.stdout or "SEARCH-RAN" in r.stdout
+
+
+def test_diskann_style_backend_host_logic(tmp_path, built_libs):
+    """Mirror of DiskannBuilder/DiskannSearcher (diskann_backend.py): files, PQ budget rule, errors."""
+    from leann_amd import Mi355xDiskannBackend, Mi355xDiskannSearcher, _lib
+    from leann_amd import csr_format as cf
+    from leann_amd._compat import BACKEND_REGISTRY
+    from leann_amd.backend import pq_bytes_for_budget, write_leann_bundle
+
+    assert BACKEND_REGISTRY["mi355x_diskann"] is Mi355xDiskannBackend
+    assert pq_bytes_for_budget(10**6, 384) == 96  # ~ D*4/10 = 153.6 B/vector, capped at 96 (LUT must stay in LDS)
+    assert 384 % pq_bytes_for_budget(10**6, 384) == 0 and pq_bytes_for_budget(10**6, 384) % 4 == 0
+    x = clustered(300, 32, 2)
+    texts = [f"t{i}" for i in range(300)]
+    p = str(tmp_path / "d.leann")
+    write_leann_bundle(p, texts, x, "sentence-transformers/all-MiniLM-L6-v2", backend_name="mi355x_diskann",
+                       distance_metric="l2", graph_degree=16, complexity=32, pq_bytes=8)
+    g = cf.read_index(tmp_path / "d.index")
+    assert g.max_level == 0 and (g.levels == 1).all() and g.storage is not None  # flat graph, embeddings kept
+    z = np.load(tmp_path / "d_pq.npz")
+    assert z["codebooks"].shape == (8, 256, 4) and z["codes"].shape == (300, 8) and z["codes"].dtype == np.uint8
+    s = Mi355xDiskannSearcher(p)
+    with pytest.raises(ValueError, match="zmq_port must be provided"):  # diskann_backend.py:424-426
+        s.search(x[:1], 3, recompute_embeddings=True)
+    with pytest.raises(NotImplementedError, match="proportional"):  # :434-437
+        s.search(x[:1], 3, pruning_strategy="proportional")
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.LeannMi355xError, match="no HIP device"):
+            s.search(x[:1], 3)
+    os.remove(tmp_path / "d_pq.npz")
+    with pytest.raises(FileNotFoundError):
+        Mi355xDiskannSearcher(p)
