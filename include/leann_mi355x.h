@@ -181,6 +181,13 @@ int lm_dist_gather(const void *d_table, int32_t dtype, int32_t d_padded, int32_t
 int lm_topk_merge(const int64_t *d_in_ids, const float *d_in_dist, int32_t S, int32_t B, int32_t k,
                   int32_t metric, int64_t *d_out_ids, float *d_out_dist, void *stream);
 
+/* ---- fused encoder elementwise ops ---------------------------------------------------------------
+ * out = LayerNorm(x + residual) * gamma + beta over the last dim; fp16 in/out, fp32 arithmetic;
+ * residual may be NULL.  Part of the BERT forward inside compute_embeddings
+ * (leann/embedding_compute.py:229-239); GEMMs/attention stay in hipBLASLt/SDPA. */
+int lm_add_layernorm_f16(const void *d_x, const void *d_residual, const void *d_gamma, const void *d_beta,
+                         void *d_out, int64_t rows, int32_t hidden, float eps, void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_update_sort(WsDev ws, UpdateArgs a) {
 
 // ---- variant 0 (default): sort only the NEW keys, then merge with the (already sorted) pool by rank ----
 // LDS: pool[ef] | newk[Pn] | out[ef]   (a.P2 carries ef_lds = ef rounded up to 2, Pn is per block)
-template <int NCH, bool L2, bool F16>
+template <int NCH, bool L2, bool F16, bool BYRANK>
 __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned long long s_best;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
         int32_t v0 = newid[i];
         int32_t v1 = has2 ? newid[i2] : v0;
         int64_t s0 = v0, s1 = v1;
-        if (a.by_rank) {
+        if (BYRANK) {
             s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
             s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
         }
@@ -1071,7 +1071,8 @@ static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
 #define CASE(n)                                                                                              \
     case n:                                                                                                  \
         if (sortv) hipLaunchKernelGGL((k_update_sort<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); \
-        else hipLaunchKernelGGL((k_update<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a);          \
+        else if (a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, true>), grid, block, shmem, ix->stream, ix->ws, a); \
+        else hipLaunchKernelGGL((k_update<n, L2, F16, false>), grid, block, shmem, ix->stream, ix->ws, a);   \
         break
         CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(12); CASE(16);
 #undef CASE

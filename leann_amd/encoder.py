@@ -67,6 +67,25 @@ def config_for(model_name: str) -> EncoderConfig:
     return PRESETS["all-minilm-l6-v2"]
 
 
+def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
+    """LayerNorm(x + residual) through the hand-written HIP kernel (csrc/lm_encoder_ops.hip) for fp16 CUDA
+    tensors; plain torch otherwise (CPU / fp32 parity paths)."""
+    if x.is_cuda and x.dtype == torch.float16 and x.shape[-1] % 8 == 0 and x.is_contiguous() and (
+            residual is None or residual.is_contiguous()):
+        import ctypes as C
+
+        from . import _lib
+
+        out = torch.empty_like(x)
+        rows = x.numel() // x.shape[-1]
+        _lib.check(_lib.load().lm_add_layernorm_f16(
+            C.c_void_p(x.data_ptr()), C.c_void_p(residual.data_ptr()) if residual is not None else None,
+            C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()), C.c_void_p(out.data_ptr()), rows,
+            x.shape[-1], float(ln.eps), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_add_layernorm_f16")
+        return out
+    return ln(x if residual is None else x + residual)
+
+
 class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
@@ -78,13 +97,24 @@ class _Layer(nn.Module):
         self.ln2 = nn.LayerNorm(c.hidden, eps=c.ln_eps)
         self.heads = c.heads
 
+    def forward_packed(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
+        """x: [total_tokens, H] (sequences packed back to back), cu: int32 cumulative lengths [n+1]."""
+        from torch.nn.attention.varlen import varlen_attn
+
+        tot, h = x.shape
+        qkv = self.qkv(x).view(tot, 3, self.heads, h // self.heads)
+        a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len)
+        x = fused_add_layernorm(self.out(a.reshape(tot, h)), x, self.ln1)
+        x = fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
+        return x
+
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
         n, t, h = x.shape
         qkv = self.qkv(x).view(n, t, 3, self.heads, h // self.heads).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask)
         a = a.transpose(1, 2).reshape(n, t, h)
-        x = self.ln1(x + self.out(a))
-        x = self.ln2(x + self.fc2(F.gelu(self.fc1(x))))
+        x = fused_add_layernorm(self.out(a), x, self.ln1)
+        x = fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
         return x
 
 
@@ -186,9 +216,76 @@ class BertEncoder(nn.Module):
             e = F.normalize(e, p=2, dim=1)
         return e
 
+    # ---- packed (padding-free) path: varlen flash attention, every other op on [total_tokens, H] ----
+    _varlen_ok: Optional[bool] = None  # resolved on first use (per process)
+
+    def forward_packed(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, seq_of: torch.Tensor,
+                       lengths: torch.Tensor, max_len: int) -> torch.Tensor:
+        cfg = self.cfg
+        x = fused_add_layernorm(self.word(tok) + self.tok_type.weight[0][None], self.pos(pos), self.ln)
+        for L in self.layers:
+            x = L.forward_packed(x, cu, max_len)
+        n = lengths.shape[0]
+        if cfg.pooling == "cls":
+            e = x[cu[:-1].long()].float()
+        else:
+            e = torch.zeros((n, cfg.hidden), dtype=torch.float32, device=x.device).index_add_(0, seq_of, x.float())
+            e = e / lengths.clamp(min=1).unsqueeze(1).float()
+        if cfg.normalize:
+            e = F.normalize(e, p=2, dim=1)
+        return e
+
+    @torch.no_grad()
+    def encode_tokens_packed(self, input_ids: torch.Tensor, lengths: torch.Tensor, max_tokens: int = 262144) -> torch.Tensor:
+        """No padding anywhere: sequences are concatenated; sub-batches are cut by token budget."""
+        n, t = input_ids.shape
+        out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=input_ids.device)
+        if n == 0:
+            return out
+        lens64 = lengths.long()
+        csum = torch.cumsum(lens64, 0)
+        # sub-batch boundaries by cumulative token count (host side: one small D2H copy)
+        cs = csum.cpu()
+        bounds = [0]
+        base = 0
+        while bounds[-1] < n:
+            j = int(torch.searchsorted(cs, torch.tensor(base + max_tokens), right=True))
+            j = max(j, bounds[-1] + 1)
+            j = min(j, n)
+            bounds.append(j)
+            base = int(cs[j - 1])
+        ar = torch.arange(t, device=input_ids.device)
+        for b0, b1 in zip(bounds[:-1], bounds[1:]):
+            ids = input_ids[b0:b1]
+            ln = lengths[b0:b1]
+            valid = ar[None, :] < ln[:, None]
+            tok = ids[valid]
+            pos = ar[None, :].expand(b1 - b0, t)[valid]
+            seq_of = torch.arange(b1 - b0, device=ids.device)[:, None].expand(b1 - b0, t)[valid]
+            cu = torch.zeros(b1 - b0 + 1, dtype=torch.int32, device=ids.device)
+            cu[1:] = torch.cumsum(ln, 0)
+            out[b0:b1] = self.forward_packed(tok, pos, cu, seq_of, ln, int(ln.max()))
+        return out
+
     @torch.no_grad()
     def encode_tokens(self, input_ids: torch.Tensor, lengths: torch.Tensor, batch_size: int = 1024,
                       bucket: int = 32) -> torch.Tensor:
+        """Packed varlen path when the build supports it on this device (GPU, fp16/bf16), else the
+        length-bucketed padded path below."""
+        if input_ids.is_cuda and self.word.weight.dtype in (torch.float16, torch.bfloat16):
+            if BertEncoder._varlen_ok is None:
+                try:
+                    self.encode_tokens_packed(input_ids[:2], lengths[:2])
+                    BertEncoder._varlen_ok = True
+                except Exception:  # noqa: BLE001 - varlen flash attention unavailable in this build
+                    BertEncoder._varlen_ok = False
+            if BertEncoder._varlen_ok:
+                return self.encode_tokens_packed(input_ids, lengths, max_tokens=batch_size * 192)
+        return self.encode_tokens_padded(input_ids, lengths, batch_size, bucket)
+
+    @torch.no_grad()
+    def encode_tokens_padded(self, input_ids: torch.Tensor, lengths: torch.Tensor, batch_size: int = 1024,
+                             bucket: int = 32) -> torch.Tensor:
         """Length-bucketed batched forward: rows are grouped by ceil(len/bucket) and every group
         is truncated to its own max length, so padding waste is < bucket tokens per chunk."""
         n = input_ids.shape[0]

@@ -217,3 +217,28 @@ def test_gpu_graph_builder_quality(torch_):
     idx.attach_table(x)
     _, l = idx.search(q, 10, idx.make_params(ef=64, recompute=False))
     assert recall_at_k(l, gt) >= 0.97
+
+
+@pytest.mark.parametrize("hidden", [64, 384, 768, 1024, 1536])
+def test_fused_add_layernorm_kernel(torch_, hidden):
+    """lm_add_layernorm_f16 vs a plain PyTorch fp32 reference of the same op."""
+    torch = torch_
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import fused_add_layernorm
+
+    g = torch.Generator(device="cuda").manual_seed(hidden)
+    for rows in (1, 7, 1000, 4099):
+        x = torch.randn((rows, hidden), generator=g, device="cuda").half()
+        r = (3 * torch.randn((rows, hidden), generator=g, device="cuda")).half()
+        ln = nn.LayerNorm(hidden, eps=1e-12).to("cuda", dtype=torch.float16)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(hidden, generator=g, device="cuda"))
+            ln.bias.copy_(torch.randn(hidden, generator=g, device="cuda"))
+        ref = F.layer_norm(x.float() + r.float(), (hidden,), ln.weight.float(), ln.bias.float(), 1e-12)
+        got = fused_add_layernorm(x, r, ln)
+        assert got.dtype == torch.float16 and got.shape == x.shape
+        assert (got.float() - ref).abs().max() <= 4e-3 * max(1.0, float(ref.abs().max()))
+        ref1 = F.layer_norm(x.float(), (hidden,), ln.weight.float(), ln.bias.float(), 1e-12)
+        assert (fused_add_layernorm(x, None, ln).float() - ref1).abs().max() <= 4e-3 * max(1.0, float(ref1.abs().max()))
