@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=1_000_000)
-    ap.add_argument("--batch", type=int, default=1024, help="queries per rank per step")
+    ap.add_argument("--batch", type=int, default=2048, help="queries per rank per step")
     ap.add_argument("--ef", type=int, default=64, help="efSearch of the timed steps (BASELINE.json configs[1]: 64); 0 = smallest of the sweep with recall@10 >= 0.9")
     ap.add_argument("--no-min-ef-step", action="store_true", help="skip the extra step at the smallest ef reaching recall 0.9")
     ap.add_argument("--beam", type=int, default=1)

@@ -449,8 +449,8 @@ __global__ __launch_bounds__(256) void k_update_sort(WsDev ws, UpdateArgs a) {
 
 // ---- variant 0 (default): sort only the NEW keys, then merge with the (already sorted) pool by rank ----
 // LDS: pool[ef] | newk[Pn] | out[ef]   (a.P2 carries ef_lds = ef rounded up to 2, Pn is per block)
-template <int NCH, bool L2, bool F16, bool BYRANK>
-__global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
+template <int NCH, bool L2, bool F16, bool BYRANK, int NT>
+__global__ __launch_bounds__(NT) void k_update(WsDev ws, UpdateArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned long long s_best;
 
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
     int Pn = 1;
     while (Pn < n) Pn <<= 1;
 
-    for (int i = tid; i < npool0; i += 256) lpool[i] = pool[i];
-    for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+    for (int i = tid; i < npool0; i += NT) lpool[i] = pool[i];
+    for (int i = n + tid; i < Pn; i += NT) newk[i] = KEY_NONE;
     if (tid == 0) s_best = KEY_NONE;
 
     const int lane16 = tid & 15, sg = tid >> 4;
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
         for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
     }
     const int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
-    for (int i = sg; i < n; i += 32) {
-        const int i2 = i + 16;
+    for (int i = sg; i < n; i += NT / 8) {
+        const int i2 = i + NT / 16;
         const bool has2 = i2 < n;
         int32_t v0 = newid[i];
         int32_t v1 = has2 ? newid[i2] : v0;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
     __syncthreads();
 
     if (ph != PH_BEAM) {
-        for (int i = tid; i < n; i += 256) atomicMin(&s_best, (unsigned long long)newk[i]);
+        for (int i = tid; i < n; i += NT) atomicMin(&s_best, (unsigned long long)newk[i]);
         __syncthreads();
         if (tid == 0) {
             uint64_t best = s_best;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
         // bitonic sort of the new keys only
         for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
             for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
-                for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
+                for (unsigned i = tid; i < (unsigned)Pn; i += NT) {
                     unsigned ixj = i ^ j;
                     if (ixj > i) {
                         uint64_t x = newk[i], y = newk[ixj];
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
             }
         }
         // merge by rank: (dist,id) pairs are unique across pool U new, compare without the flag bit
-        for (int i = tid; i < npool0; i += 256) {
+        for (int i = tid; i < npool0; i += NT) {
             uint64_t key = lpool[i];
             uint64_t kk = key >> 1;
             int lo = 0, hi = n;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
             int r = i + lo;
             if (r < ef) out[r] = key;
         }
-        for (int j = tid; j < n; j += 256) {
+        for (int j = tid; j < n; j += NT) {
             uint64_t key = newk[j];
             uint64_t kk = key >> 1;
             int lo = 0, hi = npool0;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_update(WsDev ws, UpdateArgs a) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < npool1; i += 256) pool[i] = fin[i];
+    for (int i = tid; i < npool1; i += NT) pool[i] = fin[i];
 }
 
 // ---- variant 2 (split): flat, perfectly balanced distance kernel over the round's pair list ----------
@@ -951,7 +951,9 @@ struct lm_index {
     // stats / profiling
     lm_search_stats stats{};
     bool profiling = false;
-    int update_variant = 0;  // 0: sort-new + rank merge (default), 1: full bitonic sort (A/B reference)
+    int update_variant = 0;  // 0: auto (fused), 1: fused + full bitonic sort, 2: split, 3: fused wave-per-query, 4: fused workgroup-per-query
+    int wave_maxnew = 48;    // auto rule threshold on beam x mean level-0 degree
+    double avg_degree0 = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_expand, ev_provider;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -1053,6 +1055,12 @@ template <bool L2, bool F16>
 static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
     dim3 grid(ix->ws.B), block(256);
     const bool sortv = ix->update_variant == 1;
+    // one 64-lane wave per query when the per-round new-list is short (low degree x beam): keeps all 16-lane
+    // groups busy and quadruples the queries resident per CU; variant 3 forces it, variant 4 forbids it
+    // measured (profiles/r1_kernel_ab_wave_vs_wg.txt): the wave form wins only with >= 4096 queries in flight and
+    // <= ~48 expected new nodes per query per round (beam x mean level-0 degree)
+    const bool wave = ix->update_variant == 3 ||
+                      (ix->update_variant == 0 && ix->ws.B >= 4096 && ix->ws.W * ix->avg_degree0 <= (double)ix->wave_maxnew);
     if (ix->update_variant == 2) {
         // split: flat distance kernel (grid-stride over the pair list) + one-wave-per-query merge
         long cap = (long)ix->ws.B * ix->ws.maxnew;
@@ -1071,8 +1079,10 @@ static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
 #define CASE(n)                                                                                              \
     case n:                                                                                                  \
         if (sortv) hipLaunchKernelGGL((k_update_sort<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); \
-        else if (a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, true>), grid, block, shmem, ix->stream, ix->ws, a); \
-        else hipLaunchKernelGGL((k_update<n, L2, F16, false>), grid, block, shmem, ix->stream, ix->ws, a);   \
+        else if (wave && a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, true, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
+        else if (wave) hipLaunchKernelGGL((k_update<n, L2, F16, false, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
+        else if (a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, true, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
+        else hipLaunchKernelGGL((k_update<n, L2, F16, false, 256>), grid, block, shmem, ix->stream, ix->ws, a);   \
         break
         CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(12); CASE(16);
 #undef CASE
@@ -1238,6 +1248,9 @@ static void compute_degrees(lm_index* ix, const uint64_t* node_offsets, const ui
     }
     ix->maxdeg0 = m0;
     ix->maxdeg_up = mu;
+    double e0 = 0;
+    for (int64_t i = 0; i < ix->N; ++i) e0 += l0[i].count;
+    ix->avg_degree0 = ix->N ? e0 / (double)ix->N : 0.0;
 }
 
 extern "C" {
@@ -1426,8 +1439,12 @@ int lm_index_set_profiling(lm_index* ix, int32_t enable) {
 int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     if (!ix || !name) LM_FAIL(LM_EINVAL, "NULL argument");
     if (!std::strcmp(name, "update_variant")) {
-        if (value < 0 || value > 2) LM_FAIL(LM_EINVAL, "update_variant must be 0, 1 or 2");
+        if (value < 0 || value > 4) LM_FAIL(LM_EINVAL, "update_variant must be 0..4");
         ix->update_variant = (int)value;
+        return LM_OK;
+    }
+    if (!std::strcmp(name, "wave_maxnew")) {
+        ix->wave_maxnew = (int)value;
         return LM_OK;
     }
     LM_FAIL(LM_EINVAL, std::string("unknown option: ") + name);
