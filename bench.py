@@ -73,7 +73,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     K, W, B = args.steps, args.warmup, args.batch
-    n_q = B * (K + W + 1)  # +1: the extra step at the smallest ef that reaches recall 0.9
+    n_q = B * (K + W + 2)  # +2: extra steps (smallest ef reaching recall 0.9; per-call recompute memo)
     t_setup = time.time()
 
     # ---- corpus -> HBM token store ------------------------------------------------------------
@@ -207,6 +207,23 @@ def main():
             e2 = float(t.item())
         min_ef = {"ef_search": ef_min, "queries_per_s": round(world * B / e2, 3),
                   "recall_at_10": round(recall(l2.cpu().numpy(), range(lo, lo + B)), 4), "steps": 1}
+    # ---- extra (not `value`): one step with the per-call recompute memo (each node recomputed <= once per call)
+    with_memo = None
+    if not args.no_min_ef_step:
+        prm3 = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, recompute_memo=True)
+        lo = (W + K + 1) * B
+        barrier()
+        t1 = time.perf_counter()
+        _, l3 = idx.search_device(Q[lo : lo + B], 10, prm3)
+        barrier()
+        e3 = time.perf_counter() - t1
+        st3 = idx.stats()
+        if world > 1:
+            t = torch.tensor([e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e3 = float(t.item())
+        with_memo = {"ef_search": ef, "queries_per_s": round(world * B / e3, 3), "recall_at_10": round(recall(l3.cpu().numpy(), range(lo, lo + B)), 4),
+                     "recomputed_chunks_per_query": round(st3["nunique"] / B, 1), "steps": 1}
     labels_np = torch.cat(out_labels).cpu().numpy() if out_labels else np.zeros((0, 10), np.int64)
     rec = recall(labels_np, range(W * B, (W + K) * B)) if K else 0.0
     if world > 1:
@@ -250,6 +267,8 @@ def main():
     }
     if min_ef:
         result["at_min_ef"] = min_ef
+    if with_memo:
+        result["with_per_call_recompute_memo"] = with_memo
     if table_roof:
         result["roofline_table_mode"] = table_roof
 

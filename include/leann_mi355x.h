@@ -109,6 +109,9 @@ typedef struct {
     int32_t zmq_port;                /* accepted, unused: the encoder is in-process   :205 */
     int32_t recompute;               /* 1: use the provider, 0: use the attached table */
     int32_t max_batch;               /* queries in flight per pass (0 = default 4096) */
+    int32_t recompute_memo;          /* 1: within ONE search call every node is recomputed at most once (fresh
+                                        embeddings are kept in HBM until the call returns); 0 (default): dedup
+                                        per round only.  Cf. DiskANN's dedup_node_dis (diskann_backend.py:463). */
 } lm_search_params;
 void lm_search_params_default(lm_search_params *p);
 

@@ -39,6 +39,7 @@ class SearchParams(C.Structure):
         ("efSearch", C.c_int32), ("beam_size", C.c_int32), ("check_relative_distance", C.c_int32),
         ("pq_pruning_ratio", C.c_float), ("local_prune", C.c_int32), ("send_neigh_times_ratio", C.c_float),
         ("batch_size", C.c_int32), ("zmq_port", C.c_int32), ("recompute", C.c_int32), ("max_batch", C.c_int32),
+        ("recompute_memo", C.c_int32),
     ]
 
 

@@ -63,6 +63,9 @@ struct WsDev {
     int32_t* word_rank;   // nw
     int32_t* tile_sum;    // ntiles
     int32_t* uniq;        // ucap
+    // per-call embedding memo (recompute_memo): every node is recomputed at most once per search call
+    int32_t* memo_slot;   // N : row in `memo` or -1
+    float* memo;          // memo_cap x Dp
     // flat (query,node) pair list of the round (split variant): segments allocated by atomicAdd
     int32_t* seg_start;   // B
     int32_t* pair_q;      // B x maxnew
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
     for (int i = lane; i < total; i += 64) {
         const int32_t v = s_new[i];
         newid[i] = v;
-        if (use_rbm) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+        if (use_rbm == 1 || (use_rbm == 2 && ws.memo_slot[v] < 0)) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
         if (flat) {
             ws.pair_q[start + i] = q;
             ws.pair_v[start + i] = v;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void k_update_sort(WsDev ws, UpdateArgs a) {
 
 // ---- variant 0 (default): sort only the NEW keys, then merge with the (already sorted) pool by rank ----
 // LDS: pool[ef] | newk[Pn] | out[ef]   (a.P2 carries ef_lds = ef rounded up to 2, Pn is per block)
-template <int NCH, bool L2, bool F16, bool BYRANK, int NT>
+template <int NCH, bool L2, bool F16, int MODE, int NT>  // MODE 0: row = node id (table), 1: rank in the round's unique list, 2: memo slot
 __global__ __launch_bounds__(NT) void k_update(WsDev ws, UpdateArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned long long s_best;
@@ -486,9 +489,12 @@ __global__ __launch_bounds__(NT) void k_update(WsDev ws, UpdateArgs a) {
         int32_t v0 = newid[i];
         int32_t v1 = has2 ? newid[i2] : v0;
         int64_t s0 = v0, s1 = v1;
-        if (BYRANK) {
+        if (MODE == 1) {
             s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
             s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
+        } else if (MODE == 2) {
+            s0 = ws.memo_slot[v0];
+            s1 = ws.memo_slot[v1];
         }
         float4 e0[NCH], e1[NCH];
         load_row<NCH, F16>(a.E, s0, lane16, e0);
@@ -787,6 +793,16 @@ __global__ void k_finalize(WsDev ws, int32_t k, int32_t metric, int64_t* labels,
     }
 }
 
+// append this round's fresh embeddings to the per-call memo and publish their slots
+__global__ __launch_bounds__(256) void k_memo_append(WsDev ws, const float* e_new, int32_t nu, int64_t base, int32_t Dp) {
+    const int64_t nvec = (int64_t)nu * (Dp / 4);
+    const float4* src = (const float4*)e_new;
+    float4* dst = (float4*)(ws.memo + base * Dp);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nu; i += (int64_t)gridDim.x * 256)
+        ws.memo_slot[ws.uniq[i]] = (int32_t)(base + i);
+}
+
 // end-of-search totals: nexpand = sum of per-query pops (nsteps), ndis = sum of per-query evaluations
 __global__ __launch_bounds__(256) void k_stats(WsDev ws) {
     __shared__ unsigned long long red[2][4];
@@ -944,6 +960,9 @@ struct lm_index {
     WsDev ws{};
     int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0;
     int64_t ws_ucap = 0;
+    int32_t* d_memo_slot = nullptr;
+    float* d_memo = nullptr;
+    int64_t memo_cap = 0;
     std::vector<void*> ws_allocs;
     float* d_qpad = nullptr;
     int64_t qpad_cap = 0;
@@ -952,7 +971,9 @@ struct lm_index {
     lm_search_stats stats{};
     bool profiling = false;
     int update_variant = 0;  // 0: auto (fused), 1: fused + full bitonic sort, 2: split, 3: fused wave-per-query, 4: fused workgroup-per-query
-    int wave_maxnew = 48;    // auto rule threshold on beam x mean level-0 degree
+    int wave_maxnew = 0;     // auto rule threshold on beam x mean level-0 degree; 0 = never: on the 1M-chunk HNSW graph
+                             // (max degree 64, mean 9.3) the workgroup form is 1.5x faster (profiles/r1_bench_default_1M_b2048.json
+                             // vs r1_bench_default_1M.json), although the wave form wins on uniform-degree graphs
     double avg_degree0 = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_update, ev_expand, ev_provider;
     std::vector<hipEvent_t> ev_pool;
@@ -1079,10 +1100,11 @@ static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
 #define CASE(n)                                                                                              \
     case n:                                                                                                  \
         if (sortv) hipLaunchKernelGGL((k_update_sort<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); \
-        else if (wave && a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, true, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
-        else if (wave) hipLaunchKernelGGL((k_update<n, L2, F16, false, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
-        else if (a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, true, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
-        else hipLaunchKernelGGL((k_update<n, L2, F16, false, 256>), grid, block, shmem, ix->stream, ix->ws, a);   \
+        else if (a.by_rank == 2) hipLaunchKernelGGL((k_update<n, L2, F16, 2, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
+        else if (wave && a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, 1, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
+        else if (wave) hipLaunchKernelGGL((k_update<n, L2, F16, 0, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
+        else if (a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, 1, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
+        else hipLaunchKernelGGL((k_update<n, L2, F16, 0, 256>), grid, block, shmem, ix->stream, ix->ws, a);   \
         break
         CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(8); CASE(12); CASE(16);
 #undef CASE
@@ -1110,6 +1132,21 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     WsDev& ws = ix->ws;
     hipStream_t st = ix->stream;
     const bool recompute = prm.recompute != 0;
+    const bool memo = recompute && prm.recompute_memo != 0 && ix->update_variant != 1 && ix->update_variant != 2;
+    int64_t memo_used = 0;
+    if (memo) {
+        if (!ix->d_memo_slot) LM_HIP(hipMalloc((void**)&ix->d_memo_slot, (size_t)ix->N * 4));
+        const int64_t want = std::min<int64_t>(ix->N, 16ll << 20);
+        if (ix->memo_cap < want) {
+            if (ix->d_memo) (void)hipFree(ix->d_memo);
+            ix->d_memo = nullptr;
+            LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
+            ix->memo_cap = want;
+        }
+        ws.memo_slot = ix->d_memo_slot;
+        ws.memo = ix->d_memo;
+        LM_HIP(hipMemsetAsync(ix->d_memo_slot, 0xFF, (size_t)ix->N * 4, st));
+    }
     GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
     const int flat = ix->update_variant == 2 ? 1 : 0;
 
@@ -1133,7 +1170,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         if (flat) LM_HIP(hipMemsetAsync(ws.counters + C_NPAIRS, 0, sizeof(unsigned long long), st));
         {
             EvScope es(ix, &ix->ev_expand);
-            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, recompute ? 1 : 0,
+            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, recompute ? (memo ? 2 : 1) : 0,
                                (int)(rounds + 1), flat);
             if (recompute) {
                 hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
@@ -1156,8 +1193,19 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
                 int prc = ix->provider(ix->provider_user, ws.uniq, nu, &d_e, (void*)st);
                 if (prc != 0 || !d_e) LM_FAIL(LM_EPROVIDER, "embedding provider failed (rc=" + std::to_string(prc) + ")");
             }
-            ua.E = d_e;
-            ua.by_rank = 1;
+            if (memo) {
+                if (nu > 0) {
+                    if (memo_used + nu > ix->memo_cap) LM_FAIL(LM_ESTATE, "recompute memo is full (more than 16M distinct nodes in one call)");
+                    hipLaunchKernelGGL(k_memo_append, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nu * (ix->Dp / 4) + 255) / 256)),
+                                       dim3(256), 0, st, ws, (const float*)d_e, nu, memo_used, ix->Dp);
+                    memo_used += nu;
+                }
+                ua.E = ix->d_memo;
+                ua.by_rank = 2;
+            } else {
+                ua.E = d_e;
+                ua.by_rank = 1;
+            }
             EvScope es(ix, &ix->ev_update);
             rc = launch_update(ix, ua, false);
         } else {
@@ -1362,6 +1410,8 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_level_ptr) (void)hipFree(ix->d_level_ptr);
     if (ix->d_neighbors) (void)hipFree(ix->d_neighbors);
     if (ix->d_l0) (void)hipFree(ix->d_l0);
+    if (ix->d_memo_slot) (void)hipFree(ix->d_memo_slot);
+    if (ix->d_memo) (void)hipFree(ix->d_memo);
     if (ix->d_pq_codebooks) (void)hipFree(ix->d_pq_codebooks);
     if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
     if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);

@@ -122,6 +122,42 @@ def test_update_kernel_variants_parity(env, variant):
     _check(env, x, g, queries_near(x, 16, seed=6), 5, 32, 3, "provider", variant=variant, check_rel=False)
 
 
+def test_recompute_memo_same_results_fewer_recomputes(env):
+    """recompute_memo=1: every node is recomputed at most once per call; ids/distances unchanged."""
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    torch = env
+    x, g = _build(3000, 384, "mips", seed=1)
+    q = queries_near(x, 64, seed=12)
+    xdev = torch.from_numpy(x).cuda()
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    keep, seen = {}, []
+
+    def provider(d_ids, n, stream):
+        ids = as_tensor(d_ids, (n,), "int32")
+        seen.append(ids.cpu().numpy().copy())
+        keep["e"] = xdev.index_select(0, ids.long()).contiguous()
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+    res = {}
+    for memo in (False, True):
+        seen.clear()
+        d, l = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True, recompute_memo=memo))
+        torch.cuda.synchronize()
+        allids = np.concatenate(seen)
+        res[memo] = (d.cpu().numpy(), l.cpu().numpy(), idx.stats()["nunique"], allids)
+    oi, od, _ = orc.search(oracle_graph(g, 384), q, 10, ef=64, beam=2, table=x)
+    for memo in (False, True):
+        assert np.array_equal(res[memo][1], oi) and np.array_equal(res[memo][0], od)
+    assert res[True][2] < res[False][2]
+    assert len(np.unique(res[True][3])) == len(res[True][3])  # nothing recomputed twice within the call
+    assert set(res[True][3].tolist()) == set(res[False][3].tolist())
+
+
 def test_fp16_table(env):
     x, g = _build(1500, 768, "mips", seed=5)
     q = queries_near(x, 24, seed=8)

@@ -242,3 +242,40 @@ def test_fused_add_layernorm_kernel(torch_, hidden):
         assert (got.float() - ref).abs().max() <= 4e-3 * max(1.0, float(ref.abs().max()))
         ref1 = F.layer_norm(x.float(), (hidden,), ln.weight.float(), ln.bias.float(), 1e-12)
         assert (fused_add_layernorm(x, None, ln).float() - ref1).abs().max() <= 4e-3 * max(1.0, float(ref1.abs().max()))
+
+
+def test_sharded_search_merge_on_gpu(torch_):
+    """60M-chunk mode in miniature (single process): two disjoint shards searched on the GPU, per-shard
+    top-k merged by the lm_topk_merge kernel == exact merge by the oracle; ids are global."""
+    torch = torch_
+    from leann_amd.distributed import ShardedSearch, hip_merge_fn, shard_bounds
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x = clustered(6000, 64, 21)
+    q = queries_near(x, 50, 22)
+    parts = []
+    for lo, hi in shard_bounds(6000, 2):
+        g = build_hnsw(x[lo:hi], "mips", M=8, ef_construction=40)
+        idx = Mi355xIndex.from_csr(g)
+        idx.attach_table(x[lo:hi])
+        d, l = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, recompute=False))
+        l = torch.where(l >= 0, l + lo, l)
+        parts.append((d, l))
+        idx.close()
+    ids = torch.stack([p[1] for p in parts])
+    dist = torch.stack([p[0] for p in parts])
+    oi, od = hip_merge_fn(ids, dist, 0)
+    ei, ed = orc.merge_topk(ids.cpu().numpy(), dist.cpu().numpy(), 0)
+    assert np.array_equal(oi.cpu().numpy(), ei) and np.array_equal(od.cpu().numpy(), ed)
+    gt, _ = orc.bruteforce_topk(x, q, 10, 0)
+    assert recall_at_k(ei, gt) > 0.95
+    # world_size 1 ShardedSearch degenerates to a merge of one list
+    g = build_hnsw(x, "mips", M=8, ef_construction=40)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_table(x)
+    ss = ShardedSearch(lambda qq, k: idx.search_device(qq, k, idx.make_params(ef=64, recompute=False)), id_base=0, metric=0)
+    d1, i1 = ss.search(torch.from_numpy(q).cuda(), 10)
+    d2, i2 = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, recompute=False))
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
