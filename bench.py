@@ -236,8 +236,17 @@ def main():
     bytes_eval = D * 4 + 4  # D*s_e + 4 (id); the distance never goes back to HBM (fused)
     upd_s = agg["update_ms"] * 1e-3
     achieved = agg["ndis"] * bytes_eval / upd_s / 1e9 if upd_s > 0 else 0.0
+    traffic = None
+    traffic_src = None
+    try:  # HBM bytes per launch from the separate PMC pass (profiles/r1_pmc_k_update.json), scaled to this run's launch size
+        pmc = json.loads((ROOT / "profiles" / "r1_pmc_k_update.json").read_text())
+        traffic = round(pmc["hbm_bytes_per_eval_corrected_x1.08"] * agg["ndis"] / max(agg["update_launches"], 1))
+        traffic_src = "rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/r1_pmc_k_update.json), x1.08 calibration, scaled by evals/launch"
+    except Exception:  # noqa: BLE001
+        pass
     roofline = {"bound": "hbm", "kernel": "lm::k_update<6,false,false,true> (fused gather + distance + beam update, recompute mode)", "achieved": round(achieved, 2),
-                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(bytes_eval * agg["ndis"] / max(agg["update_launches"], 1)),
                 "bytes_per_eval": bytes_eval, "evals_per_launch": round(agg["ndis"] / max(agg["update_launches"], 1), 1),
                 "us_per_launch": round(1e3 * agg["update_ms"] / max(agg["update_launches"], 1), 2)}
     # encoder (MFMA bound): flops of the chunks actually recomputed / HIP-event time of the provider

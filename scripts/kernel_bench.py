@@ -28,6 +28,8 @@ ap.add_argument("--ef", type=int, default=64)
 ap.add_argument("--beam", type=int, default=4)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--provider", action="store_true", help="recompute mode: embeddings served by a provider (index_select of the table)")
+ap.add_argument("--memo", action="store_true")
 args = ap.parse_args()
 
 _lib.require_gpu()
@@ -76,11 +78,20 @@ idx.set_stream(st)
 idx.attach_table(X)
 idx.set_profiling(True)
 idx.set_option("update_variant", args.variant)
-prm = idx.make_params(ef=args.ef, beam=args.beam, recompute=False, max_batch=args.batch)
+keep = {}
+if args.provider:
+    from leann_amd.devmem import as_tensor
+
+    def provider(d_ids, n, stream):
+        keep["e"] = X.index_select(0, as_tensor(d_ids, (n,), "int32").long())
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+prm = idx.make_params(ef=args.ef, beam=args.beam, recompute=args.provider, max_batch=args.batch, recompute_memo=args.memo)
 for r in range(args.reps):
     idx.search_device(Q, 10, prm)
     s = idx.stats()
-out["search"] = {"batch": args.batch, "ef": args.ef, "beam": args.beam, "variant": args.variant, "ndis": s["ndis"],
+out["search"] = {"batch": args.batch, "ef": args.ef, "beam": args.beam, "variant": args.variant, "provider": args.provider, "memo": args.memo, "nunique": s["nunique"], "ndis": s["ndis"],
                  "launches": s["update_launches"], "update_ms": round(s["update_ms"], 3), "expand_ms": round(s["expand_ms"], 3),
                  "evals_per_launch": round(s["ndis"] / s["update_launches"], 1),
                  "update_GBps_algorithmic": round(s["ndis"] * (D * 4 + 4) / s["update_ms"] / 1e6, 1)}
