@@ -69,10 +69,10 @@ def test_token_gather_kernel(torch_):
         assert np.array_equal(lens.cpu().numpy(), el[ids.cpu().numpy()])
 
 
-def _tiny_encoder(torch, dim=64):
+def _tiny_encoder(torch, dim=64, pooling="mean"):
     from leann_amd.encoder import BertEncoder, EncoderConfig
 
-    cfg = EncoderConfig(vocab_size=30522, hidden=dim, layers=2, heads=4, ffn=128, max_pos=256, max_seq_length=256)
+    cfg = EncoderConfig(vocab_size=30522, hidden=dim, layers=2, heads=4, ffn=128, max_pos=256, max_seq_length=256, pooling=pooling)
     return BertEncoder.random_init(cfg, seed=3)
 
 
@@ -95,8 +95,9 @@ def test_encoder_gpu_matches_cpu_fp32_and_fp16(torch_):
     assert (ref - g16).abs().max() < 5e-3
 
 
-def test_recompute_search_end_to_end_bit_exact_given_same_embeddings(torch_):
-    """Full hot path: ids -> HBM token gather -> BERT -> fused distance/beam update.  The oracle
+@pytest.mark.parametrize("dim,pooling", [(64, "mean"), (768, "cls")])
+def test_recompute_search_end_to_end_bit_exact_given_same_embeddings(torch_, dim, pooling):
+    """Full hot path (dim 768 + CLS pooling = the bge-base shape of config C5, shallow): ids -> HBM token gather -> BERT -> fused distance/beam update.  The oracle
     consumes the GPU encoder's OWN outputs (captured per round), so traversal + distances must be
     bit-exact (hard part 2d)."""
     torch = torch_
@@ -111,14 +112,14 @@ def test_recompute_search_end_to_end_bit_exact_given_same_embeddings(torch_):
     c = SyntheticCorpus(CorpusSpec(n_chunks=n, n_topics=8))
     tok, off = c.chunks()
     ts = TokenStore(tok, off)
-    enc = _tiny_encoder(torch).to("cuda", dtype=torch.float16)
-    prov = RecomputeProvider(enc, ts, 64, torch.device("cuda"), batch_size=512)
+    enc = _tiny_encoder(torch, dim, pooling).to("cuda", dtype=torch.float16)
+    prov = RecomputeProvider(enc, ts, dim, torch.device("cuda"), batch_size=512)
     X = prov.embed_ids(torch.arange(n, dtype=torch.int32, device="cuda"))
     g = build_graph_gpu(X, "mips", M=12, ef_construction=60)
     g.validate()
     qt, qo, _ = c.queries(24)
     qs = TokenStore(qt, qo)
-    Q = RecomputeProvider(enc, qs, 64, torch.device("cuda")).embed_ids(torch.arange(24, dtype=torch.int32, device="cuda"))
+    Q = RecomputeProvider(enc, qs, dim, torch.device("cuda")).embed_ids(torch.arange(24, dtype=torch.int32, device="cuda"))
     idx = Mi355xIndex.from_csr(g)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
     rounds = []
@@ -127,7 +128,7 @@ def test_recompute_search_end_to_end_bit_exact_given_same_embeddings(torch_):
         from leann_amd.devmem import as_tensor
 
         p = prov(d_ids, cnt, stream)
-        rounds.append((as_tensor(d_ids, (cnt,), "int32").cpu().numpy().copy(), as_tensor(p, (cnt, 64), "float32").cpu().numpy().copy()))
+        rounds.append((as_tensor(d_ids, (cnt,), "int32").cpu().numpy().copy(), as_tensor(p, (cnt, dim), "float32").cpu().numpy().copy()))
         return p
 
     idx.set_provider(recording)
@@ -140,7 +141,7 @@ def test_recompute_search_end_to_end_bit_exact_given_same_embeddings(torch_):
         assert np.array_equal(ids, idv)
         return emb
 
-    oi, od, _ = orc.search(oracle_graph(g, 64), Q.cpu().numpy(), 10, ef=48, beam=2, provider=replay)
+    oi, od, _ = orc.search(oracle_graph(g, dim), Q.cpu().numpy(), 10, ef=48, beam=2, provider=replay)
     assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od)
     # and the recompute path finds what the stored-embedding path finds (recall sanity)
     gt, _ = orc.bruteforce_topk(X.cpu().numpy(), Q.cpu().numpy(), 10, 0)
