@@ -102,9 +102,13 @@ typedef struct {
     int32_t efSearch;                /* complexity                               :206 */
     int32_t beam_size;               /* beam_width: pops per query per round     :207 */
     int32_t check_relative_distance; /* 0 for OpenAI-cosine models               :209-217 */
-    float pq_pruning_ratio;          /* prune_ratio (two-level search; 0 = off)  :220 */
-    int32_t local_prune;             /* pruning_strategy == "local"              :223-225 */
-    float send_neigh_times_ratio;    /* pruning_strategy == "proportional"       :226-228 */
+    float pq_pruning_ratio;          /* prune_ratio: two-level search (paper Alg. 2), needs lm_pq_attach; only the
+                                        fraction 1-ratio of the candidates, ranked by PQ-ADC distance, is
+                                        recomputed exactly.  0 = off                                    :220 */
+    int32_t local_prune;             /* pruning_strategy == "local": rank this hop's neighbours only    :223-225 */
+    float send_neigh_times_ratio;    /* > 1e-6: "proportional": quota from this hop's count, taken from the
+                                        per-query approximate queue; else "global": everything unconsumed in
+                                        the top (1-ratio) fraction of the approximate queue            :226-231 */
     int32_t batch_size;              /* accepted, unused: rounds batch across queries :234 */
     int32_t zmq_port;                /* accepted, unused: the encoder is in-process   :205 */
     int32_t recompute;               /* 1: use the provider, 0: use the attached table */
@@ -135,6 +139,7 @@ typedef struct {
     double update_ms;     /* summed HIP-event time of those launches (profiling on)          */
     double expand_ms;     /* summed HIP-event time of the expand(+uniq) kernels              */
     double provider_ms;   /* summed HIP-event time spent in provider work                    */
+    int64_t nadc;         /* PQ-ADC evaluations of the two-level search (pq_pruning_ratio > 0) */
 } lm_search_stats;
 int lm_index_get_stats(const lm_index *idx, lm_search_stats *out);
 int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around kernels */

@@ -84,6 +84,15 @@ class Mi355xBuilder(LeannBackendBuilderInterface):
         g.storage = np.ascontiguousarray(data, dtype=np.float32)
         # the file always uses the CSR layout; "non-compact" in the reference == embeddings kept
         write_index(path.parent / f"{path.stem}.index", g, prune_embeddings=bool(self.is_recompute))
+        pq_bytes = int(self.build_params.get("pq_bytes", 0) or 0)
+        if pq_bytes > 0:  # optional product quantiser for the two-level search (prune_ratio), cf. the fork's PQ pruning
+            import torch
+
+            from .pq import encode_pq, train_pq
+
+            x = torch.from_numpy(np.ascontiguousarray(data))
+            cb = train_pq(x, pq_bytes, seed=0)
+            np.savez(path.parent / f"{path.stem}_pq.npz", codebooks=cb.numpy(), codes=encode_pq(x, cb).numpy())
 
 
 class _NoServer:
@@ -150,6 +159,12 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             self._index = Mi355xIndex.read(str(self.index_file), device=self.device)
             if self._index.info.d != int(self.dimensions):
                 raise ValueError(f"index dimension {self._index.info.d} != meta dimensions {self.dimensions}")
+            pqf = self.index_dir / f"{self.index_path.stem}_pq.npz"
+            self._has_pq = False
+            if pqf.exists():  # product quantiser for the two-level search (prune_ratio > 0)
+                z = np.load(pqf)
+                self._index.attach_pq(z["codebooks"], z["codes"])
+                self._has_pq = True
         return self._index
 
     def _torch_device(self):
@@ -275,6 +290,9 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
         if recompute_embeddings and self._provider is None:
             self._ensure_server_running(str(self.index_dir / f"{self.index_path.name}.meta.json"), zmq_port)
         # hnsw_backend.py:209-217: OpenAI cosine models disable the relative distance check
+        if prune_ratio and not getattr(self, "_has_pq", False):
+            logger.warning("prune_ratio > 0 needs a product quantiser (<stem>_pq.npz, build with pq_bytes=...); ignoring it")
+            prune_ratio = 0.0
         model = (self.meta.get("embedding_model") or "").lower()
         check_rel = not (self.distance_metric == "cosine" and any(m in model for m in ["text-embedding", "openai"]))
         params = idx.make_params(

@@ -63,6 +63,10 @@ struct WsDev {
     int32_t* word_rank;   // nw
     int32_t* tile_sum;    // ntiles
     int32_t* uniq;        // ucap
+    // two-level search (prune_ratio): per-query approximate queue of (PQ-ADC distance, id) keys, bit0 = consumed
+    uint64_t* aq;         // B x AQ_CAP
+    int32_t* naq;         // B
+    unsigned long long* nadc_q;  // B
     // per-call embedding memo (recompute_memo): every node is recomputed at most once per search call
     int32_t* memo_slot;   // N : row in `memo` or -1
     float* memo;          // memo_cap x Dp
@@ -74,9 +78,10 @@ struct WsDev {
     // counters: [0]=live queries this round [1]=n_uniq [2..] stats
     unsigned long long* counters;
 };
-enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NPAIRS = 5, C_NCOUNTERS = 8 };
+enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NPAIRS = 5, C_NADC = 6, C_NCOUNTERS = 8 };
 
 constexpr int UNIQ_TILE = 4096;  // words per block in the uniq scan
+constexpr int AQ_CAP = 512;       // capacity of the approximate queue (== ORC_AQ_CAP in oracle/lm_oracle.c)
 
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -92,6 +97,8 @@ __global__ void k_init(WsDev ws, int32_t max_level) {
     ws.npop[q] = 0;
     ws.nnew[q] = 0;
     ws.ndis_q[q] = 0;
+    ws.naq[q] = 0;
+    ws.nadc_q[q] = 0;
 }
 
 __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32_t level, uint64_t& b, uint32_t& cnt) {
@@ -104,7 +111,8 @@ __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32
 // one wave (64 lanes) per query.  Level-0 expansion is FLATTENED over (pop, neighbour) so that the
 // dependent chain is pop -> l0 range -> neighbour ids -> visited atomic, once per 64 neighbours
 // instead of once per popped node.  Dynamic LDS: maxnew ints (staging of the new-list).
-__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int flat) {
+__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int flat, int defer) {
+    // defer != 0: the two-level pruning kernel (k_prune) finishes the new-list: it marks the dedup bitmap and counts
     extern __shared__ int32_t s_new[];
     __shared__ uint32_t s_off[65];
     __shared__ uint64_t s_b[64];
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
     for (int i = lane; i < total; i += 64) {
         const int32_t v = s_new[i];
         newid[i] = v;
-        if (use_rbm == 1 || (use_rbm == 2 && ws.memo_slot[v] < 0)) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+        if (!defer && (use_rbm == 1 || (use_rbm == 2 && ws.memo_slot[v] < 0))) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
         if (flat) {
             ws.pair_q[start + i] = q;
             ws.pair_v[start + i] = v;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
     if (lane == 0) {
         ws.nnew[q] = total;
         if (flat) ws.seg_start[q] = start;
-        ws.ndis_q[q] += (unsigned long long)total;
+        if (!defer) ws.ndis_q[q] += (unsigned long long)total;
         // plain stores of identical values (benign): a contended same-address atomic costs ~12 ns per
         // workgroup and serialises the launch tail (MI355X_MICROARCH.md, price list row "fanin")
         ws.counters[C_LIVE] = 1ull;
@@ -256,6 +264,175 @@ __global__ __launch_bounds__(256) void k_uniq_emit(WsDev ws, int ntiles) {
         __syncthreads();
     }
     if (blockIdx.x == (unsigned)ntiles - 1 && tid == 0) ws.counters[C_NUNIQ] = (unsigned long long)run;
+}
+
+
+// ---- two-level search (paper Alg. 2; prune_ratio / pruning_strategy of hnsw_backend.py:219-231) --------
+// Per-query lookup tables for the whole batch: lut[q][j][c]  (canonical: oracle/lm_oracle_pq.c orc_pq_lut)
+struct PruneArgs {
+    const float* Q;      // B x Dp
+    float* lut;          // B x m x 256
+    const float* codebooks;
+    const uint8_t* codes;
+    int32_t Dp, metric, m, dsub;
+    float keep;          // a = 1 - prune_ratio
+    int32_t strategy;    // 0 global, 1 local, 2 proportional
+    int32_t use_rbm;     // 1: mark the dedup bitmap, 2: only nodes without a memo row, 0: stored-embedding mode
+    int32_t Pmax;        // pow2 >= maxnew
+};
+
+__global__ __launch_bounds__(256) void k_pq_lut_all(PruneArgs a) {
+    const int q = blockIdx.x;
+    const float* qv = a.Q + (size_t)q * a.Dp;
+    float* lut = a.lut + (size_t)q * a.m * 256;
+    for (int e = threadIdx.x; e < a.m * 256; e += 256) {
+        const int j = e >> 8;
+        const float* cb = a.codebooks + (size_t)e * a.dsub;
+        const float* qs = qv + j * a.dsub;
+        float acc = 0.0f;
+        if (a.metric == LM_METRIC_L2) {
+            for (int t = 0; t < a.dsub; ++t) {
+                float d = qs[t] - cb[t];
+                acc = __builtin_fmaf(d, d, acc);
+            }
+        } else {
+            for (int t = 0; t < a.dsub; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+            acc = -acc;
+        }
+        lut[e] = acc;
+    }
+}
+
+// one workgroup per query: ADC of the fresh list, approximate-queue update, selection of the nodes that get
+// an exact (recomputed) distance this round.  dynamic LDS: nk[Pmax] | aq[AQ_CAP] | out[AQ_CAP]  (u64)
+__global__ __launch_bounds__(256) void k_prune(WsDev ws, PruneArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_cnt;
+    uint64_t* nk = (uint64_t*)smem;
+    uint64_t* aq = nk + a.Pmax;
+    uint64_t* out = aq + AQ_CAP;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int ph = ws.phase[q];
+    if (ph == PH_DONE) return;
+    int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
+    const int n = ws.nnew[q];
+    auto mark = [&](int32_t v) {
+        if (a.use_rbm == 1 || (a.use_rbm == 2 && ws.memo_slot[v] < 0)) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
+    };
+    if (ph != PH_BEAM) {  // seed / upper levels: no pruning, just finish what k_expand deferred
+        for (int i = tid; i < n; i += 256) mark(newid[i]);
+        if (tid == 0) ws.ndis_q[q] += (unsigned long long)n;
+        return;
+    }
+    // ---- ADC of the fresh nodes: 4 lanes per vector, LUT in global/L2 ----
+    const float* lut = a.lut + (size_t)q * a.m * 256;
+    const int mw = a.m >> 2;
+    int Pn = 1;
+    while (Pn < n) Pn <<= 1;
+    {
+        const int r = tid & 3, gi = tid >> 2;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + gi;
+            const int32_t v = i < n ? newid[i] : newid[0];
+            const uint32_t* cw = (const uint32_t*)(a.codes + (size_t)v * a.m);
+            float p = 0.0f;
+            for (int w = 0; w < mw; ++w) {
+                uint32_t word = cw[w];
+                p = p + lut[((4 * w + r) << 8) + ((word >> (8 * r)) & 255u)];
+            }
+            float s01 = p + __shfl_xor(p, 1, 4);
+            float tot = s01 + __shfl_xor(s01, 2, 4);
+            if (r == 0 && i < n) nk[i] = make_key(tot, v);
+        }
+        for (int i = n + tid; i < Pn; i += 256) nk[i] = KEY_NONE;
+    }
+    const int naq0 = ws.naq[q];
+    uint64_t* gaq = ws.aq + (size_t)q * AQ_CAP;
+    if (a.strategy != 1)
+        for (int i = tid; i < naq0; i += 256) aq[i] = gaq[i];
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1)
+        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+            for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
+                unsigned ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t x = nk[i], y = nk[ixj];
+                    bool up = (i & k2) == 0;
+                    if ((x > y) == up) {
+                        nk[i] = y;
+                        nk[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const int quota = (int)ceilf(a.keep * (float)n);
+    int nsel = 0;
+    if (a.strategy == 1) {  // local: the best of this hop
+        nsel = min(quota, n);
+        for (int i = tid; i < nsel; i += 256) {
+            int32_t v = key_id(nk[i]);
+            newid[i] = v;
+            mark(v);
+        }
+    } else {
+        // merge the sorted fresh keys into the approximate queue by rank (ids are unique: visited filter)
+        const int naq1 = min(AQ_CAP, naq0 + n);
+        for (int i = tid; i < naq0; i += 256) {
+            uint64_t key = aq[i];
+            uint64_t kk = key >> 1;
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((nk[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+            if (i + lo < AQ_CAP) out[i + lo] = key;
+        }
+        for (int j = tid; j < n; j += 256) {
+            uint64_t key = nk[j];
+            uint64_t kk = key >> 1;
+            int lo = 0, hi = naq0;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((aq[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+            if (j + lo < AQ_CAP) out[j + lo] = key;
+        }
+        __syncthreads();
+        // global: every unconsumed entry inside the top keep-fraction of the queue;
+        // proportional: the first `quota` unconsumed entries of the queue
+        const int lim = a.strategy == 0 ? min(naq1, (int)ceilf(a.keep * (float)naq1)) : naq1;
+        const int cap = a.strategy == 0 ? AQ_CAP : quota;
+        if (tid < 64) {
+            int found = 0;
+            for (int base = 0; base < lim && found < cap; base += 64) {
+                int i = base + tid;
+                bool un = i < lim && !(out[i] & KEY_EXPANDED);
+                unsigned long long m = __ballot(un);
+                int r = found + __popcll(m & ((1ull << tid) - 1ull));
+                if (un && r < cap) {
+                    out[i] |= KEY_EXPANDED;
+                    int32_t v = key_id(out[i]);
+                    newid[r] = v;
+                    mark(v);
+                }
+                found += __popcll(m);
+            }
+            if (tid == 0) s_cnt = min(found, cap);
+        }
+        __syncthreads();
+        nsel = s_cnt;
+        for (int i = tid; i < naq1; i += 256) gaq[i] = out[i];
+        if (tid == 0) ws.naq[q] = naq1;
+    }
+    if (tid == 0) {
+        ws.nnew[q] = nsel;
+        ws.ndis_q[q] += (unsigned long long)nsel;
+        ws.nadc_q[q] += (unsigned long long)n;
+    }
 }
 
 // ---- canonical distance: 16 lanes per row, lane t owns float4 chunks t, t+16, ... -------------
@@ -806,23 +983,28 @@ __global__ __launch_bounds__(256) void k_memo_append(WsDev ws, const float* e_ne
 // end-of-search totals: nexpand = sum of per-query pops (nsteps), ndis = sum of per-query evaluations
 __global__ __launch_bounds__(256) void k_stats(WsDev ws) {
     __shared__ unsigned long long red[2][4];
-    unsigned long long a = 0, b = 0;
+    __shared__ unsigned long long red2[4];
+    unsigned long long a = 0, b = 0, c = 0;
     for (int q = threadIdx.x; q < ws.B; q += 256) {
         a += ws.ndis_q[q];
         b += (unsigned long long)ws.nsteps[q];
+        c += ws.nadc_q[q];
     }
     for (int m = 32; m >= 1; m >>= 1) {
         a += __shfl_xor(a, m);
         b += __shfl_xor(b, m);
+        c += __shfl_xor(c, m);
     }
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = a;
         red[1][threadIdx.x >> 6] = b;
+        red2[threadIdx.x >> 6] = c;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         ws.counters[C_NDIS] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         ws.counters[C_NEXPAND] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        ws.counters[C_NADC] = red2[0] + red2[1] + red2[2] + red2[3];
     }
 }
 
@@ -948,6 +1130,8 @@ struct lm_index {
     unsigned long long* d_pq_nadc = nullptr;
     int32_t* d_pq_rounds = nullptr;
     int64_t pq_cap = 0;
+    float* d_lut = nullptr;  // two-level search: B x m x 256
+    int64_t lut_cap = 0;
     // stored embeddings
     void* d_table = nullptr;
     bool table_owned = false;
@@ -996,8 +1180,9 @@ static int ws_alloc(lm_index* ix, T** p, size_t count) {
     return LM_OK;
 }
 
-static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W) {
+static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune = false) {
     int32_t maxnew = std::max({W * ix->maxdeg0, ix->maxdeg_up, 1});
+    if (prune) maxnew = std::max(maxnew, (int32_t)AQ_CAP);
     if (B <= ix->ws_B && ef == ix->ws_ef && W == ix->ws_W && maxnew == ix->ws_maxnew) {
         ix->ws.B = B;
         return LM_OK;
@@ -1009,6 +1194,7 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W) {
     int rc;
 #define A(ptr, cnt) if ((rc = ws_alloc(ix, &w.ptr, (cnt))) != LM_OK) return rc
     A(phase, B); A(level, B); A(cur_key, B); A(nsteps, B); A(npool, B); A(npop, B); A(nnew, B); A(ndis_q, B);
+    A(naq, B); A(nadc_q, B); A(aq, (size_t)B * AQ_CAP);
     A(pop, (size_t)B * W); A(newid, (size_t)B * maxnew); A(pool, (size_t)B * ef);
     A(visited, (size_t)B * w.nw);
     A(rbm, w.nw); A(rbm_snap, w.nw); A(word_rank, w.nw);
@@ -1127,11 +1313,35 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
                        float* d_dist, int64_t* d_labels) {
     const int32_t ef = std::max(prm.efSearch, k);  // faiss: max(efSearch, k)
     const int32_t W = std::max(prm.beam_size, 1);
-    int rc = ensure_ws(ix, B, ef, W);
+    const bool prune = prm.pq_pruning_ratio > 0.0f;
+    if (prune) {
+        if (!ix->d_pq_codes) LM_FAIL(LM_ESTATE, "pq_pruning_ratio > 0 needs a product quantiser (lm_pq_attach)");
+        if (prm.pq_pruning_ratio >= 1.0f) LM_FAIL(LM_EINVAL, "pq_pruning_ratio must be < 1");
+        if (ix->update_variant == 2) LM_FAIL(LM_EINVAL, "two-level search is not available with the split update variant");
+    }
+    int rc = ensure_ws(ix, B, ef, W, prune);
     if (rc) return rc;
     WsDev& ws = ix->ws;
     hipStream_t st = ix->stream;
     const bool recompute = prm.recompute != 0;
+    PruneArgs pa{};
+    size_t prune_shmem = 0;
+    if (prune) {
+        const int64_t need = (int64_t)B * ix->pq_m * 256;
+        if (need > ix->lut_cap) {
+            if (ix->d_lut) (void)hipFree(ix->d_lut);
+            ix->d_lut = nullptr;
+            LM_HIP(hipMalloc((void**)&ix->d_lut, (size_t)need * 4));
+            ix->lut_cap = need;
+        }
+        pa.Q = d_q; pa.lut = ix->d_lut; pa.codebooks = ix->d_pq_codebooks; pa.codes = ix->d_pq_codes;
+        pa.Dp = ix->Dp; pa.metric = ix->metric; pa.m = ix->pq_m; pa.dsub = ix->D / ix->pq_m;
+        pa.keep = 1.0f - prm.pq_pruning_ratio;
+        pa.strategy = prm.local_prune ? 1 : (prm.send_neigh_times_ratio > 1e-6f ? 2 : 0);  // hnsw_backend.py:222-231
+        pa.Pmax = next_pow2(ws.maxnew);
+        prune_shmem = ((size_t)pa.Pmax + 2 * AQ_CAP) * 8;
+        hipLaunchKernelGGL(k_pq_lut_all, dim3(B), dim3(256), 0, st, pa);
+    }
     const bool memo = recompute && prm.recompute_memo != 0 && ix->update_variant != 1 && ix->update_variant != 2;
     int64_t memo_used = 0;
     if (memo) {
@@ -1171,7 +1381,11 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         {
             EvScope es(ix, &ix->ev_expand);
             hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, recompute ? (memo ? 2 : 1) : 0,
-                               (int)(rounds + 1), flat);
+                               (int)(rounds + 1), flat, prune ? 1 : 0);
+            if (prune) {
+                pa.use_rbm = recompute ? (memo ? 2 : 1) : 0;
+                hipLaunchKernelGGL(k_prune, dim3(B), dim3(256), prune_shmem, st, ws, pa);
+            }
             if (recompute) {
                 hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
                 hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
@@ -1225,6 +1439,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     ix->stats.nrounds += (int64_t)hc[C_ROUNDS];
     ix->stats.ndis += (int64_t)hc[C_NDIS];
     ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
+    ix->stats.nadc += (int64_t)hc[C_NADC];
     return LM_OK;
 }
 
@@ -1416,6 +1631,7 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
     if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
     if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
+    if (ix->d_lut) (void)hipFree(ix->d_lut);
     if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
     if (ix->d_qpad) (void)hipFree(ix->d_qpad);
     if (ix->h_counters) (void)hipHostFree(ix->h_counters);

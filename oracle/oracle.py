@@ -44,11 +44,15 @@ class _Graph(C.Structure):
 
 
 class _Params(C.Structure):
-    _fields_ = [("ef", C.c_int32), ("beam", C.c_int32), ("k", C.c_int32), ("check_relative_distance", C.c_int32)]
+    _fields_ = [("ef", C.c_int32), ("beam", C.c_int32), ("k", C.c_int32), ("check_relative_distance", C.c_int32),
+                ("prune_ratio", C.c_float), ("prune_strategy", C.c_int32)]
 
 
 class _Stats(C.Structure):
-    _fields_ = [("ndis", C.c_int64), ("nunique", C.c_int64), ("nrounds", C.c_int64), ("nexpand", C.c_int64)]
+    _fields_ = [("ndis", C.c_int64), ("nunique", C.c_int64), ("nrounds", C.c_int64), ("nexpand", C.c_int64), ("nadc", C.c_int64)]
+
+
+PRUNE_STRATEGY = {"global": 0, "local": 1, "proportional": 2}
 
 
 class _Pq(C.Structure):
@@ -80,6 +84,11 @@ def lib():
         _lib.orc_search.argtypes = [
             C.POINTER(_Graph), C.c_void_p, _PROVIDER, C.c_void_p, C.c_void_p, C.c_int32,
             C.POINTER(_Params), C.c_void_p, C.c_void_p, C.POINTER(_Stats),
+        ]
+        _lib.orc_search_pq.restype = C.c_int
+        _lib.orc_search_pq.argtypes = [
+            C.POINTER(_Graph), C.c_void_p, _PROVIDER, C.c_void_p, C.c_void_p, C.c_int32,
+            C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Stats),
         ]
         _lib.orc_bruteforce_topk.restype = C.c_int
         _lib.orc_bruteforce_topk.argtypes = [
@@ -146,7 +155,8 @@ class OracleGraph:
 
 def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: int = 1,
            check_relative_distance: bool = True, table: Optional[np.ndarray] = None,
-           provider: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+           provider: Optional[Callable[[np.ndarray], np.ndarray]] = None, prune_ratio: float = 0.0,
+           pruning_strategy: str = "global", pq=None):
     """Run the oracle search.  Exactly one of ``table`` (N x D, stored embeddings) or
     ``provider`` (callable: sorted unique int32 ids -> (n, D) float32) must be given.
     Returns (ids int64 (B,k), dist float32 (B,k), stats dict)."""
@@ -157,8 +167,13 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
     ids = np.empty((B, k), dtype=np.int64)
     dd = np.empty((B, k), dtype=np.float32)
     st = _Stats()
-    prm = _Params(ef, beam, k, 1 if check_relative_distance else 0)
+    prm = _Params(ef, beam, k, 1 if check_relative_distance else 0, float(prune_ratio), PRUNE_STRATEGY[pruning_strategy])
     g = graph.cstruct()
+    pqs = None
+    if pq is not None:  # (codebooks [m,256,dsub], codes [N,m]) for the two-level search
+        cbk = np.ascontiguousarray(pq[0], dtype=np.float32)
+        cds = np.ascontiguousarray(pq[1], dtype=np.uint8)
+        pqs = _Pq(cbk.shape[0], cbk.shape[2], _ptr(cbk), _ptr(cds))
     tab = None
     err: list = []
     if table is not None:
@@ -180,7 +195,8 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
                 return 1
 
         cb = _PROVIDER(_cb)
-    rc = lib().orc_search(C.byref(g), _ptr(tab), cb, None, _ptr(q), B, C.byref(prm), _ptr(ids), _ptr(dd), C.byref(st))
+    rc = lib().orc_search_pq(C.byref(g), _ptr(tab), cb, None, _ptr(q), B, C.byref(prm), C.byref(pqs) if pqs is not None else None,
+                             _ptr(ids), _ptr(dd), C.byref(st))
     if err:
         raise err[0]
     if rc:

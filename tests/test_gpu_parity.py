@@ -288,3 +288,52 @@ def test_topk_merge_kernel(env):
         torch.cuda.synchronize()
         ei, ed = orc.merge_topk(ids, dist, metric)
         assert np.array_equal(oi.cpu().numpy(), ei) and np.array_equal(od.cpu().numpy(), ed)
+
+
+@pytest.mark.parametrize("strategy", ["global", "local", "proportional"])
+def test_two_level_search_parity(env, strategy):
+    """prune_ratio / pruning_strategy (hnsw_backend.py:219-231; paper Alg. 2): PQ-ADC ranked pruning before the
+    exact evaluation -- bit-exact with the oracle in stored-embedding and recompute (+memo) modes."""
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.pq import encode_pq, train_pq
+    from oracle import oracle as orc
+
+    torch = env
+    x, g = _build(3000, 96, "mips", seed=21)
+    q = queries_near(x, 40, seed=22)
+    cb = train_pq(torch.from_numpy(x), 24, iters=6, seed=1).numpy()
+    codes = encode_pq(torch.from_numpy(x), torch.from_numpy(cb)).numpy()
+    og = oracle_graph(g, 96)
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(RuntimeError):  # no PQ attached yet
+        idx.attach_table(x)
+        idx.search(q, 10, idx.make_params(ef=32, recompute=False, prune_ratio=0.5))
+    idx.attach_pq(cb, codes)
+    xdev = torch.zeros((3000, idx.info.d_padded), device="cuda")
+    xdev[:, :96] = torch.from_numpy(x).cuda()
+    keep = {}
+
+    def provider(d_ids, n, stream):
+        keep["e"] = xdev.index_select(0, as_tensor(d_ids, (n,), "int32").long()).contiguous()
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+    base = None
+    for ratio in (0.3, 0.6):
+        for ef, beam in ((32, 1), (64, 3)):
+            oi, od, ost = orc.search(og, q, 10, ef=ef, beam=beam, table=x, prune_ratio=ratio, pruning_strategy=strategy, pq=(cb, codes))
+            kw = dict(ef=ef, beam=beam, prune_ratio=ratio, local_prune=(strategy == "local"),
+                      send_neigh_times_ratio=(1.0 if strategy == "proportional" else 0.0))
+            for mode in ("table", "provider", "memo"):
+                prm = idx.make_params(recompute=(mode != "table"), recompute_memo=(mode == "memo"), **kw)
+                gd, gi = idx.search(q, 10, prm)
+                st = idx.stats()
+                assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (ratio, ef, beam, mode)
+                assert st["ndis"] == ost["ndis"] and st["nadc"] == ost["nadc"] and st["nrounds"] == ost["nrounds"], (st, ost)
+            if base is None:
+                _, _, bst = orc.search(og, q, 10, ef=ef, beam=beam, table=x)
+                assert ost["ndis"] < bst["ndis"]  # fewer exact evaluations than the unpruned search
+                base = bst
+    idx.close()
