@@ -73,7 +73,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     K, W, B = args.steps, args.warmup, args.batch
-    n_q = B * (K + W + 2)  # +2: extra steps (smallest ef reaching recall 0.9; per-call recompute memo)
+    n_q = B * (K + W + 3)  # +3: extra steps (smallest ef reaching recall 0.9; per-call recompute memo; two-level search)
     t_setup = time.time()
 
     # ---- corpus -> HBM token store ------------------------------------------------------------
@@ -224,6 +224,32 @@ def main():
             e3 = float(t.item())
         with_memo = {"ef_search": ef, "queries_per_s": round(world * B / e3, 3), "recall_at_10": round(recall(l3.cpu().numpy(), range(lo, lo + B)), 4),
                      "recomputed_chunks_per_query": round(st3["nunique"] / B, 1), "steps": 1}
+    # ---- extra (not `value`): two-level search (paper Alg. 2): prune_ratio 0.5, global strategy, PQ m=48 -------
+    two_level = None
+    if not args.no_min_ef_step:
+        from leann_amd.pq import encode_pq, train_pq
+
+        t1 = time.time()
+        cb = train_pq(X, 48, iters=8, seed=0)
+        codes = encode_pq(X, cb)
+        idx.attach_pq(cb.cpu().numpy(), codes.cpu().numpy())
+        t_pq = time.time() - t1
+        prm4 = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, prune_ratio=0.5)
+        lo = (W + K + 2) * B
+        barrier()
+        t1 = time.perf_counter()
+        _, l4 = idx.search_device(Q[lo : lo + B], 10, prm4)
+        barrier()
+        e4 = time.perf_counter() - t1
+        st4 = idx.stats()
+        if world > 1:
+            t = torch.tensor([e4], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e4 = float(t.item())
+        two_level = {"ef_search": ef, "prune_ratio": 0.5, "pruning_strategy": "global", "pq_bytes": 48,
+                     "queries_per_s": round(world * B / e4, 3), "recall_at_10": round(recall(l4.cpu().numpy(), range(lo, lo + B)), 4),
+                     "recomputed_chunks_per_query": round(st4["nunique"] / B, 1), "adc_evals_per_query": round(st4["nadc"] / B, 1),
+                     "pq_train_encode_s": round(t_pq, 1), "steps": 1}
     labels_np = torch.cat(out_labels).cpu().numpy() if out_labels else np.zeros((0, 10), np.int64)
     rec = recall(labels_np, range(W * B, (W + K) * B)) if K else 0.0
     if world > 1:
@@ -278,6 +304,8 @@ def main():
         result["at_min_ef"] = min_ef
     if with_memo:
         result["with_per_call_recompute_memo"] = with_memo
+    if two_level:
+        result["with_two_level_search"] = two_level
     if table_roof:
         result["roofline_table_mode"] = table_roof
 
