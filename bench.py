@@ -49,7 +49,8 @@ def main():
     ap.add_argument("--efc", type=int, default=200)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--table-roofline", action="store_true", help="also time the stored-embedding (HBM gather) mode")
+    ap.add_argument("--table-roofline", action="store_true", default=True, help="also time the stored-embedding (HBM gather) mode (default on)")
+    ap.add_argument("--no-table-roofline", dest="table_roofline", action="store_false")
     args = ap.parse_args()
 
     import torch
