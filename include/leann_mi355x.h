@@ -143,6 +143,8 @@ typedef struct {
 } lm_search_stats;
 int lm_index_get_stats(const lm_index *idx, lm_search_stats *out);
 int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around kernels */
+/* Mean event-pair time around an empty kernel (us): the fixed part of every update_ms/launch. */
+int lm_index_event_overhead_us(lm_index *idx, double *out_us);
 /* Tuning knobs (A/B measurements): "update_variant" 0 = fused, sort-new + rank-merge (default), 1 = fused, full bitonic sort,
  * 2 = split (flat distance kernel over the pair list + one-wave-per-query merge kernel). */
 int lm_index_set_option(lm_index *idx, const char *name, int64_t value);

@@ -70,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "lm_index_read", "lm_index_create_from_csr", "lm_index_free", "lm_index_info",
     "lm_index_attach_table", "lm_index_set_provider", "lm_index_set_stream",
     "lm_search_params_default", "lm_index_search", "lm_index_search_device",
-    "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option",
+    "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_event_overhead_us",
     "lm_dist_gather", "lm_topk_merge",
     "lm_pq_attach", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
     "lm_add_layernorm_f16",
@@ -110,6 +110,7 @@ def load() -> C.CDLL:
     lib.lm_index_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
     lib.lm_index_set_profiling.argtypes = [vp, i32]
     lib.lm_index_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.lm_index_event_overhead_us.argtypes = [vp, C.POINTER(C.c_double)]
     lib.lm_dist_gather.argtypes = [vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]
     lib.lm_topk_merge.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.lm_pq_attach.argtypes = [vp, i32, vp, vp, i64]

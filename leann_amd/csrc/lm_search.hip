@@ -1716,6 +1716,43 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     LM_FAIL(LM_EINVAL, std::string("unknown option: ") + name);
 }
 
+// Mean HIP-event-pair time around an EMPTY kernel on the index' stream: the fixed dispatch + event cost that
+// every per-kernel event measurement (lm_search_stats.update_ms) contains.
+int lm_index_event_overhead_us(lm_index* ix, double* out_us) {
+    if (!ix || !out_us) LM_FAIL(LM_EINVAL, "NULL argument");
+    LM_HIP(hipSetDevice(ix->device));
+    const int reps = 256;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev(reps);
+    int64_t* dl = nullptr;
+    float* dd = nullptr;
+    LM_HIP(hipMalloc((void**)&dl, 64));
+    LM_HIP(hipMalloc((void**)&dd, 64));
+    for (int w = 0; w < 2; ++w) {
+        for (int i = 0; i < reps; ++i) {
+            if (w == 0) {
+                (void)hipEventCreate(&ev[i].first);
+                (void)hipEventCreate(&ev[i].second);
+            }
+            (void)hipEventRecord(ev[i].first, ix->stream);
+            hipLaunchKernelGGL(k_fill_empty, dim3(1), dim3(64), 0, ix->stream, (int64_t)0, 0, dl, dd);
+            (void)hipEventRecord(ev[i].second, ix->stream);
+        }
+        LM_HIP(hipStreamSynchronize(ix->stream));
+    }
+    double ms = 0;
+    for (auto& p : ev) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, p.first, p.second);
+        ms += t;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    (void)hipFree(dl);
+    (void)hipFree(dd);
+    *out_us = 1e3 * ms / reps;
+    return LM_OK;
+}
+
 int lm_index_get_stats(const lm_index* ix, lm_search_stats* out) {
     if (!ix || !out) LM_FAIL(LM_EINVAL, "NULL argument");
     *out = ix->stats;

@@ -118,6 +118,11 @@ class Mi355xIndex:
     def set_option(self, name: str, value: int) -> None:
         check(self._lib.lm_index_set_option(self._h, name.encode(), int(value)), "lm_index_set_option")
 
+    def event_overhead_us(self) -> float:
+        out = C.c_double()
+        check(self._lib.lm_index_event_overhead_us(self._h, C.byref(out)), "lm_index_event_overhead_us")
+        return float(out.value)
+
     def set_profiling(self, on: bool) -> None:
         check(self._lib.lm_index_set_profiling(self._h, 1 if on else 0))
 
