@@ -198,6 +198,12 @@ int lm_topk_merge(const int64_t *d_in_ids, const float *d_in_dist, int32_t S, in
 int lm_add_layernorm_f16(const void *d_x, const void *d_residual, const void *d_gamma, const void *d_beta,
                          void *d_out, int64_t rows, int32_t hidden, float eps, void *stream);
 
+/* Fused self-attention for packed variable-length sequences, head_dim 32 (hidden = heads*32), lengths 1..256:
+ * d_qkv [total_tokens][3][heads][32] fp16 (the QKV GEMM output), d_cu_seqlens int32[n_seqs+1],
+ * d_out [total_tokens][heads*32] fp16.  softmax(QK^T/sqrt(32))V per (sequence, head), MFMA 32x32x16 f16. */
+int lm_attn_varlen_hd32_f16(const void *d_qkv, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t heads,
+                            int32_t max_len, void *d_out, void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

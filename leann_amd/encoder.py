@@ -86,6 +86,28 @@ def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: n
     return ln(x if residual is None else x + residual)
 
 
+def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_len: int) -> Optional[torch.Tensor]:
+    """Hand-written MFMA varlen attention (csrc/lm_encoder_ops.hip) for head_dim 32, lengths <= 256, fp16 on the
+    GPU; returns None when the shape is outside that envelope (caller falls back to torch's varlen_attn)."""
+    import os
+
+    tot, h3 = qkv.shape
+    hidden = h3 // 3
+    if not (qkv.is_cuda and qkv.dtype == torch.float16 and qkv.is_contiguous() and hidden == heads * 32 and 0 < max_len <= 256):
+        return None
+    if os.environ.get("LEANN_MI355X_ATTN", "1") == "0":
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    out = torch.empty((tot, hidden), dtype=torch.float16, device=qkv.device)
+    _lib.check(_lib.load().lm_attn_varlen_hd32_f16(
+        C.c_void_p(qkv.data_ptr()), C.c_void_p(cu.data_ptr()), cu.shape[0] - 1, heads, int(max_len), C.c_void_p(out.data_ptr()),
+        C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)), "lm_attn_varlen_hd32_f16")
+    return out
+
+
 class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
@@ -102,9 +124,12 @@ class _Layer(nn.Module):
         from torch.nn.attention.varlen import varlen_attn
 
         tot, h = x.shape
-        qkv = self.qkv(x).view(tot, 3, self.heads, h // self.heads)
-        a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len)
-        x = fused_add_layernorm(self.out(a.reshape(tot, h)), x, self.ln1)
+        qkv2 = self.qkv(x)
+        a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
+        if a is None:
+            qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
+            a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
+        x = fused_add_layernorm(self.out(a), x, self.ln1)
         x = fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
         return x
 

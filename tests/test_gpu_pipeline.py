@@ -280,3 +280,43 @@ def test_sharded_search_merge_on_gpu(torch_):
     d1, i1 = ss.search(torch.from_numpy(q).cuda(), 10)
     d2, i2 = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, recompute=False))
     assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("heads,maxlen", [(12, 256), (12, 70), (4, 33), (2, 1)])
+def test_fused_attention_hd32_kernel(torch_, heads, maxlen):
+    """lm_attn_varlen_hd32_f16 vs a plain PyTorch fp32 reference of the same op (per sequence softmax(QK^T/sqrt d)V)."""
+    torch = torch_
+    from leann_amd.encoder import fused_attention_hd32
+
+    g = torch.Generator(device="cpu").manual_seed(heads * 1000 + maxlen)
+    lens = torch.randint(1, maxlen + 1, (37,), generator=g)
+    lens[0], lens[-1] = maxlen, 1
+    cu = torch.zeros(38, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    tot, H = int(cu[-1]), heads * 32
+    qkv = (torch.randn((tot, 3 * H), generator=g) * 1.5).half().cuda()
+    out = fused_attention_hd32(qkv, cu.cuda(), heads, int(lens.max()))
+    assert out is not None and out.shape == (tot, H)
+    q3 = qkv.float().view(tot, 3, heads, 32)
+    ref = torch.empty((tot, H), device="cuda")
+    for i in range(37):
+        a, b = int(cu[i]), int(cu[i + 1])
+        q, k, v = (q3[a:b, j].transpose(0, 1) for j in range(3))  # [heads, L, 32]
+        p = torch.softmax(q @ k.transpose(1, 2) / 32**0.5, dim=-1)
+        ref[a:b] = (p @ v).transpose(0, 1).reshape(b - a, H)
+    err = (out.float() - ref).abs().max().item()
+    assert err < 4e-3, err
+
+
+def test_encoder_packed_fused_attention_matches_library_attention(torch_, monkeypatch):
+    torch = torch_
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=300, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    a = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_ATTN", "0")
+    b = enc.encode_tokens_packed(ti, tl)
+    assert (a - b).abs().max() < 2e-3
