@@ -210,14 +210,14 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32(const __half* __restri
                 }
             cm = fmaxf(cm, __shfl_xor(cm, 32));
             const float mnew = fmaxf(mx, cm);
-            const float alpha = exp2f((mx - mnew) * scale_log2e);  // 0 on the first chunk (mx = -3e38)
+            const float alpha = __builtin_amdgcn_exp2f((mx - mnew) * scale_log2e);  // 0 on the first chunk (mx = -3e38)
             mx = mnew;
             float cs = 0.f;
 #pragma unroll
             for (int tt = 0; tt < CH; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = exp2f((s[tt][r] - mx) * scale_log2e);
+                    float p = __builtin_amdgcn_exp2f((s[tt][r] - mx) * scale_log2e);
                     s[tt][r] = p;
                     cs += p;
                 }
