@@ -140,6 +140,9 @@ typedef struct {
     double expand_ms;     /* summed HIP-event time of the expand(+uniq) kernels              */
     double provider_ms;   /* summed HIP-event time spent in provider work                    */
     int64_t nadc;         /* PQ-ADC evaluations of the two-level search (pq_pruning_ratio > 0) */
+    double update_span_ms; /* profiling on: summed execution span (max end - min start over workgroups, device
+                              wall clock) of the fused update kernel = what rocprofv3 reports as its duration */
+    int64_t update_span_launches;
 } lm_search_stats;
 int lm_index_get_stats(const lm_index *idx, lm_search_stats *out);
 int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around kernels */

@@ -47,7 +47,7 @@ class SearchStats(C.Structure):
     _fields_ = [
         ("ndis", C.c_int64), ("nunique", C.c_int64), ("nrounds", C.c_int64), ("nexpand", C.c_int64),
         ("update_launches", C.c_int64), ("update_ms", C.c_double), ("expand_ms", C.c_double),
-        ("provider_ms", C.c_double), ("nadc", C.c_int64),
+        ("provider_ms", C.c_double), ("nadc", C.c_int64), ("update_span_ms", C.c_double), ("update_span_launches", C.c_int64),
     ]
 
 

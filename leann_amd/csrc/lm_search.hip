@@ -487,6 +487,7 @@ struct UpdateArgs {
     int32_t check_rel;
     int32_t max_level;
     int32_t P2;           // pow2 >= ef + maxnew
+    unsigned long long* tstamp;  // profiling: 2 x B wall-clock stamps (NULL = off)
 };
 
 template <int NCH, bool L2, bool F16>
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void k_update_sort(WsDev ws, UpdateArgs a) {
 // ---- variant 0 (default): sort only the NEW keys, then merge with the (already sorted) pool by rank ----
 // LDS: pool[ef] | newk[Pn] | out[ef]   (a.P2 carries ef_lds = ef rounded up to 2, Pn is per block)
 template <int NCH, bool L2, bool F16, int MODE, int NT>  // MODE 0: row = node id (table), 1: rank in the round's unique list, 2: memo slot
-__global__ __launch_bounds__(NT) void k_update(WsDev ws, UpdateArgs a) {
+__device__ __forceinline__ void update_body(const WsDev& ws, const UpdateArgs& a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned long long s_best;
 
@@ -792,6 +793,43 @@ __global__ __launch_bounds__(NT) void k_update(WsDev ws, UpdateArgs a) {
     }
     __syncthreads();
     for (int i = tid; i < npool1; i += NT) pool[i] = fin[i];
+}
+
+template <int NCH, bool L2, bool F16, int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_update(WsDev ws, UpdateArgs a) {
+    // profiling: per-workgroup start/end stamps of the constant-rate wall clock; k_span turns them into the
+    // launch's execution span (max end - min start), the quantity rocprofv3 reports as the kernel duration
+    unsigned long long t0 = 0;
+    if (a.tstamp && threadIdx.x == 0) t0 = wall_clock64();
+    update_body<NCH, L2, F16, MODE, NT>(ws, a);
+    if (a.tstamp && threadIdx.x == 0) {
+        a.tstamp[2 * blockIdx.x] = t0;
+        a.tstamp[2 * blockIdx.x + 1] = wall_clock64();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_span(const unsigned long long* tstamp, int nblocks, unsigned long long* acc) {
+    __shared__ unsigned long long smin[4], smax[4];
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        lo = min(lo, tstamp[2 * i]);
+        hi = max(hi, tstamp[2 * i + 1]);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = min(lo, (unsigned long long)__shfl_xor(lo, m));
+        hi = max(hi, (unsigned long long)__shfl_xor(hi, m));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = lo;
+        smax[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
+        hi = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+        acc[0] += hi - lo;  // ticks
+        acc[1] += 1;
+    }
 }
 
 // ---- variant 2 (split): flat, perfectly balanced distance kernel over the round's pair list ----------
@@ -1131,6 +1169,10 @@ struct lm_index {
     int32_t* d_pq_rounds = nullptr;
     int64_t pq_cap = 0;
     float* d_lut = nullptr;  // two-level search: B x m x 256
+    unsigned long long* d_tstamp = nullptr;  // profiling: 2 x B stamps + [2] accumulator at the end
+    int64_t tstamp_cap = 0;
+    double span_ms = 0;
+    int64_t span_launches = 0;
     int64_t lut_cap = 0;
     // stored embeddings
     void* d_table = nullptr;
@@ -1330,6 +1372,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         const int64_t need = (int64_t)B * ix->pq_m * 256;
         if (need > ix->lut_cap) {
             if (ix->d_lut) (void)hipFree(ix->d_lut);
+    if (ix->d_tstamp) (void)hipFree(ix->d_tstamp);
             ix->d_lut = nullptr;
             LM_HIP(hipMalloc((void**)&ix->d_lut, (size_t)need * 4));
             ix->lut_cap = need;
@@ -1365,6 +1408,18 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     hipLaunchKernelGGL(k_init, dim3((B + 255) / 256), dim3(256), 0, st, ws, ix->max_level);
 
     UpdateArgs ua{};
+    unsigned long long* span_acc = nullptr;
+    if (ix->profiling) {
+        if (ix->tstamp_cap < B) {
+            if (ix->d_tstamp) (void)hipFree(ix->d_tstamp);
+            ix->d_tstamp = nullptr;
+            LM_HIP(hipMalloc((void**)&ix->d_tstamp, ((size_t)2 * B + 2) * 8));
+            ix->tstamp_cap = B;
+        }
+        ua.tstamp = ix->d_tstamp;
+        span_acc = ix->d_tstamp + (size_t)2 * ix->tstamp_cap;
+        LM_HIP(hipMemsetAsync(ix->d_tstamp, 0, ((size_t)2 * ix->tstamp_cap + 2) * 8, st));
+    }
     ua.Q = d_q;
     ua.check_rel = prm.check_relative_distance;
     ua.max_level = ix->max_level;
@@ -1429,6 +1484,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             rc = launch_update(ix, ua, ix->table_dtype == LM_DTYPE_F16);
         }
         if (rc) return rc;
+        if (span_acc && ix->update_variant == 0) hipLaunchKernelGGL(k_span, dim3(1), dim3(256), 0, st, ix->d_tstamp, B, span_acc);
         ix->stats.update_launches++;
     }
     hipLaunchKernelGGL(k_finalize, dim3((B * k + 255) / 256), dim3(256), 0, st, ws, k, ix->metric, d_labels, d_dist);
@@ -1440,6 +1496,14 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     ix->stats.ndis += (int64_t)hc[C_NDIS];
     ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
     ix->stats.nadc += (int64_t)hc[C_NADC];
+    if (span_acc) {
+        unsigned long long acc[2] = {0, 0};
+        LM_HIP(hipMemcpy(acc, span_acc, sizeof(acc), hipMemcpyDeviceToHost));
+        int khz = 100000;
+        (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ix->device);
+        ix->span_ms += (double)acc[0] / (double)khz;
+        ix->span_launches += (int64_t)acc[1];
+    }
     return LM_OK;
 }
 
@@ -1450,6 +1514,8 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     if (prm.efSearch <= 0) LM_FAIL(LM_EINVAL, "efSearch must be positive");
     LM_HIP(hipSetDevice(ix->device));
     ix->stats = lm_search_stats{};
+    ix->span_ms = 0;
+    ix->span_launches = 0;
     if (n == 0) return LM_OK;
     hipStream_t st = ix->stream;
     if (ix->N == 0 || ix->entry_point < 0) {
@@ -1492,6 +1558,8 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
         ix->stats.update_ms = drain_events(ix, ix->ev_update);
         ix->stats.expand_ms = drain_events(ix, ix->ev_expand);
         ix->stats.provider_ms = drain_events(ix, ix->ev_provider);
+        ix->stats.update_span_ms = ix->span_ms;
+        ix->stats.update_span_launches = ix->span_launches;
     }
     (void)total;
     return LM_OK;

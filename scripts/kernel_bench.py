@@ -92,7 +92,8 @@ for r in range(args.reps):
     idx.search_device(Q, 10, prm)
     s = idx.stats()
 out["search"] = {"batch": args.batch, "ef": args.ef, "beam": args.beam, "variant": args.variant, "provider": args.provider, "memo": args.memo, "nunique": s["nunique"], "ndis": s["ndis"],
-                 "launches": s["update_launches"], "update_ms": round(s["update_ms"], 3), "expand_ms": round(s["expand_ms"], 3),
+                 "launches": s["update_launches"], "update_ms": round(s["update_ms"], 3), "update_span_ms": round(s["update_span_ms"], 3), "expand_ms": round(s["expand_ms"], 3),
                  "evals_per_launch": round(s["ndis"] / s["update_launches"], 1),
-                 "update_GBps_algorithmic": round(s["ndis"] * (D * 4 + 4) / s["update_ms"] / 1e6, 1)}
+                 "update_GBps_algorithmic": round(s["ndis"] * (D * 4 + 4) / s["update_ms"] / 1e6, 1),
+                 "update_GBps_span": round(s["ndis"] * (D * 4 + 4) / max(s["update_span_ms"], 1e-9) / 1e6, 1)}
 print(json.dumps(out))
