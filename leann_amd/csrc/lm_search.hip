@@ -1372,7 +1372,6 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         const int64_t need = (int64_t)B * ix->pq_m * 256;
         if (need > ix->lut_cap) {
             if (ix->d_lut) (void)hipFree(ix->d_lut);
-    if (ix->d_tstamp) (void)hipFree(ix->d_tstamp);
             ix->d_lut = nullptr;
             LM_HIP(hipMalloc((void**)&ix->d_lut, (size_t)need * 4));
             ix->lut_cap = need;
@@ -1700,6 +1699,7 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
     if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
     if (ix->d_lut) (void)hipFree(ix->d_lut);
+    if (ix->d_tstamp) (void)hipFree(ix->d_tstamp);
     if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
     if (ix->d_qpad) (void)hipFree(ix->d_qpad);
     if (ix->h_counters) (void)hipHostFree(ix->h_counters);

@@ -307,6 +307,7 @@ def test_two_level_search_parity(env, strategy):
     og = oracle_graph(g, 96)
     idx = Mi355xIndex.from_csr(g)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_profiling(True)  # exercise the timing buffers across mode switches as well
     with pytest.raises(RuntimeError):  # no PQ attached yet
         idx.attach_table(x)
         idx.search(q, 10, idx.make_params(ef=32, recompute=False, prune_ratio=0.5))
@@ -332,6 +333,7 @@ def test_two_level_search_parity(env, strategy):
                 st = idx.stats()
                 assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (ratio, ef, beam, mode)
                 assert st["ndis"] == ost["ndis"] and st["nadc"] == ost["nadc"] and st["nrounds"] == ost["nrounds"], (st, ost)
+                assert st["update_span_launches"] == st["update_launches"] > 0 and 0 < st["update_span_ms"] <= st["update_ms"] * 1.05
             if base is None:
                 _, _, bst = orc.search(og, q, 10, ef=ef, beam=beam, table=x)
                 assert ost["ndis"] < bst["ndis"]  # fewer exact evaluations than the unpruned search
