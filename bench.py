@@ -146,20 +146,20 @@ def main():
         Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
         bytes_eval = D * 4 + 4
         table_roof = {}
-        for variant in (0, 0):
+        for persistent in (1, 0, 1, 0):  # interleaved A/B: persistent one-launch kernel vs lock-step rounds
             for beam_t, ef_t in ((4, ef), (1, ef)):
-                idx.set_option("update_variant", variant)
+                idx.set_option("persistent_table", persistent)
                 prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=16384)
                 idx.search_device(Qbig, 10, prm)
                 st = idx.stats()
-                key = f"v{variant}_beam{beam_t}_ef{ef_t}"
+                key = f"{'k_search_table_persistent' if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}"
                 net_ms = max(st["update_span_ms"], 1e-6)
                 r = {"GBps": round(st["ndis"] * bytes_eval / (net_ms * 1e-3) / 1e9, 1), "launches": st["update_launches"],
                      "us_per_launch": round(1e3 * net_ms / max(st["update_launches"], 1), 2),
                      "us_per_launch_event_pair": round(1e3 * st["update_ms"] / max(st["update_launches"], 1), 2),
                      "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
                 table_roof.setdefault(key, []).append(r)
-        idx.set_option("update_variant", 0)
+        idx.set_option("persistent_table", 1)
         idx.set_profiling(False)
 
     # ---- timed region: recompute mode ---------------------------------------------------------------

@@ -149,7 +149,9 @@ int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around 
 /* Mean event-pair time around an empty kernel (us): the fixed part of every update_ms/launch. */
 int lm_index_event_overhead_us(lm_index *idx, double *out_us);
 /* Tuning knobs (A/B measurements): "update_variant" 0 = fused, sort-new + rank-merge (default), 1 = fused, full bitonic sort,
- * 2 = split (flat distance kernel over the pair list + one-wave-per-query merge kernel). */
+ * 2 = split (flat distance kernel over the pair list + one-wave-per-query merge kernel), 3/4 = fused with a
+ * wave / a workgroup per query.  "persistent_table" 1 (default) = stored-embedding searches run as ONE persistent
+ * launch per batch, 0 = lock-step rounds. */
 int lm_index_set_option(lm_index *idx, const char *name, int64_t value);
 
 /* ---- DiskANN-style path: PQ-ADC traversal + deferred exact rerank ---------------------------------

@@ -158,6 +158,26 @@ def test_recompute_memo_same_results_fewer_recomputes(env):
     assert set(res[True][3].tolist()) == set(res[False][3].tolist())
 
 
+def test_lockstep_table_mode_still_matches(env):
+    """Stored-embedding mode defaults to the persistent kernel; the lock-step path must give the same answers."""
+    from leann_amd.index import Mi355xIndex
+
+    x, g = _build(3000, 384, "mips", seed=1)
+    q = queries_near(x, 32, seed=2)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_table(x)
+    res = []
+    for persistent in (1, 0):
+        idx.set_option("persistent_table", persistent)
+        for ef, beam, cr in ((64, 1, True), (48, 4, True), (24, 2, False)):
+            d, l = idx.search(q, 10, idx.make_params(ef=ef, beam=beam, recompute=False, check_relative_distance=cr))
+            st = idx.stats()
+            res.append((persistent, d, l, st["ndis"], st["nexpand"], st["nrounds"]))
+    h = len(res) // 2
+    for a, b in zip(res[:h], res[h:]):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:], (a[3:], b[3:])
+
+
 def test_fp16_table(env):
     x, g = _build(1500, 768, "mips", seed=5)
     q = queries_near(x, 24, seed=8)
