@@ -336,7 +336,6 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     import torch
 
     from leann_amd.encoder import BertEncoder
-    from leann_amd.synth import pad_batch
     from oracle import oracle as orc
 
     ncores = orc.usable_cores()  # affinity / cgroup aware (the GPU box exposes 256 threads, 16 usable)

@@ -25,7 +25,7 @@ from ._compat import (
     LeannBackendSearcherInterface,
     register_backend,
 )
-from .csr_format import METRIC_INNER_PRODUCT, METRIC_L2, read_index, write_index
+from .csr_format import METRIC_INNER_PRODUCT, METRIC_L2, write_index
 
 logger = logging.getLogger(__name__)
 

@@ -1,19 +1,22 @@
-// lm_search.hip -- HBM-resident compact-CSR graph + lock-step selective-recompute beam search
-// for MI355X (gfx950).  Kernels:
-//   k_init        reset per-query state
-//   k_expand      one wave per query: pop list -> CSR neighbour gather -> visited test-and-set
-//                 (per-query bitmap) -> per-query new-list; sets the round's dedup bitmap
-//   k_uniq_count / k_uniq_emit   round bitmap -> SORTED unique node list + per-word ranks
-//   k_update<..>  one workgroup per query: LDS/regs-staged query, 16-lane row dot products with the
-//                 canonical reduction (bit-exact with oracle/lm_oracle.c:orc_dist), bitonic merge
-//                 into the ef-pool, next pops, phase transitions
-//   k_finalize    pool -> (labels, distances)
+// lm_search.hip -- HBM-resident compact-CSR graph + selective-recompute beam search for MI355X (gfx950).
+// Kernels (details at each definition):
+//   k_init / k_finalize / k_stats   per-query state reset, pool -> (labels, distances), end-of-search totals
+//   k_expand      one wave per query: (pop, neighbour) pairs flattened over the lanes -> CSR neighbour gather ->
+//                 visited test-and-set (per-query bitmap) -> per-query new-list; marks the round's dedup bitmap
+//   k_uniq_count / k_uniq_emit      round bitmap -> SORTED unique node list + per-word ranks
+//   k_pq_lut_all / k_prune          two-level search: PQ-ADC ranking of the new-list, approximate queue, selection
+//   k_update<NCH,L2,F16,MODE,NT>    fused gather + distance + beam update, one workgroup (or wave) per query:
+//                 query slice in registers, 16-lane row dot products with the canonical reduction (bit-exact with
+//                 oracle/lm_oracle.c:orc_dist), new keys sorted + rank-merged into the ef-pool in LDS, next pops
+//   k_update_sort / k_dist_flat + k_merge   A/B variants (full bitonic sort; split distance / merge kernels)
+//   k_memo_append per-call embedding memo (recompute_memo)
+//   k_search_table persistent stored-embedding search: a query's whole traversal in one workgroup, one launch/batch
+//   lm_pq_impl.h  DiskANN-style path: k_pq_traverse (persistent PQ-ADC traversal), k_pq_rerank
 // Algorithm contract: oracle/lm_oracle.c header (set semantics under the (dist,id) total order).
 // Reference call site replaced: index.search(...) leann_backend_hnsw/hnsw_backend.py:241-248.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <mutex>
 
 #include <hip/hip_fp16.h>
 
@@ -1853,16 +1856,13 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     // bound the visited bitmaps to 8 GiB
     int64_t nwbytes = ((ix->N + 31) / 32) * 4;
     maxb = std::max<int64_t>(1, std::min<int64_t>(maxb, (8ll << 30) / std::max<int64_t>(nwbytes, 1)));
-    lm_search_stats total{};
     for (int64_t off = 0; off < n; off += maxb) {
         int32_t B = (int32_t)std::min<int64_t>(maxb, n - off);
-        lm_search_stats keep = ix->stats;
         int rc = 1;
         if (!prm.recompute && prm.pq_pruning_ratio <= 0.0f && ix->persistent_table && ix->update_variant == 0 && std::max(prm.beam_size, 1) <= 64)
             rc = search_pass_persistent(ix, B, d_q + (size_t)off * ix->Dp, k, prm, d_dist + (size_t)off * k, d_labels + (size_t)off * k);
         if (rc == 1)  // not applicable (or LDS budget exceeded): lock-step rounds
             rc = search_pass(ix, B, d_q + (size_t)off * ix->Dp, k, prm, d_dist + (size_t)off * k, d_labels + (size_t)off * k);
-        (void)keep;
         if (rc) return rc;
     }
     LM_HIP(hipStreamSynchronize(st));
@@ -1877,7 +1877,6 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
             ix->stats.update_span_launches = ix->stats.update_launches;
         }
     }
-    (void)total;
     return LM_OK;
 }
 

@@ -21,7 +21,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Optional, Tuple
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

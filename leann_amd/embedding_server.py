@@ -23,7 +23,6 @@ from __future__ import annotations
 import argparse
 import json
 import logging
-import struct
 import threading
 from pathlib import Path
 from typing import Optional

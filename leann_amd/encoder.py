@@ -14,7 +14,6 @@ distance and beam-update kernels are the hand-written HIP in csrc/.
 
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, replace
 from pathlib import Path
 from typing import Optional

@@ -11,7 +11,6 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 import torch
 
-from leann_amd.devmem import as_tensor
 from leann_amd.gpu_graph_build import build_graph_gpu
 from leann_amd.index import Mi355xIndex
 from leann_amd.pq import encode_pq, flat_graph, train_pq
@@ -23,7 +22,7 @@ ap.add_argument("--m", type=int, default=96)
 ap.add_argument("--batch", type=int, default=1024)
 args = ap.parse_args()
 dev = torch.device("cuda")
-from leann_amd.encoder import BertEncoder, config_for
+from leann_amd.encoder import BertEncoder
 from leann_amd.recompute import RecomputeProvider
 from leann_amd.synth import CorpusSpec, SyntheticCorpus
 from leann_amd.token_store import TokenStore
