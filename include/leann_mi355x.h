@@ -93,6 +93,12 @@ int lm_index_attach_table(lm_index *idx, const void *table, int32_t dtype, int64
 typedef int (*lm_provider_fn)(void *user, const int32_t *d_ids, int32_t n, void **d_out, void *stream);
 int lm_index_set_provider(lm_index *idx, lm_provider_fn fn, void *user);
 
+/* Hub-embedding cache (LEANN paper section 5: caching the embeddings of the highest-degree ~10 % nodes): the rows
+ * of d_embeddings [n][d_padded] (fp32, device) are copied into HBM owned by the index; nodes listed in `ids` (host,
+ * unique) are never sent to the provider again.  n = 0 clears the cache.  Cf. num_nodes_to_cache of the DiskANN
+ * backend (diskann_backend.py:347). */
+int lm_index_set_hub_cache(lm_index *idx, const int32_t *ids, int32_t n, const float *d_embeddings);
+
 /* hipStream_t all kernels of this index are enqueued on (default: the null stream). */
 int lm_index_set_stream(lm_index *idx, void *hip_stream);
 

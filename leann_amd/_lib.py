@@ -68,7 +68,7 @@ PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(
 EXPORTED_SYMBOLS = [
     "lm_last_error", "lm_device_count", "lm_version",
     "lm_index_read", "lm_index_create_from_csr", "lm_index_free", "lm_index_info",
-    "lm_index_attach_table", "lm_index_set_provider", "lm_index_set_stream",
+    "lm_index_attach_table", "lm_index_set_provider", "lm_index_set_hub_cache", "lm_index_set_stream",
     "lm_search_params_default", "lm_index_search", "lm_index_search_device",
     "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_event_overhead_us",
     "lm_dist_gather", "lm_topk_merge",
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
     lib.lm_index_attach_table.argtypes = [vp, vp, i32, i64, i32, i32]
     lib.lm_index_set_provider.argtypes = [vp, PROVIDER_FN, vp]
     lib.lm_index_set_stream.argtypes = [vp, vp]
+    lib.lm_index_set_hub_cache.argtypes = [vp, vp, i32, vp]
     lib.lm_search_params_default.argtypes = [C.POINTER(SearchParams)]
     lib.lm_search_params_default.restype = None
     lib.lm_index_search.argtypes = [vp, i64, f32p, i32, vp, vp, C.POINTER(SearchParams)]

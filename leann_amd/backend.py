@@ -25,7 +25,7 @@ from ._compat import (
     LeannBackendSearcherInterface,
     register_backend,
 )
-from .csr_format import METRIC_INNER_PRODUCT, METRIC_L2, write_index
+from .csr_format import METRIC_INNER_PRODUCT, METRIC_L2, HnswCsr, read_index, write_index
 
 logger = logging.getLogger(__name__)
 
@@ -37,6 +37,24 @@ def normalize_l2(data: np.ndarray) -> np.ndarray:
     norms = np.linalg.norm(data, axis=1, keepdims=True)
     norms[norms == 0] = 1
     return data / norms
+
+
+def hub_nodes(g: HnswCsr, ratio: float) -> np.ndarray:
+    """The ceil(ratio*N) nodes with the highest level-0 in-degree (ties: smaller id), sorted ascending --
+    the hubs whose embeddings the paper keeps cached."""
+    n = g.ntotal
+    k = min(n, int(np.ceil(ratio * n)))
+    if k <= 0:
+        return np.zeros(0, np.int32)
+    p0 = g.node_offsets[:-1].astype(np.int64)
+    beg, end = g.level_ptr[p0].astype(np.int64), g.level_ptr[p0 + 1].astype(np.int64)
+    mask = np.zeros(g.neighbors.shape[0] + 1, np.int64)
+    np.add.at(mask, beg, 1)
+    np.add.at(mask, end, -1)
+    lvl0 = np.cumsum(mask[:-1]) > 0
+    indeg = np.bincount(g.neighbors[lvl0], minlength=n)
+    order = np.lexsort((np.arange(n), -indeg))
+    return np.sort(order[:k]).astype(np.int32)
 
 
 @register_backend("mi355x")
@@ -133,6 +151,9 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
         self.device = int(kwargs.get("device", 0))
         self.encoder_batch = int(kwargs.get("encoder_batch", 2048))
         self.encoder_dtype = kwargs.get("encoder_dtype", "float16")
+        # fraction of the highest in-degree nodes whose embeddings stay cached in HBM (LEANN paper section 5;
+        # 0 = pure recompute, the reference's behaviour)
+        self.hub_cache_ratio = float(kwargs.get("hub_cache_ratio", bk.get("hub_cache_ratio", 0.0)) or 0.0)
         self._index = None
         self._provider = None
         self._encoder = None
@@ -246,7 +267,22 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             self._provider = RecomputeProvider(enc, self._tokens, idx.info.d_padded, self._torch_device(),
                                                batch_size=self.encoder_batch)
             idx.set_provider(self._provider)
+            if self.hub_cache_ratio > 0:
+                self._attach_hub_cache(idx)
         return int(port) if port is not None else 0
+
+    def _attach_hub_cache(self, idx) -> None:
+        import torch
+
+        ids = hub_nodes(read_index(self.index_file), self.hub_cache_ratio)
+        if ids.shape[0] == 0:
+            return
+        dev = self._torch_device()
+        emb = self._provider.embed_ids(torch.from_numpy(ids).to(dev))
+        buf = torch.zeros((ids.shape[0], idx.info.d_padded), dtype=torch.float32, device=dev)
+        buf[:, : emb.shape[1]] = emb
+        idx.set_hub_cache(ids, buf)
+        logger.info(f"hub cache: {ids.shape[0]} embeddings kept in HBM")
 
     def compute_query_embedding(self, query: str, use_server_if_available: bool = True,
                                 zmq_port: Optional[int] = None) -> np.ndarray:

@@ -1268,6 +1268,11 @@ __global__ __launch_bounds__(256) void k_memo_append(WsDev ws, const float* e_ne
         ws.memo_slot[ws.uniq[i]] = (int32_t)(base + i);
 }
 
+// hub cache without the per-call memo: forget this round's fresh rows again (their slots go back to -1)
+__global__ __launch_bounds__(256) void k_memo_release(WsDev ws, int32_t nu) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nu; i += (int64_t)gridDim.x * 256) ws.memo_slot[ws.uniq[i]] = -1;
+}
+
 // end-of-search totals: nexpand = sum of per-query pops (nsteps), ndis = sum of per-query evaluations
 __global__ __launch_bounds__(256) void k_stats(WsDev ws) {
     __shared__ unsigned long long red[2][4];
@@ -1439,6 +1444,8 @@ struct lm_index {
     int32_t* d_memo_slot = nullptr;
     float* d_memo = nullptr;
     int64_t memo_cap = 0;
+    int32_t* d_hub_slot_init = nullptr;  // N: slot of every hub node, -1 elsewhere (hub-embedding cache)
+    int64_t hub_n = 0;
     std::vector<void*> ws_allocs;
     float* d_qpad = nullptr;
     int64_t qpad_cap = 0;
@@ -1696,12 +1703,16 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         prune_shmem = ((size_t)pa.Pmax + 2 * AQ_CAP) * 8;
         hipLaunchKernelGGL(k_pq_lut_all, dim3(B), dim3(256), 0, st, pa);
     }
-    const bool memo = recompute && prm.recompute_memo != 0 && ix->update_variant != 1 && ix->update_variant != 2;
+    const bool slots_ok = ix->update_variant != 1 && ix->update_variant != 2;
+    const bool hub = recompute && ix->hub_n > 0 && slots_ok;
+    const bool memo_call = recompute && prm.recompute_memo != 0 && slots_ok;  // keep rows until the call returns
+    const bool memo = memo_call || hub;                                       // rows are addressed through memo_slot
     int64_t memo_used = 0;
     if (memo) {
         if (!ix->d_memo_slot) LM_HIP(hipMalloc((void**)&ix->d_memo_slot, (size_t)ix->N * 4));
         const int64_t want = std::min<int64_t>(ix->N, 16ll << 20);
         if (ix->memo_cap < want) {
+            if (hub) LM_FAIL(LM_ESTATE, "internal: memo buffer must be allocated when the hub cache is set");
             if (ix->d_memo) (void)hipFree(ix->d_memo);
             ix->d_memo = nullptr;
             LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
@@ -1709,7 +1720,12 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         }
         ws.memo_slot = ix->d_memo_slot;
         ws.memo = ix->d_memo;
-        LM_HIP(hipMemsetAsync(ix->d_memo_slot, 0xFF, (size_t)ix->N * 4, st));
+        if (hub) {
+            LM_HIP(hipMemcpyAsync(ix->d_memo_slot, ix->d_hub_slot_init, (size_t)ix->N * 4, hipMemcpyDeviceToDevice, st));
+            memo_used = ix->hub_n;
+        } else {
+            LM_HIP(hipMemsetAsync(ix->d_memo_slot, 0xFF, (size_t)ix->N * 4, st));
+        }
     }
     GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
     const int flat = ix->update_variant == 2 ? 1 : 0;
@@ -1778,7 +1794,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
                     if (memo_used + nu > ix->memo_cap) LM_FAIL(LM_ESTATE, "recompute memo is full (more than 16M distinct nodes in one call)");
                     hipLaunchKernelGGL(k_memo_append, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nu * (ix->Dp / 4) + 255) / 256)),
                                        dim3(256), 0, st, ws, (const float*)d_e, nu, memo_used, ix->Dp);
-                    memo_used += nu;
+                    if (memo_call) memo_used += nu;
                 }
                 ua.E = ix->d_memo;
                 ua.by_rank = 2;
@@ -1795,6 +1811,9 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             rc = launch_update(ix, ua, ix->table_dtype == LM_DTYPE_F16);
         }
         if (rc) return rc;
+        if (hub && !memo_call && recompute && hc[C_NUNIQ] > 0)
+            hipLaunchKernelGGL(k_memo_release, dim3((unsigned)std::min<int64_t>(1024, ((int64_t)hc[C_NUNIQ] + 255) / 256)), dim3(256), 0, st, ws,
+                               (int32_t)hc[C_NUNIQ]);
         if (span_acc && ix->update_variant == 0) hipLaunchKernelGGL(k_span, dim3(1), dim3(256), 0, st, ix->d_tstamp, B, span_acc);
         ix->stats.update_launches++;
     }
@@ -2064,6 +2083,34 @@ int lm_index_attach_table(lm_index* ix, const void* table, int32_t dtype, int64_
         LM_HIP(hipDeviceSynchronize());
         (void)hipFree(tmp);
     }
+    return LM_OK;
+}
+
+int lm_index_set_hub_cache(lm_index* ix, const int32_t* ids, int32_t n, const float* d_embeddings) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    LM_HIP(hipSetDevice(ix->device));
+    if (n == 0) {
+        ix->hub_n = 0;
+        return LM_OK;
+    }
+    if (n < 0 || !ids || !d_embeddings || n > ix->N) LM_FAIL(LM_EINVAL, "bad hub cache arguments");
+    std::vector<int32_t> slot((size_t)ix->N, -1);
+    for (int32_t i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= ix->N || slot[ids[i]] >= 0) LM_FAIL(LM_EINVAL, "hub ids must be unique and in range");
+        slot[ids[i]] = i;
+    }
+    const int64_t want = std::min<int64_t>(ix->N, 16ll << 20);
+    if (n > want / 2) LM_FAIL(LM_EINVAL, "hub cache too large (more than half of the memo capacity)");
+    if (ix->memo_cap < want) {
+        if (ix->d_memo) (void)hipFree(ix->d_memo);
+        ix->d_memo = nullptr;
+        LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
+        ix->memo_cap = want;
+    }
+    if (!ix->d_hub_slot_init) LM_HIP(hipMalloc((void**)&ix->d_hub_slot_init, (size_t)ix->N * 4));
+    LM_HIP(hipMemcpy(ix->d_hub_slot_init, slot.data(), (size_t)ix->N * 4, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(ix->d_memo, d_embeddings, (size_t)n * ix->Dp * 4, hipMemcpyDeviceToDevice));
+    ix->hub_n = n;
     return LM_OK;
 }
 

@@ -112,6 +112,16 @@ class Mi355xIndex:
         check(self._lib.lm_index_set_provider(self._h, cb, None))
         self._refresh()
 
+    def set_hub_cache(self, ids: Optional[np.ndarray], embeddings=None) -> None:
+        """Cache the embeddings (device torch tensor fp32 [n, d_padded]) of the nodes ``ids``; ``None`` clears it."""
+        if ids is None or len(ids) == 0:
+            check(self._lib.lm_index_set_hub_cache(self._h, None, 0, None), "lm_index_set_hub_cache")
+            return
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        assert embeddings.is_cuda and embeddings.is_contiguous() and tuple(embeddings.shape) == (ids.shape[0], self.info.d_padded)
+        check(self._lib.lm_index_set_hub_cache(self._h, _np_ptr(ids), ids.shape[0], C.c_void_p(embeddings.data_ptr())),
+              "lm_index_set_hub_cache")
+
     def set_stream(self, stream_ptr: int) -> None:
         check(self._lib.lm_index_set_stream(self._h, C.c_void_p(stream_ptr)))
 

@@ -178,6 +178,47 @@ def test_lockstep_table_mode_still_matches(env):
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:], (a[3:], b[3:])
 
 
+def test_hub_cache_same_results_fewer_recomputes(env):
+    """Hub-embedding cache: cached nodes never reach the provider; ids/distances unchanged (with and without memo)."""
+    from leann_amd.backend import hub_nodes
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    torch = env
+    x, g = _build(3000, 384, "mips", seed=1)
+    q = queries_near(x, 64, seed=13)
+    xdev = torch.from_numpy(x).cuda()
+    hubs = hub_nodes(g, 0.1)
+    assert hubs.shape[0] == 300 and np.all(np.diff(hubs) > 0)
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    keep, seen = {}, []
+
+    def provider(d_ids, n, stream):
+        ids = as_tensor(d_ids, (n,), "int32")
+        seen.append(ids.cpu().numpy().copy())
+        keep["e"] = xdev.index_select(0, ids.long()).contiguous()
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+    oi, od, _ = orc.search(oracle_graph(g, 384), q, 10, ef=64, beam=2, table=x)
+    d0, l0 = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))
+    base = idx.stats()["nunique"]
+    idx.set_hub_cache(hubs, xdev[torch.from_numpy(hubs).long().cuda()].contiguous())
+    for memo in (False, True):
+        seen.clear()
+        d, l = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True, recompute_memo=memo))
+        torch.cuda.synchronize()
+        assert np.array_equal(l.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od)
+        allids = np.concatenate(seen)
+        assert not np.isin(allids, hubs).any() and idx.stats()["nunique"] < base
+    idx.set_hub_cache(None)
+    seen.clear()
+    idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))
+    assert idx.stats()["nunique"] == base and np.isin(np.concatenate(seen), hubs).any()
+
+
 def test_fp16_table(env):
     x, g = _build(1500, 768, "mips", seed=5)
     q = queries_near(x, 24, seed=8)
