@@ -1,0 +1,90 @@
+"""CPU tests of host-side helpers: synthetic corpus, hub selection, PQ training/encoding, flat graph,
+and the batched graph builder driven by the oracle search (the GPU default is injected away)."""
+import numpy as np
+import torch
+
+from tests.util import clustered, oracle_graph, queries_near, recall_at_k
+
+
+def test_synthetic_corpus_is_deterministic_and_structured():
+    from leann_amd.synth import CLS_ID, SEP_ID, CorpusSpec, SyntheticCorpus, pad_batch
+
+    spec = CorpusSpec(n_chunks=3000, n_topics=12)
+    a_tok, a_off = SyntheticCorpus(spec).chunks(block=1024)
+    b_tok, b_off = SyntheticCorpus(spec).chunks(block=1024)
+    assert np.array_equal(a_tok, b_tok) and np.array_equal(a_off, b_off)
+    lens = np.diff(a_off.astype(np.int64))
+    assert lens.min() >= 16 and lens.max() <= 256 and 150 < lens.mean() < 210
+    assert (a_tok[a_off[:-1].astype(np.int64)] == CLS_ID).all() and (a_tok[a_off[1:].astype(np.int64) - 1] == SEP_ID).all()
+    ids, ln = pad_batch(a_tok, a_off, 256)
+    assert ids.shape == (3000, 256) and (ids[np.arange(3000), ln - 1] == SEP_ID).all()
+    # chunks of one document share vocabulary: Jaccard overlap inside a doc >> across docs
+    sets = [set(ids[i, : ln[i]].tolist()) for i in range(64)]
+    same = np.mean([len(sets[i] & sets[i + 1]) / len(sets[i] | sets[i + 1]) for i in range(0, 15)])  # doc 0
+    diff = np.mean([len(sets[i] & sets[i + 32]) / len(sets[i] | sets[i + 32]) for i in range(0, 15)])  # doc 0 vs doc 2
+    assert same > 2 * diff
+    q_tok, q_off, docs = SyntheticCorpus(spec).queries(10, seed=7)
+    q2 = SyntheticCorpus(spec).queries(10, seed=7)
+    assert np.array_equal(q_tok, q2[0]) and docs.shape == (10,)
+
+
+def test_hub_nodes_by_in_degree(built_libs):
+    from leann_amd.backend import hub_nodes
+    from leann_amd.hnsw_builder import build_hnsw
+
+    x = clustered(2000, 32, 3)
+    g = build_hnsw(x, "mips", M=8, ef_construction=40)
+    indeg = np.zeros(2000, np.int64)
+    for i in range(2000):
+        np.add.at(indeg, g.neighbors_of(i, 0), 1)
+    hubs = hub_nodes(g, 0.05)
+    assert hubs.shape == (100,) and np.all(np.diff(hubs) > 0)
+    assert indeg[hubs].min() >= np.sort(indeg)[-100]  # exactly the top-100 by in-degree (ties by id)
+    assert hub_nodes(g, 0.0).shape == (0,) and hub_nodes(g, 1.0).shape == (2000,)
+
+
+def test_pq_train_encode_and_flat_graph(built_libs):
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.pq import encode_pq, flat_graph, train_pq
+    from oracle import oracle as orc
+
+    x = clustered(4000, 64, 5, n_centers=32, sigma=0.5)
+    cb = train_pq(torch.from_numpy(x), 16, iters=6, seed=0)
+    codes = encode_pq(torch.from_numpy(x), cb)
+    assert cb.shape == (16, 256, 4) and codes.shape == (4000, 16) and codes.dtype == torch.uint8
+    rec = cb[torch.arange(16)[None, :], codes.long()].reshape(4000, 64).numpy()
+    assert np.mean((rec - x) ** 2) < 0.35 * np.mean(x**2)  # the quantiser explains most of the variance
+    cb2 = train_pq(torch.from_numpy(x), 16, iters=6, seed=0)
+    assert torch.equal(cb, cb2)  # deterministic
+    g = build_hnsw(x, "l2", M=8, ef_construction=40)
+    fg = flat_graph(g, x)
+    fg.validate()
+    assert fg.max_level == 0 and (fg.levels == 1).all()
+    assert all(np.array_equal(fg.neighbors_of(i, 0), g.neighbors_of(i, 0)) for i in (0, 17, 3999))
+    mean = x.mean(0)
+    assert fg.entry_point == int(np.argmin(((x - mean) ** 2).sum(1)))
+    # DiskANN-style oracle search on it reaches high recall after the exact rerank
+    q = queries_near(x, 40, 6)
+    ids, _, _ = orc.pq_search(oracle_graph(fg, 64), cb.numpy(), codes.numpy(), q, 10, L=96, W=4, table=x)
+    gt, _ = orc.bruteforce_topk(x, q, 10, 1)
+    assert recall_at_k(ids, gt) > 0.9
+
+
+def test_batched_graph_builder_with_injected_search(built_libs):
+    """gpu_graph_build.build_graph_gpu on CPU tensors with the oracle as candidate search: quality comparable to
+    the sequential HNSW builder, all structural invariants hold."""
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from oracle import oracle as orc
+
+    def oracle_search_fn(g, table, queries, ef, k):
+        ids, dd, _ = orc.search(oracle_graph(g, g.d), queries.numpy(), k, ef=ef, beam=2, table=table.numpy())
+        return torch.from_numpy(ids), torch.from_numpy(dd if g.metric_type == 0 else -dd)
+
+    x = clustered(6000, 48, 9, n_centers=60, sigma=0.5)
+    g = build_graph_gpu(torch.from_numpy(x), "mips", M=12, ef_construction=60, search_fn=oracle_search_fn, seed_nodes=512)
+    g.validate()
+    assert g.level0_degrees().max() <= 24 and g.level0_degrees().min() >= 1
+    q = queries_near(x, 100, 10)
+    gt, _ = orc.bruteforce_topk(x, q, 10, 0)
+    ids, _, _ = orc.search(oracle_graph(g, 48), q, 10, ef=64, table=x)
+    assert recall_at_k(ids, gt) > 0.97
