@@ -141,26 +141,33 @@ def main():
 
     # optional: HBM-gather roofline of the fused kernel in stored-embedding mode, big batch
     table_roof = None
-    if args.table_roofline:
-        idx.set_profiling(True)
-        Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
-        bytes_eval = D * 4 + 4
-        table_roof = {}
-        for persistent in (1, 0, 1, 0):  # interleaved A/B: persistent one-launch kernel vs lock-step rounds
-            for beam_t, ef_t in ((4, ef), (1, ef)):
-                idx.set_option("persistent_table", persistent)
-                prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=16384)
-                idx.search_device(Qbig, 10, prm)
-                st = idx.stats()
-                key = f"{'k_search_table_persistent' if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}"
-                net_ms = max(st["update_span_ms"], 1e-6)
-                r = {"GBps": round(st["ndis"] * bytes_eval / (net_ms * 1e-3) / 1e9, 1), "launches": st["update_launches"],
-                     "us_per_launch": round(1e3 * net_ms / max(st["update_launches"], 1), 2),
-                     "us_per_launch_event_pair": round(1e3 * st["update_ms"] / max(st["update_launches"], 1), 2),
-                     "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
-                table_roof.setdefault(key, []).append(r)
-        idx.set_option("persistent_table", 1)
-        idx.set_profiling(False)
+    extras_errors = {}
+    if args.table_roofline and world == 1:
+        try:
+            idx.set_profiling(True)
+            Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
+            bytes_eval = D * 4 + 4
+            table_roof = {}
+            for persistent in (1, 0, 1, 0):  # interleaved A/B: persistent one-launch kernel vs lock-step rounds
+                for beam_t, ef_t in ((4, ef), (1, ef)):
+                    idx.set_option("persistent_table", persistent)
+                    prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=16384)
+                    idx.search_device(Qbig, 10, prm)
+                    st = idx.stats()
+                    key = f"{'k_search_table_persistent' if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}"
+                    net_ms = max(st["update_span_ms"], 1e-6)
+                    r = {"GBps": round(st["ndis"] * bytes_eval / (net_ms * 1e-3) / 1e9, 1), "launches": st["update_launches"],
+                         "us_per_launch": round(1e3 * net_ms / max(st["update_launches"], 1), 2),
+                         "us_per_launch_event_pair": round(1e3 * st["update_ms"] / max(st["update_launches"], 1), 2),
+                         "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
+                    table_roof.setdefault(key, []).append(r)
+            idx.set_option("persistent_table", 1)
+            idx.set_profiling(False)
+        except Exception as ex:  # noqa: BLE001 - an optional measurement must never cost the headline line
+            extras_errors["roofline_table_mode"] = repr(ex)[:300]
+            table_roof = None
+            idx.set_option("persistent_table", 1)
+            idx.set_profiling(False)
 
     # ---- timed region: recompute mode ---------------------------------------------------------------
     idx.set_provider(provider)
@@ -195,87 +202,66 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # ---- extra (not `value`): one step at the smallest ef of the sweep with recall@10 >= 0.9 -------------
-    min_ef = None
-    if not args.no_min_ef_step and ef_min != ef:
-        prm2 = idx.make_params(ef=ef_min, beam=args.beam, recompute=True, max_batch=B)
-        lo = (W + K) * B
-        barrier()
-        t1 = time.perf_counter()
-        _, l2 = idx.search_device(Q[lo : lo + B], 10, prm2)
-        barrier()
-        e2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([e2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
-        min_ef = {"ef_search": ef_min, "queries_per_s": round(world * B / e2, 3),
-                  "recall_at_10": round(recall(l2.cpu().numpy(), range(lo, lo + B)), 4), "steps": 1}
-    # ---- extra (not `value`): one step with the per-call recompute memo (each node recomputed <= once per call)
-    with_memo = None
-    if not args.no_min_ef_step:
-        prm3 = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, recompute_memo=True)
-        lo = (W + K + 1) * B
-        barrier()
-        t1 = time.perf_counter()
-        _, l3 = idx.search_device(Q[lo : lo + B], 10, prm3)
-        barrier()
-        e3 = time.perf_counter() - t1
-        st3 = idx.stats()
-        if world > 1:
-            t = torch.tensor([e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e3 = float(t.item())
-        with_memo = {"ef_search": ef, "queries_per_s": round(world * B / e3, 3), "recall_at_10": round(recall(l3.cpu().numpy(), range(lo, lo + B)), 4),
-                     "recomputed_chunks_per_query": round(st3["nunique"] / B, 1), "steps": 1}
-    # ---- extra (not `value`): hub-embedding cache, 10 % highest in-degree nodes (LEANN paper section 5) --------------
-    with_hub = None
-    if not args.no_min_ef_step:
-        from leann_amd.backend import hub_nodes
+    # ---- extras (NOT `value`; single-GPU runs only -- they contain no collectives and may never cost the headline
+    #      line): one extra step each, on fresh queries ----------------------------------------------------------
+    min_ef = with_memo = with_hub = two_level = None
+    do_extras = world == 1 and not args.no_min_ef_step
 
-        hubs = hub_nodes(g, 0.10)
-        idx.set_hub_cache(hubs, X[torch.from_numpy(hubs).long().to(dev)].contiguous())
-        lo = (W + K + 3) * B
-        barrier()
-        t1 = time.perf_counter()
-        _, l5 = idx.search_device(Q[lo : lo + B], 10, prm)
-        barrier()
-        e5 = time.perf_counter() - t1
-        st5 = idx.stats()
-        idx.set_hub_cache(None)
-        if world > 1:
-            t = torch.tensor([e5], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e5 = float(t.item())
-        with_hub = {"ef_search": ef, "hub_cache_ratio": 0.10, "cached_embeddings_MB": round(hubs.shape[0] * D * 4 / 1e6, 1),
-                    "queries_per_s": round(world * B / e5, 3), "recall_at_10": round(recall(l5.cpu().numpy(), range(lo, lo + B)), 4),
-                    "recomputed_chunks_per_query": round(st5["nunique"] / B, 1), "steps": 1}
-    # ---- extra (not `value`): two-level search (paper Alg. 2): prune_ratio 0.5, global strategy, PQ m=48 -------
-    two_level = None
-    if not args.no_min_ef_step:
-        from leann_amd.pq import encode_pq, train_pq
+    def extra_step(params, slot):
+        lo_ = (W + K + slot) * B
+        torch.cuda.synchronize()
+        t1_ = time.perf_counter()
+        _, lx = idx.search_device(Q[lo_ : lo_ + B], 10, params)
+        torch.cuda.synchronize()
+        ex_ = time.perf_counter() - t1_
+        return ex_, round(recall(lx.cpu().numpy(), range(lo_, lo_ + B)), 4), idx.stats()
 
-        t1 = time.time()
-        cb = train_pq(X, 48, iters=8, seed=0)
-        codes = encode_pq(X, cb)
-        idx.attach_pq(cb.cpu().numpy(), codes.cpu().numpy())
-        t_pq = time.time() - t1
-        prm4 = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, prune_ratio=0.5)
-        lo = (W + K + 2) * B
-        barrier()
-        t1 = time.perf_counter()
-        _, l4 = idx.search_device(Q[lo : lo + B], 10, prm4)
-        barrier()
-        e4 = time.perf_counter() - t1
-        st4 = idx.stats()
-        if world > 1:
-            t = torch.tensor([e4], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e4 = float(t.item())
-        two_level = {"ef_search": ef, "prune_ratio": 0.5, "pruning_strategy": "global", "pq_bytes": 48,
-                     "queries_per_s": round(world * B / e4, 3), "recall_at_10": round(recall(l4.cpu().numpy(), range(lo, lo + B)), 4),
-                     "recomputed_chunks_per_query": round(st4["nunique"] / B, 1), "adc_evals_per_query": round(st4["nadc"] / B, 1),
-                     "pq_train_encode_s": round(t_pq, 1), "steps": 1}
+    if do_extras and ef_min != ef:  # the smallest ef of the sweep with recall@10 >= 0.9
+        try:
+            e2, r2, _ = extra_step(idx.make_params(ef=ef_min, beam=args.beam, recompute=True, max_batch=B), 0)
+            min_ef = {"ef_search": ef_min, "queries_per_s": round(B / e2, 3), "recall_at_10": r2, "steps": 1}
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["at_min_ef"] = repr(ex)[:300]
+    if do_extras:  # per-call recompute memo: each node recomputed at most once per search call
+        try:
+            e3, r3, st3 = extra_step(idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, recompute_memo=True), 1)
+            with_memo = {"ef_search": ef, "queries_per_s": round(B / e3, 3), "recall_at_10": r3,
+                         "recomputed_chunks_per_query": round(st3["nunique"] / B, 1), "steps": 1}
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["with_per_call_recompute_memo"] = repr(ex)[:300]
+    if do_extras:  # hub-embedding cache, 10 % highest in-degree nodes (LEANN paper section 5)
+        try:
+            from leann_amd.backend import hub_nodes
+
+            hubs = hub_nodes(g, 0.10)
+            idx.set_hub_cache(hubs, X[torch.from_numpy(hubs).long().to(dev)].contiguous())
+            e5, r5, st5 = extra_step(prm, 3)
+            with_hub = {"ef_search": ef, "hub_cache_ratio": 0.10, "cached_embeddings_MB": round(hubs.shape[0] * D * 4 / 1e6, 1),
+                        "queries_per_s": round(B / e5, 3), "recall_at_10": r5,
+                        "recomputed_chunks_per_query": round(st5["nunique"] / B, 1), "steps": 1}
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["with_hub_cache"] = repr(ex)[:300]
+        finally:
+            try:
+                idx.set_hub_cache(None)
+            except Exception:  # noqa: BLE001
+                pass
+    if do_extras:  # two-level search (paper Alg. 2): prune_ratio 0.5, global strategy, PQ 48 B/vector
+        try:
+            from leann_amd.pq import encode_pq, train_pq
+
+            t1 = time.time()
+            cb = train_pq(X, 48, iters=8, seed=0)
+            codes = encode_pq(X, cb)
+            idx.attach_pq(cb.cpu().numpy(), codes.cpu().numpy())
+            t_pq = time.time() - t1
+            e4, r4, st4 = extra_step(idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, prune_ratio=0.5), 2)
+            two_level = {"ef_search": ef, "prune_ratio": 0.5, "pruning_strategy": "global", "pq_bytes": 48,
+                         "queries_per_s": round(B / e4, 3), "recall_at_10": r4,
+                         "recomputed_chunks_per_query": round(st4["nunique"] / B, 1), "adc_evals_per_query": round(st4["nadc"] / B, 1),
+                         "pq_train_encode_s": round(t_pq, 1), "steps": 1}
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["with_two_level_search"] = repr(ex)[:300]
     labels_np = torch.cat(out_labels).cpu().numpy() if out_labels else np.zeros((0, 10), np.int64)
     rec = recall(labels_np, range(W * B, (W + K) * B)) if K else 0.0
     if world > 1:
@@ -343,10 +329,15 @@ def main():
         result["with_two_level_search"] = two_level
     if table_roof:
         result["roofline_table_mode"] = table_roof
+    if extras_errors:
+        result["extras_errors"] = extras_errors
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle + fp32 CPU encoder on a bounded sample ---------
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, g, Q, tok, off, cfg, ef, args.beam)
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, g, Q, tok, off, cfg, ef, args.beam)
+        except Exception as ex:  # noqa: BLE001 - report, never lose the line
+            result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
