@@ -152,3 +152,35 @@ def test_merge_topk():
     for b in range(B):
         allp = sorted(zip(d[:, b].ravel().tolist(), ids[:, b].ravel().tolist()))[:k]
         assert [p[1] for p in allp] == oi[b].tolist()
+
+
+def test_two_level_search_oracle_semantics(built_libs):
+    """prune_ratio (paper Alg. 2): fewer exact evaluations, recall stays high for the global strategy; prune_ratio 0
+    or no PQ == plain search; the three strategies order as documented (local prunes hardest per hop)."""
+    import torch
+
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.pq import encode_pq, train_pq
+
+    x = clustered(6000, 64, 11, n_centers=64, sigma=0.5)
+    q = queries_near(x, 60, 12)
+    g = build_hnsw(x, "mips", M=12, ef_construction=60)
+    og = oracle_graph(g, 64)
+    cb = train_pq(torch.from_numpy(x), 16, iters=6, seed=0).numpy()
+    codes = encode_pq(torch.from_numpy(x), torch.from_numpy(cb)).numpy()
+    gt, _ = orc.bruteforce_topk(x, q, 10, METRIC_INNER_PRODUCT)
+    base_i, base_d, base = orc.search(og, q, 10, ef=64, table=x)
+    same_i, same_d, st0 = orc.search(og, q, 10, ef=64, table=x, prune_ratio=0.0, pq=(cb, codes))
+    assert np.array_equal(base_i, same_i) and np.array_equal(base_d, same_d) and st0["nadc"] == 0
+    res = {}
+    for strat in ("global", "local", "proportional"):
+        ids, _, st = orc.search(og, q, 10, ef=64, table=x, prune_ratio=0.5, pruning_strategy=strat, pq=(cb, codes))
+        res[strat] = (recall_at_k(ids, gt), st["ndis"], st["nadc"])
+        assert st["ndis"] < 0.75 * base["ndis"] and st["nadc"] > 0
+    assert res["global"][0] >= 0.97 and res["proportional"][0] >= 0.97
+    assert res["local"][0] <= res["global"][0] + 1e-9
+    # provider mode sees only the surviving nodes
+    seen = []
+    orc.search(og, q[:5], 10, ef=32, provider=lambda idv: (seen.append(len(idv)), x[idv])[1], prune_ratio=0.6, pq=(cb, codes))
+    _, _, stp = orc.search(og, q[:5], 10, ef=32, table=x, prune_ratio=0.6, pq=(cb, codes))
+    assert sum(seen) <= stp["ndis"]
