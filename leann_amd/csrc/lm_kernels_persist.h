@@ -1,0 +1,254 @@
+// lm_kernels_persist.h -- k_search_table: persistent stored-embedding search, k_rounds_max.
+// Part of lm_search.hip's translation unit (included there, in this order); see its header comment.
+#pragma once
+
+namespace lm {
+
+// ---- persistent stored-embedding search: the whole traversal of a query inside ONE workgroup ----------------
+// (recompute_embeddings=False path of hnsw_backend.py:189-193; also what the GPU graph builder searches with.)
+// No encoder sits between the rounds in this mode, so nothing forces lock-step kernel launches: every workgroup
+// walks its own query from the entry point to termination -- greedy descent on the upper levels, then the level-0
+// beam with the same pop / visited / merge rules as k_expand + k_update (set semantics => identical results) --
+// keeping pool, frontier and new-list in LDS.  One launch per batch, no host round trips, no launch gaps.
+// dynamic LDS: lpool[ef] | out[ef] | newk[Pmax] (u64) | s_new[maxnew] (i32)
+struct PersistArgs {
+    const float* Q;
+    const void* E;
+    int32_t check_rel, max_level, Pmax, k, metric;
+    int64_t* labels;
+    float* dist;
+    int32_t* rounds_q;
+};
+
+template <int NCH, bool L2, bool F16>
+__global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, PersistArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_off[65];
+    __shared__ uint64_t s_b[64];
+    __shared__ int32_t s_pop[64];
+    __shared__ int s_npop, s_wcnt[4];
+    __shared__ unsigned long long s_best;
+    const int ef = ws.ef;
+    uint64_t* lpool = (uint64_t*)smem;
+    uint64_t* outp = lpool + ef;
+    uint64_t* newk = outp + ef;
+    int32_t* s_new = (int32_t*)(newk + a.Pmax);
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane16 = tid & 15, sg = tid >> 4;
+    float4 qv[NCH];
+    {
+        const float4* qrow = (const float4*)(a.Q + (size_t)q * (NCH * 64));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
+    }
+    uint32_t* vis = ws.visited + (size_t)q * ws.nw;
+    unsigned long long ndis = 0;
+    int rounds = 0, nsteps = 0;
+
+    // distances of s_new[0..n) -> newk[0..n)   (two rows in flight per 16-lane group, canonical reduction)
+    auto eval_new = [&](int n) {
+        for (int i = sg; i < n; i += 32) {
+            const int i2 = i + 16;
+            const bool has2 = i2 < n;
+            const int32_t v0 = s_new[i];
+            const int32_t v1 = has2 ? s_new[i2] : v0;
+            float4 e0[NCH], e1[NCH];
+            load_row<NCH, F16>(a.E, (int64_t)v0, lane16, e0);
+            load_row<NCH, F16>(a.E, (int64_t)v1, lane16, e1);
+            const float d0 = row_reduce<NCH, L2>(e0, qv);
+            const float d1 = row_reduce<NCH, L2>(e1, qv);
+            if (lane16 == 0) {
+                newk[i] = make_key(d0, v0);
+                if (has2) newk[i2] = make_key(d1, v1);
+            }
+        }
+    };
+
+    // ---- seed: distance of the entry point ----
+    if (tid == 0) {
+        s_new[0] = g.entry_point;
+        s_best = KEY_NONE;
+    }
+    __syncthreads();
+    eval_new(1);
+    __syncthreads();
+    uint64_t cur = newk[0];
+    ndis += 1;
+    rounds = 1;
+    // ---- upper levels: greedy descent (faiss greedy_update_nearest) ----
+    for (int level = a.max_level; level > 0;) {
+        uint64_t b;
+        uint32_t cnt;
+        nbr_range(g, key_id(cur), level, b, cnt);
+        for (uint32_t j = tid; j < cnt; j += 256) s_new[j] = g.neighbors[b + j];
+        if (tid == 0) s_best = KEY_NONE;
+        __syncthreads();
+        eval_new((int)cnt);
+        __syncthreads();
+        for (int i = tid; i < (int)cnt; i += 256) atomicMin(&s_best, (unsigned long long)newk[i]);
+        __syncthreads();
+        const uint64_t best = s_best;
+        ndis += cnt;
+        rounds++;
+        if (best != KEY_NONE && best < cur) cur = best;
+        else level--;
+        __syncthreads();
+    }
+    // ---- level 0 ----
+    if (tid == 0) {
+        const int32_t c = key_id(cur);
+        atomicOr(&vis[c >> 5], 1u << (c & 31));
+        lpool[0] = cur;
+    }
+    int npool = 1;
+    __syncthreads();
+    for (;;) {
+        if (tid < 64) {
+            int allowed = ws.W;
+            if (!a.check_rel) allowed = min(allowed, max(0, ef + 1 - nsteps));
+            int found = 0;
+            for (int base = 0; base < npool && found < allowed; base += 64) {
+                int i = base + tid;
+                bool un = i < npool && !(lpool[i] & KEY_EXPANDED);
+                unsigned long long m = __ballot(un);
+                int r = found + __popcll(m & ((1ull << tid) - 1ull));
+                if (un && r < allowed) {
+                    lpool[i] |= KEY_EXPANDED;
+                    s_pop[r] = key_id(lpool[i]);
+                }
+                found += __popcll(m);
+            }
+            found = min(found, allowed);
+            uint32_t cnt = 0;
+            if (tid < found) {
+                L0Range r = g.l0[s_pop[tid]];
+                s_b[tid] = r.begin;
+                cnt = r.count;
+            }
+            uint32_t x = cnt;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t y = __shfl_up(x, d);
+                if (tid >= d) x += y;
+            }
+            if (tid == 0) {
+                s_off[0] = 0;
+                s_npop = found;
+            }
+            if (tid < found) s_off[tid + 1] = x;
+        }
+        __syncthreads();
+        const int np = s_npop;
+        if (np == 0) break;
+        nsteps += np;
+        rounds++;
+        const uint32_t totalc = s_off[np];
+        int total = 0;
+        for (uint32_t f0 = 0; f0 < totalc; f0 += 256) {
+            const uint32_t f = f0 + tid;
+            bool fresh = false;
+            int32_t v = -1;
+            if (f < totalc) {
+                int lo = 0, hi = np - 1;
+                while (lo < hi) {
+                    int mid = (lo + hi + 1) >> 1;
+                    if (s_off[mid] <= f) lo = mid;
+                    else hi = mid - 1;
+                }
+                v = g.neighbors[s_b[lo] + (f - s_off[lo])];
+                uint32_t bit = 1u << (v & 31);
+                uint32_t old = atomicOr(&vis[v >> 5], bit);
+                fresh = !(old & bit);
+            }
+            unsigned long long m = __ballot(fresh);
+            if (lane == 0) s_wcnt[wv] = __popcll(m);
+            __syncthreads();
+            int woff = 0;
+            for (int i = 0; i < wv; ++i) woff += s_wcnt[i];
+            if (fresh) s_new[total + woff + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            __syncthreads();
+        }
+        const int n = total;
+        ndis += (unsigned long long)n;
+        int Pn = 1;
+        while (Pn < n) Pn <<= 1;
+        eval_new(n);
+        for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+        __syncthreads();
+        if (n > 0) {
+            for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
+                for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+                    for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
+                        unsigned ixj = i ^ j;
+                        if (ixj > i) {
+                            uint64_t x = newk[i], y = newk[ixj];
+                            bool up = (i & k2) == 0;
+                            if ((x > y) == up) {
+                                newk[i] = y;
+                                newk[ixj] = x;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < npool; i += 256) {
+                uint64_t key = lpool[i];
+                uint64_t kk = key >> 1;
+                int lo = 0, hi = n;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if ((newk[mid] >> 1) < kk) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (i + lo < ef) outp[i + lo] = key;
+            }
+            for (int j = tid; j < n; j += 256) {
+                uint64_t key = newk[j];
+                uint64_t kk = key >> 1;
+                int lo = 0, hi = npool;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if ((lpool[mid] >> 1) < kk) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (j + lo < ef) outp[j + lo] = key;
+            }
+            __syncthreads();
+            npool = min(ef, npool + n);
+            for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
+            __syncthreads();
+        }
+    }
+    // ---- results (same as k_finalize) + per-query statistics ----
+    for (int i = tid; i < a.k; i += 256) {
+        const size_t t = (size_t)q * a.k + i;
+        if (i < npool) {
+            const float d = key_dist(lpool[i]);
+            a.labels[t] = key_id(lpool[i]);
+            a.dist[t] = a.metric == LM_METRIC_L2 ? d : -d;
+        } else {
+            a.labels[t] = -1;
+            a.dist[t] = a.metric == LM_METRIC_L2 ? __builtin_inff() : -__builtin_inff();
+        }
+    }
+    if (tid == 0) {
+        ws.ndis_q[q] = ndis;
+        ws.nsteps[q] = nsteps;
+        ws.nadc_q[q] = 0;
+        a.rounds_q[q] = rounds;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rounds_max(WsDev ws, const int32_t* rounds_q) {
+    __shared__ int red[4];
+    int r = 0;
+    for (int q = threadIdx.x; q < ws.B; q += 256) r = max(r, rounds_q[q]);
+    for (int m = 32; m >= 1; m >>= 1) r = max(r, __shfl_xor(r, m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) ws.counters[C_ROUNDS] = (unsigned long long)max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+
+}  // namespace lm
