@@ -287,6 +287,13 @@ def test_recall_full_size_property(env):
         assert np.all(np.diff(d, axis=1) <= 0)  # +IP descending
         recs.append(recall_at_k(l, gt))
     assert recs[1] >= 0.9 and recs[0] <= recs[1] + 1e-9 <= recs[2] + 2e-9, recs
+    # idempotence + launch-structure independence: same call twice, persistent vs lock-step -> identical output
+    prm = idx.make_params(ef=64, beam=2, recompute=False)
+    d1, l1 = idx.search(q, 10, prm)
+    d2, l2 = idx.search(q, 10, prm)
+    idx.set_option("persistent_table", 0)
+    d3, l3 = idx.search(q, 10, prm)
+    assert np.array_equal(l1, l2) and np.array_equal(d1, d2) and np.array_equal(l1, l3) and np.array_equal(d1, d3)
 
 
 def test_dist_gather_kernel(env):

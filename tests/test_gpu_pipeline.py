@@ -320,3 +320,47 @@ def test_encoder_packed_fused_attention_matches_library_attention(torch_, monkey
     monkeypatch.setenv("LEANN_MI355X_ATTN", "0")
     b = enc.encode_tokens_packed(ti, tl)
     assert (a - b).abs().max() < 2e-3
+
+
+def test_backend_no_recompute_mode_and_hub_cache_kwarg(torch_, tmp_path):
+    """recompute_embeddings=False on an index that keeps its embeddings (is_recompute=False => non-compact,
+    hnsw_backend.py:58-64): stored-embedding search, no encoder involved.  Then the hub_cache_ratio kwarg on a
+    pruned index: same answers as plain recompute."""
+    torch = torch_
+    from leann_amd._compat import BACKEND_REGISTRY
+    from leann_amd.backend import write_leann_bundle
+
+    x = clustered(400, 384, 31)
+    texts = [f"passage {i} " + " ".join(f"w{(i * 7 + j) % 50}" for j in range(12)) for i in range(400)]
+    p = str(tmp_path / "full.leann")
+    write_leann_bundle(p, texts, x, "sentence-transformers/all-MiniLM-L6-v2", distance_metric="l2", M=8, efConstruction=40,
+                       is_recompute=False)
+    s = BACKEND_REGISTRY["mi355x"].searcher(p)
+    assert s.is_pruned is False
+    r = s.search(x[:9] + 1e-4, 3, complexity=32, recompute_embeddings=False)
+    assert [row[0] for row in r["labels"]] == [str(i) for i in range(9)]
+    assert np.all(np.diff(r["distances"], axis=1) >= 0) and r["distances"][:, 0].max() < 1e-3  # squared L2 ascending
+    s.cleanup()
+    # pruned index + hub cache: embeddings come from the in-process encoder
+    from leann_amd.encoder import BertEncoder
+    from leann_amd.tokenizer import load_tokenizer
+
+    model = "sentence-transformers/all-MiniLM-L6-v2"
+    p2 = str(tmp_path / "pruned.leann")
+    enc = BertEncoder.load(model).to("cuda", dtype=torch.float16)
+    tok = load_tokenizer(model, 256, p2, texts, enc.cfg.vocab_size)
+    seqs = tok.encode_batch(texts)
+    T = max(len(q) for q in seqs)
+    ids = torch.zeros((len(seqs), T), dtype=torch.int32)
+    for i, q in enumerate(seqs):
+        ids[i, : len(q)] = torch.tensor(q, dtype=torch.int32)
+    emb = enc.encode_tokens(ids.cuda(), torch.tensor([len(q) for q in seqs], dtype=torch.int32).cuda()).cpu().numpy()
+    write_leann_bundle(p2, texts, emb, model, distance_metric="mips", M=8, efConstruction=40)
+    plain = BACKEND_REGISTRY["mi355x"].searcher(p2)
+    cached = BACKEND_REGISTRY["mi355x"].searcher(p2, hub_cache_ratio=0.2)
+    ra = plain.search(emb[:6], 4, complexity=32, recompute_embeddings=True, zmq_port=5557)
+    rb = cached.search(emb[:6], 4, complexity=32, recompute_embeddings=True, zmq_port=5557)
+    assert ra["labels"] == rb["labels"] and np.allclose(ra["distances"], rb["distances"], atol=2e-3)
+    assert cached.last_stats()["nunique"] < plain.last_stats()["nunique"]
+    plain.cleanup()
+    cached.cleanup()
