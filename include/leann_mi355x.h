@@ -96,7 +96,7 @@ int lm_index_set_provider(lm_index *idx, lm_provider_fn fn, void *user);
 /* Hub-embedding cache (LEANN paper section 5: caching the embeddings of the highest-degree ~10 % nodes): the rows
  * of d_embeddings [n][d_padded] (fp32, device) are copied into HBM owned by the index; nodes listed in `ids` (host,
  * unique) are never sent to the provider again.  n = 0 clears the cache.  Cf. num_nodes_to_cache of the DiskANN
- * backend (diskann_backend.py:347). */
+ * backend (diskann_backend.py:345). */
 int lm_index_set_hub_cache(lm_index *idx, const int32_t *ids, int32_t n, const float *d_embeddings);
 
 /* hipStream_t all kernels of this index are enqueued on (default: the null stream). */
