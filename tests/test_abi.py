@@ -70,3 +70,34 @@ def test_argument_validation_precedes_device_use(built_libs):
     lib.lm_search_params_default(C.byref(p))
     assert (p.efSearch, p.beam_size, p.check_relative_distance, p.recompute) == (64, 1, 1, 1)
     assert lib.lm_index_search(None, 1, None, 1, None, None, C.byref(p)) == _lib.LM_EINVAL
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+
+    exe = tmp_path / "abi_host"
+    lib_dir = ROOT / "leann_amd" / "lib"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}", "-o", str(exe),
+                    str(ROOT / "tests" / "abi" / "abi_host.c"), f"-L{lib_dir}", "-lleann_mi355x", "-lm", f"-Wl,-rpath,{lib_dir}"],
+                   check=True, capture_output=True)
+    return exe
+
+
+def test_plain_c_host(built_libs, tmp_path):
+    """A C11 program (no Python, no torch) compiles against include/leann_mi355x.h with -Werror, links the library and
+    passes its checks: argument validation everywhere; without a GPU the loud LM_EHIP path."""
+    import subprocess
+
+    r = subprocess.run([str(_build_c_host(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "PATH-OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_host_known_answer_on_gpu(tmp_path):
+    """Same program on the GPU box: the hand-traced line graph searched through lm_index_search from C."""
+    import subprocess
+
+    r = subprocess.run([str(_build_c_host(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "GPU-PATH-OK" in r.stdout
