@@ -388,7 +388,13 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     ua.check_rel = prm.check_relative_distance;
     ua.max_level = ix->max_level;
     ua.P2 = next_pow2(ef + ws.maxnew);
-    if ((size_t)ua.P2 * 8 > 64 * 1024) LM_FAIL(LM_EINVAL, "efSearch * beam too large for the LDS pool (ef + beam*degree <= 8192)");
+    {
+        // dynamic LDS of the update kernel (default launch limit 64 KiB): full-sort variant holds pool+new in one array,
+        // the others hold pool | merged pool | new keys
+        const size_t need = ix->update_variant == 1 ? (size_t)ua.P2 * 8 : ((size_t)2 * ef + next_pow2(ws.maxnew)) * 8;
+        if (need > 64 * 1024)
+            LM_FAIL(LM_EINVAL, "efSearch / beam_size too large for the LDS-resident pool (2*max(efSearch,k) + beam*max_degree keys must fit 64 KiB)");
+    }
     const int ntiles = (int)((ws.nw + UNIQ_TILE - 1) / UNIQ_TILE);
     const int sync_every = recompute ? 1 : 4;
     int64_t rounds = 0;
