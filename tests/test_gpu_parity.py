@@ -407,3 +407,40 @@ def test_two_level_search_parity(env, strategy):
                 assert ost["ndis"] < bst["ndis"]  # fewer exact evaluations than the unpruned search
                 base = bst
     idx.close()
+
+
+def test_random_degenerate_graphs_match_oracle(env):
+    """Seeded random tiny graphs with empty neighbour lists, unreachable nodes, upper-level stubs: GPU == oracle in
+    stored-embedding (persistent and lock-step) and recompute modes, incl. unfilled result slots."""
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+    from tests.test_oracle_properties import _random_graph
+
+    torch = env
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(1, 30))
+        metric = int(rng.integers(0, 2))
+        x, g, _ = _random_graph(rng, n, 64, metric)
+        q = rng.standard_normal((5, 64)).astype(np.float32)
+        k, ef, beam = int(rng.integers(1, 7)), int(rng.integers(1, n + 5)), int(rng.integers(1, 5))
+        oi, od, ost = orc.search(oracle_graph(g, 64), q, k, ef=ef, beam=beam, table=x)
+        idx = Mi355xIndex.from_csr(g)
+        idx.set_stream(torch.cuda.current_stream().cuda_stream)
+        idx.attach_table(x)
+        xdev = torch.from_numpy(x).cuda()
+        keep = {}
+
+        def provider(d_ids, cnt, stream):
+            keep["e"] = xdev.index_select(0, as_tensor(d_ids, (cnt,), "int32").long()).contiguous()
+            return keep["e"].data_ptr()
+
+        idx.set_provider(provider)
+        for mode in ("persistent", "lockstep", "provider"):
+            idx.set_option("persistent_table", 1 if mode == "persistent" else 0)
+            d, l = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=(mode == "provider")))
+            st = idx.stats()
+            assert np.array_equal(l, oi) and np.array_equal(d.view(np.uint32), od.view(np.uint32)), (seed, mode, n, k, ef, beam)
+            assert (st["ndis"], st["nexpand"], st["nrounds"]) == (ost["ndis"], ost["nexpand"], ost["nrounds"]), (seed, mode, st, ost)
+        idx.close()
