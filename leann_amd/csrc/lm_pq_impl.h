@@ -363,7 +363,8 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     pa.Pmax = next_pow2(ws.maxnew);
     pa.n_adc_q = ix->d_pq_nadc; pa.rounds_q = ix->d_pq_rounds;
     size_t shmem = (size_t)ix->pq_m * 256 * 4 + (size_t)2 * L * 8 + (size_t)pa.Pmax * 8 + (size_t)ws.maxnew * 4;
-    if (shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "PQ search state does not fit the 160 KB LDS (reduce m, complexity or beam_width)");
+    if (shmem > 158 * 1024)  // 160 KiB per workgroup minus the kernel's ~1.1 KiB of static LDS
+        LM_FAIL(LM_EINVAL, "PQ search state does not fit the 160 KB LDS (reduce m, complexity or beam_width)");
     LM_HIP(hipFuncSetAttribute((const void*)k_pq_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
     LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
