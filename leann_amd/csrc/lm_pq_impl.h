@@ -352,6 +352,9 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     if ((int64_t)B > ix->pq_cap) {
         if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
         if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
+        ix->d_pq_nadc = nullptr;
+        ix->d_pq_rounds = nullptr;
+        ix->pq_cap = 0;
         LM_HIP(hipMalloc((void**)&ix->d_pq_nadc, (size_t)B * 8));
         LM_HIP(hipMalloc((void**)&ix->d_pq_rounds, (size_t)B * 4));
         ix->pq_cap = B;
@@ -382,6 +385,7 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
         UpdateArgs ua{};
         ua.Q = d_q;
         ua.P2 = next_pow2(L);
+        if ((size_t)ua.P2 * 8 > 64 * 1024) LM_FAIL(LM_EINVAL, "complexity too large for the rerank kernel (<= 8192 candidates per query)");
         if (prm.use_deferred_fetch && ix->provider) {
             // ONE deferred fetch for the union of all candidate lists
             const int ntiles = (int)((ws.nw + UNIQ_TILE - 1) / UNIQ_TILE);
@@ -470,6 +474,8 @@ static int pq_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     if (ix->D != ix->Dp) {
         if (n > ix->qpad_cap) {
             if (ix->d_qpad) (void)hipFree(ix->d_qpad);
+            ix->d_qpad = nullptr;
+            ix->qpad_cap = 0;
             LM_HIP(hipMalloc((void**)&ix->d_qpad, (size_t)n * ix->Dp * sizeof(float)));
             ix->qpad_cap = n;
         }
@@ -509,11 +515,16 @@ int lm_pq_batch_search(lm_index* ix, int64_t n, const float* x, int32_t k, const
     float* d_x = nullptr;
     float* d_d = nullptr;
     int64_t* d_l = nullptr;
-    LM_HIP(hipMalloc((void**)&d_x, (size_t)n * ix->D * 4));
-    LM_HIP(hipMalloc((void**)&d_d, (size_t)n * k * 4));
-    LM_HIP(hipMalloc((void**)&d_l, (size_t)n * k * 8));
     int rc = LM_OK;
-    if (hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = LM_EHIP;
+    if (hipMalloc((void**)&d_x, (size_t)n * ix->D * 4) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * k * 4) != hipSuccess ||
+        hipMalloc((void**)&d_l, (size_t)n * k * 8) != hipSuccess) {
+        set_error("out of device memory for the query / result staging buffers");
+        rc = LM_EHIP;
+    }
+    if (!rc && hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+        set_error("query upload failed");
+        rc = LM_EHIP;
+    }
     if (!rc) rc = pq_search_device(ix, n, d_x, k, params, d_l, d_d);
     if (!rc && (hipMemcpyAsync(distances, d_d, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
                 hipMemcpyAsync(labels, d_l, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
@@ -521,9 +532,9 @@ int lm_pq_batch_search(lm_index* ix, int64_t n, const float* x, int32_t k, const
         set_error("result copy failed");
         rc = LM_EHIP;
     }
-    (void)hipFree(d_x);
-    (void)hipFree(d_d);
-    (void)hipFree(d_l);
+    if (d_x) (void)hipFree(d_x);
+    if (d_d) (void)hipFree(d_d);
+    if (d_l) (void)hipFree(d_l);
     return rc;
 }
 

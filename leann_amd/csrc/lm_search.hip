@@ -274,6 +274,9 @@ static int search_pass_persistent(lm_index* ix, int32_t B, const float* d_q, int
     if ((int64_t)B > ix->pq_cap) {
         if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
         if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
+        ix->d_pq_nadc = nullptr;
+        ix->d_pq_rounds = nullptr;
+        ix->pq_cap = 0;
         LM_HIP(hipMalloc((void**)&ix->d_pq_nadc, (size_t)B * 8));
         LM_HIP(hipMalloc((void**)&ix->d_pq_rounds, (size_t)B * 4));
         ix->pq_cap = B;
@@ -329,6 +332,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         if (need > ix->lut_cap) {
             if (ix->d_lut) (void)hipFree(ix->d_lut);
             ix->d_lut = nullptr;
+            ix->lut_cap = 0;
             LM_HIP(hipMalloc((void**)&ix->d_lut, (size_t)need * 4));
             ix->lut_cap = need;
         }
@@ -352,6 +356,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             if (hub) LM_FAIL(LM_ESTATE, "internal: memo buffer must be allocated when the hub cache is set");
             if (ix->d_memo) (void)hipFree(ix->d_memo);
             ix->d_memo = nullptr;
+            ix->memo_cap = 0;
             LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
             ix->memo_cap = want;
         }
@@ -377,6 +382,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         if (ix->tstamp_cap < B) {
             if (ix->d_tstamp) (void)hipFree(ix->d_tstamp);
             ix->d_tstamp = nullptr;
+            ix->tstamp_cap = 0;
             LM_HIP(hipMalloc((void**)&ix->d_tstamp, ((size_t)2 * B + 2) * 8));
             ix->tstamp_cap = B;
         }
@@ -489,6 +495,9 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     ix->stats = lm_search_stats{};
     ix->span_ms = 0;
     ix->span_launches = 0;
+    (void)drain_events(ix, ix->ev_update);  // pairs left behind by a call that failed midway
+    (void)drain_events(ix, ix->ev_expand);
+    (void)drain_events(ix, ix->ev_provider);
     if (n == 0) return LM_OK;
     hipStream_t st = ix->stream;
     if (ix->N == 0 || ix->entry_point < 0) {
@@ -507,6 +516,8 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     if (ix->D != ix->Dp) {
         if (n > ix->qpad_cap) {
             if (ix->d_qpad) (void)hipFree(ix->d_qpad);
+            ix->d_qpad = nullptr;
+            ix->qpad_cap = 0;
             LM_HIP(hipMalloc((void**)&ix->d_qpad, (size_t)n * ix->Dp * sizeof(float)));
             ix->qpad_cap = n;
         }
@@ -672,6 +683,7 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_l0) (void)hipFree(ix->d_l0);
     if (ix->d_memo_slot) (void)hipFree(ix->d_memo_slot);
     if (ix->d_memo) (void)hipFree(ix->d_memo);
+    if (ix->d_hub_slot_init) (void)hipFree(ix->d_hub_slot_init);
     if (ix->d_pq_codebooks) (void)hipFree(ix->d_pq_codebooks);
     if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
     if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
@@ -681,6 +693,9 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_table && ix->table_owned) (void)hipFree(ix->d_table);
     if (ix->d_qpad) (void)hipFree(ix->d_qpad);
     if (ix->h_counters) (void)hipHostFree(ix->h_counters);
+    (void)drain_events(ix, ix->ev_update);
+    (void)drain_events(ix, ix->ev_expand);
+    (void)drain_events(ix, ix->ev_provider);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -717,14 +732,18 @@ int lm_index_attach_table(lm_index* ix, const void* table, int32_t dtype, int64_
     } else {
         void* tmp = nullptr;
         LM_HIP(hipMalloc(&tmp, std::max<size_t>((size_t)ntotal * d * es, 16)));
-        LM_HIP(hipMemcpy(tmp, table, (size_t)ntotal * d * es, hipMemcpyHostToDevice));
+        if (hipMemcpy(tmp, table, (size_t)ntotal * d * es, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(tmp);
+            LM_FAIL(LM_EHIP, "table upload failed");
+        }
         int64_t tot = ntotal * ix->Dp;
         if (dtype == LM_DTYPE_F32)
             hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, (const float*)tmp, ntotal, d, ix->Dp, (float*)dst);
         else
             hipLaunchKernelGGL(k_pad_rows_f16, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, (const __half*)tmp, ntotal, d, ix->Dp, (__half*)dst);
-        LM_HIP(hipDeviceSynchronize());
+        const hipError_t pe = hipDeviceSynchronize();
         (void)hipFree(tmp);
+        LM_HIP(pe);
     }
     return LM_OK;
 }
@@ -747,6 +766,7 @@ int lm_index_set_hub_cache(lm_index* ix, const int32_t* ids, int32_t n, const fl
     if (ix->memo_cap < want) {
         if (ix->d_memo) (void)hipFree(ix->d_memo);
         ix->d_memo = nullptr;
+        ix->memo_cap = 0;
         LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
         ix->memo_cap = want;
     }
@@ -853,11 +873,16 @@ int lm_index_search(lm_index* ix, int64_t n, const float* x, int32_t k, float* d
     float* d_x = nullptr;
     float* d_d = nullptr;
     int64_t* d_l = nullptr;
-    LM_HIP(hipMalloc((void**)&d_x, (size_t)n * ix->D * 4));
-    LM_HIP(hipMalloc((void**)&d_d, (size_t)n * k * 4));
-    LM_HIP(hipMalloc((void**)&d_l, (size_t)n * k * 8));
     int rc = LM_OK;
-    if (hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = LM_EHIP;
+    if (hipMalloc((void**)&d_x, (size_t)n * ix->D * 4) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * k * 4) != hipSuccess ||
+        hipMalloc((void**)&d_l, (size_t)n * k * 8) != hipSuccess) {
+        set_error("out of device memory for the query / result staging buffers");
+        rc = LM_EHIP;
+    }
+    if (!rc && hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+        set_error("query upload failed");
+        rc = LM_EHIP;
+    }
     if (!rc) rc = do_search_device(ix, n, d_x, k, d_d, d_l, params);
     if (!rc && (hipMemcpyAsync(distances, d_d, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
                 hipMemcpyAsync(labels, d_l, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
@@ -865,9 +890,9 @@ int lm_index_search(lm_index* ix, int64_t n, const float* x, int32_t k, float* d
         set_error("result copy failed");
         rc = LM_EHIP;
     }
-    (void)hipFree(d_x);
-    (void)hipFree(d_d);
-    (void)hipFree(d_l);
+    if (d_x) (void)hipFree(d_x);
+    if (d_d) (void)hipFree(d_d);
+    if (d_l) (void)hipFree(d_l);
     return rc;
 }
 
