@@ -1,0 +1,218 @@
+// lm_attn_v2.hip -- second revision of the hd=32 packed-sequence attention kernel (see lm_encoder_ops.hip for
+// the first one and the algorithm: swapped S^T = K Q^T, P registers reused as the B operand of O^T = V^T P^T).
+//
+// STATUS: opt-in (environment LEANN_MI355X_ATTN=2); the default stays revision 1 until this one has been
+// validated and timed on an MI355X (tests/test_gpu_next.py).
+//
+// Why a revision: the ISA of revision 1 spends ~17 VALU issue slots per score (2234 instructions per 32-query
+// block, 32 of them MFMA): at head_dim 32 a 32x32 score tile costs 2 MFMAs (64 cycles) but 16 registers x 17
+// VALU operations, so the kernel is VALU bound, not MFMA / LDS / HBM bound.  This revision puts the softmax
+// on a diet:
+//   * key masking (compare + select per score) only in tiles that straddle the sequence end -- a
+//     workgroup-uniform branch; full tiles need none because K rows are real;
+//   * (s - max) * c  ->  one fused multiply-add with a per-chunk constant, issued as v_pk_fma_f32 on pairs;
+//   * row sums accumulate with v_pk_add_f32 on pairs;
+//   * MFMA results stay in VGPRs (-mllvm -amdgpu-mfma-vgpr-form, this file only): no v_accvgpr copies;
+//   * K / V staging issues all global loads of a thread before the first LDS store (one HBM latency per
+//     workgroup instead of one per 256-row slice), and V^T is written as packed key pairs (ds_write_b32).
+// Role in the reference: part of compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
+#include <hip/hip_fp16.h>
+
+#include "lm_internal.h"
+
+namespace lm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+constexpr int A2_HD = 32;
+constexpr int A2_KSTRIDE = 40;  // halfs per K row in LDS (80 B): conflict-free ds_read_b128 fragments
+
+template <int NT>  // NT = number of 32-key tiles (max_len <= 32*NT), 1..8
+__global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                             __half* __restrict__ out, int heads, float scale_log2e) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int tok0 = cu[seq];
+    const int len = cu[seq + 1] - tok0;
+    const int H = heads * A2_HD;
+    const int64_t rstride = 3 * (int64_t)H;  // halfs per token row of qkv
+    constexpr int Tp = 32 * NT;
+    constexpr int VSTRIDE = Tp + 4;                  // halfs per V^T row (even: key pairs are dword aligned)
+    _Float16* Ks = (_Float16*)smem;                  // [Tp][A2_KSTRIDE]
+    _Float16* Vt = Ks + (size_t)Tp * A2_KSTRIDE;     // [32][VSTRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const _Float16* base = (const _Float16*)qkv + (int64_t)tok0 * rstride + h * A2_HD;
+
+    // ---- stage K (row major, padded) and V^T (transposed, padded); rows >= len are zero ----
+    // work item = (key pair, 8-half part): Tp/2 * 4 items; all loads of a thread are issued before its stores
+    {
+        constexpr int ITEMS = Tp * 2, NIT = (ITEMS + 255) / 256;
+        half8 k0[NIT], k1[NIT], v0[NIT], v1[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + 256 * it;
+            const int key = (c >> 2) * 2, part = c & 3;
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            k0[it] = z; k1[it] = z; v0[it] = z; v1[it] = z;
+            if (c < ITEMS && key < len) {
+                const _Float16* p = base + (int64_t)key * rstride + part * 8;
+                k0[it] = *(const half8*)(p + H);
+                v0[it] = *(const half8*)(p + 2 * H);
+                if (key + 1 < len) {
+                    k1[it] = *(const half8*)(p + rstride + H);
+                    v1[it] = *(const half8*)(p + rstride + 2 * H);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = tid + 256 * it;
+            const int key = (c >> 2) * 2, part = c & 3;
+            if (c < ITEMS) {
+                *(half8*)(Ks + key * A2_KSTRIDE + part * 8) = k0[it];
+                *(half8*)(Ks + (key + 1) * A2_KSTRIDE + part * 8) = k1[it];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    half2v pr = {v0[it][i], v1[it][i]};
+                    *(half2v*)(Vt + (part * 8 + i) * VSTRIDE + key) = pr;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int r31 = lane & 31, g = lane >> 5;
+    const float2v c2 = {scale_log2e, scale_log2e};
+    for (int qb = wv; qb * 32 < len; qb += 4) {
+        // Q^T fragment (B operand): lane (n = q row, g) holds hd slots 16*ks + 8*g .. +8
+        const int qrow = qb * 32 + r31;
+        half8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            qf[ks] = qrow < len ? *(const half8*)(base + (int64_t)qrow * rstride + ks * 16 + g * 8) : z;
+        }
+        // per-lane mask limit; the empty asm keeps the compiler from hoisting all 16*NT key comparisons out of the
+        // q-block loop (revision 1 does: 176 SGPR pairs spilled to VGPR lanes and a ~700-instruction preamble)
+        int lenv = len - 4 * g;
+        asm volatile("" : "+v"(lenv));
+        // ---- online softmax over chunks of CH 32-key tiles ----
+        constexpr int CH = NT < 2 ? NT : 2;
+        float mx = -3.0e38f, sum = 0.f;
+        float16v o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c0 = 0; c0 < NT; c0 += CH) {
+            if (c0 * 32 >= len) break;
+            float16v s[CH];
+            // S^T tiles: keys x q.  lane (q = r31, g) holds keys 32t + (reg&3) + 8*(reg>>2) + 4g
+#pragma unroll
+            for (int tt = 0; tt < CH; ++tt) {
+                const int t = c0 + tt;
+                float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (t < NT) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        half8 kf = *(const half8*)(Ks + (t * 32 + r31) * A2_KSTRIDE + ks * 16 + g * 8);  // A: m = key
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], acc, 0, 0, 0);
+                    }
+                }
+                s[tt] = acc;
+            }
+            // mask keys >= len: only tiles that reach past the sequence end (uniform branch)
+#pragma unroll
+            for (int tt = 0; tt < CH; ++tt) {
+                if (32 * (c0 + tt + 1) > len) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int keyc = 32 * (c0 + tt) + (r & 3) + 8 * (r >> 2);  // + 4g is folded into lenv
+                        s[tt][r] = keyc < lenv ? s[tt][r] : -3.0e38f;
+                    }
+                }
+            }
+            float cm = s[0][0];
+#pragma unroll
+            for (int tt = 0; tt < CH; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cm = fmaxf(cm, s[tt][r]);
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float mnew = fmaxf(mx, cm);
+            const float alpha = __builtin_amdgcn_exp2f((mx - mnew) * scale_log2e);  // 0 on the first chunk (mx = -3e38)
+            mx = mnew;
+            const float nb = -mx * scale_log2e;
+            const float2v nb2 = {nb, nb};
+            float2v cs2 = {0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < CH; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    float2v v = {s[tt][r], s[tt][r + 1]};
+                    v = __builtin_elementwise_fma(v, c2, nb2);  // s*c - max*c
+                    float2v p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+                    s[tt][r] = p[0];
+                    s[tt][r + 1] = p[1];
+                    cs2 += p;
+                }
+            float cs = cs2[0] + cs2[1];
+            cs += __shfl_xor(cs, 32);
+            sum = sum * alpha + cs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            // O^T += V^T P^T : A = V^T (m = d), B = P^T (n = q); k-slots (g, j) <-> keys the lane already holds
+#pragma unroll
+            for (int tt = 0; tt < CH; ++tt) {
+                const int t = c0 + tt;
+                if (t < NT) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        half8 pf;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) pf[jj] = (_Float16)s[tt][8 * u + jj];
+                        // regs 8u..8u+3 -> keys 32t+16u+4g+{0..3} ; regs 8u+4..8u+7 -> keys 32t+16u+8+4g+{0..3}
+                        const _Float16* vrow = Vt + r31 * VSTRIDE + 32 * t + 16 * u + 4 * g;
+                        half4 va = *(const half4*)vrow, vb = *(const half4*)(vrow + 8);
+                        half8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const float inv = 1.0f / sum;
+        // lane (q = r31, g) holds d = (reg&3) + 8*(reg>>2) + 4g
+        if (qrow < len) {
+            _Float16* orow = (_Float16*)out + (int64_t)(tok0 + qrow) * H + h * A2_HD;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                half4 w = {(_Float16)(o[4 * r4] * inv), (_Float16)(o[4 * r4 + 1] * inv), (_Float16)(o[4 * r4 + 2] * inv),
+                           (_Float16)(o[4 * r4 + 3] * inv)};
+                *(half4*)(orow + 8 * r4 + 4 * g) = w;
+            }
+        }
+    }
+}
+
+}  // namespace lm
+
+// launched by lm_attn_varlen_hd32_f16 (lm_encoder_ops.hip) when LEANN_MI355X_ATTN=2
+int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len,
+                      void* d_out, void* stream) {
+    using namespace lm;
+    const int nt = (max_len + 31) / 32;
+    const size_t shmem = ((size_t)32 * nt * A2_KSTRIDE + (size_t)32 * (32 * nt + 4)) * 2;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)A2_HD);
+    dim3 grid((unsigned)(n_seqs * heads)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const __half* q = (const __half*)d_qkv;
+    __half* o = (__half*)d_out;
+    switch (nt) {
+#define CASEA(n) case n: hipLaunchKernelGGL((k_attn_varlen_hd32_v2<n>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e); break
+        CASEA(1); CASEA(2); CASEA(3); CASEA(4); CASEA(5); CASEA(6); CASEA(7); CASEA(8);
+#undef CASEA
+        default: LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}

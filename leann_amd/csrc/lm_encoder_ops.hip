@@ -6,6 +6,8 @@
 // for hidden=384 (rocprofv3, profiles/r1_encoder_packed_kernel_stats.csv); this kernel is one pass:
 // 2 reads + 1 write of [rows, H] fp16, one 64-lane wave per row, 16-byte loads, wave-shuffle reductions.
 // Role in the reference: part of compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 
 #include "lm_internal.h"
@@ -266,6 +268,10 @@ extern "C" int lm_attn_varlen_hd32_f16(const void* d_qkv, const int32_t* d_cu_se
     if (n_seqs == 0) return LM_OK;
     if (!d_qkv || !d_cu_seqlens || !d_out || n_seqs < 0 || heads <= 0) LM_FAIL(LM_EINVAL, "bad attention arguments");
     if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
+    {
+        const char* rev = getenv("LEANN_MI355X_ATTN");  // "2": revision 2 (lm_attn_v2.hip), opt-in until validated on hardware
+        if (rev && rev[0] == '2' && rev[1] == 0) return lm_attn_v2_launch(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
+    }
     const int nt = (max_len + 31) / 32;
     const size_t shmem = ((size_t)32 * nt * ATT_KSTRIDE + (size_t)32 * (32 * nt + 4)) * 2;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)ATT_HD);

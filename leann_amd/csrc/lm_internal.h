@@ -65,3 +65,7 @@ struct HostCsr {
 int read_csr_file(const char* path, HostCsr& out);  // returns LM_* code
 
 }  // namespace lm
+
+// lm_attn_v2.hip: revision 2 of the hd=32 attention kernel (opt-in, LEANN_MI355X_ATTN=2); arguments as lm_attn_varlen_hd32_f16
+int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out,
+                      void* stream);
