@@ -215,6 +215,20 @@ int lm_add_layernorm_f16(const void *d_x, const void *d_residual, const void *d_
 int lm_attn_varlen_hd32_f16(const void *d_qkv, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t heads,
                             int32_t max_len, void *d_out, void *stream);
 
+/* Embedding front end in one pass: d_out[r] = LayerNorm(half(word[tok[r]] + type0) + pos_table[pos[r]]);
+ * tables and output fp16, hidden <= 768.  Replaces the three gathers/adds before the embedding LayerNorm of
+ * the BERT forward (leann/embedding_compute.py:229-239).  The Python host uses it only with
+ * LEANN_MI355X_EMBED=1 until it has been validated on hardware. */
+int lm_embed_layernorm_f16(const int32_t *d_tok, const int32_t *d_pos, const void *d_word, const void *d_pos_table,
+                           const void *d_type0, const void *d_gamma, const void *d_beta, void *d_out, int64_t rows,
+                           int32_t hidden, float eps, void *stream);
+
+/* Mean pooling over the tokens of each packed sequence (+ optional L2 normalisation), fp16 in, fp32 out
+ * [n_seqs][hidden]; fixed summation order (deterministic).  sentence-transformers Pooling as done in
+ * leann/embedding_compute.py:323-334.  Host switch: LEANN_MI355X_POOL=1. */
+int lm_meanpool_varlen_f16(const void *d_x, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t hidden,
+                           int32_t normalize, float *d_out, void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_event_overhead_us",
     "lm_dist_gather", "lm_topk_merge",
     "lm_pq_attach", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
-    "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16",
+    "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
 ]
 
@@ -121,6 +121,8 @@ def load() -> C.CDLL:
     lib.lm_pq_batch_search_device.argtypes = [vp, i64, vp, i32, C.POINTER(PqSearchParams), vp, vp]
     lib.lm_add_layernorm_f16.argtypes = [vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
     lib.lm_attn_varlen_hd32_f16.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.lm_embed_layernorm_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
+    lib.lm_meanpool_varlen_f16.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.lm_tokens_create.argtypes = [vp, vp, i64, C.c_int, C.POINTER(vp)]
     lib.lm_tokens_free.argtypes = [vp]
     lib.lm_tokens_free.restype = None

@@ -98,6 +98,11 @@ extern "C" int lm_add_layernorm_f16(const void* d_x, const void* d_residual, con
     if (rows == 0) return LM_OK;
     if (!d_x || !d_gamma || !d_beta || !d_out || rows < 0) LM_FAIL(LM_EINVAL, "bad add_layernorm arguments");
     if (hidden <= 0 || hidden % 8 || hidden > 2048) LM_FAIL(LM_EINVAL, "hidden must be a multiple of 8, <= 2048");
+    {
+        const char* rev = getenv("LEANN_MI355X_LN");  // "2": 16 lanes per row (lm_encoder_ops2.hip), opt-in until validated on hardware
+        if (rev && rev[0] == '2' && rev[1] == 0 && hidden <= 768)
+            return lm_add_layernorm_r16_launch(d_x, d_residual, d_gamma, d_beta, d_out, rows, hidden, eps, stream);
+    }
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const __half *x = (const __half*)d_x, *r = (const __half*)d_residual, *g = (const __half*)d_gamma, *b = (const __half*)d_beta;

@@ -69,3 +69,6 @@ int read_csr_file(const char* path, HostCsr& out);  // returns LM_* code
 // lm_attn_v2.hip: revision 2 of the hd=32 attention kernel (opt-in, LEANN_MI355X_ATTN=2); arguments as lm_attn_varlen_hd32_f16
 int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out,
                       void* stream);
+// lm_encoder_ops2.hip: 16-lanes-per-row LayerNorm (opt-in, LEANN_MI355X_LN=2, hidden <= 768); arguments as lm_add_layernorm_f16
+int lm_add_layernorm_r16_launch(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, void* d_out,
+                                int64_t rows, int32_t hidden, float eps, void* stream);

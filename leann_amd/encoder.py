@@ -107,6 +107,53 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
     return out
 
 
+def fused_embed_layernorm(tok: torch.Tensor, pos: torch.Tensor, word: nn.Embedding, posw: nn.Embedding, type0: torch.Tensor,
+                          ln: nn.LayerNorm) -> Optional[torch.Tensor]:
+    """Embedding gathers + adds + LayerNorm in one kernel (csrc/lm_encoder_ops2.hip).  Opt-in (LEANN_MI355X_EMBED=1)
+    until validated on hardware; None = not applicable, the caller takes the torch path."""
+    import os
+
+    if os.environ.get("LEANN_MI355X_EMBED", "0") != "1":
+        return None
+    h = word.weight.shape[1]
+    if not (tok.is_cuda and word.weight.dtype == torch.float16 and h % 8 == 0 and h <= 768):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    t32, p32 = tok.to(torch.int32).contiguous(), pos.to(torch.int32).contiguous()
+    out = torch.empty((t32.shape[0], h), dtype=torch.float16, device=tok.device)
+    _lib.check(_lib.load().lm_embed_layernorm_f16(
+        C.c_void_p(t32.data_ptr()), C.c_void_p(p32.data_ptr()), C.c_void_p(word.weight.data_ptr()), C.c_void_p(posw.weight.data_ptr()),
+        C.c_void_p(type0.contiguous().data_ptr()), C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()),
+        C.c_void_p(out.data_ptr()), t32.shape[0], h, float(ln.eps), C.c_void_p(torch.cuda.current_stream(tok.device).cuda_stream)),
+        "lm_embed_layernorm_f16")
+    return out
+
+
+def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool) -> Optional[torch.Tensor]:
+    """Segmented mean (+ L2 normalise) over packed sequences (csrc/lm_encoder_ops2.hip), fp32 [n, H].  Opt-in
+    (LEANN_MI355X_POOL=1) until validated on hardware; None = the caller takes the torch path."""
+    import os
+
+    if os.environ.get("LEANN_MI355X_POOL", "0") != "1":
+        return None
+    h = x.shape[1]
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and h % 8 == 0 and h <= 2048):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    n = cu.shape[0] - 1
+    out = torch.empty((n, h), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().lm_meanpool_varlen_f16(
+        C.c_void_p(x.data_ptr()), C.c_void_p(cu.data_ptr()), n, h, 1 if normalize else 0, C.c_void_p(out.data_ptr()),
+        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_meanpool_varlen_f16")
+    return out
+
+
 class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
@@ -246,10 +293,16 @@ class BertEncoder(nn.Module):
     def forward_packed(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, seq_of: torch.Tensor,
                        lengths: torch.Tensor, max_len: int) -> torch.Tensor:
         cfg = self.cfg
-        x = fused_add_layernorm(self.word(tok) + self.tok_type.weight[0][None], self.pos(pos), self.ln)
+        x = fused_embed_layernorm(tok, pos, self.word, self.pos, self.tok_type.weight[0], self.ln)
+        if x is None:
+            x = fused_add_layernorm(self.word(tok) + self.tok_type.weight[0][None], self.pos(pos), self.ln)
         for L in self.layers:
             x = L.forward_packed(x, cu, max_len)
         n = lengths.shape[0]
+        if cfg.pooling != "cls":
+            e = fused_meanpool(x, cu, cfg.normalize)
+            if e is not None:
+                return e
         if cfg.pooling == "cls":
             e = x[cu[:-1].long()].float()
         else:

@@ -75,3 +75,93 @@ def test_encoder_forward_with_attention_revision2(monkeypatch):
     monkeypatch.setenv("LEANN_MI355X_ATTN", "2")
     a = enc.encode_tokens_packed(ti, tl)
     assert (a - b).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("hidden", [64, 128, 320, 384, 768])
+def test_layernorm_16_lanes_per_row(hidden, monkeypatch):
+    """k_add_layernorm_f16_r16 (LEANN_MI355X_LN=2) vs a plain PyTorch fp32 reference and vs the default kernel."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import fused_add_layernorm
+
+    g = torch.Generator(device="cuda").manual_seed(hidden)
+    for rows in (1, 15, 16, 17, 1000, 4099):
+        x = torch.randn((rows, hidden), generator=g, device="cuda").half()
+        r = (3 * torch.randn((rows, hidden), generator=g, device="cuda")).half()
+        ln = nn.LayerNorm(hidden, eps=1e-12).to("cuda", dtype=torch.float16)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(hidden, generator=g, device="cuda"))
+            ln.bias.copy_(torch.randn(hidden, generator=g, device="cuda"))
+        ref = F.layer_norm(x.float() + r.float(), (hidden,), ln.weight.float(), ln.bias.float(), 1e-12)
+        ref1 = F.layer_norm(x.float(), (hidden,), ln.weight.float(), ln.bias.float(), 1e-12)
+        monkeypatch.setenv("LEANN_MI355X_LN", "1")
+        d, d1 = fused_add_layernorm(x, r, ln), fused_add_layernorm(x, None, ln)
+        monkeypatch.setenv("LEANN_MI355X_LN", "2")
+        got, got1 = fused_add_layernorm(x, r, ln), fused_add_layernorm(x, None, ln)
+        assert (got.float() - ref).abs().max() <= 4e-3 * max(1.0, float(ref.abs().max()))
+        assert (got1.float() - ref1).abs().max() <= 4e-3 * max(1.0, float(ref1.abs().max()))
+        # same arithmetic up to the fp32 summation order: at most one fp16 ulp apart from the default kernel
+        assert (got.float() - d.float()).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+        assert (got1.float() - d1.float()).abs().max() <= 2e-3 * max(1.0, float(ref1.abs().max()))
+
+
+@pytest.mark.parametrize("hidden,normalize", [(384, True), (384, False), (768, True), (64, True), (1024, False)])
+def test_meanpool_varlen(hidden, normalize, monkeypatch):
+    """lm_meanpool_varlen_f16 vs a plain PyTorch fp32 reference (per-sequence mean, optional L2 normalise)."""
+    import torch
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import fused_meanpool
+
+    g = torch.Generator(device="cpu").manual_seed(hidden + int(normalize))
+    lens = torch.randint(1, 257, (53,), generator=g)
+    lens[0], lens[1], lens[-1] = 256, 1, 2
+    cu = torch.zeros(54, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    x = torch.randn((int(cu[-1]), hidden), generator=g).half().cuda()
+    monkeypatch.setenv("LEANN_MI355X_POOL", "1")
+    got = fused_meanpool(x, cu.cuda(), normalize)
+    assert got is not None and got.dtype == torch.float32 and got.shape == (53, hidden)
+    ref = torch.stack([x[int(cu[i]):int(cu[i + 1])].float().mean(0) for i in range(53)])
+    if normalize:
+        ref = F.normalize(ref, p=2, dim=1)
+    assert (got - ref).abs().max().item() < 1e-5
+    monkeypatch.setenv("LEANN_MI355X_POOL", "0")
+    assert fused_meanpool(x, cu.cuda(), normalize) is None
+
+
+def test_embed_layernorm_matches_torch_path(monkeypatch):
+    """lm_embed_layernorm_f16 vs the default path (torch gathers + lm_add_layernorm_f16): same fp16 rounding points."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for, fused_add_layernorm, fused_embed_layernorm
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tok = torch.randint(0, enc.cfg.vocab_size, (5001,), generator=g).cuda()
+    pos = torch.randint(0, 256, (5001,), generator=g).cuda()
+    monkeypatch.setenv("LEANN_MI355X_EMBED", "1")
+    got = fused_embed_layernorm(tok, pos, enc.word, enc.pos, enc.tok_type.weight[0], enc.ln)
+    assert got is not None
+    ref = fused_add_layernorm(enc.word(tok) + enc.tok_type.weight[0][None], enc.pos(pos), enc.ln)
+    assert (got.float() - ref.float()).abs().max().item() <= 2e-3
+
+
+def test_encoder_forward_with_every_opt_in_kernel(monkeypatch):
+    """Whole packed forward with all opt-in kernels vs the torch-attention / default-kernel forward."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=300, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    monkeypatch.setenv("LEANN_MI355X_ATTN", "0")
+    b = enc.encode_tokens_packed(ti, tl)
+    for k, v in (("LEANN_MI355X_ATTN", "2"), ("LEANN_MI355X_LN", "2"), ("LEANN_MI355X_POOL", "1"), ("LEANN_MI355X_EMBED", "1")):
+        monkeypatch.setenv(k, v)
+    a = enc.encode_tokens_packed(ti, tl)
+    assert (a - b).abs().max() < 2e-3
