@@ -229,6 +229,16 @@ int lm_embed_layernorm_f16(const int32_t *d_tok, const int32_t *d_pos, const voi
 int lm_meanpool_varlen_f16(const void *d_x, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t hidden,
                            int32_t normalize, float *d_out, void *stream);
 
+/* The feed-forward block of a BERT layer with hidden size 384 in one kernel:
+ *   d_out = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2) * gamma + beta,   x / d_out [tokens][384] fp16,
+ * d_w1 [ffn][384] fp16 (nn.Linear layout), d_w2p = W2 packed as [ffn/32][384][32] fp16 with the k order of
+ * leann_amd/encoder.py: fused_mlp_k_permutation, biases fp32, GELU = exact erf form, ffn % 32 == 0.
+ * MFMA 32x32x16 f16 with the 1536-wide intermediate held in accumulators (never written to HBM).  Part of the
+ * BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).  Host switch: LEANN_MI355X_MLP=1. */
+int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, const void *d_w2p, const float *d_b2,
+                          const void *d_gamma, const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps,
+                          void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

@@ -1,0 +1,303 @@
+// lm_mlp_fused.hip -- the whole feed-forward block of a BERT layer in ONE kernel, hidden size 384:
+//
+//     y = LayerNorm( x + GELU(x W1^T + b1) W2^T + b2 ) * gamma + beta          x, y: [T, 384] fp16
+//
+// STATUS: opt-in (LEANN_MI355X_MLP=1) until validated and timed on an MI355X (tests/test_gpu_next.py,
+// scripts/encoder_ops_bench.py).  The lane-level data flow is mirrored by tests/mfma_emulation.py, which checks
+// the index algebra below on the CPU against a plain fp32 MLP.
+//
+// Why: per layer the default path runs fc1 (hipBLASLt, ~780 us per 262k tokens), an erf-GELU kernel (~440 us,
+// pure HBM traffic on the [T, 1536] intermediate), fc2 (~590 us) and add+LayerNorm (~200 us) -- 46 % of the
+// encoder forward (profiles/r1_final_bench_default_kernel_stats.csv).  The 1536-wide intermediate (12 KB per
+// token written and read twice) never needs to exist: here it lives in MFMA accumulators.
+//
+// Design (one 256-thread workgroup = 4 waves = 128 tokens; one wave = 32 tokens; one wave per SIMD):
+//   * everything is computed TRANSPOSED with v_mfma_f32_32x32x16_f16 so that activations stay in registers:
+//       H^T slab [32 hidden x 32 tokens] = W1_slab (A operand, from LDS) . x^T (B operand, 24 register fragments)
+//       out^T    [384       x 32 tokens] += W2_slab (A operand, from LDS) . GELU(H^T) (B operand = the accumulator
+//                 registers of the first product, packed to fp16 in place: the k-slot <-> hidden-unit assignment
+//                 of an MFMA is free as long as A and B agree, so W2 is pre-permuted on the host instead);
+//   * a lane ends up with all 384 output features of its token in 192 accumulators (its lane^32 partner holds the
+//     other half): bias, residual and LayerNorm are in-register plus one cross-lane exchange per statistic;
+//   * weights stream through LDS in 32-hidden-unit slabs (24.5 KB of W1 + 30 KB of W2), double buffered: the
+//     global loads of slab s+1 are issued before the MFMAs of slab s and stored after them; one barrier per slab;
+//   * LDS rows are padded (784 B / 80 B) so that the ds_read_b128 fragment reads are bank-conflict free;
+//   * GELU is the exact erf form evaluated with Abramowitz-Stegun 7.1.26 in packed fp32 (|abs err| < 3.4e-7,
+//     at most 1 fp16 ulp from torch's erff path; checked in tests/test_host_helpers.py).
+// Budget per wave: 192 accumulator registers (out^T) + 96 (x^T fragments) + 16 (H^T) + 48 (prefetch) => one wave
+// per SIMD by design; MFMA work per slab and wave: 24 + 24 instructions.
+// Role in the reference: the FFN inside compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
+#include <hip/hip_fp16.h>
+
+#include "lm_internal.h"
+
+namespace lm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ML_H = 384;                 // hidden size
+constexpr int ML_KS = ML_H / 16;          // 24 k-steps of the first product
+constexpr int ML_NJ = ML_H / 32;          // 12 row tiles of out^T
+constexpr int ML_W1_STRIDE = ML_H + 8;    // halfs per W1 row in LDS (784 B)
+constexpr int ML_W2_STRIDE = 40;          // halfs per permuted W2 row in LDS (80 B)
+constexpr int ML_W1_BYTES = 32 * ML_W1_STRIDE * 2;     // 25088
+constexpr int ML_W2_BYTES = ML_H * ML_W2_STRIDE * 2;   // 30720
+constexpr int ML_BUF = ML_W1_BYTES + ML_W2_BYTES;      // 55808 per stage
+constexpr int ML_CHUNKS = 32 * ML_H * 2 / 16;          // 1536 16-byte chunks per weight slab (same for W1 and W2)
+constexpr int ML_NPRE = ML_CHUNKS / 256;               // 6 chunks per thread and matrix
+
+// exact (erf) GELU on a pair: max(x,0) - 0.5|x| t P(t) exp(-x^2/2), t = 1/(1 + p|x|/sqrt2)   (A&S 7.1.26).
+// Three stages of ~8 instructions each, so that one stage can be issued behind each MFMA (32 cycles in the matrix pipe).
+struct Gelu2 {
+    float2v x, ax, t, w, ph;
+    __device__ inline void stage_a(float2v xin) {  // 2 transcendental (rcp)
+        x = xin;
+        ax = __builtin_elementwise_abs(x);
+        const float2v d = __builtin_elementwise_fma(ax, (float2v){0.3275911f * 0.70710678f, 0.3275911f * 0.70710678f}, (float2v){1.0f, 1.0f});
+        t = (float2v){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        w = x * x * (float2v){-0.72134752f, -0.72134752f};  // -0.5 * log2(e)
+    }
+    __device__ inline void stage_b() {  // polynomial
+        float2v p = __builtin_elementwise_fma(t, (float2v){1.061405429f, 1.061405429f}, (float2v){-1.453152027f, -1.453152027f});
+        p = __builtin_elementwise_fma(p, t, (float2v){1.421413741f, 1.421413741f});
+        p = __builtin_elementwise_fma(p, t, (float2v){-0.284496736f, -0.284496736f});
+        p = __builtin_elementwise_fma(p, t, (float2v){0.254829592f, 0.254829592f});
+        ph = p * (ax * t * (float2v){0.5f, 0.5f});
+    }
+    __device__ inline float2v stage_c() {  // 2 transcendental (exp2)
+        const float2v ex = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+        const float2v pos = {__builtin_amdgcn_fmed3f(x[0], 0.0f, __builtin_inff()), __builtin_amdgcn_fmed3f(x[1], 0.0f, __builtin_inff())};
+        return pos - ph * ex;
+    }
+};
+__device__ inline float2v gelu2(float2v x) {
+    Gelu2 g;
+    g.stage_a(x);
+    g.stage_b();
+    return g.stage_c();
+}
+
+// w1:  [F][384] fp16 (nn.Linear weight, slab s = rows 32s..32s+31: contiguous)
+// w2p: [F/32][384][32] fp16: w2p[s][f][16u + 8g + e] = W2[f][32s + 16u + 4g + e]          (e < 4)
+//                                                      W2[f][32s + 16u + 8 + 4g + e - 4]  (e >= 4)
+// b1, b2: fp32 copies of the biases
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_fused_h384(const __half* __restrict__ x, const __half* __restrict__ w1,
+                                                        const float* __restrict__ b1, const __half* __restrict__ w2p,
+                                                        const float* __restrict__ b2, const __half* __restrict__ gamma,
+                                                        const __half* __restrict__ beta, __half* __restrict__ out, int T, int F,
+                                                        float eps) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* b1s = (float*)(smem + 2 * ML_BUF);  // [F]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r31 = lane & 31, g = lane >> 5;
+    const int token = blockIdx.x * 128 + wv * 32 + r31;
+    const bool valid = token < T;
+    const int nslab = F >> 5;
+
+    // ---- x^T fragments (B operand of the first product): lane (n = token, g) holds x[token][16ks + 8g .. +8] ----
+    half8 xf[ML_KS];
+    {
+        const _Float16* xr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < ML_KS; ++ks) {
+            half8 v = *(const half8*)(xr + 16 * ks);
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xf[ks] = valid ? v : z;
+        }
+    }
+    for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
+
+    // ---- weight staging: thread t owns chunks t + 256 i of each matrix; LDS offsets are slab independent ----
+    int off1[ML_NPRE], off2[ML_NPRE];
+#pragma unroll
+    for (int i = 0; i < ML_NPRE; ++i) {
+        const int c = tid + 256 * i;
+        off1[i] = (c / 48) * (ML_W1_STRIDE * 2) + (c % 48) * 16;
+        off2[i] = ML_W1_BYTES + (c >> 2) * (ML_W2_STRIDE * 2) + (c & 3) * 16;
+    }
+    u32x4 pre[ML_NPRE];
+    {
+        const u32x4* s1 = (const u32x4*)w1 + tid;
+        const u32x4* s2 = (const u32x4*)w2p + tid;
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) pre[i] = s1[256 * i];
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(smem + off1[i]) = pre[i];
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) pre[i] = s2[256 * i];
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(smem + off2[i]) = pre[i];
+    }
+    __syncthreads();
+
+    float16v o[ML_NJ];
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j) o[j] = (float16v){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int s = 0; s < nslab; ++s) {
+        unsigned char* cur = smem + (s & 1) * ML_BUF;
+        unsigned char* nxt = smem + ((s + 1) & 1) * ML_BUF;
+        const bool more = s + 1 < nslab;
+        // global loads of the next slab fly during this slab's MFMAs; W1 and W2 halves are staged one after the
+        // other (24 registers in flight instead of 48: the wave already holds 192 + 96 + 16 for its tiles)
+        if (more) {
+            const u32x4* s1 = (const u32x4*)w1 + (int64_t)(s + 1) * ML_CHUNKS + tid;
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) pre[i] = s1[256 * i];
+        }
+        // ---- H^T slab = b1 + W1_slab . x^T : lane (token r31, g) gets hidden units 32s + (r&3) + 8(r>>2) + 4g ----
+        float16v acc;
+        {
+            const float* bs = b1s + 32 * s + 4 * g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4v bv = *(const float4v*)(bs + 8 * q);
+                acc[4 * q] = bv[0];
+                acc[4 * q + 1] = bv[1];
+                acc[4 * q + 2] = bv[2];
+                acc[4 * q + 3] = bv[3];
+            }
+        }
+        {
+            const _Float16* W1s = (const _Float16*)cur + r31 * ML_W1_STRIDE + 8 * g;  // A: m = hidden unit r31
+#pragma unroll
+            for (int ks = 0; ks < ML_KS; ++ks) {
+                half8 a = *(const half8*)(W1s + 16 * ks);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[ks], acc, 0, 0, 0);
+            }
+            // schedule: bias + 4 fragments ahead, then one LDS read per MFMA (the default scheduler serialises
+            // read -> wait -> MFMA on one register quad under this kernel's register pressure)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < ML_KS - 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(nxt + off1[i]) = pre[i];
+            const u32x4* s2 = (const u32x4*)w2p + (int64_t)(s + 1) * ML_CHUNKS + tid;
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) pre[i] = s2[256 * i];
+        }
+        // ---- GELU in place, packed to fp16: registers 8u .. 8u+7 are the B fragment of k-step u.
+        //      out^T += W2_slab . GELU(H^T): the u = 0 products only need the first eight registers, so the GELU of
+        //      the second eight is interleaved with them (VALU and the matrix pipe run side by side) ----
+        half8 pf[2];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 2) {
+            float2v v = gelu2((float2v){acc[jj], acc[jj + 1]});
+            pf[0][jj] = (_Float16)v[0];
+            pf[0][jj + 1] = (_Float16)v[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // Written in the order it should issue (under this kernel's register pressure the scheduler falls back
+            // to source order): a ring of 4 A fragments read 4 products ahead; after every third u = 0 product one
+            // register pair of the second-half GELU, so VALU/transcendental work runs under the matrix pipe.
+            const _Float16* W2s = (const _Float16*)(cur + ML_W1_BYTES) + r31 * ML_W2_STRIDE + 8 * g;  // A: m = out feature
+            half8 ring[4];
+            Gelu2 gs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = *(const half8*)(W2s + 32 * i * ML_W2_STRIDE);
+#pragma unroll
+            for (int n = 0; n < 2 * ML_NJ; ++n) {  // product n: u = n / 12, tile j = n % 12
+                const int u = n / ML_NJ, j = n % ML_NJ;
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[n & 3], pf[u], o[j], 0, 0, 0);
+                if (n + 4 < 2 * ML_NJ) {
+                    const int u2 = (n + 4) / ML_NJ, j2 = (n + 4) % ML_NJ;
+                    ring[n & 3] = *(const half8*)(W2s + 32 * j2 * ML_W2_STRIDE + 16 * u2);
+                }
+                if (u == 0) {  // one GELU stage of register pair 8 + 2 (j / 3) behind each u = 0 product
+                    const int jj = 2 * (j / 3);
+                    if (j % 3 == 0) gs.stage_a((float2v){acc[8 + jj], acc[8 + jj + 1]});
+                    if (j % 3 == 1) gs.stage_b();
+                    if (j % 3 == 2) {
+                        float2v v = gs.stage_c();
+                        pf[1][jj] = (_Float16)v[0];
+                        pf[1][jj + 1] = (_Float16)v[1];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(nxt + off2[i]) = pre[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: + b2 + residual, LayerNorm over the 384 features of the token (lane pair r31 / r31+32) ----
+    // lane (token r31, g), tile j, register r = 4q + i  <->  feature 32j + 8q + 4g + i
+    const _Float16* xres = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 4 * g;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * j + 8 * q;
+            half4 xr = *(const half4*)(xres + f0);
+            float4v bb = *(const float4v*)(b2 + f0 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = o[j][4 * q + i] + ((float)xr[i] + bb[i]);
+                o[j][4 * q + i] = v;
+                sum += v;
+            }
+        }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / ML_H);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float d = o[j][r] - mean;
+            sq += d * d;
+        }
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
+    if (valid) {
+        _Float16* yr = (_Float16*)out + (int64_t)token * ML_H + 4 * g;
+        const _Float16* gm = (const _Float16*)gamma + 4 * g;
+        const _Float16* bt = (const _Float16*)beta + 4 * g;
+#pragma unroll
+        for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * j + 8 * q;
+                half4 gv = *(const half4*)(gm + f0), bv = *(const half4*)(bt + f0), y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (_Float16)((o[j][4 * q + i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
+                *(half4*)(yr + f0) = y;
+            }
+    }
+}
+
+}  // namespace lm
+
+extern "C" int lm_mlp_fused_h384_f16(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2,
+                                     const void* d_gamma, const void* d_beta, void* d_out, int64_t tokens, int32_t ffn, float eps,
+                                     void* stream) {
+    using namespace lm;
+    if (tokens == 0) return LM_OK;
+    if (!d_x || !d_w1 || !d_b1 || !d_w2p || !d_b2 || !d_gamma || !d_beta || !d_out || tokens < 0 || tokens > 0x7fffffff)
+        LM_FAIL(LM_EINVAL, "bad fused MLP arguments");
+    if (ffn <= 0 || ffn % 32) LM_FAIL(LM_EINVAL, "ffn size must be a positive multiple of 32");
+    const size_t shmem = (size_t)2 * ML_BUF + (size_t)ffn * 4;
+    if (shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "ffn size too large for the LDS-resident bias (<= 13056)");
+    LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
+    hipLaunchKernelGGL(k_mlp_fused_h384, grid, block, shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w1, d_b1,
+                       (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out, (int)tokens, ffn, eps);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}

@@ -154,6 +154,51 @@ def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool) -> Option
     return out
 
 
+def fused_mlp_k_permutation() -> torch.Tensor:
+    """Order of the 32 hidden units of a slab inside a packed W2 row (csrc/lm_mlp_fused.hip): position
+    16u + 8g + e holds unit 16u + 4g + e (e < 4) or 16u + 8 + 4g + e - 4 (e >= 4) -- the hidden units whose GELU
+    outputs lane group g already has in registers 8u .. 8u+7 of the first product's accumulator."""
+    pos = torch.arange(32)
+    u, g, e = pos // 16, (pos % 16) // 8, pos % 8
+    return torch.where(e < 4, 16 * u + 4 * g + e, 16 * u + 8 + 4 * g + e - 4)
+
+
+def pack_w2_fused_mlp(w2: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [H, F] -> [F/32, H, 32] slabs with the k permutation above (contiguous 24 KB per slab)."""
+    h, f = w2.shape
+    perm = fused_mlp_k_permutation().to(w2.device)
+    return w2.reshape(h, f // 32, 32)[:, :, perm].permute(1, 0, 2).contiguous()
+
+
+def fused_mlp(x: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
+    """LayerNorm(x + fc2(GELU(fc1(x)))) in one kernel (csrc/lm_mlp_fused.hip) for hidden 384, fp16 on the GPU.
+    Opt-in (LEANN_MI355X_MLP=1) until validated on hardware; None = the caller takes the default path."""
+    import os
+
+    if os.environ.get("LEANN_MI355X_MLP", "0") != "1":
+        return None
+    f, h = layer.fc1.weight.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and h == 384 and f % 32 == 0 and f <= 13056):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    pk = getattr(layer, "_mlp_pack", None)
+    if pk is None or pk[0].device != x.device:
+        pk = (pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
+              layer.fc2.bias.detach().float().contiguous(), layer.fc1.weight.detach().contiguous())
+        layer._mlp_pack = pk
+    w2p, b1, b2, w1 = pk
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().lm_mlp_fused_h384_f16(
+        C.c_void_p(x.data_ptr()), C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2p.data_ptr()),
+        C.c_void_p(b2.data_ptr()), C.c_void_p(layer.ln2.weight.data_ptr()), C.c_void_p(layer.ln2.bias.data_ptr()),
+        C.c_void_p(out.data_ptr()), x.shape[0], f, float(layer.ln2.eps), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+        "lm_mlp_fused_h384_f16")
+    return out
+
+
 class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
@@ -176,6 +221,9 @@ class _Layer(nn.Module):
             qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
             a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
         x = fused_add_layernorm(self.out(a), x, self.ln1)
+        y = fused_mlp(x, self)
+        if y is not None:
+            return y
         x = fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
         return x
 

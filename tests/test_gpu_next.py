@@ -165,3 +165,38 @@ def test_encoder_forward_with_every_opt_in_kernel(monkeypatch):
         monkeypatch.setenv(k, v)
     a = enc.encode_tokens_packed(ti, tl)
     assert (a - b).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 32), (300, 3072)])
+def test_fused_mlp_h384(tokens, ffn, monkeypatch):
+    """lm_mlp_fused_h384_f16 (LEANN_MI355X_MLP=1) vs a plain PyTorch fp32 reference of the same block and vs the
+    default path (hipBLASLt GEMMs + GELU kernel + lm_add_layernorm_f16)."""
+    import torch
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import EncoderConfig, _Layer, fused_add_layernorm, fused_mlp
+
+    torch.manual_seed(tokens + ffn)
+    cfg = EncoderConfig(hidden=384, layers=1, heads=12, ffn=ffn)
+    layer = _Layer(cfg).to("cuda", dtype=torch.float16)
+    with torch.no_grad():
+        layer.ln2.weight.copy_(1 + 0.1 * torch.randn(384))
+        layer.ln2.bias.copy_(0.1 * torch.randn(384))
+        layer.fc1.bias.copy_(0.2 * torch.randn(ffn))
+        layer.fc2.bias.copy_(0.2 * torch.randn(384))
+    x = torch.randn((tokens, 384), device="cuda").half()
+    monkeypatch.setenv("LEANN_MI355X_MLP", "1")
+    with torch.no_grad():
+        got = fused_mlp(x, layer)
+        assert got is not None and got.shape == x.shape and got.dtype == torch.float16
+        xf = x.float()
+        hid = F.gelu(xf @ layer.fc1.weight.float().t() + layer.fc1.bias.float())
+        z = xf + hid @ layer.fc2.weight.float().t() + layer.fc2.bias.float()
+        ref = F.layer_norm(z, (384,), layer.ln2.weight.float(), layer.ln2.bias.float(), layer.ln2.eps)
+        dflt = fused_add_layernorm(layer.fc2(F.gelu(layer.fc1(x))), x, layer.ln2)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any()
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got.float() - ref).abs().max().item() <= 6e-3 * scale
+    # the default path rounds the 1536-wide intermediate to fp16 twice more than the fused kernel does
+    assert (got.float() - dflt.float()).abs().max().item() <= 1.2e-2 * scale
