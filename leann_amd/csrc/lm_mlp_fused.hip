@@ -27,6 +27,8 @@
 // Budget per wave: 192 accumulator registers (out^T) + 96 (x^T fragments) + 16 (H^T) + 48 (prefetch) => one wave
 // per SIMD by design; MFMA work per slab and wave: 24 + 24 instructions.
 // Role in the reference: the FFN inside compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 
 #include "lm_internal.h"
@@ -80,6 +82,56 @@ __device__ inline float2v gelu2(float2v x) {
     g.stage_a(x);
     g.stage_b();
     return g.stage_c();
+}
+
+// epilogue shared by both kernels: + b2 + residual, LayerNorm over the 384 features of the token (lane pair
+// r31 / r31+32); lane (token r31, g), tile j, register r = 4q + i  <->  feature 32j + 8q + 4g + i
+__device__ inline void mlp_epilogue(float16v (&o)[ML_NJ], const __half* __restrict__ x, const float* __restrict__ b2,
+                                    const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out,
+                                    int token, bool valid, int g, float eps) {
+    const _Float16* xres = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 4 * g;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * j + 8 * q;
+            half4 xr = *(const half4*)(xres + f0);
+            float4v bb = *(const float4v*)(b2 + f0 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = o[j][4 * q + i] + ((float)xr[i] + bb[i]);
+                o[j][4 * q + i] = v;
+                sum += v;
+            }
+        }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / ML_H);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float d = o[j][r] - mean;
+            sq += d * d;
+        }
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
+    if (valid) {
+        _Float16* yr = (_Float16*)out + (int64_t)token * ML_H + 4 * g;
+        const _Float16* gm = (const _Float16*)gamma + 4 * g;
+        const _Float16* bt = (const _Float16*)beta + 4 * g;
+#pragma unroll
+        for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * j + 8 * q;
+                half4 gv = *(const half4*)(gm + f0), bv = *(const half4*)(bt + f0), y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (_Float16)((o[j][4 * q + i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
+                *(half4*)(yr + f0) = y;
+            }
+    }
 }
 
 // w1:  [F][384] fp16 (nn.Linear weight, slab s = rows 32s..32s+31: contiguous)
@@ -235,51 +287,195 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
     }
 
-    // ---- epilogue: + b2 + residual, LayerNorm over the 384 features of the token (lane pair r31 / r31+32) ----
-    // lane (token r31, g), tile j, register r = 4q + i  <->  feature 32j + 8q + 4g + i
-    const _Float16* xres = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 4 * g;
-    float sum = 0.f;
+    mlp_epilogue(o, x, b2, gamma, beta, out, token, valid, g, eps);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant 2 (LEANN_MI355X_MLP=1 with LEANN_MI355X_MLP_VARIANT=2): software pipelined ACROSS slabs.  In the kernel above the matrix pipe idles
+// while a wave evaluates the GELU of the first eight accumulator registers (one wave per SIMD: nobody else can
+// use it).  Here the first product of slab s+1 is issued while the GELU of slab s is evaluated: one GELU stage
+// (~8 VALU instructions) behind each of its 24 MFMAs covers register pairs 0..5, pairs 6..7 ride behind the
+// first six u = 0 products of the second product as before.  W1 is staged one slab further ahead than W2:
+//     iteration s reads  W1[s+1] from stage (s+1)&1  and  W2[s] from stage s&1,
+//                 writes W1[s+2] to   stage  s&1      and  W2[s+1] to stage (s+1)&1   (both regions idle by then).
+// Same arithmetic, same results as variant 1.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_fused_h384_p(
+    const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
+    const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
+    int F, float eps) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* b1s = (float*)(smem + 2 * ML_BUF);  // [F]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r31 = lane & 31, g = lane >> 5;
+    const int token = blockIdx.x * 128 + wv * 32 + r31;
+    const bool valid = token < T;
+    const int nslab = F >> 5;
+
+    half8 xf[ML_KS];
+    {
+        const _Float16* xr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
 #pragma unroll
-    for (int j = 0; j < ML_NJ; ++j)
+        for (int ks = 0; ks < ML_KS; ++ks) {
+            half8 v = *(const half8*)(xr + 16 * ks);
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xf[ks] = valid ? v : z;
+        }
+    }
+    for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
+
+    int off1[ML_NPRE], off2[ML_NPRE];
+#pragma unroll
+    for (int i = 0; i < ML_NPRE; ++i) {
+        const int c = tid + 256 * i;
+        off1[i] = (c / 48) * (ML_W1_STRIDE * 2) + (c % 48) * 16;
+        off2[i] = ML_W1_BYTES + (c >> 2) * (ML_W2_STRIDE * 2) + (c & 3) * 16;
+    }
+    u32x4 pre[ML_NPRE];
+    const u32x4* g1 = (const u32x4*)w1 + tid;   // + slab * ML_CHUNKS + 256 i
+    const u32x4* g2 = (const u32x4*)w2p + tid;
+    {   // W1[0], W2[0] -> stage 0; W1[1] -> stage 1
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) pre[i] = g1[256 * i];
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(smem + off1[i]) = pre[i];
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) pre[i] = g2[256 * i];
+#pragma unroll
+        for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(smem + off2[i]) = pre[i];
+        if (nslab > 1) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) pre[i] = g1[ML_CHUNKS + 256 * i];
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(smem + ML_BUF + off1[i]) = pre[i];
+        }
+    }
+    __syncthreads();
+
+    float16v o[ML_NJ];
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j) o[j] = (float16v){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // first product of slab 0 (nothing to overlap it with)
+    float16v accn;
+    {
+        const float* bs = b1s + 4 * g;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int f0 = 32 * j + 8 * q;
-            half4 xr = *(const half4*)(xres + f0);
-            float4v bb = *(const float4v*)(b2 + f0 + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = o[j][4 * q + i] + ((float)xr[i] + bb[i]);
-                o[j][4 * q + i] = v;
-                sum += v;
-            }
+            float4v bv = *(const float4v*)(bs + 8 * q);
+            accn[4 * q] = bv[0];
+            accn[4 * q + 1] = bv[1];
+            accn[4 * q + 2] = bv[2];
+            accn[4 * q + 3] = bv[3];
         }
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / ML_H);
-    float sq = 0.f;
+        const _Float16* W1s = (const _Float16*)smem + r31 * ML_W1_STRIDE + 8 * g;
+        half8 ring[4];
 #pragma unroll
-    for (int j = 0; j < ML_NJ; ++j)
+        for (int i = 0; i < 4; ++i) ring[i] = *(const half8*)(W1s + 16 * i);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float d = o[j][r] - mean;
-            sq += d * d;
+        for (int ks = 0; ks < ML_KS; ++ks) {
+            accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[ks & 3], xf[ks], accn, 0, 0, 0);
+            if (ks + 4 < ML_KS) ring[ks & 3] = *(const half8*)(W1s + 16 * (ks + 4));
+            __builtin_amdgcn_sched_barrier(0);
         }
-    sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
-    if (valid) {
-        _Float16* yr = (_Float16*)out + (int64_t)token * ML_H + 4 * g;
-        const _Float16* gm = (const _Float16*)gamma + 4 * g;
-        const _Float16* bt = (const _Float16*)beta + 4 * g;
+    }
+    __syncthreads();  // iteration 0 overwrites W1[0] (stage 0) with W1[2]: every wave must be done reading it
+
+    for (int s = 0; s < nslab; ++s) {
+        unsigned char* cur = smem + (s & 1) * ML_BUF;        // W2[s]; receives W1[s+2]
+        unsigned char* oth = smem + ((s + 1) & 1) * ML_BUF;  // W1[s+1]; receives W2[s+1]
+        const bool more = s + 1 < nslab, more2 = s + 2 < nslab;
+        float acc[16];  // H^T of slab s (bias included), about to go through GELU
 #pragma unroll
-        for (int j = 0; j < ML_NJ; ++j)
+        for (int r = 0; r < 16; ++r) acc[r] = accn[r];
+        if (more2) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) pre[i] = g1[(int64_t)(s + 2) * ML_CHUNKS + 256 * i];
+        }
+        half8 pf[2];
+        Gelu2 gs;
+        if (more) {
+            // ---- first product of slab s+1, one GELU stage of slab s behind each MFMA (pairs 0..5) ----
+            const float* bs = b1s + 32 * (s + 1) + 4 * g;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int f0 = 32 * j + 8 * q;
-                half4 gv = *(const half4*)(gm + f0), bv = *(const half4*)(bt + f0), y;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = (_Float16)((o[j][4 * q + i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
-                *(half4*)(yr + f0) = y;
+                float4v bv = *(const float4v*)(bs + 8 * q);
+                accn[4 * q] = bv[0];
+                accn[4 * q + 1] = bv[1];
+                accn[4 * q + 2] = bv[2];
+                accn[4 * q + 3] = bv[3];
             }
+            const _Float16* W1s = (const _Float16*)oth + r31 * ML_W1_STRIDE + 8 * g;
+            half8 ring[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = *(const half8*)(W1s + 16 * i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < ML_KS; ++ks) {
+                accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[ks & 3], xf[ks], accn, 0, 0, 0);
+                if (ks + 4 < ML_KS) ring[ks & 3] = *(const half8*)(W1s + 16 * (ks + 4));
+                if (ks < 18) {
+                    const int pr = ks / 3;  // register pair 2pr, 2pr+1 -> pf[pr / 4][2 (pr % 4) ..]
+                    if (ks % 3 == 0) gs.stage_a((float2v){acc[2 * pr], acc[2 * pr + 1]});
+                    if (ks % 3 == 1) gs.stage_b();
+                    if (ks % 3 == 2) {
+                        float2v v = gs.stage_c();
+                        pf[pr / 4][2 * (pr % 4)] = (_Float16)v[0];
+                        pf[pr / 4][2 * (pr % 4) + 1] = (_Float16)v[1];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                float2v v = gelu2((float2v){acc[2 * pr], acc[2 * pr + 1]});
+                pf[pr / 4][2 * (pr % 4)] = (_Float16)v[0];
+                pf[pr / 4][2 * (pr % 4) + 1] = (_Float16)v[1];
+            }
+        }
+        if (more2) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(cur + off1[i]) = pre[i];
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) pre[i] = g2[(int64_t)(s + 1) * ML_CHUNKS + 256 * i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // ---- out^T += W2[s] . GELU(H^T[s]); GELU pairs 6, 7 (-> pf[1][4..7]) behind the first six products ----
+            const _Float16* W2s = (const _Float16*)(cur + ML_W1_BYTES) + r31 * ML_W2_STRIDE + 8 * g;
+            half8 ring[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = *(const half8*)(W2s + 32 * i * ML_W2_STRIDE);
+#pragma unroll
+            for (int n = 0; n < 2 * ML_NJ; ++n) {  // product n: u = n / 12, tile j = n % 12
+                const int u = n / ML_NJ, j = n % ML_NJ;
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[n & 3], pf[u], o[j], 0, 0, 0);
+                if (n + 4 < 2 * ML_NJ) {
+                    const int u2 = (n + 4) / ML_NJ, j2 = (n + 4) % ML_NJ;
+                    ring[n & 3] = *(const half8*)(W2s + 32 * j2 * ML_W2_STRIDE + 16 * u2);
+                }
+                if (n < 6) {
+                    const int pr = 6 + n / 3;
+                    if (n % 3 == 0) gs.stage_a((float2v){acc[2 * pr], acc[2 * pr + 1]});
+                    if (n % 3 == 1) gs.stage_b();
+                    if (n % 3 == 2) {
+                        float2v v = gs.stage_c();
+                        pf[1][2 * (pr % 4)] = (_Float16)v[0];
+                        pf[1][2 * (pr % 4) + 1] = (_Float16)v[1];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < ML_NPRE; ++i) *(u32x4*)(oth + off2[i]) = pre[i];
+        }
+        __syncthreads();
     }
+    mlp_epilogue(o, x, b2, gamma, beta, out, token, valid, g, eps);
 }
 
 }  // namespace lm
@@ -294,10 +490,17 @@ extern "C" int lm_mlp_fused_h384_f16(const void* d_x, const void* d_w1, const fl
     if (ffn <= 0 || ffn % 32) LM_FAIL(LM_EINVAL, "ffn size must be a positive multiple of 32");
     const size_t shmem = (size_t)2 * ML_BUF + (size_t)ffn * 4;
     if (shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "ffn size too large for the LDS-resident bias (<= 13056)");
-    LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
-    hipLaunchKernelGGL(k_mlp_fused_h384, grid, block, shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w1, d_b1,
-                       (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out, (int)tokens, ffn, eps);
+    const char* var = getenv("LEANN_MI355X_MLP_VARIANT");  // "2": cross-slab software pipelining (k_mlp_fused_h384_p)
+    if (var && var[0] == '2' && var[1] == 0) {
+        LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384_p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k_mlp_fused_h384_p, grid, block, shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w1, d_b1,
+                           (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out, (int)tokens, ffn, eps);
+    } else {
+        LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k_mlp_fused_h384, grid, block, shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w1, d_b1,
+                           (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out, (int)tokens, ffn, eps);
+    }
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -27,7 +27,7 @@ flops = sum(cfg.flops_per_chunk(int(t)) for t in lens)
 
 
 def clear():
-    for k in SWITCHES:
+    for k in list(SWITCHES) + ["LEANN_MI355X_MLP_VARIANT"]:
         os.environ.pop(k, None)
 
 
@@ -56,7 +56,15 @@ for k, v in SWITCHES.items():
         r["max_abs_diff_vs_default"] = float((e - ref).abs().max())
     out[f"{k}={v}"] = r
 clear()
+os.environ["LEANN_MI355X_MLP"] = "1"
+os.environ["LEANN_MI355X_MLP_VARIANT"] = "2"
+e, r = timed("mlp2")
+if e is not None and ref is not None:
+    r["max_abs_diff_vs_default"] = float((e - ref).abs().max())
+out["LEANN_MI355X_MLP=1,VARIANT=2"] = r
+clear()
 os.environ.update(SWITCHES)
+os.environ["LEANN_MI355X_MLP_VARIANT"] = "2"
 e, r = timed("all")
 if e is not None and ref is not None:
     r["max_abs_diff_vs_default"] = float((e - ref).abs().max())

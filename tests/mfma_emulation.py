@@ -123,3 +123,90 @@ def emulate_mlp_wave(x, w1, b1, w2p, b2, gamma, beta, eps, gelu):
                 val = (o[j][:, 4 * q + i] - mean) * rstd * gamma[f].astype(np.float32) + beta[f].astype(np.float32)
                 y[r31, f] = val.astype(np.float16)
     return y
+
+
+def _stage_store(lds: np.ndarray, base: int, which: int, src_bytes: np.ndarray, slab: int) -> None:
+    """All 256 threads store their 6 chunks of one matrix' slab (which = 1: W1 -> off1, 2: W2 -> off2) at stage base."""
+    for tid in range(256):
+        for i in range(ML_NPRE):
+            c = tid + 256 * i
+            off = (c // 48) * (ML_W1_STRIDE * 2) + (c % 48) * 16 if which == 1 else ML_W1_BYTES + (c >> 2) * (ML_W2_STRIDE * 2) + (c & 3) * 16
+            src = (slab * ML_CHUNKS + c) * 16
+            lds[base + off:base + off + 16] = src_bytes[src:src + 16]
+
+
+def emulate_mlp_wave_pipelined(x, w1, b1, w2p, b2, gamma, beta, eps, gelu):
+    """k_mlp_fused_h384_p: same arithmetic, but W1 is staged one slab ahead of W2 and the first product of slab
+    s+1 is computed during iteration s.  The two LDS stages are modelled as one byte array that is only written at
+    the program points where the kernel writes it, so a wrong stage parity or slab index shows up as a wrong result."""
+    F = w1.shape[0]
+    nslab = F // 32
+    lane = np.arange(LANES)
+    r31, g = lane % 32, lane // 32
+    w1_bytes = np.ascontiguousarray(w1).view(np.uint8).reshape(-1)
+    w2p_bytes = np.ascontiguousarray(w2p).view(np.uint8).reshape(-1)
+    xf = [np.stack([x[r31, 16 * ks + 8 * g + e] for e in range(8)], axis=1) for ks in range(ML_KS)]
+    lds = np.full(2 * ML_BUF, 0xEE, np.uint8)  # poison: reading a stage that was never written gives garbage
+    _stage_store(lds, 0, 1, w1_bytes, 0)
+    _stage_store(lds, 0, 2, w2p_bytes, 0)
+    if nslab > 1:
+        _stage_store(lds, ML_BUF, 1, w1_bytes, 1)
+
+    def first_product(stage_base: int, slab: int) -> np.ndarray:
+        acc = np.zeros((LANES, 16), np.float32)
+        for q in range(4):
+            for i in range(4):
+                acc[:, 4 * q + i] = b1[32 * slab + 4 * g + 8 * q + i]
+        halfs = lds.view(np.float16)
+        w1s = stage_base // 2 + r31 * ML_W1_STRIDE + 8 * g
+        for ks in range(ML_KS):
+            acc = mfma_32x32x16(_half8_at(halfs, w1s + 16 * ks), xf[ks], acc)
+        return acc
+
+    o = [np.zeros((LANES, 16), np.float32) for _ in range(ML_NJ)]
+    accn = first_product(0, 0)
+    for s in range(nslab):
+        cur, oth = (s & 1) * ML_BUF, ((s + 1) & 1) * ML_BUF
+        more, more2 = s + 1 < nslab, s + 2 < nslab
+        acc = accn.copy()
+        if more:
+            accn = first_product(oth, s + 1)
+        pf = [np.zeros((LANES, 8), np.float16) for _ in range(2)]
+        for pr in range(8):  # pairs 0..5 behind the first product, 6..7 behind the second: same values either way
+            for e in range(2):
+                pf[pr // 4][:, 2 * (pr % 4) + e] = gelu(acc[:, 2 * pr + e]).astype(np.float16)
+        if more2:
+            _stage_store(lds, cur, 1, w1_bytes, s + 2)
+        halfs = lds.view(np.float16)
+        w2s = (cur + ML_W1_BYTES) // 2 + r31 * ML_W2_STRIDE + 8 * g
+        for n in range(2 * ML_NJ):
+            u, j = n // ML_NJ, n % ML_NJ
+            o[j] = mfma_32x32x16(_half8_at(halfs, w2s + 32 * j * ML_W2_STRIDE + 16 * u), pf[u], o[j])
+        if more:
+            _stage_store(lds, oth, 2, w2p_bytes, s + 1)
+    # epilogue identical to emulate_mlp_wave
+    y = np.zeros((32, ML_H), np.float16)
+    tot = np.zeros(LANES, np.float32)
+    for j in range(ML_NJ):
+        for q in range(4):
+            for i in range(4):
+                f = 32 * j + 8 * q + 4 * g + i
+                v = o[j][:, 4 * q + i] + (x[r31, f].astype(np.float32) + b2[f])
+                o[j][:, 4 * q + i] = v
+                tot += v
+    tot = tot + tot[lane ^ 32]
+    mean = tot / ML_H
+    sq = np.zeros(LANES, np.float32)
+    for j in range(ML_NJ):
+        for r in range(16):
+            d = o[j][:, r] - mean
+            sq += d * d
+    sq = sq + sq[lane ^ 32]
+    rstd = 1.0 / np.sqrt(sq / ML_H + eps)
+    for j in range(ML_NJ):
+        for q in range(4):
+            for i in range(4):
+                f = 32 * j + 8 * q + 4 * g + i
+                val = (o[j][:, 4 * q + i] - mean) * rstd * gamma[f].astype(np.float32) + beta[f].astype(np.float32)
+                y[r31, f] = val.astype(np.float16)
+    return y

@@ -167,8 +167,9 @@ def test_encoder_forward_with_every_opt_in_kernel(monkeypatch):
     assert (a - b).abs().max() < 2e-3
 
 
-@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 32), (300, 3072)])
-def test_fused_mlp_h384(tokens, ffn, monkeypatch):
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 32), (300, 64), (300, 3072)])
+def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):
     """lm_mlp_fused_h384_f16 (LEANN_MI355X_MLP=1) vs a plain PyTorch fp32 reference of the same block and vs the
     default path (hipBLASLt GEMMs + GELU kernel + lm_add_layernorm_f16)."""
     import torch
@@ -186,6 +187,7 @@ def test_fused_mlp_h384(tokens, ffn, monkeypatch):
         layer.fc2.bias.copy_(0.2 * torch.randn(384))
     x = torch.randn((tokens, 384), device="cuda").half()
     monkeypatch.setenv("LEANN_MI355X_MLP", "1")
+    monkeypatch.setenv("LEANN_MI355X_MLP_VARIANT", variant)  # 2: cross-slab software pipelining
     with torch.no_grad():
         got = fused_mlp(x, layer)
         assert got is not None and got.shape == x.shape and got.dtype == torch.float16

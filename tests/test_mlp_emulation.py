@@ -43,7 +43,7 @@ def test_k_permutation_is_a_bijection_matching_the_accumulator_layout():
     assert torch.is_tensor(fused_mlp_k_permutation())
 
 
-@pytest.mark.parametrize("ffn", [32, 96])
+@pytest.mark.parametrize("ffn", [32, 64, 160])
 def test_fused_mlp_lane_level_data_flow_matches_a_plain_mlp(ffn):
     torch = pytest.importorskip("torch")
     from leann_amd.encoder import pack_w2_fused_mlp
@@ -60,6 +60,9 @@ def test_fused_mlp_lane_level_data_flow_matches_a_plain_mlp(ffn):
     w2p = pack_w2_fused_mlp(torch.from_numpy(w2)).numpy()
     assert w2p.shape == (ffn // 32, h, 32)
     y = me.emulate_mlp_wave(x, w1, b1, w2p, b2, gamma, beta, 1e-12, _gelu_exact)
+    # the cross-slab pipelined variant moves the same bytes through the two LDS stages on a different timetable
+    yp = me.emulate_mlp_wave_pipelined(x, w1, b1, w2p, b2, gamma, beta, 1e-12, _gelu_exact)
+    assert np.array_equal(y.view(np.uint16), yp.view(np.uint16))
     # plain MLP with the same rounding points (fp32 accumulation, fp16 GELU output)
     hid = x.astype(np.float64) @ w1.astype(np.float64).T + b1
     p = _gelu_exact(hid.astype(np.float32)).astype(np.float16)
