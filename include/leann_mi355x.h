@@ -239,6 +239,16 @@ int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, 
                           const void *d_gamma, const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps,
                           void *stream);
 
+/* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
+ *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
+ *   d_out[tokens][384]   = LayerNorm(residual + x W^T + b) gamma+beta (d_residual != NULL, n_out == 384)
+ * x / out / residual fp16, bias fp32, d_wp = W packed as [P][12][384][32] fp16 (leann_amd/encoder.py:
+ * pack_w_linear_h384).  MFMA 32x32x16 f16 with the token slice of x held in registers.  The attention
+ * projections of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).
+ * Host switch: LEANN_MI355X_LINEAR=1. */
+int lm_linear_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
+                       const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

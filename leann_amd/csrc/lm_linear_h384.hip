@@ -1,0 +1,151 @@
+// lm_linear_h384.hip -- linear layers with 384 input features on the transposed MFMA layout of lm_mlp_fused.hip:
+//
+//   MODE 0   out[T][N] = x W^T + b                          N = 384 P   (QKV projection: P = 3)
+//   MODE 1   out[T][384] = LayerNorm(res + x W^T + b)                   (attention output projection + LN1)
+//
+// STATUS: opt-in (LEANN_MI355X_LINEAR=1) until validated and timed on an MI355X (tests/test_gpu_next.py,
+// scripts/encoder_ops_bench.py).
+//
+// Why: with K = 384 the library GEMMs of the layer run at ~240 TFLOP/s (12 k-iterations per 256x256 tile: the
+// prologue / epilogue of every tile is as long as its main loop) -- 1.3 ms of a 4.3 ms layer for 262k tokens
+// (profiles/r1_final_bench_default_kernel_stats.csv, MT128x256x32: 2 calls per layer).  K = 384 is small enough
+// to keep a wave's whole input slice in registers instead: x^T of 32 tokens = 24 B fragments (96 registers), so
+// the main loop is MFMA + one LDS read per MFMA and nothing else.
+//
+// One 256-thread workgroup = 4 waves = 128 tokens; per pass a wave accumulates out^T [384 x 32 tokens] in 192
+// registers:  out^T += W[384 rows][k slab] (A operand, LDS) . x^T[k slab] (B operand, registers).
+// Weights stream through LDS in slabs of 32 input features (384 rows x 64 B = 24 KB, rows padded to 80 B),
+// double buffered, 12 slabs per pass; W is packed on the host as [P][12][384][32] so that a slab is one
+// contiguous 24 KB block (leann_amd/encoder.py: pack_w_linear_h384).  MODE 1 finishes with the shared
+// bias + residual + LayerNorm epilogue (a lane pair holds all 384 features of its token).
+// Role in the reference: the attention projections inside compute_embeddings' BERT forward
+// (leann/embedding_compute.py:229-239).
+#include <cstdlib>
+
+#include "lm_h384_common.h"
+
+namespace lm {
+
+constexpr int LN_STRIDE = 40;                         // halfs per weight row in LDS (80 B)
+constexpr int LN_BUF = ML_H * LN_STRIDE * 2;          // 30720 B per stage
+constexpr int LN_CHUNKS = ML_H * 32 * 2 / 16;         // 1536 16-byte chunks per slab
+constexpr int LN_NPRE = LN_CHUNKS / 256;              // 6 per thread
+constexpr int LN_SLABS = ML_H / 32;                   // 12 slabs per pass
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linear_h384(
+    const __half* __restrict__ x, const __half* __restrict__ wp, const float* __restrict__ bias, const __half* __restrict__ res,
+    const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T, int P, float eps) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r31 = lane & 31, g = lane >> 5;
+    const int token = blockIdx.x * 128 + wv * 32 + r31;
+    const bool valid = token < T;
+    const int N = ML_H * P;
+
+    // x^T fragments (B operand): lane (n = token, g) holds x[token][16ks + 8g .. +8]
+    half8 xf[ML_KS];
+    {
+        const _Float16* xr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < ML_KS; ++ks) {
+            half8 v = *(const half8*)(xr + 16 * ks);
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xf[ks] = valid ? v : z;
+        }
+    }
+    int off[LN_NPRE];
+#pragma unroll
+    for (int i = 0; i < LN_NPRE; ++i) {
+        const int c = tid + 256 * i;
+        off[i] = (c >> 2) * (LN_STRIDE * 2) + (c & 3) * 16;
+    }
+    u32x4 pre[LN_NPRE];
+    const u32x4* gw = (const u32x4*)wp + tid;  // + slab * LN_CHUNKS + 256 i   (slab = 12 p + s)
+#pragma unroll
+    for (int i = 0; i < LN_NPRE; ++i) pre[i] = gw[256 * i];
+#pragma unroll
+    for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(smem + off[i]) = pre[i];
+    __syncthreads();
+
+    const _Float16* Ws = (const _Float16*)smem + r31 * LN_STRIDE + 8 * g;  // A fragment base inside a stage (m = out row r31)
+    for (int p = 0; p < P; ++p) {
+        float16v o[ML_NJ];
+#pragma unroll
+        for (int j = 0; j < ML_NJ; ++j) o[j] = (float16v){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < LN_SLABS; ++s) {  // unrolled: xf is indexed by 2s + u
+            // stage parity: slab t = 12p + s lives in stage t & 1 = s & 1 (12 is even)
+            const _Float16* cur = Ws + (s & 1) * (LN_BUF / 2);
+            unsigned char* nxt = smem + ((s + 1) & 1) * LN_BUF;
+            const bool more = s + 1 < LN_SLABS || p + 1 < P;
+            if (more) {
+                const u32x4* src = gw + (int64_t)(LN_SLABS * p + s + 1) * LN_CHUNKS;
+#pragma unroll
+                for (int i = 0; i < LN_NPRE; ++i) pre[i] = src[256 * i];
+            }
+            // 24 products, a ring of 4 A fragments read 4 products ahead (source order = issue order)
+            half8 ring[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = *(const half8*)(cur + 32 * i * LN_STRIDE);
+#pragma unroll
+            for (int n = 0; n < 2 * ML_NJ; ++n) {  // product n: k-step u = n / 12, tile j = n % 12
+                const int u = n / ML_NJ, j = n % ML_NJ;
+                o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[n & 3], xf[2 * s + u], o[j], 0, 0, 0);
+                if (n + 4 < 2 * ML_NJ) {
+                    const int u2 = (n + 4) / ML_NJ, j2 = (n + 4) % ML_NJ;
+                    ring[n & 3] = *(const half8*)(cur + 32 * j2 * LN_STRIDE + 16 * u2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(nxt + off[i]) = pre[i];
+            }
+            __syncthreads();
+        }
+        if (MODE == 1) {
+            mlp_epilogue(o, res, bias, gamma, beta, out, token, valid, g, eps);
+        } else if (valid) {
+            // lane (token r31, g), tile j, register 4q + i <-> output column 384p + 32j + 8q + 4g + i
+            _Float16* yr = (_Float16*)out + (int64_t)token * N + ML_H * p + 4 * g;
+            const float* bp = bias + ML_H * p + 4 * g;
+#pragma unroll
+            for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * j + 8 * q;
+                    float4v bb = *(const float4v*)(bp + f0);
+                    half4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = (_Float16)(o[j][4 * q + i] + bb[i]);
+                    *(half4*)(yr + f0) = y;
+                }
+        }
+    }
+}
+
+}  // namespace lm
+
+extern "C" int lm_linear_h384_f16(const void* d_x, const void* d_wp, const float* d_bias, int32_t n_out, const void* d_residual,
+                                  const void* d_gamma, const void* d_beta, float eps, void* d_out, int64_t tokens, void* stream) {
+    using namespace lm;
+    if (tokens == 0) return LM_OK;
+    if (!d_x || !d_wp || !d_bias || !d_out || tokens < 0 || tokens > 0x7fffffff) LM_FAIL(LM_EINVAL, "bad linear arguments");
+    if (n_out <= 0 || n_out % ML_H) LM_FAIL(LM_EINVAL, "n_out must be a positive multiple of 384");
+    const bool ln = d_residual != nullptr;
+    if (ln && (n_out != ML_H || !d_gamma || !d_beta)) LM_FAIL(LM_EINVAL, "residual + LayerNorm mode needs n_out == 384, gamma and beta");
+    const size_t shmem = (size_t)2 * LN_BUF;
+    dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const __half *x = (const __half*)d_x, *w = (const __half*)d_wp, *r = (const __half*)d_residual;
+    const __half *gm = (const __half*)d_gamma, *bt = (const __half*)d_beta;
+    if (ln) {
+        hipLaunchKernelGGL(k_linear_h384<1>, grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, 1, eps);
+    } else {
+        hipLaunchKernelGGL(k_linear_h384<0>, grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, n_out / ML_H,
+                           eps);
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}

@@ -199,6 +199,45 @@ def fused_mlp(x: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
     return out
 
 
+def pack_w_linear_h384(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [384 P, 384] -> [P, 12, 384, 32]: pass p, input-feature slab s, output row f, 32 inputs --
+    one contiguous 24 KB block per (p, s) for csrc/lm_linear_h384.hip."""
+    n, k = w.shape
+    return w.reshape(n // 384, 384, k // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
+def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor] = None,
+                      ln: Optional[nn.LayerNorm] = None) -> Optional[torch.Tensor]:
+    """x W^T + b (and, with residual + ln, LayerNorm(residual + x W^T + b)) for 384 input features through the
+    hand-written MFMA kernel (csrc/lm_linear_h384.hip).  Opt-in (LEANN_MI355X_LINEAR=1) until validated on
+    hardware; None = the caller takes the hipBLASLt path."""
+    import os
+
+    if os.environ.get("LEANN_MI355X_LINEAR", "0") != "1":
+        return None
+    n, k = lin.weight.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n % 384 == 0 and lin.bias is not None):
+        return None
+    if (residual is None) != (ln is None) or (ln is not None and (n != 384 or not residual.is_contiguous())):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    pk = getattr(lin, "_h384_pack", None)
+    if pk is None or pk[0].device != x.device:
+        pk = (pack_w_linear_h384(lin.weight.detach()), lin.bias.detach().float().contiguous())
+        lin._h384_pack = pk
+    out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().lm_linear_h384_f16(
+        C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), n,
+        C.c_void_p(residual.data_ptr()) if residual is not None else None,
+        C.c_void_p(ln.weight.data_ptr()) if ln is not None else None, C.c_void_p(ln.bias.data_ptr()) if ln is not None else None,
+        float(ln.eps) if ln is not None else 0.0, C.c_void_p(out.data_ptr()), x.shape[0],
+        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_linear_h384_f16")
+    return out
+
+
 class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
@@ -215,12 +254,15 @@ class _Layer(nn.Module):
         from torch.nn.attention.varlen import varlen_attn
 
         tot, h = x.shape
-        qkv2 = self.qkv(x)
+        qkv2 = fused_linear_h384(x, self.qkv)
+        if qkv2 is None:
+            qkv2 = self.qkv(x)
         a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
         if a is None:
             qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
             a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
-        x = fused_add_layernorm(self.out(a), x, self.ln1)
+        y = fused_linear_h384(a, self.out, residual=x, ln=self.ln1)
+        x = y if y is not None else fused_add_layernorm(self.out(a), x, self.ln1)
         y = fused_mlp(x, self)
         if y is not None:
             return y

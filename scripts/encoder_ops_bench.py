@@ -3,7 +3,8 @@
 kernels switched on one at a time and all together.  Prints one JSON object; run on the GPU box:
     python scripts/encoder_ops_bench.py
 Switches: LEANN_MI355X_ATTN=2 (lm_attn_v2.hip), LEANN_MI355X_LN=2, LEANN_MI355X_POOL=1, LEANN_MI355X_EMBED=1,
-LEANN_MI355X_MLP=1 (lm_mlp_fused.hip, when built)."""
+LEANN_MI355X_MLP=1 (lm_mlp_fused.hip; LEANN_MI355X_MLP_VARIANT=2 = cross-slab pipelining), LEANN_MI355X_LINEAR=1
+(lm_linear_h384.hip)."""
 import json
 import os
 import sys
@@ -17,7 +18,7 @@ from leann_amd.encoder import BertEncoder, config_for
 from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
 
 SWITCHES = {"LEANN_MI355X_ATTN": "2", "LEANN_MI355X_LN": "2", "LEANN_MI355X_POOL": "1", "LEANN_MI355X_EMBED": "1",
-            "LEANN_MI355X_MLP": "1"}
+            "LEANN_MI355X_MLP": "1", "LEANN_MI355X_LINEAR": "1"}
 dev = torch.device("cuda")
 cfg = config_for("all-MiniLM-L6-v2")
 enc = BertEncoder.random_init(cfg, 0).to(dev, dtype=torch.float16)

@@ -210,3 +210,51 @@ def emulate_mlp_wave_pipelined(x, w1, b1, w2p, b2, gamma, beta, eps, gelu):
                 val = (o[j][:, 4 * q + i] - mean) * rstd * gamma[f].astype(np.float32) + beta[f].astype(np.float32)
                 y[r31, f] = val.astype(np.float16)
     return y
+
+
+# ---- csrc/lm_linear_h384.hip ----
+LN_STRIDE = 40
+LN_BUF = ML_H * LN_STRIDE * 2
+LN_CHUNKS = ML_H * 32 * 2 // 16
+LN_NPRE = LN_CHUNKS // 256
+LN_SLABS = ML_H // 32
+
+
+def emulate_linear_wave(x, wp, bias):
+    """k_linear_h384<0> for one 32-token wave: x [32, 384] fp16, wp packed [P, 12, 384, 32] fp16, bias fp32 [384 P].
+    Returns out [32, 384 P] fp16.  The two LDS stages are written only where the kernel writes them."""
+    P = wp.shape[0]
+    lane = np.arange(LANES)
+    r31, g = lane % 32, lane // 32
+    wbytes = np.ascontiguousarray(wp).view(np.uint8).reshape(-1)
+    xf = [np.stack([x[r31, 16 * ks + 8 * g + e] for e in range(8)], axis=1) for ks in range(ML_KS)]
+    lds = np.full(2 * LN_BUF, 0xEE, np.uint8)
+
+    def store(stage: int, slab: int) -> None:
+        for tid in range(256):
+            for i in range(LN_NPRE):
+                c = tid + 256 * i
+                off = (c >> 2) * (LN_STRIDE * 2) + (c & 3) * 16
+                src = (slab * LN_CHUNKS + c) * 16
+                lds[stage * LN_BUF + off:stage * LN_BUF + off + 16] = wbytes[src:src + 16]
+
+    store(0, 0)
+    out = np.zeros((32, ML_H * P), np.float16)
+    ws = r31 * LN_STRIDE + 8 * g
+    for p in range(P):
+        o = [np.zeros((LANES, 16), np.float32) for _ in range(ML_NJ)]
+        for s in range(LN_SLABS):
+            halfs = lds.view(np.float16)
+            cur = ws + (s & 1) * (LN_BUF // 2)
+            more = s + 1 < LN_SLABS or p + 1 < P
+            for n in range(2 * ML_NJ):
+                u, j = n // ML_NJ, n % ML_NJ
+                o[j] = mfma_32x32x16(_half8_at(halfs, cur + 32 * j * LN_STRIDE + 16 * u), xf[2 * s + u], o[j])
+            if more:
+                store((s + 1) & 1, LN_SLABS * p + s + 1)
+        for j in range(ML_NJ):
+            for q in range(4):
+                for i in range(4):
+                    col = ML_H * p + 32 * j + 8 * q + 4 * g + i
+                    out[r31, col] = (o[j][:, 4 * q + i] + bias[col]).astype(np.float16)
+    return out

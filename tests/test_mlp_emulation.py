@@ -92,3 +92,20 @@ def test_gelu_approximation_is_within_one_fp16_ulp_of_erf_gelu():
     assert (np.abs(got - ref) <= 4e-7 + 1.2e-7 * np.abs(ref)).all()  # 3.4e-7 absolute, plus fp32 rounding of large results
     ulps = np.abs(got.astype(np.float16).view(np.int16).astype(np.int32) - ref.astype(np.float16).view(np.int16).astype(np.int32))
     assert ulps.max() <= 1
+
+
+@pytest.mark.parametrize("passes", [1, 3])
+def test_linear_h384_lane_level_data_flow_matches_a_plain_linear(passes):
+    torch = pytest.importorskip("torch")
+    from leann_amd.encoder import pack_w_linear_h384
+
+    rng = np.random.default_rng(passes)
+    h, n = me.ML_H, me.ML_H * passes
+    x = rng.standard_normal((32, h)).astype(np.float16)
+    w = (rng.standard_normal((n, h)) / np.sqrt(h)).astype(np.float16)
+    b = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    wp = pack_w_linear_h384(torch.from_numpy(w)).numpy()
+    assert wp.shape == (passes, 12, h, 32)
+    got = me.emulate_linear_wave(x, wp, b)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    assert np.abs(got.astype(np.float64) - ref).max() < 4e-3
