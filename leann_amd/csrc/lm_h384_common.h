@@ -23,6 +23,9 @@ constexpr int ML_NJ = ML_H / 32;          // 12 row tiles of out^T
 __device__ inline void mlp_epilogue(float16v (&o)[ML_NJ], const __half* __restrict__ x, const float* __restrict__ b2,
                                     const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out,
                                     int token, bool valid, int g, float eps) {
+    // keep the epilogue's loads below the main loop: in a fully unrolled kernel (one basic block) the scheduler would
+    // otherwise hoist all ~200 of them to the top and spill them (868 B of scratch per lane in k_linear_h384<1>)
+    __builtin_amdgcn_sched_barrier(0);
     const _Float16* xres = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 4 * g;
     float sum = 0.f;
 #pragma unroll

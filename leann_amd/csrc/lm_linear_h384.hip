@@ -103,9 +103,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(nxt + off[i]) = pre[i];
             }
             __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);  // the 12 slabs are one basic block: nothing may drift from one slab into another
         }
         if (MODE == 1) {
-            mlp_epilogue(o, res, bias, gamma, beta, out, token, valid, g, eps);
+            // T > 0 always holds; the branch only gives the epilogue its own basic block.  Inside the unrolled slab
+            // sequence its ~100 chain-free loads (read-only arguments) are placed at the TOP of the kernel by instruction
+            // selection and spilled (820 B of scratch per lane); sched_barrier does not stop that.
+            if (T > 0) mlp_epilogue(o, res, bias, gamma, beta, out, token, valid, g, eps);
         } else if (valid) {
             // lane (token r31, g), tile j, register 4q + i <-> output column 384p + 32j + 8q + 4g + i
             _Float16* yr = (_Float16*)out + (int64_t)token * N + ML_H * p + 4 * g;
