@@ -27,7 +27,9 @@ __device__ inline void mlp_epilogue(float16v (&o)[ML_NJ], const __half* __restri
     // otherwise hoist all ~200 of them to the top and spill them (868 B of scratch per lane in k_linear_h384<1>)
     __builtin_amdgcn_sched_barrier(0);
     const _Float16* xres = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 4 * g;
-    float sum = 0.f;
+    // packed fp32 pairs and two independent partial sums per statistic: 192 values per lane would otherwise be two
+    // 192-long dependent v_add_f32 chains
+    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
@@ -35,25 +37,32 @@ __device__ inline void mlp_epilogue(float16v (&o)[ML_NJ], const __half* __restri
             const int f0 = 32 * j + 8 * q;
             half4 xr = *(const half4*)(xres + f0);
             float4v bb = *(const float4v*)(b2 + f0 + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = o[j][4 * q + i] + ((float)xr[i] + bb[i]);
-                o[j][4 * q + i] = v;
-                sum += v;
-            }
+            float2v v0 = (float2v){o[j][4 * q], o[j][4 * q + 1]} + ((float2v){(float)xr[0], (float)xr[1]} + (float2v){bb[0], bb[1]});
+            float2v v1 = (float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + ((float2v){(float)xr[2], (float)xr[3]} + (float2v){bb[2], bb[3]});
+            o[j][4 * q] = v0[0];
+            o[j][4 * q + 1] = v0[1];
+            o[j][4 * q + 2] = v1[0];
+            o[j][4 * q + 3] = v1[1];
+            sa += v0;
+            sb += v1;
         }
+    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]);
     sum += __shfl_xor(sum, 32);
     const float mean = sum * (1.0f / ML_H);
-    float sq = 0.f;
+    const float2v nm = {-mean, -mean};
+    float2v qa = {0.f, 0.f}, qb = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float d = o[j][r] - mean;
-            sq += d * d;
+        for (int r = 0; r < 16; r += 4) {
+            float2v d0 = (float2v){o[j][r], o[j][r + 1]} + nm, d1 = (float2v){o[j][r + 2], o[j][r + 3]} + nm;
+            qa = __builtin_elementwise_fma(d0, d0, qa);
+            qb = __builtin_elementwise_fma(d1, d1, qb);
         }
+    float sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
     sq += __shfl_xor(sq, 32);
     const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
+    const float2v rs = {rstd, rstd};
     if (valid) {
         _Float16* yr = (_Float16*)out + (int64_t)token * ML_H + 4 * g;
         const _Float16* gm = (const _Float16*)gamma + 4 * g;
@@ -64,8 +73,14 @@ __device__ inline void mlp_epilogue(float16v (&o)[ML_NJ], const __half* __restri
             for (int q = 0; q < 4; ++q) {
                 const int f0 = 32 * j + 8 * q;
                 half4 gv = *(const half4*)(gm + f0), bv = *(const half4*)(bt + f0), y;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] = (_Float16)((o[j][4 * q + i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
+                float2v n0 = ((float2v){o[j][4 * q], o[j][4 * q + 1]} + nm) * rs;
+                float2v n1 = ((float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + nm) * rs;
+                float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[0], (float)gv[1]}, (float2v){(float)bv[0], (float)bv[1]});
+                float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[2], (float)gv[3]}, (float2v){(float)bv[2], (float)bv[3]});
+                y[0] = (_Float16)y0[0];
+                y[1] = (_Float16)y0[1];
+                y[2] = (_Float16)y1[0];
+                y[3] = (_Float16)y1[1];
                 *(half4*)(yr + f0) = y;
             }
     }
