@@ -313,6 +313,7 @@ def main():
                    "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
                    "parallelism": f"queries-dp{world}"},
         "recall_at_10": round(rec, 4),
+        "encoder_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LEANN_MI355X_")},  # opt-in kernels in effect
         "roofline": roofline, "roofline_encoder": roofline_encoder,
         "ef_sweep": sweep,
         "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),
