@@ -60,12 +60,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int c = tid + 256 * i;
         off[i] = (c >> 2) * (LN_STRIDE * 2) + (c & 3) * 16;
     }
-    u32x4 pre[LN_NPRE];
+    // Weight prefetch runs TWO slabs ahead in registers (a slab is only 24 MFMAs = 768 cycles, about one loaded L2
+    // round trip): slab t+2 is loaded during slab t into pre[t & 1] and written to LDS at the end of slab t+1 -- into
+    // the stage slab t was read from, which is idle by then.  LDS stays double buffered.
+    u32x4 pre[2][LN_NPRE];
     const u32x4* gw = (const u32x4*)wp + tid;  // + slab * LN_CHUNKS + 256 i   (slab = 12 p + s)
+    const int nslab = LN_SLABS * P;
 #pragma unroll
-    for (int i = 0; i < LN_NPRE; ++i) pre[i] = gw[256 * i];
+    for (int i = 0; i < LN_NPRE; ++i) pre[0][i] = gw[256 * i];
 #pragma unroll
-    for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(smem + off[i]) = pre[i];
+    for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(smem + off[i]) = pre[0][i];
+    if (nslab > 1) {
+#pragma unroll
+        for (int i = 0; i < LN_NPRE; ++i) pre[1][i] = gw[LN_CHUNKS + 256 * i];  // slab 1: stored at the end of slab 0
+    }
     __syncthreads();
 
     const _Float16* Ws = (const _Float16*)smem + r31 * LN_STRIDE + 8 * g;  // A fragment base inside a stage (m = out row r31)
@@ -78,11 +86,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // stage parity: slab t = 12p + s lives in stage t & 1 = s & 1 (12 is even)
             const _Float16* cur = Ws + (s & 1) * (LN_BUF / 2);
             unsigned char* nxt = smem + ((s + 1) & 1) * LN_BUF;
-            const bool more = s + 1 < LN_SLABS || p + 1 < P;
-            if (more) {
-                const u32x4* src = gw + (int64_t)(LN_SLABS * p + s + 1) * LN_CHUNKS;
+            const int t = LN_SLABS * p + s;
+            const bool more = t + 1 < nslab, more2 = t + 2 < nslab;
+            if (more2) {
+                const u32x4* src = gw + (int64_t)(t + 2) * LN_CHUNKS;
 #pragma unroll
-                for (int i = 0; i < LN_NPRE; ++i) pre[i] = src[256 * i];
+                for (int i = 0; i < LN_NPRE; ++i) pre[s & 1][i] = src[256 * i];
             }
             // 24 products, a ring of 4 A fragments read 4 products ahead (source order = issue order)
             half8 ring[4];
@@ -98,9 +107,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) {
+            if (more) {  // slab t+1, loaded during slab t-1 (or in the prologue)
 #pragma unroll
-                for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(nxt + off[i]) = pre[i];
+                for (int i = 0; i < LN_NPRE; ++i) *(u32x4*)(nxt + off[i]) = pre[(s + 1) & 1][i];
             }
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);  // the 12 slabs are one basic block: nothing may drift from one slab into another
