@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
         // per-lane mask limit; the empty asm keeps the compiler from hoisting all 16*NT key comparisons out of the
         // q-block loop (revision 1 does: 176 SGPR pairs spilled to VGPR lanes and a ~700-instruction preamble)
         int lenv = len - 4 * g;
-        asm volatile("" : "+v"(lenv));
+        LM_KEEP_LOCAL(lenv);
         // ---- online softmax over chunks of CH 32-key tiles ----
         constexpr int CH = NT < 2 ? NT : 2;
         float mx = -3.0e38f, sum = 0.f;
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
 
 }  // namespace lm
 
+#ifndef LM_HOST_EMULATION
 // launched by lm_attn_varlen_hd32_f16 (lm_encoder_ops.hip) when LEANN_MI355X_ATTN=2
 int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len,
                       void* d_out, void* stream) {
@@ -216,3 +217,4 @@ int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
+#endif  // LM_HOST_EMULATION

@@ -12,6 +12,7 @@
 
 #include "lm_internal.h"
 
+#ifndef LM_HOST_EMULATION  // tests/hip_emul compiles only the MFMA kernels of this file for the host
 namespace lm {
 
 template <int NV>  // NV = ceil(H / 512): 16-byte vectors (8 halfs) per lane
@@ -117,6 +118,8 @@ extern "C" int lm_add_layernorm_f16(const void* d_x, const void* d_residual, con
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
+
+#endif  // LM_HOST_EMULATION
 
 // =============================================================================================
 // lm_attn_varlen_hd32_f16 -- fused self-attention for packed variable-length sequences,
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32(const __half* __restri
 
 }  // namespace lm
 
+#ifndef LM_HOST_EMULATION
 extern "C" int lm_attn_varlen_hd32_f16(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads,
                                        int32_t max_len, void* d_out, void* stream) {
     using namespace lm;
@@ -292,3 +296,4 @@ extern "C" int lm_attn_varlen_hd32_f16(const void* d_qkv, const int32_t* d_cu_se
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
+#endif  // LM_HOST_EMULATION

@@ -22,6 +22,17 @@ void set_error(const std::string& msg);
         }                                                                                  \
     } while (0)
 
+// opaque to the optimiser: stops loop-invariant code motion of everything computed from `v` (device only; the
+// host emulation of tests/hip_emul defines it away)
+#ifndef LM_KEEP_LOCAL
+#define LM_KEEP_LOCAL(v) asm volatile("" : "+v"(v))
+#endif
+
+// kernels that hold ~450 registers per lane by design: tell the compiler not to chase a higher occupancy
+#ifndef LM_ONE_WAVE_PER_SIMD
+#define LM_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+#endif
+
 #define LM_FAIL(code, msg)        \
     do {                          \
         lm::set_error(msg);       \

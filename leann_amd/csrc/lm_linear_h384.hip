@@ -33,7 +33,7 @@ constexpr int LN_NPRE = LN_CHUNKS / 256;              // 6 per thread
 constexpr int LN_SLABS = ML_H / 32;                   // 12 slabs per pass
 
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_linear_h384(
+__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_linear_h384(
     const __half* __restrict__ x, const __half* __restrict__ wp, const float* __restrict__ bias, const __half* __restrict__ res,
     const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T, int P, float eps) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace lm
 
+#ifndef LM_HOST_EMULATION
 extern "C" int lm_linear_h384_f16(const void* d_x, const void* d_wp, const float* d_bias, int32_t n_out, const void* d_residual,
                                   const void* d_gamma, const void* d_beta, float eps, void* d_out, int64_t tokens, void* stream) {
     using namespace lm;
@@ -162,3 +163,4 @@ extern "C" int lm_linear_h384_f16(const void* d_x, const void* d_wp, const float
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
+#endif  // LM_HOST_EMULATION

@@ -76,7 +76,7 @@ __device__ inline float2v gelu2(float2v x) {
 // w2p: [F/32][384][32] fp16: w2p[s][f][16u + 8g + e] = W2[f][32s + 16u + 4g + e]          (e < 4)
 //                                                      W2[f][32s + 16u + 8 + 4g + e - 4]  (e >= 4)
 // b1, b2: fp32 copies of the biases
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_fused_h384(const __half* __restrict__ x, const __half* __restrict__ w1,
+__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384(const __half* __restrict__ x, const __half* __restrict__ w1,
                                                         const float* __restrict__ b1, const __half* __restrict__ w2p,
                                                         const float* __restrict__ b2, const __half* __restrict__ gamma,
                                                         const __half* __restrict__ beta, __half* __restrict__ out, int T, int F,
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //     iteration s reads  W1[s+1] from stage (s+1)&1  and  W2[s] from stage s&1,
 //                 writes W1[s+2] to   stage  s&1      and  W2[s+1] to stage (s+1)&1   (both regions idle by then).
 // Same arithmetic, same results as variant 1.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_fused_h384_p(
+__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_p(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
     int F, float eps) {
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace lm
 
+#ifndef LM_HOST_EMULATION
 extern "C" int lm_mlp_fused_h384_f16(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2,
                                      const void* d_gamma, const void* d_beta, void* d_out, int64_t tokens, int32_t ffn, float eps,
                                      void* stream) {
@@ -442,3 +443,4 @@ extern "C" int lm_mlp_fused_h384_f16(const void* d_x, const void* d_w1, const fl
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
+#endif  // LM_HOST_EMULATION

@@ -1,0 +1,221 @@
+// Host execution of the MFMA kernels of leann_amd/csrc (the real source files, compiled for x86 through the stubs
+// in this directory) against plain reference implementations.  Test infrastructure only; built and run by
+// tests/test_hip_emulation.py:
+//     clang++ -std=c++20 -O1 -pthread -Itests/hip_emul -Iinclude tests/hip_emul/run_kernels.cpp -o run_kernels
+// The harness is itself checked by running k_attn_varlen_hd32 (revision 1), which is validated on hardware.
+#define LM_HOST_EMULATION 1
+#define LM_KEEP_LOCAL(v) ((void)0)
+#define LM_ONE_WAVE_PER_SIMD
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <random>
+
+namespace lm {
+__attribute__((aligned(16))) unsigned char smem[160 * 1024];  // the dynamic LDS of the one workgroup that runs at a time
+}
+
+#include "../../leann_amd/csrc/lm_encoder_ops.hip"
+#include "../../leann_amd/csrc/lm_attn_v2.hip"
+#include "../../leann_amd/csrc/lm_mlp_fused.hip"
+#include "../../leann_amd/csrc/lm_linear_h384.hip"
+
+using h16 = _Float16;
+static std::mt19937 rng(12345);
+static float rnd(float s) { return s * std::normal_distribution<float>(0.f, 1.f)(rng); }
+static void fill(std::vector<h16>& v, float s) {
+    for (auto& x : v) x = (h16)rnd(s);
+}
+static void fillf(std::vector<float>& v, float s) {
+    for (auto& x : v) x = rnd(s);
+}
+static int failures = 0;
+static void report(const char* name, double err, double tol) {
+    std::printf("%-46s max_abs_err=%.3e tol=%.1e %s\n", name, err, tol, err <= tol ? "ok" : "FAIL");
+    if (!(err <= tol)) failures++;
+}
+
+// ---------------------------------------------------------------- attention
+template <int REV>
+static void test_attention(int heads, const std::vector<int>& lens) {
+    const int H = heads * 32, nseq = (int)lens.size();
+    std::vector<int32_t> cu(nseq + 1, 0);
+    int maxlen = 0;
+    for (int i = 0; i < nseq; ++i) {
+        cu[i + 1] = cu[i] + lens[i];
+        maxlen = std::max(maxlen, lens[i]);
+    }
+    const int tot = cu[nseq];
+    std::vector<h16> qkv((size_t)tot * 3 * H), out((size_t)tot * H, (h16)0);
+    fill(qkv, 1.5f);
+    const int nt = (maxlen + 31) / 32;
+    const float scale_log2e = 1.4426950408889634f / std::sqrt(32.0f);
+    for (int b = 0; b < nseq * heads; ++b) {
+        emul::run_block(b, 256, [&] {
+            const __half* q = (const __half*)qkv.data();
+            __half* o = (__half*)out.data();
+#define RUN(n)                                                                                  \
+    case n:                                                                                     \
+        if (REV == 1) lm::k_attn_varlen_hd32<n>(q, cu.data(), o, heads, scale_log2e);           \
+        else lm::k_attn_varlen_hd32_v2<n>(q, cu.data(), o, heads, scale_log2e);                 \
+        break
+            switch (nt) { RUN(1); RUN(2); RUN(3); RUN(4); RUN(5); RUN(6); RUN(7); RUN(8); }
+#undef RUN
+        });
+    }
+    double err = 0;
+    for (int s = 0; s < nseq; ++s)
+        for (int h = 0; h < heads; ++h)
+            for (int i = 0; i < lens[s]; ++i) {
+                std::vector<double> p(lens[s]);
+                double mx = -1e300, sum = 0;
+                for (int j = 0; j < lens[s]; ++j) {
+                    double d = 0;
+                    for (int e = 0; e < 32; ++e)
+                        d += (double)qkv[(size_t)(cu[s] + i) * 3 * H + h * 32 + e] * (double)qkv[(size_t)(cu[s] + j) * 3 * H + H + h * 32 + e];
+                    p[j] = d / std::sqrt(32.0);
+                    mx = std::max(mx, p[j]);
+                }
+                for (auto& x : p) {
+                    x = std::exp(x - mx);
+                    sum += x;
+                }
+                for (int e = 0; e < 32; ++e) {
+                    double o = 0;
+                    for (int j = 0; j < lens[s]; ++j) o += p[j] / sum * (double)qkv[(size_t)(cu[s] + j) * 3 * H + 2 * H + h * 32 + e];
+                    err = std::max(err, std::fabs(o - (double)out[(size_t)(cu[s] + i) * H + h * 32 + e]));
+                }
+            }
+    char name[96];
+    std::snprintf(name, sizeof name, "attention rev%d heads=%d maxlen=%d nseq=%d", REV, heads, maxlen, nseq);
+    report(name, err, 4e-3);
+}
+
+// ---------------------------------------------------------------- feed-forward block
+static std::vector<h16> pack_w2(const std::vector<h16>& w2, int F) {  // leann_amd/encoder.py: pack_w2_fused_mlp
+    std::vector<h16> p((size_t)F * 384);
+    for (int s = 0; s < F / 32; ++s)
+        for (int f = 0; f < 384; ++f)
+            for (int pos = 0; pos < 32; ++pos) {
+                const int u = pos / 16, g = (pos % 16) / 8, e = pos % 8;
+                const int unit = e < 4 ? 16 * u + 4 * g + e : 16 * u + 8 + 4 * g + e - 4;
+                p[((size_t)s * 384 + f) * 32 + pos] = w2[(size_t)f * F + 32 * s + unit];
+            }
+    return p;
+}
+static double gelu_ref(double v) { return 0.5 * v * (1.0 + std::erf(v / std::sqrt(2.0))); }
+static void layernorm_ref(std::vector<double>& z, const std::vector<h16>& gamma, const std::vector<h16>& beta) {
+    double mu = 0, var = 0;
+    for (double v : z) mu += v;
+    mu /= z.size();
+    for (double v : z) var += (v - mu) * (v - mu);
+    var /= z.size();
+    for (size_t f = 0; f < z.size(); ++f) z[f] = (z[f] - mu) / std::sqrt(var + 1e-12) * (double)gamma[f] + (double)beta[f];
+}
+
+static void test_mlp(int T, int F, int variant) {
+    std::vector<h16> x((size_t)T * 384), w1((size_t)F * 384), w2((size_t)384 * F), gamma(384), beta(384), out((size_t)T * 384, (h16)0);
+    std::vector<float> b1(F), b2(384);
+    fill(x, 1.0f);
+    fill(w1, 1.0f / std::sqrt(384.f));
+    fill(w2, 1.0f / std::sqrt((float)F));
+    fillf(b1, 0.2f);
+    fillf(b2, 0.2f);
+    for (auto& v : gamma) v = (h16)(1.0f + rnd(0.1f));
+    fill(beta, 0.1f);
+    const std::vector<h16> w2p = pack_w2(w2, F);
+    for (int b = 0; b < (T + 127) / 128; ++b)
+        emul::run_block(b, 256, [&] {
+            auto X = (const __half*)x.data();
+            auto W1 = (const __half*)w1.data();
+            auto W2 = (const __half*)w2p.data();
+            auto G = (const __half*)gamma.data();
+            auto B = (const __half*)beta.data();
+            auto O = (__half*)out.data();
+            if (variant == 1) lm::k_mlp_fused_h384(X, W1, b1.data(), W2, b2.data(), G, B, O, T, F, 1e-12f);
+            else lm::k_mlp_fused_h384_p(X, W1, b1.data(), W2, b2.data(), G, B, O, T, F, 1e-12f);
+        });
+    double err = 0;
+    for (int t = 0; t < T; ++t) {
+        std::vector<double> hid(F), z(384);
+        for (int u = 0; u < F; ++u) {
+            double a = b1[u];
+            for (int k = 0; k < 384; ++k) a += (double)x[(size_t)t * 384 + k] * (double)w1[(size_t)u * 384 + k];
+            hid[u] = (double)(h16)(float)gelu_ref(a);  // the kernel rounds GELU outputs to fp16
+        }
+        for (int f = 0; f < 384; ++f) {
+            double a = b2[f] + (double)x[(size_t)t * 384 + f];
+            for (int u = 0; u < F; ++u) a += hid[u] * (double)w2[(size_t)f * F + u];
+            z[f] = a;
+        }
+        layernorm_ref(z, gamma, beta);
+        for (int f = 0; f < 384; ++f) err = std::max(err, std::fabs(z[f] - (double)out[(size_t)t * 384 + f]));
+    }
+    char name[96];
+    std::snprintf(name, sizeof name, "fused MLP variant %d tokens=%d ffn=%d", variant, T, F);
+    report(name, err, 8e-3);
+}
+
+// ---------------------------------------------------------------- linear
+static void test_linear(int T, int P, bool ln) {
+    const int N = 384 * P;
+    std::vector<h16> x((size_t)T * 384), w((size_t)N * 384), res((size_t)T * 384), gamma(384), beta(384), out((size_t)T * N, (h16)0);
+    std::vector<float> bias(N);
+    fill(x, 1.0f);
+    fill(w, 1.0f / std::sqrt(384.f));
+    fill(res, 1.0f);
+    fillf(bias, 0.2f);
+    for (auto& v : gamma) v = (h16)(1.0f + rnd(0.1f));
+    fill(beta, 0.1f);
+    std::vector<h16> wp((size_t)N * 384);  // leann_amd/encoder.py: pack_w_linear_h384 -> [P][12][384][32]
+    for (int p = 0; p < P; ++p)
+        for (int s = 0; s < 12; ++s)
+            for (int f = 0; f < 384; ++f)
+                for (int k = 0; k < 32; ++k) wp[(((size_t)p * 12 + s) * 384 + f) * 32 + k] = w[(size_t)(384 * p + f) * 384 + 32 * s + k];
+    for (int b = 0; b < (T + 127) / 128; ++b)
+        emul::run_block(b, 256, [&] {
+            auto X = (const __half*)x.data();
+            auto W = (const __half*)wp.data();
+            auto R = (const __half*)res.data();
+            auto G = (const __half*)gamma.data();
+            auto B = (const __half*)beta.data();
+            auto O = (__half*)out.data();
+            if (ln) lm::k_linear_h384<1>(X, W, bias.data(), R, G, B, O, T, 1, 1e-12f);
+            else lm::k_linear_h384<0>(X, W, bias.data(), nullptr, nullptr, nullptr, O, T, P, 0.f);
+        });
+    double err = 0;
+    for (int t = 0; t < T; ++t) {
+        std::vector<double> z(N);
+        for (int n = 0; n < N; ++n) {
+            double a = bias[n];
+            for (int k = 0; k < 384; ++k) a += (double)x[(size_t)t * 384 + k] * (double)w[(size_t)n * 384 + k];
+            z[n] = a + (ln ? (double)res[(size_t)t * 384 + n] : 0.0);
+        }
+        if (ln) layernorm_ref(z, gamma, beta);
+        for (int n = 0; n < N; ++n) err = std::max(err, std::fabs(z[n] - (double)out[(size_t)t * N + n]));
+    }
+    char name[96];
+    std::snprintf(name, sizeof name, "linear h384 %s tokens=%d n_out=%d", ln ? "+residual+LayerNorm" : "bias only", T, N);
+    report(name, err, 6e-3);
+}
+
+int main(int argc, char** argv) {
+    const std::string what = argc > 1 ? argv[1] : "all";
+    if (what == "all" || what == "attention") {
+        test_attention<1>(2, {70, 1, 33, 64});      // harness check: revision 1 is validated on hardware
+        test_attention<2>(2, {70, 1, 33, 64, 2, 69});
+        test_attention<2>(1, {256, 255, 200, 129});
+    }
+    if (what == "all" || what == "mlp") {
+        test_mlp(130, 64, 1);   // two workgroups, the second with 2 valid tokens; 2 slabs
+        test_mlp(130, 96, 2);   // 3 slabs: every stage parity of the pipelined variant
+        test_mlp(33, 32, 2);    // single slab: the "no next slab" paths
+    }
+    if (what == "all" || what == "linear") {
+        test_linear(130, 3, false);
+        test_linear(130, 1, true);
+    }
+    std::printf("%s\n", failures ? "FAILED" : "ALL OK");
+    return failures ? 1 : 0;
+}
