@@ -22,6 +22,7 @@ using hipStream_t = void*;
 enum hipError_t { hipSuccess = 0 };
 inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+inline int min(int a, int b) { return a < b ? a : b; }
 
 #include "../emul.h"
 

@@ -20,6 +20,12 @@ __attribute__((aligned(16))) unsigned char smem[160 * 1024];  // the dynamic LDS
 #include "../../leann_amd/csrc/lm_attn_v2.hip"
 #include "../../leann_amd/csrc/lm_mlp_fused.hip"
 #include "../../leann_amd/csrc/lm_linear_h384.hip"
+// lm_encoder_ops2.hip declares its LDS arrays as static __shared__ locals (no dynamic LDS): one array per workgroup
+#undef __shared__
+#define __shared__ static
+#include "../../leann_amd/csrc/lm_encoder_ops2.hip"
+#undef __shared__
+#define __shared__
 
 using h16 = _Float16;
 static std::mt19937 rng(12345);
@@ -200,6 +206,102 @@ static void test_linear(int T, int P, bool ln) {
     report(name, err, 6e-3);
 }
 
+// ---------------------------------------------------------------- LayerNorm (16 lanes per row), embedding front end, mean pooling
+static void test_ln_pool() {
+    const int H = 384, rows = 48;  // rows % 16 == 0: the emulated shuffle is a whole-wave barrier (no early exits)
+    std::vector<h16> x((size_t)rows * H), r((size_t)rows * H), gamma(H), beta(H), out((size_t)rows * H, (h16)0);
+    fill(x, 1.0f);
+    fill(r, 3.0f);
+    for (auto& v : gamma) v = (h16)(1.0f + rnd(0.1f));
+    fill(beta, 0.1f);
+    for (int b = 0; b < rows / 16; ++b)
+        emul::run_block(b, 256, [&] {
+            lm::k_add_layernorm_f16_r16<3, true, true>((const __half*)x.data(), (const __half*)r.data(), (const __half*)gamma.data(),
+                                                       (const __half*)beta.data(), (__half*)out.data(), rows, H, 1e-12f);
+        });
+    double err = 0;
+    for (int t = 0; t < rows; ++t) {
+        std::vector<double> z(H);
+        for (int f = 0; f < H; ++f) z[f] = (double)x[(size_t)t * H + f] + (double)r[(size_t)t * H + f];
+        layernorm_ref(z, gamma, beta);
+        for (int f = 0; f < H; ++f) err = std::max(err, std::fabs(z[f] - (double)out[(size_t)t * H + f]));
+    }
+    report("LayerNorm 16 lanes/row (exact variant) H=384", err, 4e-3);
+    // non-exact variant: H = 320 (NV = 3, last vector partly out of range)
+    {
+        const int H2 = 320;
+        std::vector<h16> x2((size_t)rows * H2), o2((size_t)rows * H2, (h16)0), g2(H2), b2(H2);
+        fill(x2, 1.0f);
+        for (auto& v : g2) v = (h16)(1.0f + rnd(0.1f));
+        fill(b2, 0.1f);
+        for (int b = 0; b < rows / 16; ++b)
+            emul::run_block(b, 256, [&] {
+                lm::k_add_layernorm_f16_r16<3, false, false>((const __half*)x2.data(), nullptr, (const __half*)g2.data(),
+                                                             (const __half*)b2.data(), (__half*)o2.data(), rows, H2, 1e-12f);
+            });
+        double e2 = 0;
+        for (int t = 0; t < rows; ++t) {
+            std::vector<double> z(H2);
+            for (int f = 0; f < H2; ++f) z[f] = (double)x2[(size_t)t * H2 + f];
+            layernorm_ref(z, g2, b2);
+            for (int f = 0; f < H2; ++f) e2 = std::max(e2, std::fabs(z[f] - (double)o2[(size_t)t * H2 + f]));
+        }
+        report("LayerNorm 16 lanes/row (clamped variant) H=320", e2, 4e-3);
+    }
+    // embedding front end
+    {
+        const int V = 500, Pn = 64;
+        std::vector<h16> word((size_t)V * H), posw((size_t)Pn * H), type0(H), o3((size_t)rows * H, (h16)0);
+        fill(word, 1.0f);
+        fill(posw, 1.0f);
+        fill(type0, 0.5f);
+        std::vector<int32_t> tok(rows), pos(rows);
+        for (int t = 0; t < rows; ++t) {
+            tok[t] = (int)(rng() % V);
+            pos[t] = (int)(rng() % Pn);
+        }
+        for (int b = 0; b < rows / 16; ++b)
+            emul::run_block(b, 256, [&] {
+                lm::k_embed_layernorm_f16<3, true>(tok.data(), pos.data(), (const __half*)word.data(), (const __half*)posw.data(),
+                                                   (const __half*)type0.data(), (const __half*)gamma.data(), (const __half*)beta.data(),
+                                                   (__half*)o3.data(), rows, H, 1e-12f);
+            });
+        double e3 = 0;
+        for (int t = 0; t < rows; ++t) {
+            std::vector<double> z(H);
+            for (int f = 0; f < H; ++f)
+                z[f] = (double)(h16)((float)word[(size_t)tok[t] * H + f] + (float)type0[f]) + (double)posw[(size_t)pos[t] * H + f];
+            layernorm_ref(z, gamma, beta);
+            for (int f = 0; f < H; ++f) e3 = std::max(e3, std::fabs(z[f] - (double)o3[(size_t)t * H + f]));
+        }
+        report("embedding gather + LayerNorm H=384", e3, 4e-3);
+    }
+    // mean pooling
+    for (int normalize = 0; normalize < 2; ++normalize) {
+        const std::vector<int> lens = {7, 1, 256, 33};
+        std::vector<int32_t> cu(lens.size() + 1, 0);
+        for (size_t i = 0; i < lens.size(); ++i) cu[i + 1] = cu[i] + lens[i];
+        std::vector<h16> xs((size_t)cu.back() * H);
+        fill(xs, 1.0f);
+        std::vector<float> po(lens.size() * H, 0.f);
+        for (int b = 0; b < (int)lens.size(); ++b)
+            emul::run_block(b, 256, [&] { lm::k_meanpool_varlen_f16((const __half*)xs.data(), cu.data(), po.data(), H, normalize); });
+        double e4 = 0;
+        for (size_t s = 0; s < lens.size(); ++s) {
+            std::vector<double> m(H, 0.0);
+            for (int t = cu[s]; t < cu[s + 1]; ++t)
+                for (int f = 0; f < H; ++f) m[f] += (double)xs[(size_t)t * H + f];
+            double nn = 0;
+            for (auto& v : m) {
+                v /= lens[s];
+                nn += v * v;
+            }
+            for (int f = 0; f < H; ++f) e4 = std::max(e4, std::fabs((normalize ? m[f] / std::sqrt(nn) : m[f]) - (double)po[s * H + f]));
+        }
+        report(normalize ? "mean pooling + L2 normalise H=384" : "mean pooling H=384", e4, 1e-5);
+    }
+}
+
 int main(int argc, char** argv) {
     const std::string what = argc > 1 ? argv[1] : "all";
     if (what == "all" || what == "attention") {
@@ -216,6 +318,7 @@ int main(int argc, char** argv) {
         test_linear(130, 3, false);
         test_linear(130, 1, true);
     }
+    if (what == "all" || what == "elementwise") test_ln_pool();
     std::printf("%s\n", failures ? "FAILED" : "ALL OK");
     return failures ? 1 : 0;
 }

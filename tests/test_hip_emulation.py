@@ -1,5 +1,5 @@
 """Runs the REAL sources of the MFMA kernels (leann_amd/csrc/lm_encoder_ops.hip attention, lm_attn_v2.hip,
-lm_mlp_fused.hip, lm_linear_h384.hip) on the CPU: tests/hip_emul compiles them for x86 with stub HIP headers and
+lm_mlp_fused.hip, lm_linear_h384.hip, and the elementwise kernels of lm_encoder_ops2.hip) on the CPU: tests/hip_emul compiles them for x86 with stub HIP headers and
 executes one workgroup at a time with a thread per lane, MFMA / shuffles / __syncthreads as barriers.  The harness
 is anchored by the hardware-validated k_attn_varlen_hd32 (revision 1), which must pass in it too."""
 import shutil
@@ -24,7 +24,7 @@ def emulator(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("what", ["attention", "mlp", "linear"])
+@pytest.mark.parametrize("what", ["attention", "mlp", "linear", "elementwise"])
 def test_kernel_sources_run_correctly_on_the_host(emulator, what):
     r = subprocess.run([str(emulator), what], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
