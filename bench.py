@@ -51,7 +51,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-roofline", action="store_true", default=True, help="also time the stored-embedding (HBM gather) mode (default on)")
     ap.add_argument("--no-table-roofline", dest="table_roofline", action="store_false")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the default encoder kernels (skip leann_amd.autotune)")
     args = ap.parse_args()
+
+    # ---- encoder kernel selection (untimed set-up, before this process touches the GPU): a child process checks the
+    #      second-generation kernels against the default path on this GPU and keeps those that agree AND are faster ----
+    from leann_amd import autotune as _at
+
+    autotune_report = None
+    if not args.no_autotune and not any(k in os.environ for k in _at.ALL_KEYS):
+        t_at = time.time()
+        autotune_report = _at.pick_encoder_switches(device=int(os.environ.get("LOCAL_RANK", "0")), model=args.model, tol=5e-3)
+        os.environ.update(autotune_report["switches"])
+        autotune_report["seconds"] = round(time.time() - t_at, 1)
+        log(f"encoder autotune ({autotune_report['seconds']}s): {autotune_report['switches'] or 'default path'}")
 
     import torch
     import torch.distributed as dist
@@ -313,7 +326,8 @@ def main():
                    "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
                    "parallelism": f"queries-dp{world}"},
         "recall_at_10": round(rec, 4),
-        "encoder_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LEANN_MI355X_")},  # opt-in kernels in effect
+        "encoder_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LEANN_MI355X_")},  # kernels in effect
+        "encoder_autotune": autotune_report,
         "roofline": roofline, "roofline_encoder": roofline_encoder,
         "ef_sweep": sweep,
         "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),

@@ -16,6 +16,7 @@ for k in attention layernorm meanpool embed "fused_mlp" linear "every_opt_in"; d
 done
 
 echo "== 2. kernel A/B" | tee -a $OUT/summary.txt
+timeout 400 python -m leann_amd.autotune --device 0 > $OUT/autotune.jsonl 2> $OUT/autotune.err; echo "   autotune rc=$? $(tail -1 $OUT/autotune.jsonl | cut -c1-300)" | tee -a $OUT/summary.txt
 timeout 300 python scripts/attn_bench.py > $OUT/attn_bench.json 2> $OUT/attn_bench.err; echo "   attn_bench rc=$?" | tee -a $OUT/summary.txt
 timeout 600 python scripts/encoder_ops_bench.py > $OUT/encoder_ops_bench.json 2> $OUT/encoder_ops_bench.err; echo "   encoder_ops_bench rc=$?" | tee -a $OUT/summary.txt
 

@@ -88,3 +88,15 @@ def test_batched_graph_builder_with_injected_search(built_libs):
     gt, _ = orc.bruteforce_topk(x, q, 10, 0)
     ids, _, _ = orc.search(oracle_graph(g, 48), q, 10, ef=64, table=x)
     assert recall_at_k(ids, gt) > 0.97
+
+
+def test_encoder_autotune_falls_back_to_the_default_path_when_the_probe_process_fails():
+    """leann_amd/autotune.py: the probe runs in a child process; without a GPU it dies at start-up -- the caller
+    must get the default path (no switches) and a log entry, never an exception."""
+    from leann_amd import autotune
+
+    r = autotune.pick_encoder_switches(timeout=300)
+    assert r["switches"] == {}
+    assert any("child_exit" in e for e in r["log"])
+    keys = {k for c, _ in autotune.CANDIDATES for k in c}
+    assert keys == set(autotune.ALL_KEYS) and all(k.startswith("LEANN_MI355X_") for k in keys)
