@@ -4,7 +4,7 @@
 //   A: lane l, element e -> A[m = l % 32][k = 8 (l / 32) + e]     B: lane l, element e -> B[k = 8 (l / 32) + e][n = l % 32]
 //   D: lane l, register r -> D[m = (r & 3) + 8 (r >> 2) + 4 (l / 32)][n = l % 32]
 #pragma once
-#include <barrier>
+#include <atomic>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -19,14 +19,32 @@ struct Tls {
 };
 inline thread_local Tls tls;
 
+// Own barrier instead of std::barrier: libstdc++'s waits go through a global, address-hashed waiter pool, which makes
+// ThreadSanitizer see happens-before edges between UNRELATED barriers (a cross-wave race then goes unreported).  This one
+// synchronises only through its own two atomics, so `-fsanitize=thread` checks the kernels' __syncthreads() placement.
+struct Barrier {
+    std::atomic<int> count{0}, gen{0};
+    int n;
+    explicit Barrier(int n_) : n(n_) {}
+    void arrive_and_wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_release);
+        } else {
+            while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+        }
+    }
+};
+
 struct Wave {
-    std::barrier<> bar{64};
+    Barrier bar{64};
     _Float16 a[64][8], b[64][8];
     float f[64];
 };
 struct Block {
     int nthreads;
-    std::barrier<> bar;
+    Barrier bar;
     std::vector<std::unique_ptr<Wave>> waves;
     explicit Block(int n) : nthreads(n), bar(n) {
         for (int i = 0; i < n / 64; ++i) waves.emplace_back(new Wave());

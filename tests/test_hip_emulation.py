@@ -29,3 +29,22 @@ def test_kernel_sources_run_correctly_on_the_host(emulator, what):
     r = subprocess.run([str(emulator), what], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert "FAIL" not in r.stdout.replace("FAILED", "")
+
+
+def test_no_lds_data_race_under_thread_sanitizer(tmp_path):
+    """Same harness built with -fsanitize=thread: the emulation's barriers are the only synchronisation between lanes,
+    so a missing or misplaced __syncthreads() around the double-buffered LDS stages shows up as a data race (removing
+    the barrier after the pipelined MLP's first product, or the one at the end of a slab, is reported -- tried)."""
+    if not Path(CLANG).exists():
+        pytest.skip("needs ROCm's clang++ with the ThreadSanitizer runtime")
+    exe = tmp_path / "run_kernels_tsan"
+    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-pthread", "-w", "-fsanitize=thread", f"-I{ROOT / 'tests' / 'hip_emul'}",
+           f"-I{ROOT / 'include'}", str(ROOT / "tests" / "hip_emul" / "run_kernels.cpp"), "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "tsan" in r.stderr.lower():
+        pytest.skip("ThreadSanitizer runtime not available")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe), "all"], capture_output=True, text=True, timeout=1800, env={"TSAN_OPTIONS": "halt_on_error=0"})
+    out = r.stdout + r.stderr
+    assert "ThreadSanitizer" not in out, out[-4000:]
+    assert "ALL OK" in r.stdout
