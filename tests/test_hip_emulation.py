@@ -31,20 +31,24 @@ def test_kernel_sources_run_correctly_on_the_host(emulator, what):
     assert "FAIL" not in r.stdout.replace("FAILED", "")
 
 
-def test_no_lds_data_race_under_thread_sanitizer(tmp_path):
-    """Same harness built with -fsanitize=thread: the emulation's barriers are the only synchronisation between lanes,
-    so a missing or misplaced __syncthreads() around the double-buffered LDS stages shows up as a data race (removing
-    the barrier after the pipelined MLP's first product, or the one at the end of a slab, is reported -- tried)."""
+@pytest.mark.parametrize("sanitizer,marker", [("thread", "ThreadSanitizer"), ("address", "AddressSanitizer")])
+def test_kernels_are_clean_under_sanitizers(tmp_path, sanitizer, marker):
+    """The same harness built with -fsanitize=thread / address.
+    thread: the emulation's barriers are the only synchronisation between lanes, so a missing or misplaced
+    __syncthreads() around the double-buffered LDS stages is a data race (removing the barrier after the pipelined MLP's
+    first product, or the one at the end of a slab, is reported -- tried).
+    address: every global buffer is an exact-size heap array, so an out-of-range row / column / tail access is reported."""
     if not Path(CLANG).exists():
-        pytest.skip("needs ROCm's clang++ with the ThreadSanitizer runtime")
-    exe = tmp_path / "run_kernels_tsan"
-    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-pthread", "-w", "-fsanitize=thread", f"-I{ROOT / 'tests' / 'hip_emul'}",
+        pytest.skip("needs ROCm's clang++ with the sanitizer runtimes")
+    exe = tmp_path / f"run_kernels_{sanitizer}"
+    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-pthread", "-w", f"-fsanitize={sanitizer}", f"-I{ROOT / 'tests' / 'hip_emul'}",
            f"-I{ROOT / 'include'}", str(ROOT / "tests" / "hip_emul" / "run_kernels.cpp"), "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0 and "tsan" in r.stderr.lower():
-        pytest.skip("ThreadSanitizer runtime not available")
+    if r.returncode != 0 and "san" in r.stderr.lower() and "cannot find" in r.stderr.lower():
+        pytest.skip("sanitizer runtime not available")
     assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([str(exe), "all"], capture_output=True, text=True, timeout=1800, env={"TSAN_OPTIONS": "halt_on_error=0"})
+    r = subprocess.run([str(exe), "all"], capture_output=True, text=True, timeout=1800,
+                       env={"TSAN_OPTIONS": "halt_on_error=0", "ASAN_OPTIONS": "detect_leaks=0"})
     out = r.stdout + r.stderr
-    assert "ThreadSanitizer" not in out, out[-4000:]
-    assert "ALL OK" in r.stdout
+    assert marker not in out, out[-4000:]
+    assert r.returncode == 0 and "ALL OK" in r.stdout
