@@ -41,7 +41,7 @@ __device__ inline void ln16_finish(float (&v)[NV][8], const uint4 (&gv)[NV], con
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += v[i][j];
-    for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 16);
     const float mean = sum / (float)H;
     float sq = 0.f;
 #pragma unroll
@@ -53,7 +53,7 @@ __device__ inline void ln16_finish(float (&v)[NV][8], const uint4 (&gv)[NV], con
             sq += d * d;
         }
     }
-    for (int m = 8; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    for (int m = 8; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 16);
     const float rstd = rsqrtf(sq / (float)H + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {

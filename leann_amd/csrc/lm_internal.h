@@ -33,6 +33,15 @@ void set_error(const std::string& msg);
 #define LM_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
 
+// Wave-synchronous sections: the 64 lanes of a wave execute in lockstep, so LDS written by one lane is read by another
+// lane of the SAME wave in a later instruction without a workgroup barrier.  LM_WAVE_SYNC() marks every such hand-over.
+// It expands to nothing in the device build (the validated code is unchanged); the host emulation of tests/hip_emul,
+// whose lanes are free-running threads, defines it as a wave barrier -- which is what lets ThreadSanitizer prove that
+// these marked points are the ONLY places where the kernels rely on lockstep execution.
+#ifndef LM_WAVE_SYNC
+#define LM_WAVE_SYNC() ((void)0)
+#endif
+
 #define LM_FAIL(code, msg)        \
     do {                          \
         lm::set_error(msg);       \

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
                 found += __popcll(m);
             }
             found = min(found, allowed);
+            LM_WAVE_SYNC();  // s_pop[r] written by the popping lanes, read below by lane r
             uint32_t cnt = 0;
             if (tid < found) {
                 L0Range r = g.l0[s_pop[tid]];

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
                 found += __popcll(m);
             }
             found = min(found, a.W);
+            LM_WAVE_SYNC();  // s_pop[r] written by the popping lanes, read below by lane r
             // neighbour ranges of the pops + inclusive scan of their degrees
             uint32_t cnt = 0;
             if (tid < found) {

@@ -1,0 +1,174 @@
+"""Scenarios run against libleann_mi355x_emul.so (tests/hip_emul/build_emul_lib.py): the product's C ABI and host code,
+its HIP kernels executed on the CPU with a thread per lane.  Imported by tests/test_emulated_search.py and runnable as a
+script (the ThreadSanitizer run preloads the TSan runtime into this interpreter):
+    python -m tests.emulated_search_cases <path/to/libleann_mi355x_emul.so> [case ...]
+Every case compares with the oracle (bit-exact labels AND distances, same number of distance evaluations)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+
+def _load(lib_path: str):
+    from leann_amd import _lib
+
+    _lib.LIB_PATH = Path(lib_path)
+    _lib._lib = None
+    return _lib.load()
+
+
+class NumpyProvider:
+    """lm_provider_fn in the emulated world: 'device' pointers are host pointers."""
+
+    def __init__(self, table: np.ndarray, dp: int):
+        self.x = np.zeros((table.shape[0], dp), np.float32)
+        self.x[:, : table.shape[1]] = table
+        self.keep = None
+        self.calls = 0
+
+    def __call__(self, d_ids_ptr: int, n: int, stream_ptr: int) -> int:
+        ids = np.ctypeslib.as_array(C.cast(d_ids_ptr, C.POINTER(C.c_int32)), shape=(n,))
+        assert np.all(ids[1:] > ids[:-1])  # sorted unique, as the ABI promises
+        self.keep = np.ascontiguousarray(self.x[ids])
+        self.calls += 1
+        return self.keep.ctypes.data
+
+
+def _data(n, d, seed, nq=3):
+    from tests.util import clustered, queries_near
+
+    x = clustered(n, d, seed)
+    return x, queries_near(x, nq, seed + 1)
+
+
+def _check(tag, got, exp, st_got=None, st_exp=None):
+    d, l = got
+    el, ed = exp
+    ok = np.array_equal(l, el) and np.array_equal(d, ed)
+    if st_got is not None:
+        ok = ok and int(st_got["ndis"]) == int(st_exp["ndis"])
+    print(f"{tag}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    assert ok, tag
+
+
+def case_table(metric="mips", d=64, f16=False):
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x, q = _data(260, d, 3 + d)
+    g = build_hnsw(x, metric, M=6, ef_construction=30)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, d)
+    idx = Mi355xIndex.from_csr(g)
+    tab = x.astype(np.float16) if f16 else x
+    idx.attach_table(tab)
+    ref_tab = tab.astype(np.float32)
+    for persistent in (1, 0):
+        idx.set_option("persistent_table", persistent)
+        for beam, ef in ((1, 12), (3, 20)):
+            got = idx.search(q, 5, idx.make_params(ef=ef, beam=beam, recompute=False))
+            exp = orc.search(og, q, 5, ef=ef, beam=beam, table=ref_tab)
+            _check(f"table {metric} d={d} f16={f16} persistent={persistent} beam={beam}", got, exp[:2], idx.stats(), exp[2])
+    idx.close()
+
+
+def case_recompute(variant=0, memo=False):
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x, q = _data(240, 48, 11)  # d = 48 -> padded to 64
+    g = build_hnsw(x, "mips", M=6, ef_construction=30)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 48)
+    idx = Mi355xIndex.from_csr(g)
+    prov = NumpyProvider(x, idx.info.d_padded)
+    idx.set_provider(prov)
+    idx.set_option("update_variant", variant)
+    got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True, recompute_memo=memo))
+    exp = orc.search(og, q, 5, ef=14, beam=2, table=x)
+    _check(f"recompute variant={variant} memo={memo}", got, exp[:2], idx.stats(), exp[2])
+    assert prov.calls > 0
+    idx.close()
+
+
+def case_pq(deferred=True):
+    import torch
+
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.pq import encode_pq, flat_graph, train_pq
+    from oracle import oracle as orc
+
+    x, q = _data(300, 32, 21)
+    g = flat_graph(build_hnsw(x, "mips", M=6, ef_construction=30), x)
+    xt = torch.from_numpy(x)
+    cb = train_pq(xt, 8, iters=4, seed=0)
+    codes = encode_pq(xt, cb)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_pq(cb.numpy(), codes.numpy())
+    if deferred:
+        idx.set_provider(NumpyProvider(x, idx.info.d_padded))
+    else:
+        idx.attach_table(x)
+    prm = idx.make_pq_params(12, 2, use_deferred_fetch=deferred)
+    l, d = idx.pq_search(q, 5, prm)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 32)
+    if deferred:
+        el, ed, _ = orc.pq_search(og, cb.numpy(), codes.numpy(), q, 5, L=12, W=2, provider=lambda ids: x[ids], use_deferred_fetch=True)
+    else:
+        el, ed, _ = orc.pq_search(og, cb.numpy(), codes.numpy(), q, 5, L=12, W=2, table=x)
+    _check(f"pq traversal deferred={deferred}", (d, l), (el, ed))
+    idx.close()
+
+
+def case_two_level():
+    import torch
+
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.pq import encode_pq, train_pq
+    from oracle import oracle as orc
+
+    x, q = _data(260, 32, 31)
+    g = build_hnsw(x, "mips", M=6, ef_construction=30)
+    xt = torch.from_numpy(x)
+    cb = train_pq(xt, 8, iters=4, seed=0)
+    codes = encode_pq(xt, cb)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_pq(cb.numpy(), codes.numpy())
+    idx.set_provider(NumpyProvider(x, idx.info.d_padded))
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 32)
+    for strategy in ("global", "local"):
+        got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True, prune_ratio=0.5, local_prune=(strategy == "local")))
+        exp = orc.search(og, q, 5, ef=14, beam=2, table=x, pq=(cb.numpy(), codes.numpy()), prune_ratio=0.5, pruning_strategy=strategy)
+        _check(f"two-level search {strategy}", got, exp[:2], idx.stats(), exp[2])
+    idx.close()
+
+
+CASES = {
+    "table_mips": lambda: case_table("mips", 64),
+    "table_l2_d100": lambda: case_table("l2", 100),
+    "table_f16": lambda: case_table("mips", 64, f16=True),
+    "recompute": lambda: case_recompute(0),
+    "recompute_memo": lambda: case_recompute(0, memo=True),
+    "recompute_sort_variant": lambda: case_recompute(1),
+    "recompute_split_variant": lambda: case_recompute(2),
+    "recompute_wave_variant": lambda: case_recompute(3),
+    "pq_deferred": lambda: case_pq(True),
+    "pq_table": lambda: case_pq(False),
+    "two_level": case_two_level,
+}
+
+if __name__ == "__main__":
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    _load(sys.argv[1])
+    from oracle import oracle as _orc
+
+    import torch
+
+    torch.set_num_threads(1)
+    _orc.set_num_threads(1)  # libgomp's own synchronisation is invisible to ThreadSanitizer (false positives in the ORACLE)
+    for name in (sys.argv[2:] or list(CASES)):
+        CASES[name]()
+    print("ALL CASES OK")

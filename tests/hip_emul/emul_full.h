@@ -1,0 +1,176 @@
+// Execution engine behind tests/hip_emul/full/hip/hip_runtime.h: a launch runs block after block; inside a block every
+// lane is an OS thread.  Collectives:
+//   __syncthreads()                       barrier over the block's threads
+//   __ballot / __shfl / __shfl_up / __shfl_xor(v, m)       whole-wave exchange (all 64 lanes of the wave must call it --
+//                                         true everywhere in csrc: wave-uniform control flow around them)
+//   __shfl_xor(v, m, width)               exchange inside an aligned group of `width` lanes (only that group must call it:
+//                                         csrc uses width 4 under `if (tid < 4)` and width 16 in the row reductions)
+// Synchronisation is done with the kernels' own barriers only (see Barrier), so ThreadSanitizer checks their placement.
+#pragma once
+
+namespace emul {
+
+struct Idx {
+    unsigned x = 0, y = 0, z = 0;
+};
+struct Tls {
+    Idx thread, block, bdim, gdim;
+};
+inline thread_local Tls tls;
+
+struct Barrier {
+    std::atomic<int> count{0}, gen{0};
+    int n;
+    explicit Barrier(int n_) : n(n_) {}
+    void arrive_and_wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_release);
+        } else {
+            while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+        }
+    }
+};
+
+struct Wave {
+    Barrier bar;
+    std::vector<std::unique_ptr<Barrier>> g4, g16;  // groups of 4 / 16 lanes
+    uint64_t slot[64];
+    _Float16 ma[64][8], mb[64][8];  // MFMA operand exchange
+    explicit Wave(int lanes) : bar(lanes) {
+        for (int i = 0; i < 16; ++i) g4.emplace_back(new Barrier(4));
+        for (int i = 0; i < 4; ++i) g16.emplace_back(new Barrier(16));
+    }
+};
+struct Block {
+    Barrier bar;
+    std::vector<std::unique_ptr<Wave>> waves;
+    explicit Block(int n) : bar(n) {
+        for (int i = 0; i < (n + 63) / 64; ++i) waves.emplace_back(new Wave(std::min(64, n - 64 * i)));
+    }
+};
+inline Block* g_block = nullptr;
+alignas(16) inline unsigned char g_dyn_smem[160 * 1024];
+inline unsigned char* dyn_smem() { return g_dyn_smem; }
+
+inline Wave& my_wave() { return *g_block->waves[tls.thread.x >> 6]; }
+inline int my_lane() { return (int)(tls.thread.x & 63); }
+inline void syncthreads() { g_block->bar.arrive_and_wait(); }
+inline void wave_sync() { my_wave().bar.arrive_and_wait(); }
+
+template <class T>
+inline uint64_t to_bits(T v) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    uint64_t b = 0;
+    std::memcpy(&b, &v, sizeof(T));
+    return b;
+}
+template <class T>
+inline T from_bits(uint64_t b) {
+    T v;
+    std::memcpy(&v, &b, sizeof(T));
+    return v;
+}
+// whole-wave exchange: returns the value published by lane src(lane); own value when src is out of range
+template <class T, class F>
+inline T wave_exchange(T v, F src_of) {
+    Wave& w = my_wave();
+    const int lane = my_lane();
+    w.slot[lane] = to_bits(v);
+    w.bar.arrive_and_wait();
+    const int s = src_of(lane);
+    const T r = (s >= 0 && s < w.bar.n) ? from_bits<T>(w.slot[s]) : v;
+    w.bar.arrive_and_wait();
+    return r;
+}
+template <class T>
+inline T shfl_xor(T v, int mask) { return wave_exchange(v, [mask](int l) { return l ^ mask; }); }
+template <class T>
+inline T shfl_up(T v, int d) { return wave_exchange(v, [d](int l) { return l - d; }); }
+template <class T>
+inline T shfl_idx(T v, int src) { return wave_exchange(v, [src](int) { return src; }); }
+template <class T>
+inline T shfl_xor(T v, int mask, int width) {
+    if (width >= 64) return shfl_xor(v, mask);
+    Wave& w = my_wave();
+    const int lane = my_lane();
+    Barrier& b = width == 4 ? *w.g4[lane >> 2] : *w.g16[lane >> 4];  // csrc uses widths 4 and 16 only
+    if (width != 4 && width != 16) std::abort();
+    w.slot[lane] = to_bits(v);
+    b.arrive_and_wait();
+    const T r = from_bits<T>(w.slot[lane ^ mask]);
+    b.arrive_and_wait();
+    return r;
+}
+// v_mfma_f32_32x32x16_f16: A lane l, e -> A[m = l % 32][k = 8 (l / 32) + e]; B lane l, e -> B[k = 8 (l / 32) + e][n = l % 32];
+// D lane l, register r -> D[m = (r & 3) + 8 (r >> 2) + 4 (l / 32)][n = l % 32]
+template <class AB, class C>
+inline C mfma_32x32x16(AB a, AB b, C c) {
+    Wave& w = my_wave();
+    const int lane = my_lane();
+    for (int e = 0; e < 8; ++e) {
+        w.ma[lane][e] = a[e];
+        w.mb[lane][e] = b[e];
+    }
+    w.bar.arrive_and_wait();
+    const int n = lane & 31, g = lane >> 5;
+    C d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * g;
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) acc += (float)w.ma[m + 32 * (k >> 3)][k & 7] * (float)w.mb[n + 32 * (k >> 3)][k & 7];
+        d[r] = c[r] + acc;
+    }
+    w.bar.arrive_and_wait();
+    return d;
+}
+inline float med3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
+
+inline unsigned long long ballot(bool p) {
+    Wave& w = my_wave();
+    const int lane = my_lane();
+    w.slot[lane] = p ? 1u : 0u;
+    w.bar.arrive_and_wait();
+    unsigned long long m = 0;
+    for (int i = 0; i < w.bar.n; ++i) m |= (unsigned long long)(w.slot[i] & 1u) << i;
+    w.bar.arrive_and_wait();
+    return m;
+}
+template <class T, class V>
+inline T atomic_or(T* p, V v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class V>
+inline T atomic_add(T* p, V v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class V>
+inline T atomic_min(T* p, V v) {
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v < old && !__atomic_compare_exchange_n(p, &old, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return old;
+}
+inline long long wall_clock() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
+}
+
+// one kernel launch: blocks run one after another, lanes of a block as threads
+inline void launch(dim3 grid, dim3 block, size_t /*shmem*/, const std::function<void()>& body) {
+    const int nthreads = (int)block.x;
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        Block blk(nthreads);
+        g_block = &blk;
+        std::vector<std::thread> th;
+        th.reserve(nthreads);
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t] {
+                tls.thread.x = (unsigned)t;
+                tls.block.x = bx;
+                tls.bdim.x = block.x;
+                tls.gdim.x = grid.x;
+                body();
+            });
+        for (auto& x : th) x.join();
+        g_block = nullptr;
+    }
+}
+
+}  // namespace emul
