@@ -35,11 +35,28 @@ def build(out_dir: Path, sanitize: str | None = None) -> Path:
         t = re.sub(r"\b__shared__\b", "static", t)
         (src / f.name).write_text(t)
     lib = out_dir / ("libleann_mi355x_emul" + (f"_{sanitize}" if sanitize else "") + ".so")
-    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w", "-ffp-contract=off", "-x", "c++", f"-I{ROOT / 'tests' / 'hip_emul' / 'full'}"]
+    # plain build: -O0 (the host compile of lm_search.hip takes 6 s instead of 40; the test problems are tiny);
+    # sanitizer builds: -O1 with line tables, one compiler process per source file
+    flags = ["-std=c++20", "-fPIC", "-pthread", "-w", "-ffp-contract=off", f"-I{ROOT / 'tests' / 'hip_emul' / 'full'}"]
+    flags += ["-O1", "-gline-tables-only", f"-fsanitize={sanitize}"] if sanitize else ["-O0"]
+    objdir = out_dir / ("obj_" + (sanitize or "plain"))
+    objdir.mkdir(exist_ok=True)
+
+    def cc(name: str) -> Path:
+        o = objdir / (name + ".o")
+        r = subprocess.run([CLANG, *flags, "-x", "c++", "-c", str(src / name), "-o", str(o)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{name}:\n{r.stderr[-6000:]}")
+        return o
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(len(SRCS)) as ex:
+        objs = list(ex.map(cc, SRCS))
+    link = [CLANG, "-shared", "-pthread", *[str(o) for o in objs], "-o", str(lib)]
     if sanitize:
-        cmd += [f"-fsanitize={sanitize}", "-shared-libsan"]
-    cmd += [str(src / s) for s in SRCS] + ["-o", str(lib)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        link += [f"-fsanitize={sanitize}", "-shared-libsan"]
+    r = subprocess.run(link, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-6000:])
     return lib

@@ -152,25 +152,82 @@ inline long long wall_clock() {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10;
 }
 
-// one kernel launch: blocks run one after another, lanes of a block as threads
-inline void launch(dim3 grid, dim3 block, size_t /*shmem*/, const std::function<void()>& body) {
+// Persistent lane threads (creating 256 OS threads per block dominated the run time).  Worker i runs when ITS mailbox
+// go[i] changes, so a 64-lane block wakes 64 workers; the launch fields are published before the mailboxes (release) and
+// read after them (acquire).  Idle workers back off to short sleeps instead of spinning.
+struct Pool {
+    static constexpr int MAXT = 1024;
+    std::vector<std::thread> th;
+    std::unique_ptr<std::atomic<int>[]> go{new std::atomic<int>[MAXT]};
+    std::atomic<int> done{0};
+    std::atomic<bool> stop{false};
+    int gen = 0;
+    unsigned bx = 0;
+    dim3 block, grid;
+    const std::function<void()>* body = nullptr;
+    Pool() {
+        for (int i = 0; i < MAXT; ++i) go[i].store(0);
+    }
+    void worker(int i) {
+        int seen = 0;
+        for (;;) {
+            int spins = 0, g;
+            while ((g = go[i].load(std::memory_order_acquire)) == seen) {
+                if (++spins < 256) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+            seen = g;
+            if (stop.load(std::memory_order_relaxed)) return;
+            tls.thread.x = (unsigned)i;
+            tls.block.x = bx;
+            tls.bdim.x = block.x;
+            tls.gdim.x = grid.x;
+            (*body)();
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void run_block(unsigned bx_, dim3 grid_, dim3 block_, const std::function<void()>& f) {
+        const int n = (int)block_.x;
+        if (n > MAXT) std::abort();
+        while ((int)th.size() < n) {
+            const int i = (int)th.size();
+            th.emplace_back([this, i] { worker(i); });
+        }
+        bx = bx_;
+        grid = grid_;
+        block = block_;
+        body = &f;
+        done.store(0, std::memory_order_relaxed);
+        ++gen;
+        for (int i = 0; i < n; ++i) go[i].store(gen, std::memory_order_release);
+        while (done.load(std::memory_order_acquire) != n) std::this_thread::yield();
+    }
+    ~Pool() {
+        stop.store(true);
+        for (size_t i = 0; i < th.size(); ++i) go[i].store(-1, std::memory_order_release);
+        for (auto& t : th) t.join();
+    }
+};
+inline Pool& pool() {
+    static Pool p;
+    return p;
+}
+
+// one kernel launch: blocks run one after another, lanes of a block as threads (first_block..: run_block() below)
+inline void launch(dim3 grid, dim3 block, size_t /*shmem*/, const std::function<void()>& body, unsigned first_block = 0,
+                   unsigned n_blocks = ~0u) {
     const int nthreads = (int)block.x;
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
+    for (unsigned bx = first_block; bx < grid.x && bx - first_block < n_blocks; ++bx) {
         Block blk(nthreads);
         g_block = &blk;
-        std::vector<std::thread> th;
-        th.reserve(nthreads);
-        for (int t = 0; t < nthreads; ++t)
-            th.emplace_back([&, t] {
-                tls.thread.x = (unsigned)t;
-                tls.block.x = bx;
-                tls.bdim.x = block.x;
-                tls.gdim.x = grid.x;
-                body();
-            });
-        for (auto& x : th) x.join();
+        pool().run_block(bx, grid, block, body);
         g_block = nullptr;
     }
+}
+
+// a single workgroup of a (conceptually larger) grid
+inline void run_block(int block_id, int nthreads, const std::function<void()>& body) {
+    launch(dim3((unsigned)block_id + 1), dim3((unsigned)nthreads), 0, body, (unsigned)block_id, 1);
 }
 
 }  // namespace emul

@@ -23,6 +23,7 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __align__(n) __attribute__((aligned(n)))
+#define __shared__  // raw-source harness (run_kernels.cpp); the full-library build substitutes it textually
 
 struct dim3 {
     unsigned x, y, z;

@@ -17,7 +17,7 @@ def emulator(tmp_path_factory):
     if not Path(CLANG).exists() and not shutil.which("clang++"):
         pytest.skip("needs a clang++ (ext_vector_type, _Float16)")
     exe = tmp_path_factory.mktemp("hip_emul") / "run_kernels"
-    cmd = [CLANG if Path(CLANG).exists() else "clang++", "-std=c++20", "-O1", "-pthread", "-w", f"-I{ROOT / 'tests' / 'hip_emul'}",
+    cmd = [CLANG if Path(CLANG).exists() else "clang++", "-std=c++20", "-O1", "-pthread", "-w", f"-I{ROOT / 'tests' / 'hip_emul' / 'full'}",
            f"-I{ROOT / 'include'}", str(ROOT / "tests" / "hip_emul" / "run_kernels.cpp"), "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -41,7 +41,7 @@ def test_kernels_are_clean_under_sanitizers(tmp_path, sanitizer, marker):
     if not Path(CLANG).exists():
         pytest.skip("needs ROCm's clang++ with the sanitizer runtimes")
     exe = tmp_path / f"run_kernels_{sanitizer}"
-    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-pthread", "-w", f"-fsanitize={sanitizer}", f"-I{ROOT / 'tests' / 'hip_emul'}",
+    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-pthread", "-w", f"-fsanitize={sanitizer}", f"-I{ROOT / 'tests' / 'hip_emul' / 'full'}",
            f"-I{ROOT / 'include'}", str(ROOT / "tests" / "hip_emul" / "run_kernels.cpp"), "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "san" in r.stderr.lower() and "cannot find" in r.stderr.lower():
