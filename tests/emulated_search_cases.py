@@ -146,6 +146,93 @@ def case_two_level():
     idx.close()
 
 
+def case_degenerate_graphs(n_graphs=12):
+    """Seeded random tiny graphs with empty neighbour lists, unreachable nodes, upper-level stubs, k > reachable set
+    (unfilled result slots): the same generator as tests/test_gpu_parity.py::test_random_degenerate_graphs_match_oracle."""
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+    from tests.test_oracle_properties import _random_graph
+    from tests.util import oracle_graph
+
+    for seed in range(n_graphs):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(1, 30))
+        metric = int(rng.integers(0, 2))
+        x, g, _ = _random_graph(rng, n, 64, metric)
+        q = rng.standard_normal((3, 64)).astype(np.float32)
+        k, ef, beam = int(rng.integers(1, 7)), int(rng.integers(1, n + 5)), int(rng.integers(1, 5))
+        oi, od, ost = orc.search(oracle_graph(g, 64), q, k, ef=ef, beam=beam, table=x)
+        idx = Mi355xIndex.from_csr(g)
+        idx.attach_table(x)
+        idx.set_provider(NumpyProvider(x, idx.info.d_padded))
+        for mode in ("persistent", "lockstep", "provider"):
+            idx.set_option("persistent_table", 1 if mode == "persistent" else 0)
+            d, l = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=(mode == "provider")))
+            st = idx.stats()
+            ok = (np.array_equal(l, oi) and np.array_equal(d.view(np.uint32), od.view(np.uint32))
+                  and (st["ndis"], st["nexpand"], st["nrounds"]) == (ost["ndis"], ost["nexpand"], ost["nrounds"]))
+            assert ok, ("degenerate", seed, mode, n, k, ef, beam, st, ost)
+        idx.close()
+    print(f"degenerate graphs x{n_graphs} (persistent / lock-step / provider): ok", flush=True)
+
+
+def case_hub_cache_and_helpers():
+    """Hub-embedding cache (results identical to plain recompute, fewer provider rows), lm_topk_merge, lm_dist_gather."""
+    from leann_amd import _lib
+    from leann_amd.backend import hub_nodes
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    lib = _lib.load()
+    x, q = _data(240, 64, 41)
+    g = build_hnsw(x, "mips", M=6, ef_construction=30)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 64)
+    idx = Mi355xIndex.from_csr(g)
+    prov = NumpyProvider(x, 64)
+    rows = {"n": 0}
+    base_call = prov.__call__
+
+    def counting(d_ids, n, stream):
+        rows["n"] += n
+        return base_call(d_ids, n, stream)
+
+    idx.set_provider(counting)
+    exp = orc.search(og, q, 5, ef=14, beam=2, table=x)
+    got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True))
+    plain_rows = rows["n"]
+    _check("recompute (for the hub comparison)", got, exp[:2], idx.stats(), exp[2])
+    hubs = hub_nodes(g, 0.2)
+    emb = np.ascontiguousarray(x[hubs])
+    _lib.check(lib.lm_index_set_hub_cache(idx._h, hubs.ctypes.data_as(C.c_void_p), len(hubs), emb.ctypes.data_as(C.c_void_p)), "hub")
+    rows["n"] = 0
+    got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True))
+    _check("recompute with a 20 % hub cache", got, exp[:2], idx.stats(), exp[2])
+    assert 0 < rows["n"] < plain_rows, (rows, plain_rows)
+    idx.close()
+    # per-shard top-k merge == oracle merge
+    rng = np.random.default_rng(5)
+    S, B, k = 3, 4, 5
+    ids = rng.permutation(1000)[: S * B * k].reshape(S, B, k).astype(np.int64)
+    ids[0, 0, 3:] = -1
+    dist = np.sort(rng.standard_normal((S, B, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    dist[0, 0, 3:] = -np.inf
+    oi, od = np.empty((B, k), np.int64), np.empty((B, k), np.float32)
+    _lib.check(lib.lm_topk_merge(ids.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p), S, B, k, 0,
+                                 oi.ctypes.data_as(C.c_void_p), od.ctypes.data_as(C.c_void_p), None), "merge")
+    ei, ed = orc.merge_topk(ids, dist, 0)
+    assert np.array_equal(oi, ei) and np.array_equal(od, ed)
+    # pair distances == canonical oracle distance
+    qi = rng.integers(0, q.shape[0], 50).astype(np.int32)
+    vi = rng.integers(0, x.shape[0], 50).astype(np.int32)
+    out = np.empty(50, np.float32)
+    _lib.check(lib.lm_dist_gather(x.ctypes.data_as(C.c_void_p), 0, 64, 0, q.ctypes.data_as(C.c_void_p), qi.ctypes.data_as(C.c_void_p),
+                                  vi.ctypes.data_as(C.c_void_p), 50, out.ctypes.data_as(C.c_void_p), None), "dist")
+    ref = np.array([orc.dist(q[a], x[b], 0) for a, b in zip(qi, vi)], np.float32)
+    assert np.array_equal(out, ref), np.abs(out - ref).max()
+    print("hub cache / top-k merge / pair distances: ok", flush=True)
+
+
 CASES = {
     "table_mips": lambda: case_table("mips", 64),
     "table_l2_d100": lambda: case_table("l2", 100),
@@ -158,6 +245,8 @@ CASES = {
     "pq_deferred": lambda: case_pq(True),
     "pq_table": lambda: case_pq(False),
     "two_level": case_two_level,
+    "degenerate_graphs": case_degenerate_graphs,
+    "hub_cache_and_helpers": case_hub_cache_and_helpers,
 }
 
 if __name__ == "__main__":
