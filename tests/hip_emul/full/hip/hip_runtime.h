@@ -64,8 +64,8 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate };
 inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 inline hipError_t hipMalloc(void** p, size_t n) {
-    *p = std::aligned_alloc(256, (n + 255) / 256 * 256);
-    return *p ? hipSuccess : hipErrorInvalidValue;
+    *p = nullptr;  // exact size (AddressSanitizer then sees every byte past the end), 256-byte aligned like hipMalloc
+    return posix_memalign(p, 256, n ? n : 1) == 0 ? hipSuccess : hipErrorInvalidValue;
 }
 template <class T>
 inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }

@@ -51,3 +51,21 @@ def test_search_kernels_have_no_unmarked_lane_races(emul_dir):
     # barriers ThreadSanitizer cannot see (false positives inside liblm_oracle / libtorch_cpu)
     races = [ln for ln in out.splitlines() if ln.startswith("SUMMARY: ThreadSanitizer") and ("leann_amd/csrc" in ln or "hip_emul" in ln or "lm::" in ln)]
     assert not races, "\n".join(races[:10]) + out[-3000:]
+
+
+@pytest.mark.skipif(os.environ.get("LEANN_EMUL_ASAN") != "1", reason="opt-in (adds ~1.5 min): LEANN_EMUL_ASAN=1")
+def test_search_kernels_stay_in_bounds_under_address_sanitizer(emul_dir):
+    """Device allocations of the emulated runtime are exact-size heap blocks: any read or write past a graph / pool /
+    bitmap / table array in the kernels or the host loop is an AddressSanitizer error.  (Clean on all cases, 2026-09.)"""
+    import build_emul_lib
+
+    rt = subprocess.run([str(CLANG), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not Path(rt).exists():
+        pytest.skip("AddressSanitizer runtime not available")
+    lib = build_emul_lib.build(emul_dir, sanitize="address")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=0", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "tests.emulated_search_cases", str(lib)], cwd=str(ROOT), capture_output=True, text=True,
+                       timeout=3000, env=env)
+    out = r.stdout + r.stderr
+    assert "ALL CASES OK" in r.stdout, out[-4000:]
+    assert "ERROR: AddressSanitizer" not in out, out[-6000:]
