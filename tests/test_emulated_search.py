@@ -34,6 +34,24 @@ def test_product_library_on_the_cpu_matches_the_oracle(emul_dir):
     assert "MISMATCH" not in r.stdout
 
 
+def test_plain_c_host_known_answer_against_the_emulated_library(emul_dir):
+    """tests/abi/abi_host.c (C11, no Python) linked against the host build: with a "device" present it takes the same
+    branch as on the GPU box and checks the hand-traced known-answer search through lm_index_search."""
+    import build_emul_lib
+
+    lib = build_emul_lib.build(emul_dir)
+    link = emul_dir / "libleann_mi355x.so"  # the program links -lleann_mi355x
+    if not link.exists():
+        link.symlink_to(lib.name)
+    exe = emul_dir / "abi_host"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", f"-I{ROOT / 'include'}", "-o", str(exe),
+                    str(ROOT / "tests" / "abi" / "abi_host.c"), f"-L{emul_dir}", "-lleann_mi355x", "-lm", f"-Wl,-rpath,{emul_dir}"],
+                   check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GPU-PATH-OK" in r.stdout
+
+
 def test_search_kernels_have_no_unmarked_lane_races(emul_dir):
     import build_emul_lib
 
