@@ -82,7 +82,7 @@ def _child(device: int, model: str, n_chunks: int, tol: float, min_gain: float) 
 
 
 def pick_encoder_switches(device: int = 0, model: str = "sentence-transformers/all-MiniLM-L6-v2", n_chunks: int = 2048,
-                          tol: float = 3e-3, min_gain: float = 0.02, timeout: float = 300.0) -> dict:
+                          tol: float = 3e-3, min_gain: float = 0.02, timeout: float = 480.0) -> dict:
     """Returns {"switches": {...}, "log": [...]}; never raises (any failure = default path, reported in the log)."""
     log: list = []
     switches: dict = {}
