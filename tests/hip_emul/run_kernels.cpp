@@ -306,6 +306,8 @@ int main(int argc, char** argv) {
         test_attention<1>(2, {70, 1, 33, 64});      // harness check: revision 1 is validated on hardware
         test_attention<2>(2, {70, 1, 33, 64, 2, 69});
         test_attention<2>(1, {256, 255, 200, 129});
+        for (int ml : {20, 40, 90, 100, 150, 170, 210})  // every NT instantiation (1..7; 8 above), ragged tails
+            test_attention<2>(1, {ml, ml - 1, 1, ml / 2 + 1});
     }
     if (what == "all" || what == "mlp") {
         test_mlp(130, 64, 1);   // two workgroups, the second with 2 valid tokens; 2 slabs
