@@ -233,6 +233,95 @@ def case_hub_cache_and_helpers():
     print("hub cache / top-k merge / pair distances: ok", flush=True)
 
 
+def case_encoder_abi():
+    """The encoder entry points through the C ABI (launchers included: argument checks, grids, LDS attributes, the
+    environment-selected kernel generations) on host buffers, against numpy references."""
+    import os
+
+    import torch
+    from scipy.special import erf
+
+    from leann_amd import _lib
+    from leann_amd.encoder import pack_w2_fused_mlp, pack_w_linear_h384
+
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    T, F, H = 130, 64, 384
+    x = rng.standard_normal((T, H)).astype(np.float16)
+    gamma = (1 + 0.1 * rng.standard_normal(H)).astype(np.float16)
+    beta = (0.1 * rng.standard_normal(H)).astype(np.float16)
+
+    def ln(z):
+        mu = z.mean(1, keepdims=True)
+        var = ((z - mu) ** 2).mean(1, keepdims=True)
+        return (z - mu) / np.sqrt(var + 1e-12) * gamma.astype(np.float64) + beta.astype(np.float64)
+
+    # fused feed-forward block, both variants
+    w1 = (rng.standard_normal((F, H)) / np.sqrt(H)).astype(np.float16)
+    w2 = (rng.standard_normal((H, F)) / np.sqrt(F)).astype(np.float16)
+    b1 = (0.2 * rng.standard_normal(F)).astype(np.float32)
+    b2 = (0.2 * rng.standard_normal(H)).astype(np.float32)
+    w2p = pack_w2_fused_mlp(torch.from_numpy(w2)).numpy()
+    hid = x.astype(np.float64) @ w1.astype(np.float64).T + b1
+    p16 = (0.5 * hid * (1 + erf(hid / np.sqrt(2)))).astype(np.float16).astype(np.float64)
+    ref = ln(p16 @ w2.astype(np.float64).T + b2 + x.astype(np.float64))
+    for variant in ("1", "2"):
+        os.environ["LEANN_MI355X_MLP_VARIANT"] = variant
+        out = np.zeros((T, H), np.float16)
+        _lib.check(lib.lm_mlp_fused_h384_f16(vp(x), vp(w1), vp(b1), vp(w2p), vp(b2), vp(gamma), vp(beta), vp(out), T, F, 1e-12, None), "mlp")
+        assert np.abs(out.astype(np.float64) - ref).max() < 8e-3, variant
+    os.environ.pop("LEANN_MI355X_MLP_VARIANT")
+    assert lib.lm_mlp_fused_h384_f16(vp(x), vp(w1), vp(b1), vp(w2p), vp(b2), vp(gamma), vp(beta), vp(out), T, 48, 1e-12, None) == -1  # ffn % 32
+    # linear: QKV shape and out-projection + residual + LayerNorm
+    w = (rng.standard_normal((3 * H, H)) / np.sqrt(H)).astype(np.float16)
+    b = (0.2 * rng.standard_normal(3 * H)).astype(np.float32)
+    wp = pack_w_linear_h384(torch.from_numpy(w)).numpy()
+    out3 = np.zeros((T, 3 * H), np.float16)
+    _lib.check(lib.lm_linear_h384_f16(vp(x), vp(wp), vp(b), 3 * H, None, None, None, 0.0, vp(out3), T, None), "linear")
+    assert np.abs(out3.astype(np.float64) - (x.astype(np.float64) @ w.astype(np.float64).T + b)).max() < 6e-3
+    res = rng.standard_normal((T, H)).astype(np.float16)
+    wo, bo = np.ascontiguousarray(w[:H]), np.ascontiguousarray(b[:H])
+    wop = pack_w_linear_h384(torch.from_numpy(wo)).numpy()
+    out1 = np.zeros((T, H), np.float16)
+    _lib.check(lib.lm_linear_h384_f16(vp(x), vp(wop), vp(bo), H, vp(res), vp(gamma), vp(beta), 1e-12, vp(out1), T, None), "linear+ln")
+    assert np.abs(out1.astype(np.float64) - ln(res.astype(np.float64) + x.astype(np.float64) @ wo.astype(np.float64).T + bo)).max() < 6e-3
+    assert lib.lm_linear_h384_f16(vp(x), vp(wop), vp(bo), 400, None, None, None, 0.0, vp(out1), T, None) == -1  # n_out % 384
+    # add + LayerNorm: both generations through the same entry point
+    for gen in ("1", "2"):
+        os.environ["LEANN_MI355X_LN"] = gen
+        o = np.zeros((T, H), np.float16)
+        _lib.check(lib.lm_add_layernorm_f16(vp(x), vp(res), vp(gamma), vp(beta), vp(o), T, H, 1e-12, None), "ln")
+        assert np.abs(o.astype(np.float64) - ln(x.astype(np.float64) + res.astype(np.float64))).max() < 4e-3, gen
+    os.environ.pop("LEANN_MI355X_LN")
+    # attention: both generations; mean pooling; embedding front end
+    heads, lens = 2, np.array([70, 1, 33, 64], np.int32)
+    cu = np.zeros(5, np.int32)
+    cu[1:] = np.cumsum(lens)
+    tot, Hh = int(cu[-1]), heads * 32
+    qkv = (1.5 * rng.standard_normal((tot, 3 * Hh))).astype(np.float16)
+    q3 = qkv.astype(np.float64).reshape(tot, 3, heads, 32)
+    refa = np.zeros((tot, Hh))
+    for i in range(4):
+        a_, b_ = cu[i], cu[i + 1]
+        for h in range(heads):
+            sc = q3[a_:b_, 0, h] @ q3[a_:b_, 1, h].T / np.sqrt(32)
+            pr = np.exp(sc - sc.max(1, keepdims=True))
+            refa[a_:b_, h * 32:(h + 1) * 32] = (pr / pr.sum(1, keepdims=True)) @ q3[a_:b_, 2, h]
+    for gen in ("1", "2"):
+        os.environ["LEANN_MI355X_ATTN"] = gen
+        oa = np.zeros((tot, Hh), np.float16)
+        _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv), vp(cu), 4, heads, int(lens.max()), vp(oa), None), "attn")
+        assert np.abs(oa.astype(np.float64) - refa).max() < 4e-3, gen
+    os.environ.pop("LEANN_MI355X_ATTN")
+    xs = rng.standard_normal((tot, H)).astype(np.float16)
+    po = np.zeros((4, H), np.float32)
+    _lib.check(lib.lm_meanpool_varlen_f16(vp(xs), vp(cu), 4, H, 1, vp(po), None), "pool")
+    m = np.stack([xs[cu[i]:cu[i + 1]].astype(np.float64).mean(0) for i in range(4)])
+    assert np.abs(po - m / np.linalg.norm(m, axis=1, keepdims=True)).max() < 1e-5
+    print("encoder entry points through the C ABI: ok", flush=True)
+
+
 CASES = {
     "table_mips": lambda: case_table("mips", 64),
     "table_l2_d100": lambda: case_table("l2", 100),
@@ -247,6 +336,7 @@ CASES = {
     "two_level": case_two_level,
     "degenerate_graphs": case_degenerate_graphs,
     "hub_cache_and_helpers": case_hub_cache_and_helpers,
+    "encoder_abi": case_encoder_abi,
 }
 
 if __name__ == "__main__":
