@@ -339,6 +339,64 @@ CASES = {
     "encoder_abi": case_encoder_abi,
 }
 
+def case_encoder_python_wiring():
+    """leann_amd/encoder.py with every second-generation switch ON, run on CPU tensors through the emulated library:
+    the wrappers' argument wiring (weight packing caches, bias / LayerNorm parameters, cu_seqlens, call order) is what
+    the autotune probe will exercise on the GPU.  Only test code pretends the tensors are device tensors
+    (Tensor.is_cuda / current_stream are patched HERE); the product has no such switch."""
+    import os
+    from unittest import mock
+
+    import torch
+
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+
+    torch.manual_seed(0)
+    cfg = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=64, max_pos=64, max_seq_length=48)
+    enc = BertEncoder.random_init(cfg, 3).eval()
+    rng = np.random.default_rng(9)
+    n, t = 9, 48
+    lens = rng.integers(1, t + 1, n).astype(np.int32)
+    lens[0], lens[1] = t, 1
+    ids = np.zeros((n, t), np.int32)
+    for i in range(n):
+        ids[i, : lens[i]] = rng.integers(1, cfg.vocab_size, lens[i])
+    ti, tl = torch.from_numpy(ids), torch.from_numpy(lens)
+    with torch.no_grad():
+        ref = enc(ti, tl).float()  # fp32 padded reference path (plain torch)
+    enc16 = BertEncoder.random_init(cfg, 3).eval().half()
+
+    class _Stream:
+        cuda_stream = 0
+
+    switches = {"LEANN_MI355X_ATTN": "2", "LEANN_MI355X_LN": "2", "LEANN_MI355X_POOL": "1", "LEANN_MI355X_EMBED": "1",
+                "LEANN_MI355X_LINEAR": "1", "LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "2"}
+    from leann_amd import _lib
+
+    used = []
+    real_check = _lib.check
+
+    def recording_check(rc, what=""):
+        used.append(what)
+        return real_check(rc, what)
+
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, switches), \
+            mock.patch.object(_lib, "check", new=recording_check):
+        with torch.no_grad():
+            got = enc16.encode_tokens_packed(ti, tl, 4096)
+    expected = {"lm_embed_layernorm_f16": 1, "lm_linear_h384_f16": 2 * cfg.layers, "lm_attn_varlen_hd32_f16": cfg.layers,
+                "lm_mlp_fused_h384_f16": cfg.layers, "lm_meanpool_varlen_f16": 1}
+    counts = {k: used.count(k) for k in expected}
+    assert counts == expected and "lm_add_layernorm_f16" not in used, (counts, sorted(set(used)))  # no library GEMM, no torch op left
+    err = float((got.float() - ref).abs().max())
+    print(f"encoder.py packed forward, every switch on, through the emulated library: max|diff| vs fp32 torch = {err:.2e}", flush=True)
+    assert err < 6e-3, err
+
+
+CASES["encoder_python_wiring"] = case_encoder_python_wiring
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     _load(sys.argv[1])
