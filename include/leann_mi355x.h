@@ -223,6 +223,11 @@ int lm_embed_layernorm_f16(const int32_t *d_tok, const int32_t *d_pos, const voi
                            const void *d_type0, const void *d_gamma, const void *d_beta, void *d_out, int64_t rows,
                            int32_t hidden, float eps, void *stream);
 
+/* Packing front end: padded token ids [n][t] + lengths + cumulative lengths (int32[n+1]) -> packed token ids and
+ * positions [total].  Replaces the masked selects before the first encoder layer.  Host switch: LEANN_MI355X_PACK=1. */
+int lm_pack_tokens(const int32_t *d_ids, const int32_t *d_lens, const int32_t *d_cu_seqlens, int32_t n, int32_t t,
+                   int32_t *d_tok, int32_t *d_pos, void *stream);
+
 /* Mean pooling over the tokens of each packed sequence (+ optional L2 normalisation), fp16 in, fp32 out
  * [n_seqs][hidden]; fixed summation order (deterministic).  sentence-transformers Pooling as done in
  * leann/embedding_compute.py:323-334.  Host switch: LEANN_MI355X_POOL=1. */

@@ -28,6 +28,7 @@ CANDIDATES = [
     ({"LEANN_MI355X_LN": "2"}, "LayerNorm, 16 lanes per row"),
     ({"LEANN_MI355X_POOL": "1"}, "segmented mean pooling"),
     ({"LEANN_MI355X_EMBED": "1"}, "fused embedding front end"),
+    ({"LEANN_MI355X_PACK": "1"}, "packing front end in one kernel"),
     ({"LEANN_MI355X_LINEAR": "1"}, "hidden-384 linear kernel (QKV, out-projection + LayerNorm)"),
     ({"LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "2"}, "fused feed-forward block, cross-slab pipelined"),
     ({"LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "1"}, "fused feed-forward block"),

@@ -205,6 +205,21 @@ __global__ __launch_bounds__(256) void k_meanpool_varlen_f16(const __half* __res
     }
 }
 
+// padded [n][t] token ids + lengths + cumulative lengths -> packed token ids / positions (one wave per chunk).
+// Replaces the boolean-mask selects of the packing front end (three nonzero/gather passes and their host syncs).
+__global__ __launch_bounds__(256) void k_pack_tokens(const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
+                                                     const int32_t* __restrict__ cu, int32_t n, int32_t t, int32_t* __restrict__ tok,
+                                                     int32_t* __restrict__ pos) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= n) return;
+    const int len = min(lens[w], t), base = cu[w];
+    const int32_t* row = ids + (int64_t)w * t;
+    for (int j = lane; j < len; j += 64) {
+        tok[base + j] = row[j];
+        pos[base + j] = j;
+    }
+}
+
 }  // namespace lm
 
 #ifndef LM_HOST_EMULATION
@@ -256,6 +271,17 @@ extern "C" int lm_embed_layernorm_f16(const int32_t* d_tok, const int32_t* d_pos
         CASEE(1); CASEE(2); CASEE(3); CASEE(4); CASEE(5); CASEE(6);
 #undef CASEE
     }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+extern "C" int lm_pack_tokens(const int32_t* d_ids, const int32_t* d_lens, const int32_t* d_cu_seqlens, int32_t n, int32_t t,
+                              int32_t* d_tok, int32_t* d_pos, void* stream) {
+    using namespace lm;
+    if (n == 0) return LM_OK;
+    if (!d_ids || !d_lens || !d_cu_seqlens || !d_tok || !d_pos || n < 0 || t <= 0) LM_FAIL(LM_EINVAL, "bad pack_tokens arguments");
+    hipLaunchKernelGGL(k_pack_tokens, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_ids, d_lens, d_cu_seqlens, n, t,
+                       d_tok, d_pos);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

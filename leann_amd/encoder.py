@@ -18,6 +18,7 @@ from dataclasses import dataclass, replace
 from pathlib import Path
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -130,6 +131,29 @@ def fused_embed_layernorm(tok: torch.Tensor, pos: torch.Tensor, word: nn.Embeddi
         C.c_void_p(out.data_ptr()), t32.shape[0], h, float(ln.eps), C.c_void_p(torch.cuda.current_stream(tok.device).cuda_stream)),
         "lm_embed_layernorm_f16")
     return out
+
+
+def fused_pack_tokens(ids: torch.Tensor, lens: torch.Tensor, cu: torch.Tensor, total: int):
+    """Padded ids [n, t] + lengths + cumulative lengths -> (packed token ids, positions), int32 [total], in one kernel
+    (csrc/lm_encoder_ops2.hip) instead of three boolean-mask selects.  Opt-in (LEANN_MI355X_PACK=1) until validated on
+    hardware; None = the caller takes the torch path."""
+    import os
+
+    if os.environ.get("LEANN_MI355X_PACK", "0") != "1":
+        return None
+    if not (ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous() and lens.dtype == torch.int32 and cu.dtype == torch.int32):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    n, t = ids.shape
+    tok = torch.empty((total,), dtype=torch.int32, device=ids.device)
+    pos = torch.empty((total,), dtype=torch.int32, device=ids.device)
+    _lib.check(_lib.load().lm_pack_tokens(
+        C.c_void_p(ids.data_ptr()), C.c_void_p(lens.contiguous().data_ptr()), C.c_void_p(cu.data_ptr()), n, t, C.c_void_p(tok.data_ptr()),
+        C.c_void_p(pos.data_ptr()), C.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream)), "lm_pack_tokens")
+    return tok, pos
 
 
 def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool) -> Optional[torch.Tensor]:
@@ -396,6 +420,8 @@ class BertEncoder(nn.Module):
         if cfg.pooling == "cls":
             e = x[cu[:-1].long()].float()
         else:
+            if seq_of is None:  # packed front end: only this path needs the token -> sequence map
+                seq_of = torch.repeat_interleave(torch.arange(n, device=x.device), lengths.long(), output_size=x.shape[0])
             e = torch.zeros((n, cfg.hidden), dtype=torch.float32, device=x.device).index_add_(0, seq_of, x.float())
             e = e / lengths.clamp(min=1).unsqueeze(1).float()
         if cfg.normalize:
@@ -422,9 +448,22 @@ class BertEncoder(nn.Module):
             bounds.append(j)
             base = int(cs[j - 1])
         ar = torch.arange(t, device=input_ids.device)
+        import os
+
+        pack_on = os.environ.get("LEANN_MI355X_PACK", "0") == "1"  # packed front end in one kernel (fused_pack_tokens)
+        cs_np = cs.numpy()
+        lens_np = cs_np - np.concatenate(([0], cs_np[:-1]))  # host copy of the lengths: no further syncs below
         for b0, b1 in zip(bounds[:-1], bounds[1:]):
             ids = input_ids[b0:b1]
             ln = lengths[b0:b1]
+            if pack_on and ln.dtype == torch.int32:
+                cu = torch.zeros(b1 - b0 + 1, dtype=torch.int32, device=ids.device)
+                cu[1:] = torch.cumsum(ln, 0)
+                total = int(cs_np[b1 - 1]) - (int(cs_np[b0 - 1]) if b0 else 0)
+                packed = fused_pack_tokens(ids, ln, cu, total)
+                if packed is not None:
+                    out[b0:b1] = self.forward_packed(packed[0], packed[1], cu, None, ln, int(lens_np[b0:b1].max()))
+                    continue
             valid = ar[None, :] < ln[:, None]
             tok = ids[valid]
             pos = ar[None, :].expand(b1 - b0, t)[valid]

@@ -18,7 +18,7 @@ from leann_amd.encoder import BertEncoder, config_for
 from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
 
 SWITCHES = {"LEANN_MI355X_ATTN": "2", "LEANN_MI355X_LN": "2", "LEANN_MI355X_POOL": "1", "LEANN_MI355X_EMBED": "1",
-            "LEANN_MI355X_MLP": "1", "LEANN_MI355X_LINEAR": "1"}
+            "LEANN_MI355X_MLP": "1", "LEANN_MI355X_LINEAR": "1", "LEANN_MI355X_PACK": "1"}
 dev = torch.device("cuda")
 cfg = config_for("all-MiniLM-L6-v2")
 enc = BertEncoder.random_init(cfg, 0).to(dev, dtype=torch.float16)

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 
 echo "== 1. gpu_next tests (one pytest process per kernel family: a device fault in one does not hide the others)" | tee $OUT/summary.txt
-for k in attention layernorm meanpool embed "fused_mlp" linear "every_opt_in"; do
+for k in attention layernorm meanpool embed pack_tokens "fused_mlp" linear "every_opt_in"; do
     timeout 300 python -m pytest tests/test_gpu_next.py -m gpu_next -q -x -k "$k" > $OUT/test_$k.log 2>&1
     echo "   $k: rc=$? $(tail -1 $OUT/test_$k.log)" | tee -a $OUT/summary.txt
 done
@@ -21,14 +21,14 @@ timeout 300 python scripts/attn_bench.py > $OUT/attn_bench.json 2> $OUT/attn_ben
 timeout 600 python scripts/encoder_ops_bench.py > $OUT/encoder_ops_bench.json 2> $OUT/encoder_ops_bench.err; echo "   encoder_ops_bench rc=$?" | tee -a $OUT/summary.txt
 
 echo "== 3. per-kernel times with every switch on (rocprofv3 --kernel-trace --stats)" | tee -a $OUT/summary.txt
-( cd /tmp && LEANN_MI355X_ATTN=2 LEANN_MI355X_LN=2 LEANN_MI355X_POOL=1 LEANN_MI355X_EMBED=1 LEANN_MI355X_MLP=1 LEANN_MI355X_MLP_VARIANT=2 LEANN_MI355X_LINEAR=1 \
+( cd /tmp && LEANN_MI355X_ATTN=2 LEANN_MI355X_LN=2 LEANN_MI355X_POOL=1 LEANN_MI355X_EMBED=1 LEANN_MI355X_MLP=1 LEANN_MI355X_MLP_VARIANT=2 LEANN_MI355X_LINEAR=1 LEANN_MI355X_PACK=1 \
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_next -- python $OLDPWD/scripts/encoder_bench.py > $OLDPWD/$OUT/encoder_bench_all_on.json 2> $OLDPWD/$OUT/rocprof.err )
 find /tmp/prof_next -name "*kernel_stats.csv" -exec cp {} $OUT/encoder_all_on_kernel_stats.csv \; 2>/dev/null
 echo "   rocprof rc=$?" | tee -a $OUT/summary.txt
 
 echo "== 4. bench with the switches that passed (edit the list below after reading summary.txt if something failed)" | tee -a $OUT/summary.txt
 if ! grep -q "rc=[1-9]" $OUT/summary.txt; then
-    LEANN_MI355X_ATTN=2 LEANN_MI355X_LN=2 LEANN_MI355X_POOL=1 LEANN_MI355X_EMBED=1 LEANN_MI355X_MLP=1 LEANN_MI355X_MLP_VARIANT=2 LEANN_MI355X_LINEAR=1 \
+    LEANN_MI355X_ATTN=2 LEANN_MI355X_LN=2 LEANN_MI355X_POOL=1 LEANN_MI355X_EMBED=1 LEANN_MI355X_MLP=1 LEANN_MI355X_MLP_VARIANT=2 LEANN_MI355X_LINEAR=1 LEANN_MI355X_PACK=1 \
       timeout 1500 python bench.py --no-cpu-baseline > $OUT/bench_all_on.json 2> $OUT/bench_all_on.err
     echo "   bench rc=$? $(python -c "import json;d=json.load(open('$OUT/bench_all_on.json'));print(d['value'],d['recall_at_10'],d['roofline_encoder'])" 2>/dev/null)" | tee -a $OUT/summary.txt
 else

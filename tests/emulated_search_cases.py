@@ -370,7 +370,7 @@ def case_encoder_python_wiring():
         cuda_stream = 0
 
     switches = {"LEANN_MI355X_ATTN": "2", "LEANN_MI355X_LN": "2", "LEANN_MI355X_POOL": "1", "LEANN_MI355X_EMBED": "1",
-                "LEANN_MI355X_LINEAR": "1", "LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "2"}
+                "LEANN_MI355X_LINEAR": "1", "LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "2", "LEANN_MI355X_PACK": "1"}
     from leann_amd import _lib
 
     used = []
@@ -385,10 +385,19 @@ def case_encoder_python_wiring():
             mock.patch.object(_lib, "check", new=recording_check):
         with torch.no_grad():
             got = enc16.encode_tokens_packed(ti, tl, 4096)
-    expected = {"lm_embed_layernorm_f16": 1, "lm_linear_h384_f16": 2 * cfg.layers, "lm_attn_varlen_hd32_f16": cfg.layers,
+    expected = {"lm_pack_tokens": 1, "lm_embed_layernorm_f16": 1, "lm_linear_h384_f16": 2 * cfg.layers, "lm_attn_varlen_hd32_f16": cfg.layers,
                 "lm_mlp_fused_h384_f16": cfg.layers, "lm_meanpool_varlen_f16": 1}
     counts = {k: used.count(k) for k in expected}
     assert counts == expected and "lm_add_layernorm_f16" not in used, (counts, sorted(set(used)))  # no library GEMM, no torch op left
+    # mixed configuration: packing kernel + torch pooling (needs the lazily built token -> sequence map) + torch embedding
+    mixed = {k: v for k, v in switches.items() if k not in ("LEANN_MI355X_POOL", "LEANN_MI355X_EMBED")}
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, mixed):
+        for k in ("LEANN_MI355X_POOL", "LEANN_MI355X_EMBED"):
+            os.environ.pop(k, None)
+        with torch.no_grad():
+            got2 = enc16.encode_tokens_packed(ti, tl, 4096)
+    assert float((got2.float() - ref).abs().max()) < 6e-3
     err = float((got.float() - ref).abs().max())
     print(f"encoder.py packed forward, every switch on, through the emulated library: max|diff| vs fp32 torch = {err:.2e}", flush=True)
     assert err < 6e-3, err

@@ -238,3 +238,26 @@ def test_linear_h384_qkv_and_out_projection(tokens, monkeypatch):
     torch.cuda.synchronize()
     monkeypatch.setenv("LEANN_MI355X_LINEAR", "0")
     assert fused_linear_h384(x, qkv) is None
+
+
+def test_pack_tokens_front_end(monkeypatch):
+    """lm_pack_tokens (LEANN_MI355X_PACK=1) == the boolean-mask selects it replaces; whole forward unchanged."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for, fused_pack_tokens
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=300, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    cu = torch.zeros(301, dtype=torch.int32, device="cuda")
+    cu[1:] = torch.cumsum(tl, 0)
+    monkeypatch.setenv("LEANN_MI355X_PACK", "1")
+    tok, pos = fused_pack_tokens(ti, tl, cu, int(cu[-1]))
+    ar = torch.arange(256, device="cuda")
+    valid = ar[None, :] < tl[:, None]
+    assert torch.equal(tok, ti[valid]) and torch.equal(pos.long(), ar[None, :].expand(300, 256)[valid])
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    a = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_PACK", "0")
+    b = enc.encode_tokens_packed(ti, tl)
+    assert torch.equal(a, b)
