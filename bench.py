@@ -8,6 +8,10 @@ lm_index_search_device(recompute=1) -> per round: CSR expand / visited / dedup k
 gather, BERT forward (PyTorch-ROCm fp16), fused distance + beam-update kernel.  Queries, graph,
 token store and results are HBM resident when the timed region starts.
 
+Encoder kernels: before touching the GPU, leann_amd.autotune probes the second-generation hand-written kernels in a
+child process and switches on those that reproduce the default path's embeddings AND are faster on this GPU
+(`--no-autotune` keeps the default path; the choice is recorded in the JSON line).
+
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 For N > 1 the driver launches one rank per GPU through torch.distributed.run; the graph and the
 token store are replicated, the query batch is partitioned across ranks, there is no collective on

@@ -233,6 +233,28 @@ def case_hub_cache_and_helpers():
     print("hub cache / top-k merge / pair distances: ok", flush=True)
 
 
+def case_dims_and_batches():
+    """The padded-dimension instantiations the bench / configs use (NCH = 6, 12, 16) and a search split over several passes."""
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    for d in (384, 768, 1024):
+        x, q = _data(120, d, 50 + d, nq=5)
+        g = build_hnsw(x, "mips", M=6, ef_construction=30)
+        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, d)
+        exp = orc.search(og, q, 5, ef=12, beam=2, table=x)
+        idx = Mi355xIndex.from_csr(g)
+        idx.attach_table(x)
+        idx.set_provider(NumpyProvider(x, idx.info.d_padded))
+        for mode, kw in (("persistent", dict(recompute=False)), ("recompute, 3 passes of <= 2 queries", dict(recompute=True, max_batch=2))):
+            got = idx.search(q, 5, idx.make_params(ef=12, beam=2, **kw))
+            ok = np.array_equal(got[1], exp[0]) and np.array_equal(got[0], exp[1]) and int(idx.stats()["ndis"]) == int(exp[2]["ndis"])
+            assert ok, (d, mode)
+        idx.close()
+    print("D = 384 / 768 / 1024, multi-pass batches: ok", flush=True)
+
+
 def case_encoder_abi():
     """The encoder entry points through the C ABI (launchers included: argument checks, grids, LDS attributes, the
     environment-selected kernel generations) on host buffers, against numpy references."""
@@ -337,6 +359,7 @@ CASES = {
     "degenerate_graphs": case_degenerate_graphs,
     "hub_cache_and_helpers": case_hub_cache_and_helpers,
     "encoder_abi": case_encoder_abi,
+    "dims_and_batches": case_dims_and_batches,
 }
 
 def case_encoder_python_wiring():
