@@ -21,6 +21,7 @@
 // Role in the reference: the attention projections inside compute_embeddings' BERT forward
 // (leann/embedding_compute.py:229-239).
 #include <cstdlib>
+#include <cstring>
 
 #include "lm_h384_common.h"
 
@@ -31,8 +32,10 @@ constexpr int LN_BUF = ML_H * LN_STRIDE * 2;          // 30720 B per stage
 constexpr int LN_CHUNKS = ML_H * 32 * 2 / 16;         // 1536 16-byte chunks per slab
 constexpr int LN_NPRE = LN_CHUNKS / 256;              // 6 per thread
 constexpr int LN_SLABS = ML_H / 32;                   // 12 slabs per pass
+constexpr int LN_TILE_STRIDE = ML_H + 8;              // halfs per row of a wave's output staging tile (784 B)
+constexpr int LN_TILE_BYTES = 4 * 32 * LN_TILE_STRIDE * 2;  // 100352 B for the four waves
 
-template <int MODE>
+template <int MODE, bool LDS_STORE>
 __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_linear_h384(
     const __half* __restrict__ x, const __half* __restrict__ wp, const float* __restrict__ bias, const __half* __restrict__ res,
     const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T, int P, float eps) {
@@ -119,6 +122,39 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_linear_h384(
             // sequence its ~100 chain-free loads (read-only arguments) are placed at the TOP of the kernel by instruction
             // selection and spilled (820 B of scratch per lane); sched_barrier does not stop that.
             if (T > 0) mlp_epilogue(o, res, bias, gamma, beta, out, token, valid, g, eps);
+        } else if (LDS_STORE) {
+            // Coalesced output: the transposed accumulator layout gives every lane 4 consecutive columns of ITS token, i.e. a
+            // wave store instruction would touch 32 rows with 16 bytes each.  Stage the wave's 32 x 384 tile in LDS (row major,
+            // 784-byte rows: conflict-free 8-byte writes) and write it out as 24 fully contiguous 1 KB wave stores.
+            // The staging area lies behind the two weight stages (the next pass's first slab is already in stage 0).
+            _Float16* tile = (_Float16*)(smem + 2 * LN_BUF) + wv * (32 * LN_TILE_STRIDE);
+            int g_e = g;
+            LM_KEEP_LOCAL(g_e);
+            const float* bp = bias + ML_H * p + 4 * g_e;
+#pragma unroll
+            for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * j + 8 * q;
+                    float4v bb = *(const float4v*)(bp + f0);
+                    half4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = (_Float16)(o[j][4 * q + i] + bb[i]);
+                    *(half4*)(tile + r31 * LN_TILE_STRIDE + f0 + 4 * g_e) = y;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            LM_WAVE_SYNC();  // the tile is written and read by the same wave only
+            const int tok0 = blockIdx.x * 128 + wv * 32;
+            int lane_e = lane;
+            LM_KEEP_LOCAL(lane_e);  // keep the 24 address computations here (hoisted to the pass header they are spilled)
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int c = lane_e + 64 * i, row = c / 48, col = (c % 48) * 8;
+                half8 v = *(const half8*)(tile + row * LN_TILE_STRIDE + col);
+                if (tok0 + row < T) *(half8*)((_Float16*)out + (int64_t)(tok0 + row) * N + ML_H * p + col) = v;
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 tile reads in flight (16 registers, not 96)
+            }
+            LM_WAVE_SYNC();  // the next pass overwrites the tile
         } else if (valid) {
             // lane (token r31, g), tile j, register 4q + i <-> output column 384p + 32j + 8q + 4g + i
             _Float16* yr = (_Float16*)out + (int64_t)token * N + ML_H * p + 4 * g;
@@ -149,16 +185,22 @@ extern "C" int lm_linear_h384_f16(const void* d_x, const void* d_wp, const float
     if (n_out <= 0 || n_out % ML_H) LM_FAIL(LM_EINVAL, "n_out must be a positive multiple of 384");
     const bool ln = d_residual != nullptr;
     if (ln && (n_out != ML_H || !d_gamma || !d_beta)) LM_FAIL(LM_EINVAL, "residual + LayerNorm mode needs n_out == 384, gamma and beta");
-    const size_t shmem = (size_t)2 * LN_BUF;
+    const char* st_env = getenv("LEANN_MI355X_LINEAR_STORE");  // "direct": 8-byte scattered stores straight from the accumulators (A/B)
+    const bool lds_store = !ln && !(st_env && !strcmp(st_env, "direct"));
+    const size_t shmem = (size_t)2 * LN_BUF + (lds_store ? LN_TILE_BYTES : 0);  // 61440 (+ 100352 = 161792 <= 160 KiB)
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const __half *x = (const __half*)d_x, *w = (const __half*)d_wp, *r = (const __half*)d_residual;
     const __half *gm = (const __half*)d_gamma, *bt = (const __half*)d_beta;
     if (ln) {
-        hipLaunchKernelGGL(k_linear_h384<1>, grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, 1, eps);
+        hipLaunchKernelGGL((k_linear_h384<1, false>), grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, 1, eps);
+    } else if (lds_store) {
+        LM_HIP(hipFuncSetAttribute((const void*)k_linear_h384<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((k_linear_h384<0, true>), grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens,
+                           n_out / ML_H, eps);
     } else {
-        hipLaunchKernelGGL(k_linear_h384<0>, grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, n_out / ML_H,
-                           eps);
+        hipLaunchKernelGGL((k_linear_h384<0, false>), grid, block, shmem, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens,
+                           n_out / ML_H, eps);
     }
     LM_HIP(hipGetLastError());
     return LM_OK;

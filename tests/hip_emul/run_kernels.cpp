@@ -162,7 +162,7 @@ static void test_mlp(int T, int F, int variant) {
 }
 
 // ---------------------------------------------------------------- linear
-static void test_linear(int T, int P, bool ln) {
+static void test_linear(int T, int P, bool ln, bool lds_store = false) {
     const int N = 384 * P;
     std::vector<h16> x((size_t)T * 384), w((size_t)N * 384), res((size_t)T * 384), gamma(384), beta(384), out((size_t)T * N, (h16)0);
     std::vector<float> bias(N);
@@ -185,8 +185,9 @@ static void test_linear(int T, int P, bool ln) {
             auto G = (const __half*)gamma.data();
             auto B = (const __half*)beta.data();
             auto O = (__half*)out.data();
-            if (ln) lm::k_linear_h384<1>(X, W, bias.data(), R, G, B, O, T, 1, 1e-12f);
-            else lm::k_linear_h384<0>(X, W, bias.data(), nullptr, nullptr, nullptr, O, T, P, 0.f);
+            if (ln) lm::k_linear_h384<1, false>(X, W, bias.data(), R, G, B, O, T, 1, 1e-12f);
+            else if (lds_store) lm::k_linear_h384<0, true>(X, W, bias.data(), nullptr, nullptr, nullptr, O, T, P, 0.f);
+            else lm::k_linear_h384<0, false>(X, W, bias.data(), nullptr, nullptr, nullptr, O, T, P, 0.f);
         });
     double err = 0;
     for (int t = 0; t < T; ++t) {
@@ -200,7 +201,7 @@ static void test_linear(int T, int P, bool ln) {
         for (int n = 0; n < N; ++n) err = std::max(err, std::fabs(z[n] - (double)out[(size_t)t * N + n]));
     }
     char name[96];
-    std::snprintf(name, sizeof name, "linear h384 %s tokens=%d n_out=%d", ln ? "+residual+LayerNorm" : "bias only", T, N);
+    std::snprintf(name, sizeof name, "linear h384 %s tokens=%d n_out=%d", ln ? "+residual+LayerNorm" : (lds_store ? "bias only, LDS-staged store" : "bias only, direct store"), T, N);
     report(name, err, 6e-3);
 }
 
@@ -316,6 +317,8 @@ int main(int argc, char** argv) {
     }
     if (what == "all" || what == "linear") {
         test_linear(130, 3, false);
+        test_linear(130, 3, false, true);
+        test_linear(5, 1, false, true);
         test_linear(130, 1, true);
     }
     if (what == "all" || what == "elementwise") test_ln_pool();
