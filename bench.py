@@ -8,9 +8,9 @@ lm_index_search_device(recompute=1) -> per round: CSR expand / visited / dedup k
 gather, BERT forward (PyTorch-ROCm fp16), fused distance + beam-update kernel.  Queries, graph,
 token store and results are HBM resident when the timed region starts.
 
-Encoder kernels: before touching the GPU, leann_amd.autotune probes the second-generation hand-written kernels in a
-child process and switches on those that reproduce the default path's embeddings AND are faster on this GPU
-(`--no-autotune` keeps the default path; the choice is recorded in the JSON line).
+Encoder kernels: the default set (the one `pytest -m gpu` tests).  `--autotune` additionally lets
+leann_amd.autotune A/B the remaining switchable kernels in a child process before the GPU is touched (recorded in
+the JSON line); the timed steps run with profiling OFF, the roofline figures come from one extra profiled step.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 For N > 1 the driver launches one rank per GPU through torch.distributed.run; the graph and the
@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-roofline", action="store_true", default=True, help="also time the stored-embedding (HBM gather) mode (default on)")
     ap.add_argument("--no-table-roofline", dest="table_roofline", action="store_false")
-    ap.add_argument("--no-autotune", action="store_true", help="keep the default encoder kernels (skip leann_amd.autotune)")
+    ap.add_argument("--autotune", action="store_true", help="A/B the switchable encoder kernels at start-up (leann_amd.autotune); default: the tested default set")
     args = ap.parse_args()
 
     # ---- encoder kernel selection (untimed set-up, before this process touches the GPU): a child process checks the
@@ -63,7 +63,7 @@ def main():
     from leann_amd import autotune as _at
 
     autotune_report = None
-    if not args.no_autotune and not any(k in os.environ for k in _at.ALL_KEYS):
+    if args.autotune and not any(k in os.environ for k in _at.ALL_KEYS):
         t_at = time.time()
         autotune_report = _at.pick_encoder_switches(device=int(os.environ.get("LOCAL_RANK", "0")), model=args.model, tol=5e-3)
         os.environ.update(autotune_report["switches"])
@@ -91,7 +91,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     K, W, B = args.steps, args.warmup, args.batch
-    n_q = B * (K + W + 4)  # +4: extra steps (smallest ef reaching recall 0.9; per-call memo; hub cache; two-level search)
+    n_q = B * (K + W + 5)  # +5: the profiled step and the extra steps (smallest ef reaching recall 0.9; per-call memo; hub cache; two-level search)
     t_setup = time.time()
 
     # ---- corpus -> HBM token store ------------------------------------------------------------
@@ -103,7 +103,7 @@ def main():
 
     # ---- encoder ------------------------------------------------------------------------------
     cfg = config_for(args.model)
-    enc = BertEncoder.load(args.model).to(dev, dtype=torch.float16).eval()
+    enc = BertEncoder.load(args.model, allow_random=True).to(dev, dtype=torch.float16).eval()
     D = cfg.hidden
     provider = RecomputeProvider(enc, tokens, (D + 63) // 64 * 64, dev)
 
@@ -189,7 +189,7 @@ def main():
     # ---- timed region: recompute mode ---------------------------------------------------------------
     idx.set_provider(provider)
     prm = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B)
-    idx.set_profiling(True)
+    idx.set_profiling(False)  # the timed steps carry no event pairs / span stamps; one extra profiled step follows them
     setup_s = time.time() - t_setup
     log(f"setup done in {setup_s:.1f}s; ef={ef}; timing {K} steps x {B} queries (+{W} warmup)")
 
@@ -201,8 +201,7 @@ def main():
     out_labels = []
     for w in range(W):
         _, l = idx.search_device(Q[w * B : (w + 1) * B], 10, prm)
-    agg = {"ndis": 0, "nunique": 0, "nrounds": 0, "update_ms": 0.0, "update_launches": 0, "provider_ms": 0.0, "expand_ms": 0.0,
-           "update_span_ms": 0.0, "update_span_launches": 0}
+    agg = {"ndis": 0, "nunique": 0, "nrounds": 0, "update_launches": 0}
     provider.chunks = 0
     barrier()
     t0 = time.perf_counter()
@@ -219,13 +218,24 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- one more step of the same workload WITH profiling (HIP event pairs + device span stamps per launch): the
+    #      source of the roofline figures; not part of `value` ----------------------------------------------------
+    idx.set_profiling(True)
+    lo = (W + K) * B
+    torch.cuda.synchronize()
+    t1p = time.perf_counter()
+    idx.search_device(Q[lo : lo + B], 10, prm)
+    torch.cuda.synchronize()
+    prof_step_s = time.perf_counter() - t1p
+    prof = idx.stats()
+    idx.set_profiling(False)
     # ---- extras (NOT `value`; single-GPU runs only -- they contain no collectives and may never cost the headline
     #      line): one extra step each, on fresh queries ----------------------------------------------------------
     min_ef = with_memo = with_hub = two_level = None
     do_extras = world == 1 and not args.no_min_ef_step
 
     def extra_step(params, slot):
-        lo_ = (W + K + slot) * B
+        lo_ = (W + K + 1 + slot) * B
         torch.cuda.synchronize()
         t1_ = time.perf_counter()
         _, lx = idx.search_device(Q[lo_ : lo_ + B], 10, params)
@@ -293,31 +303,33 @@ def main():
     # max end - min start): the same quantity rocprofv3 --kernel-trace --stats reports.  The HIP-event pair around
     # each launch (which also contains dispatch latency) is reported next to it.
     ev_over = idx.event_overhead_us()
-    raw_us = 1e3 * agg["update_ms"] / max(agg["update_launches"], 1)
-    net_us = 1e3 * agg["update_span_ms"] / max(agg["update_span_launches"], 1)
-    upd_s = agg["update_span_ms"] * 1e-3
-    achieved = agg["ndis"] * bytes_eval / upd_s / 1e9 if upd_s > 0 else 0.0
+    raw_us = 1e3 * prof["update_ms"] / max(prof["update_launches"], 1)
+    net_us = 1e3 * prof["update_span_ms"] / max(prof["update_span_launches"], 1)
+    upd_s = prof["update_span_ms"] * 1e-3
+    achieved = prof["ndis"] * bytes_eval / upd_s / 1e9 if upd_s > 0 else 0.0
     traffic = None
     traffic_src = None
     try:  # HBM bytes per launch from the separate PMC pass (profiles/r1_pmc_k_update.json), scaled to this run's launch size
         pmc = json.loads((ROOT / "profiles" / "r1_pmc_k_update.json").read_text())
-        traffic = round(pmc["hbm_bytes_per_eval_corrected_x1.08"] * agg["ndis"] / max(agg["update_launches"], 1))
+        traffic = round(pmc["hbm_bytes_per_eval_corrected_x1.08"] * prof["ndis"] / max(prof["update_launches"], 1))
         traffic_src = "rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/r1_pmc_k_update.json), x1.08 calibration, scaled by evals/launch"
     except Exception:  # noqa: BLE001
         pass
     roofline = {"bound": "hbm", "kernel": "lm::k_update<6,false,false,true> (fused gather + distance + beam update, recompute mode)", "achieved": round(achieved, 2),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(bytes_eval * agg["ndis"] / max(agg["update_launches"], 1)),
-                "bytes_per_eval": bytes_eval, "evals_per_launch": round(agg["ndis"] / max(agg["update_launches"], 1), 1),
+                "algorithmic_bytes_per_launch": round(bytes_eval * prof["ndis"] / max(prof["update_launches"], 1)),
+                "bytes_per_eval": bytes_eval, "evals_per_launch": round(prof["ndis"] / max(prof["update_launches"], 1), 1),
                 "us_per_launch": round(net_us, 2), "us_per_launch_event_pair": round(raw_us, 2), "empty_kernel_event_pair_us": round(ev_over, 2),
-                "timing": "device wall-clock span per launch (HIP events alongside)"}
+                "timing": "device wall-clock span per launch (HIP events alongside), from one profiled step after the timed ones",
+                "profiled_step_ms": round(1e3 * prof_step_s, 1)}
     # encoder (MFMA bound): flops of the chunks actually recomputed / HIP-event time of the provider
     lens = np.diff(off.astype(np.int64))
     mean_flops = float(np.mean([cfg.flops_per_chunk(int(t)) for t in np.random.default_rng(0).choice(lens, 4096)]))
-    enc_tf = agg["nunique"] * mean_flops / (agg["provider_ms"] * 1e-3) / 1e12 if agg["provider_ms"] > 0 else 0.0
+    enc_tf = prof["nunique"] * mean_flops / (prof["provider_ms"] * 1e-3) / 1e12 if prof["provider_ms"] > 0 else 0.0
     roofline_encoder = {"bound": "mfma", "achieved": round(enc_tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": round(enc_tf / 2500.0, 5), "chunks_per_query": round(agg["nunique"] / max(K * B, 1), 1),
-                        "mean_gflop_per_chunk": round(mean_flops / 1e9, 3), "provider_ms_share": round(agg["provider_ms"] / (elapsed * 1e3), 4)}
+                        "mean_gflop_per_chunk": round(mean_flops / 1e9, 3), "provider_ms_share": round(prof["provider_ms"] / (prof_step_s * 1e3), 4),
+                        "whole_step_TFLOPs": round(agg["nunique"] * mean_flops / max(elapsed, 1e-9) / 1e12, 2)}
 
     result = {
         "metric": "queries/sec at recall@10>=0.9, 1M-chunk HNSW, MiniLM-L6 recompute",
@@ -375,7 +387,7 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     ncores = orc.usable_cores()  # affinity / cgroup aware (the GPU box exposes 256 threads, 16 usable)
     orc.set_num_threads(ncores)
     torch.set_num_threads(ncores)
-    enc = BertEncoder.load(args.model).float().eval()
+    enc = BertEncoder.load(args.model, allow_random=True).float().eval()
     og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, cfg.hidden)
     lens_all = np.diff(off.astype(np.int64))
     T = int(lens_all.max())

@@ -157,6 +157,13 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
         # probe the second-generation encoder kernels on this GPU before the encoder is first used (leann_amd/autotune.py:
         # child process, keeps what matches the default path and is faster); off unless asked for
         self.autotune_kernels = bool(kwargs.get("autotune_kernels", False))
+        # Seeded random encoder weights + a stand-in vocabulary when the embedding model's checkpoint is not available
+        # locally: ONLY for synthetic corpora / tests whose index was built with the same random encoder.  Off by default:
+        # a production index must be searched with the weights it was built from, so a missing checkpoint raises.
+        import os as _os
+
+        self.allow_random_weights = bool(kwargs.get("allow_random_weights", bk.get(
+            "allow_random_weights", _os.environ.get("LEANN_MI355X_ALLOW_RANDOM_WEIGHTS", "0") == "1")))
         self.autotune_report = None
         self._index = None
         self._provider = None
@@ -215,7 +222,7 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
                     self.autotune_report = autotune.pick_encoder_switches(device=self.device, model=self.embedding_model, tol=5e-3)
                     os.environ.update(self.autotune_report["switches"])
                     logger.info(f"encoder kernels: {self.autotune_report['switches'] or 'default path'}")
-            enc = BertEncoder.load(self.embedding_model)
+            enc = BertEncoder.load(self.embedding_model, allow_random=self.allow_random_weights)
             dt = torch.float16 if self.encoder_dtype == "float16" else torch.float32
             self._encoder = enc.to(self._torch_device(), dtype=dt).eval()
         return self._encoder
@@ -270,7 +277,8 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             if len(texts) != idx.info.ntotal:
                 raise ValueError(f"{len(texts)} passages but the index holds {idx.info.ntotal} nodes")
             max_len = min(enc.cfg.max_seq_length, enc.cfg.max_pos)
-            self._tokenizer = load_tokenizer(self.embedding_model, max_len, str(self.index_path), texts, enc.cfg.vocab_size)
+            self._tokenizer = load_tokenizer(self.embedding_model, max_len, str(self.index_path), texts, enc.cfg.vocab_size,
+                                             allow_stand_in=enc.weights_source == "random")
             seqs = self._tokenizer.encode_batch(texts)
             self._tokens = TokenStore.from_lists(seqs, device=self.device)
             logger.info(f"token store ready: {len(texts)} passages in {time.time() - t0:.2f}s ({self._tokenizer.kind})")
@@ -308,7 +316,8 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             from .tokenizer import load_tokenizer
 
             self._tokenizer = load_tokenizer(self.embedding_model, min(enc.cfg.max_seq_length, enc.cfg.max_pos),
-                                             str(self.index_path), None, enc.cfg.vocab_size)
+                                             str(self.index_path), None, enc.cfg.vocab_size,
+                                             allow_stand_in=enc.weights_source == "random")
         ids = self._tokenizer.encode_batch([query])[0]
         dev = self._torch_device()
         t = torch.tensor([ids], dtype=torch.int32, device=dev)
@@ -486,14 +495,11 @@ class Mi355xDiskannSearcher(Mi355xSearcher):
         self.pq_file = self.index_dir / f"{self.index_path.stem}_pq.npz"
         if not self.pq_file.exists():
             raise FileNotFoundError(f"PQ file not found at {self.pq_file}")
-        self._pq_attached = False
 
     def _ensure_index_loaded(self):
-        idx = super()._ensure_index_loaded()
-        if not self._pq_attached:
-            z = np.load(self.pq_file)
-            idx.attach_pq(z["codebooks"], z["codes"])
-            self._pq_attached = True
+        idx = super()._ensure_index_loaded()  # attaches <stem>_pq.npz (checked to exist in __init__): one upload only
+        if not self._has_pq:
+            raise FileNotFoundError(f"PQ file not found at {self.pq_file}")
         return idx
 
     def search(self, query: np.ndarray, top_k: int, complexity: int = 64, beam_width: int = 1, prune_ratio: float = 0.0,

@@ -1,8 +1,8 @@
 // lm_attn_v2.hip -- second revision of the hd=32 packed-sequence attention kernel (see lm_encoder_ops.hip for
 // the first one and the algorithm: swapped S^T = K Q^T, P registers reused as the B operand of O^T = V^T P^T).
 //
-// STATUS: opt-in (environment LEANN_MI355X_ATTN=2); the default stays revision 1 until this one has been
-// validated and timed on an MI355X (tests/test_gpu_next.py).
+// STATUS: default since round 2 (round-1 driver bench on an MI355X: 23.62 -> 21.68 ms per 2048-chunk forward,
+// max|diff| 3.1e-5); LEANN_MI355X_ATTN=1 selects revision 1 for A/B (tests/test_gpu_encoder_kernels.py).
 //
 // Why a revision: the ISA of revision 1 spends ~17 VALU issue slots per score (2234 instructions per 32-query
 // block, 32 of them MFMA): at head_dim 32 a 32x32 score tile costs 2 MFMAs (64 cycles) but 16 registers x 17

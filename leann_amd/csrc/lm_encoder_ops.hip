@@ -100,8 +100,8 @@ extern "C" int lm_add_layernorm_f16(const void* d_x, const void* d_residual, con
     if (!d_x || !d_gamma || !d_beta || !d_out || rows < 0) LM_FAIL(LM_EINVAL, "bad add_layernorm arguments");
     if (hidden <= 0 || hidden % 8 || hidden > 2048) LM_FAIL(LM_EINVAL, "hidden must be a multiple of 8, <= 2048");
     {
-        const char* rev = getenv("LEANN_MI355X_LN");  // "2": 16 lanes per row (lm_encoder_ops2.hip), opt-in until validated on hardware
-        if (rev && rev[0] == '2' && rev[1] == 0 && hidden <= 768)
+        const char* rev = getenv("LEANN_MI355X_LN");  // default: 16 lanes per row (lm_encoder_ops2.hip); "1" = first generation (A/B)
+        if (!(rev && rev[0] == '1' && rev[1] == 0) && hidden <= 768)
             return lm_add_layernorm_r16_launch(d_x, d_residual, d_gamma, d_beta, d_out, rows, hidden, eps, stream);
     }
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
@@ -278,8 +278,8 @@ extern "C" int lm_attn_varlen_hd32_f16(const void* d_qkv, const int32_t* d_cu_se
     if (!d_qkv || !d_cu_seqlens || !d_out || n_seqs < 0 || heads <= 0) LM_FAIL(LM_EINVAL, "bad attention arguments");
     if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
     {
-        const char* rev = getenv("LEANN_MI355X_ATTN");  // "2": revision 2 (lm_attn_v2.hip), opt-in until validated on hardware
-        if (rev && rev[0] == '2' && rev[1] == 0) return lm_attn_v2_launch(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
+        const char* rev = getenv("LEANN_MI355X_ATTN");  // default: revision 2 (lm_attn_v2.hip); "1" = revision 1 (A/B)
+        if (!(rev && rev[0] == '1' && rev[1] == 0)) return lm_attn_v2_launch(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
     }
     const int nt = (max_len + 31) / 32;
     const size_t shmem = ((size_t)32 * nt * ATT_KSTRIDE + (size_t)32 * (32 * nt + 4)) * 2;

@@ -1,9 +1,11 @@
 // lm_encoder_ops2.hip -- second batch of hand-written encoder kernels around the GEMMs.
 //
-// STATUS: opt-in until validated and timed on an MI355X (tests/test_gpu_next.py, scripts/encoder_ops_bench.py):
-//   LEANN_MI355X_LN=2      lm_add_layernorm_f16 -> k_add_layernorm_f16_r16 (16 lanes per row, 4 rows per wave)
-//   LEANN_MI355X_POOL=1    mean pooling (+ L2 normalise) of packed sequences -> lm_meanpool_varlen_f16
-//   LEANN_MI355X_EMBED=1   word + type + position embedding gather fused with the embedding LayerNorm -> lm_embed_layernorm_f16
+// STATUS: default since round 2 (each one agreed with the first-generation path to 3e-5 and was faster in the round-1
+// driver run on an MI355X); the switches select the first-generation path for A/B (tests/test_gpu_encoder_kernels.py):
+//   LEANN_MI355X_LN=1      lm_add_layernorm_f16 -> one wave per row instead of k_add_layernorm_f16_r16 (16 lanes per row)
+//   LEANN_MI355X_POOL=0    mean pooling through torch index_add_ instead of lm_meanpool_varlen_f16
+//   LEANN_MI355X_EMBED=0   torch embedding gathers + lm_add_layernorm_f16 instead of lm_embed_layernorm_f16
+//   LEANN_MI355X_PACK=0    boolean-mask packing instead of lm_pack_tokens
 //
 // Why (rocprofv3 of the default bench, profiles/r1_final_bench_default_kernel_stats.csv):
 //   * k_add_layernorm_f16<1> runs at ~3 TB/s for hidden 384: one wave per row keeps only 48 of 64 lanes busy and

@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import json
 import logging
+import os
 import threading
 from pathlib import Path
 from typing import Optional
@@ -300,7 +301,8 @@ class Mi355xEmbeddingService:
             ctx.term()
 
 
-def service_from_meta(passages_file: str, model_name: str, distance_metric: str = "mips", device_index: int = 0):
+def service_from_meta(passages_file: str, model_name: str, distance_metric: str = "mips", device_index: int = 0,
+                      allow_random: bool = False):
     """Build the service the way the reference servers do from ``--passages-file <index>.meta.json``
     (hnsw_embedding_server.py:60-87): passages JSONL -> tokens in HBM."""
     import torch
@@ -319,9 +321,10 @@ def service_from_meta(passages_file: str, model_name: str, distance_metric: str 
                     texts += [json.loads(line).get("text", "") for line in f if line.strip()]
                 break
     dev = torch.device("cuda", device_index)
-    enc = BertEncoder.load(model_name).to(dev, dtype=torch.float16).eval()
+    enc = BertEncoder.load(model_name, allow_random=allow_random).to(dev, dtype=torch.float16).eval()
     index_path = str(meta_path)[: -len(".meta.json")] if str(meta_path).endswith(".meta.json") else str(meta_path)
-    tok = load_tokenizer(model_name, min(enc.cfg.max_seq_length, enc.cfg.max_pos), index_path, texts, enc.cfg.vocab_size)
+    tok = load_tokenizer(model_name, min(enc.cfg.max_seq_length, enc.cfg.max_pos), index_path, texts, enc.cfg.vocab_size,
+                         allow_stand_in=enc.weights_source == "random")
     tokens = TokenStore.from_lists(tok.encode_batch(texts), device=device_index)
     return Mi355xEmbeddingService(model_name, enc, tokens, tok, distance_metric, dev)
 
@@ -336,7 +339,9 @@ def main(argv=None):
     ap.add_argument("--embedding-mode", type=str, default="sentence-transformers", choices=["sentence-transformers"])
     ap.add_argument("--protocol", type=str, default="hnsw", choices=["hnsw", "diskann"])
     args = ap.parse_args(argv)
-    svc = service_from_meta(args.passages_file, args.model_name, args.distance_metric)
+    # random weights only on explicit request (synthetic corpora): the reference CLI has no such flag, hence the environment
+    svc = service_from_meta(args.passages_file, args.model_name, args.distance_metric,
+                            allow_random=os.environ.get("LEANN_MI355X_ALLOW_RANDOM_WEIGHTS", "0") == "1")
     svc.serve(args.zmq_port, args.protocol)
 
 

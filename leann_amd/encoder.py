@@ -59,12 +59,52 @@ PRESETS = {
 }
 
 
-def config_for(model_name: str) -> EncoderConfig:
+def config_for(model_name: str, strict: bool = False) -> EncoderConfig:
+    """Architecture preset by model name.  ``strict`` (every path that loads REAL weights) raises for a name that
+    matches no preset instead of assuming the MiniLM one: a wrong pooling / normalisation / length cap would
+    silently produce embeddings unrelated to the ones the index was built from."""
     key = (model_name or "").lower()
     for k, v in PRESETS.items():
         if k in key:
             return v
+    if strict:
+        raise ValueError(f"no architecture preset for embedding model {model_name!r}; known: {sorted(PRESETS)}")
     return PRESETS["all-minilm-l6-v2"]
+
+
+def _read_json(path: Path) -> Optional[dict]:
+    import json
+
+    try:
+        with open(path, encoding="utf-8") as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def sentence_transformers_settings(model_dir: Path) -> dict:
+    """Pooling / normalisation / max_seq_length as the checkpoint's own sentence-transformers files state them
+    (modules.json, 1_Pooling/config.json, sentence_bert_config.json) -- what ``SentenceTransformer(...).encode``
+    applies in the reference (embedding_compute.py:229-239 passes normalize_embeddings=False, so normalisation is
+    exactly the presence of a Normalize module).  Keys absent from the result were not stated by the checkpoint."""
+    out: dict = {}
+    mods = _read_json(model_dir / "modules.json")
+    if isinstance(mods, list):
+        types = [str(m.get("type", "")) for m in mods]
+        out["normalize"] = any(t.endswith("Normalize") for t in types)
+        for m in mods:
+            if str(m.get("type", "")).endswith("Pooling"):
+                pc = _read_json(model_dir / m.get("path", "1_Pooling") / "config.json") or {}
+                if pc.get("pooling_mode_cls_token"):
+                    out["pooling"] = "cls"
+                elif pc.get("pooling_mode_mean_tokens"):
+                    out["pooling"] = "mean"
+                elif pc:
+                    raise ValueError(f"unsupported sentence-transformers pooling in {model_dir}: {pc}")
+    sb = _read_json(model_dir / "sentence_bert_config.json")
+    if sb and sb.get("max_seq_length"):
+        out["max_seq_length"] = int(sb["max_seq_length"])
+    return out
 
 
 def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
@@ -110,11 +150,10 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
 
 def fused_embed_layernorm(tok: torch.Tensor, pos: torch.Tensor, word: nn.Embedding, posw: nn.Embedding, type0: torch.Tensor,
                           ln: nn.LayerNorm) -> Optional[torch.Tensor]:
-    """Embedding gathers + adds + LayerNorm in one kernel (csrc/lm_encoder_ops2.hip).  Opt-in (LEANN_MI355X_EMBED=1)
-    until validated on hardware; None = not applicable, the caller takes the torch path."""
+    """Embedding gathers + adds + LayerNorm in one kernel (csrc/lm_encoder_ops2.hip).  Default on (LEANN_MI355X_EMBED=0 = torch path, A/B); None = not applicable, the caller takes the torch path."""
     import os
 
-    if os.environ.get("LEANN_MI355X_EMBED", "0") != "1":
+    if os.environ.get("LEANN_MI355X_EMBED", "1") != "1":
         return None
     h = word.weight.shape[1]
     if not (tok.is_cuda and word.weight.dtype == torch.float16 and h % 8 == 0 and h <= 768):
@@ -135,11 +174,10 @@ def fused_embed_layernorm(tok: torch.Tensor, pos: torch.Tensor, word: nn.Embeddi
 
 def fused_pack_tokens(ids: torch.Tensor, lens: torch.Tensor, cu: torch.Tensor, total: int):
     """Padded ids [n, t] + lengths + cumulative lengths -> (packed token ids, positions), int32 [total], in one kernel
-    (csrc/lm_encoder_ops2.hip) instead of three boolean-mask selects.  Opt-in (LEANN_MI355X_PACK=1) until validated on
-    hardware; None = the caller takes the torch path."""
+    (csrc/lm_encoder_ops2.hip) instead of three boolean-mask selects.  Default on (LEANN_MI355X_PACK=0 = torch path, A/B); None = the caller takes the torch path."""
     import os
 
-    if os.environ.get("LEANN_MI355X_PACK", "0") != "1":
+    if os.environ.get("LEANN_MI355X_PACK", "1") != "1":
         return None
     if not (ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous() and lens.dtype == torch.int32 and cu.dtype == torch.int32):
         return None
@@ -157,11 +195,11 @@ def fused_pack_tokens(ids: torch.Tensor, lens: torch.Tensor, cu: torch.Tensor, t
 
 
 def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool) -> Optional[torch.Tensor]:
-    """Segmented mean (+ L2 normalise) over packed sequences (csrc/lm_encoder_ops2.hip), fp32 [n, H].  Opt-in
-    (LEANN_MI355X_POOL=1) until validated on hardware; None = the caller takes the torch path."""
+    """Segmented mean (+ L2 normalise) over packed sequences (csrc/lm_encoder_ops2.hip), fp32 [n, H].  Default on
+    (LEANN_MI355X_POOL=0 = torch path, A/B); None = the caller takes the torch path."""
     import os
 
-    if os.environ.get("LEANN_MI355X_POOL", "0") != "1":
+    if os.environ.get("LEANN_MI355X_POOL", "1") != "1":
         return None
     h = x.shape[1]
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and h % 8 == 0 and h <= 2048):
@@ -196,10 +234,10 @@ def pack_w2_fused_mlp(w2: torch.Tensor) -> torch.Tensor:
 
 def fused_mlp(x: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
     """LayerNorm(x + fc2(GELU(fc1(x)))) in one kernel (csrc/lm_mlp_fused.hip) for hidden 384, fp16 on the GPU.
-    Opt-in (LEANN_MI355X_MLP=1) until validated on hardware; None = the caller takes the default path."""
+    Default on (LEANN_MI355X_MLP=0 = library GEMM path, A/B); None = the caller takes the default path."""
     import os
 
-    if os.environ.get("LEANN_MI355X_MLP", "0") != "1":
+    if os.environ.get("LEANN_MI355X_MLP", "1") != "1":
         return None
     f, h = layer.fc1.weight.shape
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and h == 384 and f % 32 == 0 and f <= 13056):
@@ -306,6 +344,8 @@ class _Layer(nn.Module):
 class BertEncoder(nn.Module):
     """BERT encoder + sentence pooling.  ``forward(input_ids[n,T], lengths[n]) -> [n, hidden] fp32``."""
 
+    weights_source = "unset"  # "checkpoint" | "random": which tokenizers are admissible (tokenizer.load_tokenizer)
+
     def __init__(self, cfg: EncoderConfig):
         super().__init__()
         self.cfg = cfg
@@ -331,6 +371,7 @@ class BertEncoder(nn.Module):
                 elif isinstance(mod, nn.LayerNorm):
                     mod.weight.fill_(1.0)
                     mod.bias.zero_()
+        m.weights_source = "random"
         return m.eval()
 
     @classmethod
@@ -358,25 +399,54 @@ class BertEncoder(nn.Module):
                 L.fc2.bias.copy_(sd[p + "output.dense.bias"])
                 L.ln2.weight.copy_(sd[p + "output.LayerNorm.weight"])
                 L.ln2.bias.copy_(sd[p + "output.LayerNorm.bias"])
+        m.weights_source = "checkpoint"
         return m.eval()
 
     @classmethod
-    def load(cls, model_name: str, seed: int = 0) -> "BertEncoder":
-        """Local Hugging Face checkpoint if ``model_name`` is a directory (or in the offline HF
-        cache); otherwise seeded random weights of the preset architecture."""
-        cfg = config_for(model_name)
+    def load(cls, model_name: str, seed: int = 0, allow_random: bool = False) -> "BertEncoder":
+        """Weights of a local Hugging Face BERT checkpoint (``model_name`` = a directory, or a hub id present in the
+        offline HF cache).  Pooling / normalisation / max_seq_length come from the checkpoint's own
+        sentence-transformers files when it has them, else from the name preset (strict: unknown names raise).
+
+        No silent fallback: a checkpoint that cannot be loaded, or one that is not a plain BERT (``model_type !=
+        "bert"``: MPNet, XLM-R ... have different state dicts), raises.  ``allow_random=True`` -- tests, the synthetic
+        benchmark, kernel autotuning: anything that measures throughput or compares the GPU path with itself --
+        instead returns seeded random weights of the preset architecture when no checkpoint is available."""
+        import logging
+
+        log = logging.getLogger(__name__)
         try:
             from transformers import AutoConfig, AutoModel
 
-            path = model_name if Path(model_name).is_dir() else model_name
-            hc = AutoConfig.from_pretrained(path, local_files_only=True)
-            hf = AutoModel.from_pretrained(path, local_files_only=True)
-            cfg = replace(cfg, vocab_size=hc.vocab_size, hidden=hc.hidden_size, layers=hc.num_hidden_layers,
-                          heads=hc.num_attention_heads, ffn=hc.intermediate_size, max_pos=hc.max_position_embeddings,
-                          type_vocab=hc.type_vocab_size, ln_eps=hc.layer_norm_eps)
-            return cls.from_hf_state_dict(cfg, hf.state_dict())
-        except Exception:  # noqa: BLE001 - offline: no checkpoint available
-            return cls.random_init(cfg, seed)
+            hc = AutoConfig.from_pretrained(model_name, local_files_only=True)
+        except Exception as ex:  # noqa: BLE001 - not in the offline cache / not a checkpoint directory
+            if allow_random:
+                log.warning(f"embedding model {model_name!r}: no local checkpoint ({type(ex).__name__}); "
+                            "using SEEDED RANDOM weights of the preset architecture (allow_random=True)")
+                return cls.random_init(config_for(model_name), seed)
+            raise RuntimeError(
+                f"embedding model {model_name!r} is not available locally ({type(ex).__name__}: {ex}). Recompute search needs the "
+                "weights the index was built with; pass a checkpoint directory, or allow_random=True for synthetic runs.") from ex
+        if getattr(hc, "model_type", None) != "bert":
+            raise RuntimeError(f"embedding model {model_name!r} has model_type={getattr(hc, 'model_type', None)!r}; only BERT-architecture "
+                               "checkpoints (all-MiniLM, bge, contriever ...) are supported by the MI355X encoder")
+        hf = AutoModel.from_pretrained(model_name, local_files_only=True)
+        mdir = Path(model_name) if Path(model_name).is_dir() else Path(getattr(hf, "name_or_path", "") or "")
+        st = sentence_transformers_settings(mdir) if mdir.is_dir() else {}
+        if not {"pooling", "normalize"} <= set(st):  # hub-cache snapshot without the ST files: fall back to the name preset
+            try:
+                from huggingface_hub import snapshot_download
+
+                st = {**sentence_transformers_settings(Path(snapshot_download(model_name, local_files_only=True))), **st}
+            except Exception:  # noqa: BLE001
+                pass
+        base = config_for(model_name, strict=not {"pooling", "normalize"} <= set(st))
+        cfg = replace(base, vocab_size=hc.vocab_size, hidden=hc.hidden_size, layers=hc.num_hidden_layers,
+                      heads=hc.num_attention_heads, ffn=hc.intermediate_size, max_pos=hc.max_position_embeddings,
+                      type_vocab=hc.type_vocab_size, ln_eps=hc.layer_norm_eps, **st)
+        log.info(f"embedding model {model_name!r}: loaded checkpoint weights (pooling={cfg.pooling}, normalize={cfg.normalize}, "
+                 f"max_seq_length={cfg.max_seq_length})")
+        return cls.from_hf_state_dict(cfg, hf.state_dict())
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, input_ids: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
@@ -450,7 +520,7 @@ class BertEncoder(nn.Module):
         ar = torch.arange(t, device=input_ids.device)
         import os
 
-        pack_on = os.environ.get("LEANN_MI355X_PACK", "0") == "1"  # packed front end in one kernel (fused_pack_tokens)
+        pack_on = os.environ.get("LEANN_MI355X_PACK", "1") == "1"  # packed front end in one kernel (fused_pack_tokens)
         cs_np = cs.numpy()
         lens_np = cs_np - np.concatenate(([0], cs_np[:-1]))  # host copy of the lengths: no further syncs below
         for b0, b1 in zip(bounds[:-1], bounds[1:]):

@@ -63,6 +63,6 @@ class RecomputeProvider:
         """Embeddings of the given node ids (device int32 tensor) -> fp32 [n, D] (new tensor)."""
         n = ids.shape[0]
         self._ensure(n)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream(self.device).cuda_stream
         self.tokens.gather(ids.data_ptr(), n, self.T, self.encoder.cfg.pad_id, self._ids[:n], self._lens[:n], stream)
         return self.encoder.encode_tokens(self._ids[:n], self._lens[:n], batch_size=self.batch_size, bucket=self.bucket)

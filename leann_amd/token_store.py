@@ -18,6 +18,9 @@ class TokenStore:
     def __init__(self, tokens: np.ndarray, offsets: np.ndarray, device: int = 0):
         """``tokens``: u16[total] packed token ids; ``offsets``: u64[n+1]."""
         self._lib = _lib.load()
+        tokens = np.asarray(tokens)
+        if tokens.dtype != np.uint16 and tokens.size and (int(tokens.max()) > 0xFFFF or int(tokens.min()) < 0):
+            raise ValueError(f"token id {int(tokens.max())} does not fit the u16 token store (vocabularies up to 65536 entries)")
         tok = np.ascontiguousarray(tokens, dtype=np.uint16)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         if off.ndim != 1 or off.shape[0] < 1 or int(off[-1]) != tok.shape[0]:
@@ -33,7 +36,7 @@ class TokenStore:
         lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
         off = np.zeros(len(seqs) + 1, np.uint64)
         off[1:] = np.cumsum(lens)
-        tok = np.fromiter((t for s in seqs for t in s), dtype=np.uint16, count=int(off[-1]))
+        tok = np.fromiter((t for s in seqs for t in s), dtype=np.int64, count=int(off[-1]))  # range-checked in __init__
         return cls(tok, off, device)
 
     def gather(self, d_ids_ptr: int, n: int, T: int, pad_id: int, out_ids, out_len, stream_ptr: int = 0) -> None:

@@ -30,7 +30,7 @@ from leann_amd.token_store import TokenStore
 corpus = SyntheticCorpus(CorpusSpec(n_chunks=args.n, seed=1234))
 tok, off = corpus.chunks()
 tokens = TokenStore(tok, off)
-enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2").to(dev, dtype=torch.float16).eval()
+enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2", allow_random=True).to(dev, dtype=torch.float16).eval()
 provider = RecomputeProvider(enc, tokens, 384, dev)
 X = torch.empty((args.n, 384), dtype=torch.float32, device=dev)
 for b0 in range(0, args.n, 32768):

@@ -13,7 +13,6 @@ os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_next: opt-in kernels awaiting their first run on an MI355X (tests/test_gpu_next.py)")
 
 
 @pytest.fixture(scope="session")

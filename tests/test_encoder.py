@@ -62,7 +62,7 @@ def test_flops_formula_matches_survey():
 
 
 def test_load_falls_back_to_seeded_weights_offline():
-    enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2")
+    enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2", allow_random=True)
     ref = BertEncoder.random_init(PRESETS["all-minilm-l6-v2"], seed=0)
     if not all(torch.equal(v, ref.state_dict()[k]) for k, v in enc.state_dict().items()):
         pytest.skip("a real checkpoint is available locally")
@@ -70,3 +70,94 @@ def test_load_falls_back_to_seeded_weights_offline():
     with torch.no_grad():
         e = enc(ids, torch.tensor([20, 5, 11]))
     assert e.shape == (3, 384) and np.allclose(e.norm(dim=1).numpy(), 1.0, atol=1e-5)
+
+
+def test_load_without_checkpoint_raises_unless_random_is_allowed():
+    """no silent random weights in the production path."""
+    with pytest.raises(RuntimeError, match="not available locally"):
+        BertEncoder.load("sentence-transformers/definitely-not-a-cached-model")
+    enc = BertEncoder.load("sentence-transformers/definitely-not-a-cached-model", allow_random=True)
+    assert enc.weights_source == "random"
+    with pytest.raises(ValueError, match="no architecture preset"):
+        config_for("some/unknown-model", strict=True)
+
+
+def _save_tiny_checkpoint(tmp_path, model_type="bert", pooling="cls", normalize=False, max_seq_length=77):
+    import json
+
+    import transformers
+
+    if model_type == "bert":
+        hc = transformers.BertConfig(vocab_size=120, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                                     max_position_embeddings=96)
+        hf = transformers.BertModel(hc, add_pooling_layer=False)
+    else:
+        hc = transformers.MPNetConfig(vocab_size=120, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                                      max_position_embeddings=96)
+        hf = transformers.MPNetModel(hc, add_pooling_layer=False)
+    d = tmp_path / f"ckpt_{model_type}_{pooling}"
+    hf.save_pretrained(d)
+    mods = [{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+            {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]
+    if normalize:
+        mods.append({"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"})
+    (d / "modules.json").write_text(json.dumps(mods))
+    (d / "1_Pooling").mkdir()
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({"word_embedding_dimension": 32, "pooling_mode_cls_token": pooling == "cls",
+                                                               "pooling_mode_mean_tokens": pooling == "mean"}))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": max_seq_length, "do_lower_case": True}))
+    (d / "vocab.txt").write_text("\n".join(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"w{i}" for i in range(115)]) + "\n")
+    return d, hf
+
+
+def test_load_reads_pooling_and_length_from_the_checkpoints_sentence_transformers_files(tmp_path):
+    """pooling / normalize / max_seq_length come from the checkpoint, not from a name match --
+    this directory name matches no preset at all."""
+    d, hf = _save_tiny_checkpoint(tmp_path, pooling="cls", normalize=False, max_seq_length=77)
+    enc = BertEncoder.load(str(d))
+    assert enc.weights_source == "checkpoint"
+    assert (enc.cfg.pooling, enc.cfg.normalize, enc.cfg.max_seq_length, enc.cfg.hidden, enc.cfg.vocab_size) == ("cls", False, 77, 32, 120)
+    ids = torch.randint(5, 120, (4, 12), dtype=torch.int32)
+    lens = torch.tensor([12, 3, 7, 1])
+    with torch.no_grad():
+        got = enc(ids, lens)
+    ref = hf_reference_embed(hf.eval(), ids, lens, "cls", False)
+    assert (got - ref).abs().max() < 1e-5
+    d2, _ = _save_tiny_checkpoint(tmp_path, pooling="mean", normalize=True)
+    e2 = BertEncoder.load(str(d2))
+    assert (e2.cfg.pooling, e2.cfg.normalize) == ("mean", True)
+
+
+def test_load_rejects_non_bert_architectures(tmp_path):
+    """all-mpnet-base-v2 (the reference server's default --model-name) is an MPNetModel: different state dict."""
+    d, _ = _save_tiny_checkpoint(tmp_path, model_type="mpnet", pooling="mean")
+    with pytest.raises(RuntimeError, match="model_type='mpnet'"):
+        BertEncoder.load(str(d))
+    with pytest.raises(RuntimeError, match="model_type='mpnet'"):
+        BertEncoder.load(str(d), allow_random=True)  # a present-but-unsupported checkpoint never degrades to random weights
+
+
+def test_tokenizer_comes_from_the_checkpoint_vocabulary_or_raises(tmp_path):
+    """vocab.txt-only checkpoints get a real WordPiece pipeline; a stand-in vocabulary is only
+    admissible with random weights; a vocabulary larger than the embedding table is rejected."""
+    from leann_amd.tokenizer import load_tokenizer
+
+    d, _ = _save_tiny_checkpoint(tmp_path)
+    t = load_tokenizer(str(d), 16, None, None, vocab_size=120)
+    assert t.kind == "hf-local-vocab" and t.vocab_size == 120
+    assert t.encode_batch(["w3 w4 zzz"])[0] == [2, 8, 9, 1, 3]  # [CLS] w3 w4 [UNK] [SEP]
+    with pytest.raises(ValueError, match="embedding table"):
+        load_tokenizer(str(d), 16, None, None, vocab_size=100)
+    with pytest.raises(FileNotFoundError, match="stand-in"):
+        load_tokenizer("sentence-transformers/definitely-not-a-cached-model", 16, str(tmp_path / "i.leann"), ["a b c"], 30522)
+    s = load_tokenizer("sentence-transformers/definitely-not-a-cached-model", 16, str(tmp_path / "i.leann"), ["a b c", "c d"], 30522,
+                       allow_stand_in=True)
+    assert s.kind == "stand-in-trained"
+
+
+def test_token_store_rejects_ids_beyond_u16():
+    """multilingual vocabularies (119k) must not wrap silently."""
+    from leann_amd.token_store import TokenStore
+
+    with pytest.raises(ValueError, match="u16 token store"):
+        TokenStore.from_lists([[101, 70000, 102]])

@@ -1,10 +1,8 @@
-"""Kernels that are written and cross-compiled but NOT yet validated on an MI355X: they are opt-in in the product
-(environment switches) and their tests carry the ``gpu_next`` marker, which neither ``-m gpu`` nor a CPU run
-executes (no GPU -> skipped).  First thing to do with GPU time:
-
-    python -m pytest tests/test_gpu_next.py -m gpu_next -x -q && python scripts/attn_bench.py
-
-Once a kernel passes and wins, flip its default and move the test into test_gpu_pipeline.py."""
+"""The hand-written encoder kernels the DEFAULT path runs (attention revision 2, fused feed-forward block, 16-lane
+LayerNorm, segmented mean pooling, fused embedding / packing front ends) and the remaining opt-in one (hidden-384
+linear), each against a plain PyTorch fp32 reference of the same op and against the first-generation / library path
+that the ``LEANN_MI355X_*`` switches still select for A/B.  Part of ``pytest -m gpu``: the benchmarked path is the
+tested path."""
 import pytest
 
 
@@ -17,7 +15,11 @@ def _has_gpu() -> bool:
         return False
 
 
-pytestmark = [pytest.mark.gpu_next, pytest.mark.skipif(not _has_gpu(), reason="needs an MI355X")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _has_gpu(), reason="needs an MI355X")]
+
+# the first-generation encoder path (library GEMMs, torch attention / pooling / packing): the A/B baseline
+FIRST_GENERATION = {"LEANN_MI355X_ATTN": "0", "LEANN_MI355X_LN": "1", "LEANN_MI355X_POOL": "0", "LEANN_MI355X_EMBED": "0",
+                    "LEANN_MI355X_PACK": "0", "LEANN_MI355X_MLP": "0", "LEANN_MI355X_LINEAR": "0"}
 
 
 def _attention_case(torch, heads, maxlen, nseq=37):
@@ -149,8 +151,9 @@ def test_embed_layernorm_matches_torch_path(monkeypatch):
     assert (got.float() - ref.float()).abs().max().item() <= 2e-3
 
 
-def test_encoder_forward_with_every_opt_in_kernel(monkeypatch):
-    """Whole packed forward with all opt-in kernels vs the torch-attention / default-kernel forward."""
+def test_encoder_forward_default_and_every_kernel_vs_first_generation(monkeypatch):
+    """Whole packed forward: the default kernel set, and every hand-written kernel switched on, vs the first-generation
+    (library GEMM / torch attention) forward."""
     import torch
 
     from leann_amd.encoder import BertEncoder, config_for
@@ -159,8 +162,13 @@ def test_encoder_forward_with_every_opt_in_kernel(monkeypatch):
     enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
     ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=300, n_topics=4)).chunks(), 256)
     ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
-    monkeypatch.setenv("LEANN_MI355X_ATTN", "0")
+    for k, v in FIRST_GENERATION.items():
+        monkeypatch.setenv(k, v)
     b = enc.encode_tokens_packed(ti, tl)
+    for k in FIRST_GENERATION:
+        monkeypatch.delenv(k)
+    d = enc.encode_tokens_packed(ti, tl)  # the default path = what bench.py and the searchers run
+    assert (d - b).abs().max() < 3e-3
     for k, v in (("LEANN_MI355X_ATTN", "2"), ("LEANN_MI355X_LN", "2"), ("LEANN_MI355X_POOL", "1"), ("LEANN_MI355X_EMBED", "1"),
                  ("LEANN_MI355X_MLP", "1"), ("LEANN_MI355X_MLP_VARIANT", "2"), ("LEANN_MI355X_LINEAR", "1")):
         monkeypatch.setenv(k, v)

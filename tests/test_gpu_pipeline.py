@@ -167,8 +167,8 @@ def test_backend_plugin_end_to_end(torch_, tmp_path):
     from leann_amd.tokenizer import load_tokenizer
 
     model = "sentence-transformers/all-MiniLM-L6-v2"
-    enc = BertEncoder.load(model).to("cuda", dtype=torch.float16)
-    tok = load_tokenizer(model, 256, index_path, texts, enc.cfg.vocab_size)
+    enc = BertEncoder.load(model, allow_random=True).to("cuda", dtype=torch.float16)
+    tok = load_tokenizer(model, 256, index_path, texts, enc.cfg.vocab_size, allow_stand_in=enc.weights_source == "random")
     seqs = tok.encode_batch(texts)
     T = max(len(s) for s in seqs)
     ids = torch.zeros((len(seqs), T), dtype=torch.int32)
@@ -180,7 +180,7 @@ def test_backend_plugin_end_to_end(torch_, tmp_path):
     meta = json.loads(Path(index_path + ".meta.json").read_text())
     assert meta["backend_name"] == "mi355x" and meta["is_pruned"] is True
 
-    s = factory.searcher(index_path)
+    s = factory.searcher(index_path, allow_random_weights=True)  # the bundle was built with the seeded random encoder
     with pytest.raises(ValueError):
         s.search(emb[:1], 3, recompute_embeddings=True, zmq_port=None)
     with pytest.raises(RuntimeError):
@@ -347,8 +347,8 @@ def test_backend_no_recompute_mode_and_hub_cache_kwarg(torch_, tmp_path):
 
     model = "sentence-transformers/all-MiniLM-L6-v2"
     p2 = str(tmp_path / "pruned.leann")
-    enc = BertEncoder.load(model).to("cuda", dtype=torch.float16)
-    tok = load_tokenizer(model, 256, p2, texts, enc.cfg.vocab_size)
+    enc = BertEncoder.load(model, allow_random=True).to("cuda", dtype=torch.float16)
+    tok = load_tokenizer(model, 256, p2, texts, enc.cfg.vocab_size, allow_stand_in=enc.weights_source == "random")
     seqs = tok.encode_batch(texts)
     T = max(len(q) for q in seqs)
     ids = torch.zeros((len(seqs), T), dtype=torch.int32)
@@ -356,8 +356,8 @@ def test_backend_no_recompute_mode_and_hub_cache_kwarg(torch_, tmp_path):
         ids[i, : len(q)] = torch.tensor(q, dtype=torch.int32)
     emb = enc.encode_tokens(ids.cuda(), torch.tensor([len(q) for q in seqs], dtype=torch.int32).cuda()).cpu().numpy()
     write_leann_bundle(p2, texts, emb, model, distance_metric="mips", M=8, efConstruction=40)
-    plain = BACKEND_REGISTRY["mi355x"].searcher(p2)
-    cached = BACKEND_REGISTRY["mi355x"].searcher(p2, hub_cache_ratio=0.2)
+    plain = BACKEND_REGISTRY["mi355x"].searcher(p2, allow_random_weights=True)
+    cached = BACKEND_REGISTRY["mi355x"].searcher(p2, hub_cache_ratio=0.2, allow_random_weights=True)
     ra = plain.search(emb[:6], 4, complexity=32, recompute_embeddings=True, zmq_port=5557)
     rb = cached.search(emb[:6], 4, complexity=32, recompute_embeddings=True, zmq_port=5557)
     assert ra["labels"] == rb["labels"] and np.allclose(ra["distances"], rb["distances"], atol=2e-3)
