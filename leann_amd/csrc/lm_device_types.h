@@ -23,7 +23,8 @@ struct GraphDev {
 };
 
 struct WsDev {
-    int32_t B, ef, W, maxnew;
+    int32_t B, ef, W, maxnew;  // ef = pool capacity max(efSearch, k)
+    int32_t efs;               // the caller's efSearch: what both faiss stop rules count against (lm_beam_common.h: select_pops)
     int64_t nw;  // visited words per query
     int32_t* phase;
     int32_t* level;
@@ -50,15 +51,10 @@ struct WsDev {
     // per-call embedding memo (recompute_memo): every node is recomputed at most once per search call
     int32_t* memo_slot;   // N : row in `memo` or -1
     float* memo;          // memo_cap x Dp
-    // flat (query,node) pair list of the round (split variant): segments allocated by atomicAdd
-    int32_t* seg_start;   // B
-    int32_t* pair_q;      // B x maxnew
-    int32_t* pair_v;      // B x maxnew
-    uint64_t* pair_key;   // B x maxnew
     // counters: [0]=live queries this round [1]=n_uniq [2..] stats
     unsigned long long* counters;
 };
-enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NPAIRS = 5, C_NADC = 6, C_NCOUNTERS = 8 };
+enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_NADC = 6, C_NCOUNTERS = 8 };
 
 constexpr int UNIQ_TILE = 4096;  // words per block in the uniq scan
 constexpr int AQ_CAP = 512;       // capacity of the approximate queue (== ORC_AQ_CAP in oracle/lm_oracle.c)

@@ -32,7 +32,7 @@ __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32
 // one wave (64 lanes) per query.  Level-0 expansion is FLATTENED over (pop, neighbour) so that the
 // dependent chain is pop -> l0 range -> neighbour ids -> visited atomic, once per 64 neighbours
 // instead of once per popped node.  Dynamic LDS: maxnew ints (staging of the new-list).
-__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int flat, int defer) {
+__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int defer) {
     // defer != 0: the two-level pruning kernel (k_prune) finishes the new-list: it marks the dedup bitmap and counts
     extern __shared__ int32_t s_new[];
     __shared__ uint32_t s_off[65];
@@ -99,23 +99,13 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
     }
     __syncthreads();
     int32_t* newid = ws.newid + (size_t)q * ws.maxnew;
-    int start = 0;
-    if (flat) {
-        if (lane == 0) start = (int)atomicAdd(&ws.counters[C_NPAIRS], (unsigned long long)total);
-        start = __shfl(start, 0);
-    }
     for (int i = lane; i < total; i += 64) {
         const int32_t v = s_new[i];
         newid[i] = v;
         if (!defer && (use_rbm == 1 || (use_rbm == 2 && ws.memo_slot[v] < 0))) atomicOr(&ws.rbm[v >> 5], 1u << (v & 31));
-        if (flat) {
-            ws.pair_q[start + i] = q;
-            ws.pair_v[start + i] = v;
-        }
     }
     if (lane == 0) {
         ws.nnew[q] = total;
-        if (flat) ws.seg_start[q] = start;
         if (!defer) ws.ndis_q[q] += (unsigned long long)total;
         // plain stores of identical values (benign): a contended same-address atomic costs ~12 ns per
         // workgroup and serialises the launch tail (MI355X_MICROARCH.md, price list row "fanin")

@@ -36,11 +36,7 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lane16 = tid & 15, sg = tid >> 4;
     float4 qv[NCH];
-    {
-        const float4* qrow = (const float4*)(a.Q + (size_t)q * (NCH * 64));
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
-    }
+    load_query<NCH>(a.Q, q, lane16, qv);
     uint32_t* vis = ws.visited + (size_t)q * ws.nw;
     unsigned long long ndis = 0;
     int rounds = 0, nsteps = 0;
@@ -90,8 +86,7 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
         const uint64_t best = s_best;
         ndis += cnt;
         rounds++;
-        if (best != KEY_NONE && best < cur) cur = best;
-        else level--;
+        descent_step(PH_UPPER, best, a.max_level, cur, level);
         __syncthreads();
     }
     // ---- level 0 ----
@@ -104,21 +99,7 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
     __syncthreads();
     for (;;) {
         if (tid < 64) {
-            int allowed = ws.W;
-            if (!a.check_rel) allowed = min(allowed, max(0, ef + 1 - nsteps));
-            int found = 0;
-            for (int base = 0; base < npool && found < allowed; base += 64) {
-                int i = base + tid;
-                bool un = i < npool && !(lpool[i] & KEY_EXPANDED);
-                unsigned long long m = __ballot(un);
-                int r = found + __popcll(m & ((1ull << tid) - 1ull));
-                if (un && r < allowed) {
-                    lpool[i] |= KEY_EXPANDED;
-                    s_pop[r] = key_id(lpool[i]);
-                }
-                found += __popcll(m);
-            }
-            found = min(found, allowed);
+            const int found = select_pops(lpool, npool, ws.W, a.check_rel, ws.efs, nsteps, s_pop, tid);
             LM_WAVE_SYNC();  // s_pop[r] written by the popping lanes, read below by lane r
             uint32_t cnt = 0;
             if (tid < found) {
@@ -177,45 +158,8 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
         for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
         __syncthreads();
         if (n > 0) {
-            for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
-                for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
-                    for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
-                        unsigned ixj = i ^ j;
-                        if (ixj > i) {
-                            uint64_t x = newk[i], y = newk[ixj];
-                            bool up = (i & k2) == 0;
-                            if ((x > y) == up) {
-                                newk[i] = y;
-                                newk[ixj] = x;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-            for (int i = tid; i < npool; i += 256) {
-                uint64_t key = lpool[i];
-                uint64_t kk = key >> 1;
-                int lo = 0, hi = n;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if ((newk[mid] >> 1) < kk) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (i + lo < ef) outp[i + lo] = key;
-            }
-            for (int j = tid; j < n; j += 256) {
-                uint64_t key = newk[j];
-                uint64_t kk = key >> 1;
-                int lo = 0, hi = npool;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if ((lpool[mid] >> 1) < kk) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (j + lo < ef) outp[j + lo] = key;
-            }
-            __syncthreads();
+            sort_keys<256>(newk, Pn, tid);
+            rank_merge<256>(lpool, npool, newk, n, outp, ef, tid);
             npool = min(ef, npool + n);
             for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
             __syncthreads();

@@ -89,21 +89,7 @@ __global__ __launch_bounds__(256) void k_prune(WsDev ws, PruneArgs a) {
         for (int i = tid; i < naq0; i += 256) aq[i] = gaq[i];
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1)
-        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
-            for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
-                unsigned ixj = i ^ j;
-                if (ixj > i) {
-                    uint64_t x = nk[i], y = nk[ixj];
-                    bool up = (i & k2) == 0;
-                    if ((x > y) == up) {
-                        nk[i] = y;
-                        nk[ixj] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    sort_keys<256>(nk, Pn, tid);
     const int quota = (int)ceilf(a.keep * (float)n);
     int nsel = 0;
     if (a.strategy == 1) {  // local: the best of this hop

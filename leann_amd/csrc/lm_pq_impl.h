@@ -92,19 +92,8 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
     for (;;) {
         // ---- pops: the W smallest unexpanded (wave 0) ----
         if (tid < 64) {
-            int found = 0;
-            for (int base = 0; base < npool && found < a.W; base += 64) {
-                int i = base + tid;
-                bool un = i < npool && !(lpool[i] & KEY_EXPANDED);
-                unsigned long long m = __ballot(un);
-                int r = found + __popcll(m & ((1ull << tid) - 1ull));
-                if (un && r < a.W) {
-                    lpool[i] |= KEY_EXPANDED;
-                    s_pop[r] = key_id(lpool[i]);
-                }
-                found += __popcll(m);
-            }
-            found = min(found, a.W);
+            // DiskANN's rule: the W closest unexpanded entries of the L-list, until none is left (no step cap)
+            const int found = select_pops(lpool, npool, a.W, 1, a.L, 0, s_pop, tid);
             LM_WAVE_SYNC();  // s_pop[r] written by the popping lanes, read below by lane r
             // neighbour ranges of the pops + inclusive scan of their degrees
             uint32_t cnt = 0;
@@ -176,45 +165,8 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
         }
         __syncthreads();
         if (n > 0) {
-            for (unsigned k2 = 2; k2 <= (unsigned)Pn; k2 <<= 1) {
-                for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
-                    for (unsigned i = tid; i < (unsigned)Pn; i += 256) {
-                        unsigned ixj = i ^ j;
-                        if (ixj > i) {
-                            uint64_t x = newk[i], y = newk[ixj];
-                            bool up = (i & k2) == 0;
-                            if ((x > y) == up) {
-                                newk[i] = y;
-                                newk[ixj] = x;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-            for (int i = tid; i < npool; i += 256) {
-                uint64_t key = lpool[i];
-                uint64_t kk = key >> 1;
-                int lo = 0, hi = n;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if ((newk[mid] >> 1) < kk) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (i + lo < a.L) outp[i + lo] = key;
-            }
-            for (int j = tid; j < n; j += 256) {
-                uint64_t key = newk[j];
-                uint64_t kk = key >> 1;
-                int lo = 0, hi = npool;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if ((lpool[mid] >> 1) < kk) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (j + lo < a.L) outp[j + lo] = key;
-            }
-            __syncthreads();
+            sort_keys<256>(newk, Pn, tid);
+            rank_merge<256>(lpool, npool, newk, n, outp, a.L, tid);
             npool = min(a.L, npool + n);
             for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
             __syncthreads();
@@ -253,11 +205,7 @@ __global__ __launch_bounds__(256) void k_pq_rerank(WsDev ws, UpdateArgs a) {
     for (int i = n + tid; i < a.P2; i += 256) keys[i] = KEY_NONE;
     const int lane16 = tid & 15, sg = tid >> 4;
     float4 qv[NCH];
-    {
-        const float4* qrow = (const float4*)(a.Q + (size_t)q * (NCH * 64));
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) qv[i] = qrow[lane16 + 16 * i];
-    }
+    load_query<NCH>(a.Q, q, lane16, qv);
     for (int i = sg; i < n; i += 32) {
         const int i2 = i + 16;
         const bool has2 = i2 < n;
@@ -279,21 +227,7 @@ __global__ __launch_bounds__(256) void k_pq_rerank(WsDev ws, UpdateArgs a) {
         }
     }
     __syncthreads();
-    for (unsigned k2 = 2; k2 <= (unsigned)a.P2; k2 <<= 1)
-        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
-            for (unsigned i = tid; i < (unsigned)a.P2; i += 256) {
-                unsigned ixj = i ^ j;
-                if (ixj > i) {
-                    uint64_t x = keys[i], y = keys[ixj];
-                    bool up = (i & k2) == 0;
-                    if ((x > y) == up) {
-                        keys[i] = y;
-                        keys[ixj] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    sort_keys<256>(keys, a.P2, tid);
     for (int i = tid; i < n; i += 256) pool[i] = keys[i];
 }
 

@@ -8,7 +8,6 @@
 //   k_update<NCH,L2,F16,MODE,NT>    fused gather + distance + beam update, one workgroup (or wave) per query:
 //                 query slice in registers, 16-lane row dot products with the canonical reduction (bit-exact with
 //                 oracle/lm_oracle.c:orc_dist), new keys sorted + rank-merged into the ef-pool in LDS, next pops
-//   k_update_sort / k_dist_flat + k_merge   A/B variants (full bitonic sort; split distance / merge kernels)
 //   k_memo_append per-call embedding memo (recompute_memo)
 //   k_search_table persistent stored-embedding search: a query's whole traversal in one workgroup, one launch/batch
 //   lm_pq_impl.h  DiskANN-style path: k_pq_traverse (persistent PQ-ADC traversal), k_pq_rerank
@@ -31,6 +30,7 @@ void set_error(const std::string& msg) { g_err = msg; }
 }  // namespace lm
 
 #include "lm_device_types.h"
+#include "lm_beam_common.h"
 #include "lm_kernels_expand.h"
 #include "lm_kernels_prune.h"
 #include "lm_kernels_update.h"
@@ -90,7 +90,7 @@ struct lm_index {
     // stats / profiling
     lm_search_stats stats{};
     bool profiling = false;
-    int update_variant = 0;  // 0: auto (fused), 1: fused + full bitonic sort, 2: split, 3: fused wave-per-query, 4: fused workgroup-per-query
+    int update_variant = 0;  // 0: auto, 3: wave (64 lanes) per query, 4: workgroup (256 threads) per query   (1, 2: removed A/B forms)
     int persistent_table = 1;  // stored-embedding mode: one persistent launch per batch (0: lock-step rounds, for A/B)
     int wave_maxnew = 0;     // auto rule threshold on beam x mean level-0 degree; 0 = never: on the 1M-chunk HNSW graph
                              // (max degree 64, mean 9.3) the workgroup form is 1.5x faster (profiles/r1_bench_default_1M_b2048.json
@@ -139,7 +139,6 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune 
     A(tile_sum, std::max(ntiles, 1));
     ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * std::max(maxnew, ef));
     A(uniq, ix->ws_ucap);
-    A(seg_start, B); A(pair_q, (size_t)B * maxnew); A(pair_v, (size_t)B * maxnew); A(pair_key, (size_t)B * maxnew);
     A(counters, C_NCOUNTERS);
 #undef A
     LM_HIP(hipMemsetAsync(w.rbm, 0, w.nw * 4, ix->stream));
@@ -198,32 +197,16 @@ static int next_pow2(int x) {
 template <bool L2, bool F16>
 static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
     dim3 grid(ix->ws.B), block(256);
-    const bool sortv = ix->update_variant == 1;
     // one 64-lane wave per query when the per-round new-list is short (low degree x beam): keeps all 16-lane
     // groups busy and quadruples the queries resident per CU; variant 3 forces it, variant 4 forbids it
     // measured (profiles/r1_kernel_ab_wave_vs_wg.txt): the wave form wins only with >= 4096 queries in flight and
     // <= ~48 expected new nodes per query per round (beam x mean level-0 degree)
     const bool wave = ix->update_variant == 3 ||
                       (ix->update_variant == 0 && ix->ws.B >= 4096 && ix->ws.W * ix->avg_degree0 <= (double)ix->wave_maxnew);
-    if (ix->update_variant == 2) {
-        // split: flat distance kernel (grid-stride over the pair list) + one-wave-per-query merge
-        long cap = (long)ix->ws.B * ix->ws.maxnew;
-        dim3 fg((unsigned)std::max<long>(1, std::min<long>((cap + 31) / 32, 256L * 20)));
-        switch (ix->Dp / 64) {
-#define CASEF(n) case n: hipLaunchKernelGGL((k_dist_flat<n, L2, F16>), fg, block, 0, ix->stream, ix->ws, a); break
-            CASEF(1); CASEF(2); CASEF(3); CASEF(4); CASEF(5); CASEF(6); CASEF(8); CASEF(12); CASEF(16);
-#undef CASEF
-            default: LM_FAIL(LM_EINVAL, "unsupported padded dimension (supported: 64..384, 512, 768, 1024)");
-        }
-        hipLaunchKernelGGL(k_merge, grid, dim3(64), shmem, ix->stream, ix->ws, a);
-        LM_HIP(hipGetLastError());
-        return LM_OK;
-    }
     switch (ix->Dp / 64) {
 #define CASE(n)                                                                                              \
     case n:                                                                                                  \
-        if (sortv) hipLaunchKernelGGL((k_update_sort<n, L2, F16>), grid, block, shmem, ix->stream, ix->ws, a); \
-        else if (a.by_rank == 2) hipLaunchKernelGGL((k_update<n, L2, F16, 2, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
+        if (a.by_rank == 2) hipLaunchKernelGGL((k_update<n, L2, F16, 2, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
         else if (wave && a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, 1, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
         else if (wave) hipLaunchKernelGGL((k_update<n, L2, F16, 0, 64>), grid, dim3(64), shmem, ix->stream, ix->ws, a); \
         else if (a.by_rank) hipLaunchKernelGGL((k_update<n, L2, F16, 1, 256>), grid, block, shmem, ix->stream, ix->ws, a); \
@@ -238,8 +221,7 @@ static int launch_update_nch(lm_index* ix, const UpdateArgs& a, size_t shmem) {
 }
 
 static int launch_update(lm_index* ix, const UpdateArgs& a, bool f16) {
-    size_t shmem = ix->update_variant == 1 ? (size_t)a.P2 * sizeof(uint64_t)
-                                           : (size_t)(2 * ix->ws.ef + next_pow2(ix->ws.maxnew)) * sizeof(uint64_t);
+    size_t shmem = (size_t)(2 * ix->ws.ef + next_pow2(ix->ws.maxnew)) * sizeof(uint64_t);
     bool l2 = ix->metric == LM_METRIC_L2;
     if (l2) return f16 ? launch_update_nch<true, true>(ix, a, shmem) : launch_update_nch<true, false>(ix, a, shmem);
     return f16 ? launch_update_nch<false, true>(ix, a, shmem) : launch_update_nch<false, false>(ix, a, shmem);
@@ -270,6 +252,7 @@ static int search_pass_persistent(lm_index* ix, int32_t B, const float* d_q, int
     int rc = ensure_ws(ix, B, ef, W);
     if (rc) return rc;
     WsDev& ws = ix->ws;
+    ws.efs = prm.efSearch;
     hipStream_t st = ix->stream;
     if ((int64_t)B > ix->pq_cap) {
         if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
@@ -318,11 +301,11 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     if (prune) {
         if (!ix->d_pq_codes) LM_FAIL(LM_ESTATE, "pq_pruning_ratio > 0 needs a product quantiser (lm_pq_attach)");
         if (prm.pq_pruning_ratio >= 1.0f) LM_FAIL(LM_EINVAL, "pq_pruning_ratio must be < 1");
-        if (ix->update_variant == 2) LM_FAIL(LM_EINVAL, "two-level search is not available with the split update variant");
     }
     int rc = ensure_ws(ix, B, ef, W, prune);
     if (rc) return rc;
     WsDev& ws = ix->ws;
+    ws.efs = prm.efSearch;
     hipStream_t st = ix->stream;
     const bool recompute = prm.recompute != 0;
     PruneArgs pa{};
@@ -344,9 +327,8 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         prune_shmem = ((size_t)pa.Pmax + 2 * AQ_CAP) * 8;
         hipLaunchKernelGGL(k_pq_lut_all, dim3(B), dim3(256), 0, st, pa);
     }
-    const bool slots_ok = ix->update_variant != 1 && ix->update_variant != 2;
-    const bool hub = recompute && ix->hub_n > 0 && slots_ok;
-    const bool memo_call = recompute && prm.recompute_memo != 0 && slots_ok;  // keep rows until the call returns
+    const bool hub = recompute && ix->hub_n > 0;
+    const bool memo_call = recompute && prm.recompute_memo != 0;  // keep rows until the call returns
     const bool memo = memo_call || hub;                                       // rows are addressed through memo_slot
     int64_t memo_used = 0;
     if (memo) {
@@ -370,7 +352,6 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         }
     }
     GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
-    const int flat = ix->update_variant == 2 ? 1 : 0;
 
     LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
     LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
@@ -393,11 +374,9 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     ua.Q = d_q;
     ua.check_rel = prm.check_relative_distance;
     ua.max_level = ix->max_level;
-    ua.P2 = next_pow2(ef + ws.maxnew);
     {
-        // dynamic LDS of the update kernel (default launch limit 64 KiB): full-sort variant holds pool+new in one array,
-        // the others hold pool | merged pool | new keys
-        const size_t need = ix->update_variant == 1 ? (size_t)ua.P2 * 8 : ((size_t)2 * ef + next_pow2(ws.maxnew)) * 8;
+        // dynamic LDS of the update kernel (default launch limit 64 KiB): pool | merged pool | new keys
+        const size_t need = ((size_t)2 * ef + next_pow2(ws.maxnew)) * 8;
         if (need > 64 * 1024)
             LM_FAIL(LM_EINVAL, "efSearch / beam_size too large for the LDS-resident pool (2*max(efSearch,k) + beam*max_degree keys must fit 64 KiB)");
     }
@@ -408,11 +387,10 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
 
     for (;;) {
         LM_HIP(hipMemsetAsync(ws.counters + C_LIVE, 0, sizeof(unsigned long long), st));
-        if (flat) LM_HIP(hipMemsetAsync(ws.counters + C_NPAIRS, 0, sizeof(unsigned long long), st));
         {
             EvScope es(ix, &ix->ev_expand);
             hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, recompute ? (memo ? 2 : 1) : 0,
-                               (int)(rounds + 1), flat, prune ? 1 : 0);
+                               (int)(rounds + 1), prune ? 1 : 0);
             if (prune) {
                 pa.use_rbm = recompute ? (memo ? 2 : 1) : 0;
                 hipLaunchKernelGGL(k_prune, dim3(B), dim3(256), prune_shmem, st, ws, pa);
@@ -463,7 +441,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         if (hub && !memo_call && recompute && hc[C_NUNIQ] > 0)
             hipLaunchKernelGGL(k_memo_release, dim3((unsigned)std::min<int64_t>(1024, ((int64_t)hc[C_NUNIQ] + 255) / 256)), dim3(256), 0, st, ws,
                                (int32_t)hc[C_NUNIQ]);
-        if (span_acc && ix->update_variant == 0) hipLaunchKernelGGL(k_span, dim3(1), dim3(256), 0, st, ix->d_tstamp, B, span_acc);
+        if (span_acc) hipLaunchKernelGGL(k_span, dim3(1), dim3(256), 0, st, ix->d_tstamp, B, span_acc);
         ix->stats.update_launches++;
     }
     hipLaunchKernelGGL(k_finalize, dim3((B * k + 255) / 256), dim3(256), 0, st, ws, k, ix->metric, d_labels, d_dist);
@@ -799,7 +777,8 @@ int lm_index_set_profiling(lm_index* ix, int32_t enable) {
 int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     if (!ix || !name) LM_FAIL(LM_EINVAL, "NULL argument");
     if (!std::strcmp(name, "update_variant")) {
-        if (value < 0 || value > 4) LM_FAIL(LM_EINVAL, "update_variant must be 0..4");
+        if (value != 0 && value != 3 && value != 4)
+            LM_FAIL(LM_EINVAL, "update_variant must be 0 (auto), 3 (wave per query) or 4 (workgroup per query); 1 and 2 were removed");
         ix->update_variant = (int)value;
         return LM_OK;
     }

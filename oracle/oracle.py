@@ -68,6 +68,10 @@ class _PqStats(C.Structure):
     _fields_ = [("n_adc", C.c_int64), ("n_rerank_unique", C.c_int64), ("n_rounds", C.c_int64), ("n_expand", C.c_int64)]
 
 
+class _FaissStats(C.Structure):
+    _fields_ = [("ndis", C.c_int64), ("ndis_upper", C.c_int64), ("nstep", C.c_int64)]
+
+
 _PROVIDER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_float))
 
 _lib = None
@@ -106,6 +110,9 @@ def lib():
         _lib.orc_pq_lut.argtypes = [C.POINTER(_Pq), C.c_void_p, C.c_int32, C.c_void_p]
         _lib.orc_pq_adc.restype = C.c_float
         _lib.orc_pq_adc.argtypes = [C.POINTER(_Pq), C.c_void_p, C.c_int64]
+        _lib.orcf_search.restype = C.c_int
+        _lib.orcf_search.argtypes = [C.POINTER(_Graph), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.POINTER(_FaissStats)]
         _lib.orc_set_num_threads.argtypes = [C.c_int]
         _lib.orc_set_num_threads.restype = None
         _lib.orc_set_num_threads(usable_cores())
@@ -304,3 +311,24 @@ def set_num_threads(n: int) -> None:
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def faiss_search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, check_relative_distance: bool = True,
+                 table: Optional[np.ndarray] = None):
+    """The second oracle (oracle/lm_oracle_faiss.c): a literal heap-based transcription of upstream faiss'
+    HNSW::search / search_from_candidates / MinimaxHeap, one query at a time, stored embeddings.
+    Returns (ids int64 (B,k), dist float32 (B,k), stats dict: ndis (level 0), ndis_upper, nstep)."""
+    q = pad64(np.atleast_2d(queries))
+    B = q.shape[0]
+    assert q.shape[1] == graph.Dp, (q.shape, graph.Dp)
+    tab = pad64(table)
+    assert tab.shape == (graph.N, graph.Dp)
+    ids = np.empty((B, k), dtype=np.int64)
+    dd = np.empty((B, k), dtype=np.float32)
+    st = _FaissStats()
+    g = graph.cstruct()
+    rc = lib().orcf_search(C.byref(g), _ptr(tab), _ptr(q), B, k, ef, 1 if check_relative_distance else 0, _ptr(ids), _ptr(dd),
+                           C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orcf_search failed rc={rc}")
+    return ids, dd, {"ndis": st.ndis, "ndis_upper": st.ndis_upper, "nstep": st.nstep}

@@ -92,6 +92,34 @@ def case_recompute(variant=0, memo=False):
     idx.close()
 
 
+def case_stop_rules():
+    """Both faiss stop rules against the oracle (itself pinned by the literal transcription, tests/test_oracle_faiss.py):
+    k > efSearch (count_below(d0) >= efSearch ends the search although the pool holds k entries) and
+    check_relative_distance = 0 (at most efSearch + 1 expansions), persistent and lock-step, table and provider."""
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x, q = _data(300, 64, 17, nq=4)
+    g = build_hnsw(x, "l2", M=4, ef_construction=30)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 64)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_table(x)
+    idx.set_provider(NumpyProvider(x, idx.info.d_padded))
+    for k, ef, beam, check in ((12, 3, 1, True), (9, 4, 2, True), (5, 6, 1, False), (8, 3, 2, False)):
+        exp = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check, table=x)
+        if beam == 1:
+            fi, fd, _ = orc.faiss_search(og, q, k, ef=ef, check_relative_distance=check, table=x)
+            assert np.array_equal(fi, exp[0]) and np.array_equal(fd, exp[1])
+        for persistent in (1, 0):
+            idx.set_option("persistent_table", persistent)
+            got = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=False, check_relative_distance=check))
+            _check(f"stop rules table k={k} ef={ef} beam={beam} check={check} persistent={persistent}", got, exp[:2], idx.stats(), exp[2])
+        got = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=True, check_relative_distance=check))
+        _check(f"stop rules provider k={k} ef={ef} beam={beam} check={check}", got, exp[:2], idx.stats(), exp[2])
+    idx.close()
+
+
 def case_pq(deferred=True):
     import torch
 
@@ -350,9 +378,8 @@ CASES = {
     "table_f16": lambda: case_table("mips", 64, f16=True),
     "recompute": lambda: case_recompute(0),
     "recompute_memo": lambda: case_recompute(0, memo=True),
-    "recompute_sort_variant": lambda: case_recompute(1),
-    "recompute_split_variant": lambda: case_recompute(2),
     "recompute_wave_variant": lambda: case_recompute(3),
+    "stop_rules": case_stop_rules,
     "pq_deferred": lambda: case_pq(True),
     "pq_table": lambda: case_pq(False),
     "two_level": case_two_level,

@@ -108,7 +108,7 @@ def test_dimensions_and_padding(env, d):
     _check(env, x, g, q, 5, 32, 2, "provider")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [3, 4])
 def test_update_kernel_variants_parity(env, variant):
     """The A/B variants of the update step (1: fused + full bitonic sort, 2: split flat-distance +
     merge kernels) obey the same contract as the default."""
