@@ -254,6 +254,12 @@ int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, 
 int lm_linear_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
                        const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
 
+/* Same operation, same arguments and weight packing, second-generation kernel (csrc/lm_gemm_h384.hip): 64 tokens x 192
+ * features per wave (every weight fragment read from LDS feeds two MFMAs), weight slabs streamed L2 -> LDS by
+ * global_load_lds through four stages with counted waits.  Host switch: LEANN_MI355X_LINEAR=2. */
+int lm_gemm_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
+                     const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

@@ -271,11 +271,12 @@ def pack_w_linear_h384(w: torch.Tensor) -> torch.Tensor:
 def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor] = None,
                       ln: Optional[nn.LayerNorm] = None) -> Optional[torch.Tensor]:
     """x W^T + b (and, with residual + ln, LayerNorm(residual + x W^T + b)) for 384 input features through the
-    hand-written MFMA kernel (csrc/lm_linear_h384.hip).  Opt-in (LEANN_MI355X_LINEAR=1) until validated on
-    hardware; None = the caller takes the hipBLASLt path."""
+    hand-written MFMA kernels: LEANN_MI355X_LINEAR=1 the first generation (csrc/lm_linear_h384.hip, lost to hipBLASLt in
+    round 1), =2 the second (csrc/lm_gemm_h384.hip).  None = the caller takes the hipBLASLt path."""
     import os
 
-    if os.environ.get("LEANN_MI355X_LINEAR", "0") != "1":
+    gen = os.environ.get("LEANN_MI355X_LINEAR", "0")
+    if gen not in ("1", "2"):
         return None
     n, k = lin.weight.shape
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n % 384 == 0 and lin.bias is not None):
@@ -291,7 +292,8 @@ def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.
         pk = (pack_w_linear_h384(lin.weight.detach()), lin.bias.detach().float().contiguous())
         lin._h384_pack = pk
     out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
-    _lib.check(_lib.load().lm_linear_h384_f16(
+    fn = _lib.load().lm_gemm_h384_f16 if gen == "2" else _lib.load().lm_linear_h384_f16
+    _lib.check(fn(
         C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), n,
         C.c_void_p(residual.data_ptr()) if residual is not None else None,
         C.c_void_p(ln.weight.data_ptr()) if ln is not None else None, C.c_void_p(ln.bias.data_ptr()) if ln is not None else None,

@@ -1,0 +1,335 @@
+// kbench.cpp -- stand-alone micro-benchmark + reference check of the hand-written encoder kernels through the C ABI
+// (no Python, no torch: a run costs seconds of GPU time, not the minute a torch import takes on a fresh box).
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
+//         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
+//   ./kbench [tokens=262144] [reps=20] [what=all|linear|mlp|attn|ln]
+//
+// Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
+// ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
+// object per line.  rocBLAS fp16 GEMMs of the same shapes are timed next to them (the library number to beat).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "leann_mi355x.h"
+
+#define CK(e)                                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (e);                                                                   \
+        if (_e != hipSuccess) {                                                                \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(_e)); \
+            exit(2);                                                                           \
+        }                                                                                      \
+    } while (0)
+#define LM(e)                                                                         \
+    do {                                                                              \
+        int _r = (e);                                                                 \
+        if (_r != 0) {                                                                \
+            fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #e, _r, lm_last_error()); \
+            exit(3);                                                                  \
+        }                                                                             \
+    } while (0)
+
+static constexpr int H = 384;
+
+template <class T>
+struct Dev {
+    T* p = nullptr;
+    size_t n = 0;
+    explicit Dev(size_t n_) : n(n_) { CK(hipMalloc((void**)&p, std::max<size_t>(n * sizeof(T), 16))); }
+    Dev(const std::vector<T>& h) : Dev(h.size()) { CK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice)); }
+    ~Dev() { (void)hipFree(p); }
+    std::vector<T> host() const {
+        std::vector<T> h(n);
+        CK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+        return h;
+    }
+};
+
+static std::vector<__half> rand_half(size_t n, float scale, uint32_t seed) {
+    std::mt19937 g(seed);
+    std::normal_distribution<float> d(0.f, scale);
+    std::vector<__half> v(n);
+    for (auto& x : v) x = __float2half(d(g));
+    return v;
+}
+static std::vector<float> rand_float(size_t n, float scale, uint32_t seed) {
+    std::mt19937 g(seed);
+    std::normal_distribution<float> d(0.f, scale);
+    std::vector<float> v(n);
+    for (auto& x : v) x = d(g);
+    return v;
+}
+
+// ---- plain references (one thread per output element, fp32 accumulate; rows = a list of token indices) ----
+__global__ void ref_linear(const __half* x, const __half* w, const float* b, const int* rows, int nrows, int N, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * N) return;
+    int r = rows[i / N], c = i % N;
+    float acc = b[c];
+    for (int k = 0; k < H; ++k) acc += __half2float(x[(size_t)r * H + k]) * __half2float(w[(size_t)c * H + k]);
+    out[i] = acc;
+}
+__global__ void ref_gelu_fc1(const __half* x, const __half* w1, const float* b1, const int* rows, int nrows, int F, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * F) return;
+    int r = rows[i / F], c = i % F;
+    float acc = b1[c];
+    for (int k = 0; k < H; ++k) acc += __half2float(x[(size_t)r * H + k]) * __half2float(w1[(size_t)c * H + k]);
+    float ge = 0.5f * acc * (1.0f + erff(acc * 0.70710678f));
+    out[i] = __half2float(__float2half(ge));  // the fused kernel feeds fp16 activations to the second product
+}
+__global__ void ref_fc2(const float* hid, const __half* w2, const float* b2, int nrows, int F, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * H) return;
+    int r = i / H, c = i % H;
+    float acc = b2[c];
+    for (int k = 0; k < F; ++k) acc += hid[(size_t)r * F + k] * __half2float(w2[(size_t)c * F + k]);
+    out[i] = acc;
+}
+// out[r] = LayerNorm(z[r] + res[rows[r]]) * gamma + beta
+__global__ void ref_add_ln(const float* z, const __half* res, const int* rows, int nrows, const __half* gamma, const __half* beta, float eps,
+                           float* out) {
+    int r = blockIdx.x;
+    __shared__ float sh[H];
+    __shared__ float stat[2];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) sh[c] = z[(size_t)r * H + c] + (res ? __half2float(res[(size_t)rows[r] * H + c]) : 0.f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0, v = 0;
+        for (int c = 0; c < H; ++c) m += sh[c];
+        m /= H;
+        for (int c = 0; c < H; ++c) v += (sh[c] - m) * (sh[c] - m);
+        stat[0] = (float)m;
+        stat[1] = (float)(1.0 / sqrt(v / H + eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += blockDim.x)
+        out[(size_t)r * H + c] = (sh[c] - stat[0]) * stat[1] * __half2float(gamma[c]) + __half2float(beta[c]);
+}
+__global__ void ref_attn(const __half* qkv, const int* cu, int heads, float* out) {  // one thread per (token, head)
+    int s = blockIdx.x, h = blockIdx.y;
+    int a = cu[s], b = cu[s + 1], Hh = heads * 32;
+    for (int t = a + threadIdx.x; t < b; t += blockDim.x) {
+        float q[32], o[32], mx = -1e30f, den = 0.f;
+        for (int d = 0; d < 32; ++d) {
+            q[d] = __half2float(qkv[(size_t)t * 3 * Hh + h * 32 + d]);
+            o[d] = 0.f;
+        }
+        for (int u = a; u < b; ++u) {
+            float sc = 0.f;
+            for (int d = 0; d < 32; ++d) sc += q[d] * __half2float(qkv[(size_t)u * 3 * Hh + Hh + h * 32 + d]);
+            sc *= 0.17677669529663687f;
+            float nm = fmaxf(mx, sc), corr = expf(mx - nm), p = expf(sc - nm);
+            den = den * corr + p;
+            for (int d = 0; d < 32; ++d) o[d] = o[d] * corr + p * __half2float(qkv[(size_t)u * 3 * Hh + 2 * Hh + h * 32 + d]);
+            mx = nm;
+        }
+        for (int d = 0; d < 32; ++d) out[(size_t)t * Hh + h * 32 + d] = o[d] / den;
+    }
+}
+
+static double max_err_rows(const std::vector<__half>& got, int ncols, int col0, int width, const std::vector<int>& rows, const std::vector<float>& ref) {
+    double m = 0;
+    for (size_t i = 0; i < rows.size(); ++i)
+        for (int c = 0; c < width; ++c) {
+            double d = fabs((double)__half2float(got[(size_t)rows[i] * ncols + col0 + c]) - (double)ref[i * width + c]);
+            if (!(d <= m)) m = d;  // NaN propagates
+        }
+    return m;
+}
+
+static float time_us(hipStream_t st, int reps, const std::function<void()>& f) {
+    for (int i = 0; i < 3; ++i) f();
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b, st));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return 1e3f * ms / reps;
+}
+
+// nn.Linear weight [384 P][384] -> [P][12][384][32] (leann_amd/encoder.py: pack_w_linear_h384)
+static std::vector<__half> pack_linear(const std::vector<__half>& w, int N) {
+    std::vector<__half> p(w.size());
+    const int P = N / H;
+    for (int pp = 0; pp < P; ++pp)
+        for (int s = 0; s < 12; ++s)
+            for (int r = 0; r < H; ++r)
+                for (int c = 0; c < 32; ++c) p[(((size_t)pp * 12 + s) * H + r) * 32 + c] = w[((size_t)pp * H + r) * H + s * 32 + c];
+    return p;
+}
+// W2 [384][F] -> [F/32][384][32] with the k permutation of leann_amd/encoder.py: fused_mlp_k_permutation
+static std::vector<__half> pack_w2(const std::vector<__half>& w2, int F) {
+    int perm[32];
+    for (int pos = 0; pos < 32; ++pos) {
+        int u = pos / 16, g = (pos % 16) / 8, e = pos % 8;
+        perm[pos] = e < 4 ? 16 * u + 4 * g + e : 16 * u + 8 + 4 * g + e - 4;
+    }
+    std::vector<__half> p(w2.size());
+    for (int s = 0; s < F / 32; ++s)
+        for (int f = 0; f < H; ++f)
+            for (int pos = 0; pos < 32; ++pos) p[((size_t)s * H + f) * 32 + pos] = w2[(size_t)f * F + s * 32 + perm[pos]];
+    return p;
+}
+
+int main(int argc, char** argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 262144 - 37;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const std::string what = argc > 3 ? argv[3] : "all";
+    auto want = [&](const char* k) { return what == "all" || what.find(k) != std::string::npos; };
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    printf("{\"kbench\": \"%s\", \"tokens\": %d, \"reps\": %d}\n", lm_version(), T, reps);
+
+    std::vector<int> rows;
+    for (int i = 0; i < 192 && i < T; ++i) rows.push_back(i);
+    for (int i = std::max(192, T - 192); i < T; ++i) rows.push_back(i);
+    const int nr = (int)rows.size();
+    Dev<int> d_rows(rows);
+    auto hx = rand_half((size_t)T * H, 1.0f, 1);
+    Dev<__half> x(hx);
+    auto hres = rand_half((size_t)T * H, 1.0f, 2);
+    Dev<__half> res(hres);
+    Dev<__half> gamma(rand_half(H, 0.1f, 3)), beta(rand_half(H, 0.1f, 4));
+    {  // gamma ~ 1
+        auto g = gamma.host();
+        for (auto& v : g) v = __float2half(1.0f + __half2float(v));
+        CK(hipMemcpy(gamma.p, g.data(), H * sizeof(__half), hipMemcpyHostToDevice));
+    }
+    rocblas_handle rb;
+    rocblas_create_handle(&rb);
+    rocblas_set_stream(rb, st);
+    const float one = 1.f, zero = 0.f;
+    auto lib_gemm = [&](const __half* W, int N, int K, const __half* A, __half* C) {  // C[T][N] = A[T][K] W[N][K]^T (column-major view)
+        rocblas_gemm_ex(rb, rocblas_operation_transpose, rocblas_operation_none, N, T, K, &one, W, rocblas_datatype_f16_r, K, A,
+                        rocblas_datatype_f16_r, K, &zero, C, rocblas_datatype_f16_r, N, C, rocblas_datatype_f16_r, N, rocblas_datatype_f32_r,
+                        rocblas_gemm_algo_standard, 0, 0);
+    };
+
+    if (want("linear")) {
+        for (int mode = 0; mode < 2; ++mode) {
+            const int N = mode == 0 ? 3 * H : H;
+            auto hw = rand_half((size_t)N * H, 0.05f, 10 + mode);
+            auto hb = rand_float(N, 0.2f, 20 + mode);
+            Dev<__half> w(hw), wp(pack_linear(hw, N));
+            Dev<float> b(hb);
+            Dev<__half> out((size_t)T * N);
+            Dev<float> zref((size_t)nr * N), lref((size_t)nr * H);
+            hipLaunchKernelGGL(ref_linear, dim3((nr * N + 255) / 256), dim3(256), 0, st, x.p, w.p, b.p, d_rows.p, nr, N, zref.p);
+            if (mode == 1) hipLaunchKernelGGL(ref_add_ln, dim3(nr), dim3(128), 0, st, zref.p, res.p, d_rows.p, nr, gamma.p, beta.p, 1e-12f, lref.p);
+            CK(hipStreamSynchronize(st));
+            auto ref = mode == 0 ? zref.host() : lref.host();
+            const double gflop = 2.0 * T * (double)N * H * 1e-9;
+            for (int gen = 1; gen <= 2; ++gen) {
+                auto fn = gen == 1 ? lm_linear_h384_f16 : lm_gemm_h384_f16;
+                CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
+                auto run = [&] { LM(fn(x.p, wp.p, b.p, N, mode ? res.p : nullptr, mode ? gamma.p : nullptr, mode ? beta.p : nullptr, 1e-12f, out.p, T, st)); };
+                run();
+                CK(hipStreamSynchronize(st));
+                const double err = max_err_rows(out.host(), N, 0, N, rows, ref);
+                const float us = time_us(st, reps, run);
+                printf("{\"kernel\": \"%s\", \"mode\": \"%s\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
+                       gen == 1 ? "lm_linear_h384_f16" : "lm_gemm_h384_f16", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us * 1e-3, err);
+                fflush(stdout);
+            }
+            const float us = time_us(st, reps, [&] { lib_gemm(w.p, N, H, x.p, out.p); });
+            printf("{\"kernel\": \"rocblas_gemm_ex f16 (no bias / LN)\", \"mode\": \"N=%d K=384\", \"us\": %.1f, \"TFLOPs\": %.1f}\n", N, us, gflop / us * 1e-3);
+            fflush(stdout);
+        }
+    }
+    if (want("mlp")) {
+        const int F = 1536;
+        auto hw1 = rand_half((size_t)F * H, 0.05f, 30), hw2 = rand_half((size_t)H * F, 0.03f, 31);
+        Dev<__half> w1(hw1), w2(hw2), w2p(pack_w2(hw2, F));
+        Dev<float> b1(rand_float(F, 0.2f, 32)), b2(rand_float(H, 0.2f, 33));
+        Dev<__half> out((size_t)T * H), hid16((size_t)T * F);
+        Dev<float> hid((size_t)nr * F), z((size_t)nr * H), lref((size_t)nr * H);
+        hipLaunchKernelGGL(ref_gelu_fc1, dim3((nr * F + 255) / 256), dim3(256), 0, st, x.p, w1.p, b1.p, d_rows.p, nr, F, hid.p);
+        hipLaunchKernelGGL(ref_fc2, dim3((nr * H + 255) / 256), dim3(256), 0, st, hid.p, w2.p, b2.p, nr, F, z.p);
+        hipLaunchKernelGGL(ref_add_ln, dim3(nr), dim3(128), 0, st, z.p, x.p, d_rows.p, nr, gamma.p, beta.p, 1e-12f, lref.p);
+        CK(hipStreamSynchronize(st));
+        auto ref = lref.host();
+        const double gflop = 4.0 * T * (double)F * H * 1e-9;
+        for (const char* var : {"1", "2"}) {
+            setenv("LEANN_MI355X_MLP_VARIANT", var, 1);
+            CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
+            auto run = [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); };
+            run();
+            CK(hipStreamSynchronize(st));
+            const double err = max_err_rows(out.host(), H, 0, H, rows, ref);
+            const float us = time_us(st, reps, run);
+            printf("{\"kernel\": \"lm_mlp_fused_h384_f16\", \"mode\": \"variant %s, ffn 1536 (fc1+GELU+fc2+res+LN)\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
+                   var, us, gflop / us * 1e-3, err);
+            fflush(stdout);
+        }
+        unsetenv("LEANN_MI355X_MLP_VARIANT");
+        const float us1 = time_us(st, reps, [&] { lib_gemm(w1.p, F, H, x.p, hid16.p); });
+        const float us2 = time_us(st, reps, [&] { lib_gemm(w2.p, H, F, hid16.p, out.p); });
+        printf("{\"kernel\": \"rocblas_gemm_ex f16 fc1 + fc2 (no GELU / LN)\", \"us\": %.1f, \"fc1_us\": %.1f, \"fc2_us\": %.1f, \"TFLOPs\": %.1f}\n", us1 + us2, us1, us2,
+               gflop / (us1 + us2) * 1e-3);
+        fflush(stdout);
+    }
+    if (want("attn")) {
+        const int heads = 12;
+        std::mt19937 g(5);
+        std::normal_distribution<float> d(180.f, 50.f);
+        std::vector<int> cu{0};
+        while (true) {
+            int len = std::min(256, std::max(16, (int)lroundf(d(g))));
+            if (cu.back() + len > T) break;
+            cu.push_back(cu.back() + len);
+        }
+        const int ns = (int)cu.size() - 1, tot = cu.back();
+        Dev<int> dcu(cu);
+        Dev<__half> qkv(rand_half((size_t)tot * 3 * H, 1.0f, 40)), out((size_t)tot * H);
+        const int nchk = std::min(ns, 6);
+        Dev<float> ref((size_t)cu[nchk] * H);
+        hipLaunchKernelGGL(ref_attn, dim3(nchk, heads), dim3(64), 0, st, qkv.p, dcu.p, heads, ref.p);
+        CK(hipStreamSynchronize(st));
+        auto href = ref.host();
+        std::vector<int> arows;
+        for (int i = 0; i < cu[nchk]; ++i) arows.push_back(i);
+        double flops = 0;
+        for (int i = 0; i < ns; ++i) flops += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
+        for (const char* rev : {"1", "2"}) {
+            setenv("LEANN_MI355X_ATTN", rev, 1);
+            auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };
+            run();
+            CK(hipStreamSynchronize(st));
+            const double err = max_err_rows(out.host(), H, 0, H, arows, href);
+            const float us = time_us(st, reps, run);
+            printf("{\"kernel\": \"lm_attn_varlen_hd32_f16\", \"mode\": \"revision %s, %d sequences, %d tokens\", \"us\": %.1f, \"TFLOPs\": %.1f, \"GBps_qkv_plus_out\": %.0f, \"max_abs_err\": %.3g}\n",
+                   rev, ns, tot, us, flops / us * 1e-6, (double)tot * H * 8 / us * 1e-3, err);
+            fflush(stdout);
+        }
+        unsetenv("LEANN_MI355X_ATTN");
+    }
+    if (want("ln")) {
+        Dev<__half> out((size_t)T * H);
+        for (const char* rev : {"1", "2"}) {
+            setenv("LEANN_MI355X_LN", rev, 1);
+            const float us = time_us(st, reps, [&] { LM(lm_add_layernorm_f16(x.p, res.p, gamma.p, beta.p, out.p, T, H, 1e-12f, st)); });
+            printf("{\"kernel\": \"lm_add_layernorm_f16\", \"mode\": \"revision %s\", \"us\": %.1f, \"GBps\": %.0f}\n", rev, us, (double)T * H * 6 / us * 1e-3);
+        }
+        unsetenv("LEANN_MI355X_LN");
+    }
+    rocblas_destroy_handle(rb);
+    return 0;
+}

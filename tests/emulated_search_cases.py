@@ -337,6 +337,14 @@ def case_encoder_abi():
     _lib.check(lib.lm_linear_h384_f16(vp(x), vp(wop), vp(bo), H, vp(res), vp(gamma), vp(beta), 1e-12, vp(out1), T, None), "linear+ln")
     assert np.abs(out1.astype(np.float64) - ln(res.astype(np.float64) + x.astype(np.float64) @ wo.astype(np.float64).T + bo)).max() < 6e-3
     assert lib.lm_linear_h384_f16(vp(x), vp(wop), vp(bo), 400, None, None, None, 0.0, vp(out1), T, None) == -1  # n_out % 384
+    # second-generation linear kernel (lm_gemm_h384.hip): same arguments, same packing
+    out3b = np.zeros((T, 3 * H), np.float16)
+    _lib.check(lib.lm_gemm_h384_f16(vp(x), vp(wp), vp(b), 3 * H, None, None, None, 0.0, vp(out3b), T, None), "gemm")
+    assert np.abs(out3b.astype(np.float64) - (x.astype(np.float64) @ w.astype(np.float64).T + b)).max() < 6e-3
+    out1b = np.zeros((T, H), np.float16)
+    _lib.check(lib.lm_gemm_h384_f16(vp(x), vp(wop), vp(bo), H, vp(res), vp(gamma), vp(beta), 1e-12, vp(out1b), T, None), "gemm+ln")
+    assert np.abs(out1b.astype(np.float64) - ln(res.astype(np.float64) + x.astype(np.float64) @ wo.astype(np.float64).T + bo)).max() < 6e-3
+    assert lib.lm_gemm_h384_f16(vp(x), vp(wop), vp(bo), 400, None, None, None, 0.0, vp(out1), T, None) == -1
     # add + LayerNorm: both generations through the same entry point
     for gen in ("1", "2"):
         os.environ["LEANN_MI355X_LN"] = gen

@@ -97,6 +97,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 #define __builtin_amdgcn_fmed3f(a, b, c) emul::med3((a), (b), (c))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define LM_EMULATED_DEVICE 1  // kernels with DMA / counted waits select their host form on this
 #define LM_KEEP_LOCAL(v) ((void)0)
 #define LM_ONE_WAVE_PER_SIMD
 #define LM_WAVE_SYNC() emul::wave_sync()
