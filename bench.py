@@ -55,8 +55,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-roofline", action="store_true", default=True, help="also time the stored-embedding (HBM gather) mode (default on)")
     ap.add_argument("--no-table-roofline", dest="table_roofline", action="store_false")
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"],
+                    help="c2 (default, BASELINE.json configs[1]): 1M chunks, MiniLM-L6; c5 (configs[4]): 10M chunks, bge-base-en-v1.5 768-d fp16, "
+                         "query batch 1024 split over the ranks.  The DiskANN-style (c3) and sharded (c4) configurations have their own "
+                         "entry points: scripts/bench_c3.py, scripts/bench_c4.py")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
+    ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows")
     ap.add_argument("--autotune", action="store_true", help="A/B the switchable encoder kernels at start-up (leann_amd.autotune); default: the tested default set")
     args = ap.parse_args()
+    if args.config == "c5":  # BASELINE.json configs[4]; explicit --chunks / --model / --batch still win
+        defaults = {a.dest: a.default for a in ap._actions}
+        if args.chunks == defaults["chunks"]:
+            args.chunks = 10_000_000
+        if args.model == defaults["model"]:
+            args.model = "BAAI/bge-base-en-v1.5"
+        if args.batch == defaults["batch"]:
+            args.batch = max(1, 1024 // int(os.environ.get("WORLD_SIZE", "1")))
 
     # ---- encoder kernel selection (untimed set-up, before this process touches the GPU): a child process checks the
     #      second-generation kernels against the default path on this GPU and keeps those that agree AND are faster ----
@@ -91,7 +105,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     K, W, B = args.steps, args.warmup, args.batch
-    n_q = B * (K + W + 5)  # +5: the profiled step and the extra steps (smallest ef reaching recall 0.9; per-call memo; hub cache; two-level search)
+    EXTRA_ROWS = 4096  # small-batch latency rows + parity-check queries (fresh, after every step's block)
+    n_q = B * (K + W + 5) + EXTRA_ROWS  # +5: the profiled step and the extra steps (smallest ef reaching recall 0.9; per-call memo; hub cache; two-level search)
     t_setup = time.time()
 
     # ---- corpus -> HBM token store ------------------------------------------------------------
@@ -107,21 +122,30 @@ def main():
     D = cfg.hidden
     provider = RecomputeProvider(enc, tokens, (D + 63) // 64 * 64, dev)
 
-    # ---- embeddings of every chunk (index build time only) ---------------------------------------
+    # ---- embeddings of every chunk + graph (index build time only): built ONCE, on rank 0, then replicated over RCCL ----
     t0 = time.time()
     X = torch.empty((args.chunks, D), dtype=torch.float32, device=dev)
-    step = 32768
-    for b0 in range(0, args.chunks, step):
-        ids = torch.arange(b0, min(args.chunks, b0 + step), dtype=torch.int32, device=dev)
-        X[b0 : b0 + ids.shape[0]] = provider.embed_ids(ids)
-    torch.cuda.synchronize()
-    t_embed = time.time() - t0
-    log(f"embedded corpus in {t_embed:.1f}s ({args.chunks / t_embed:.0f} chunks/s)")
+    g = None
+    t_embed = t_graph = 0.0
+    if rank == 0:
+        step = 32768
+        for b0 in range(0, args.chunks, step):
+            ids = torch.arange(b0, min(args.chunks, b0 + step), dtype=torch.int32, device=dev)
+            X[b0 : b0 + ids.shape[0]] = provider.embed_ids(ids)
+        torch.cuda.synchronize()
+        t_embed = time.time() - t0
+        log(f"embedded corpus in {t_embed:.1f}s ({args.chunks / t_embed:.0f} chunks/s)")
+        t0 = time.time()
+        g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc, verbose=bool(os.environ.get("BENCH_VERBOSE")))
+        t_graph = time.time() - t0
+    if world > 1:
+        from leann_amd.distributed import broadcast_graph
 
-    # ---- graph ----------------------------------------------------------------------------------
-    t0 = time.time()
-    g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc, verbose=(rank == 0 and bool(os.environ.get("BENCH_VERBOSE"))))
-    t_graph = time.time() - t0
+        t0 = time.time()
+        dist.broadcast(X, 0)
+        g = broadcast_graph(g, 0, device=dev)
+        torch.cuda.synchronize()
+        log(f"index replicated to {world} ranks in {time.time() - t0:.1f}s")
     deg0 = g.level0_degrees()
     log(f"graph built in {t_graph:.1f}s: max_level={g.max_level} mean level-0 degree={deg0.mean():.1f} edges={g.neighbors.shape[0]}")
     idx = Mi355xIndex.from_csr(g, device=local_rank)
@@ -198,22 +222,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The step goes through the library's own multi-GPU host class (leann_amd/distributed.py: PartitionedSearch): the step's
+    # GLOBAL query batch (B per rank, identical tensor on every rank, HBM resident before the clock starts) is partitioned
+    # across the ranks, every rank searches its slice on its replica, and the (B x world, k) results are gathered on
+    # every rank with one RCCL all_gather -- SURVEY 8(e).  With one rank it is the plain device search.
+    from leann_amd.distributed import PartitionedSearch
+
+    ps = PartitionedSearch(lambda qq, k: idx.search_device(qq, k, prm))
+
+    def global_batch(step):
+        lo_ = step * B
+        if world == 1:
+            return Q[lo_ : lo_ + B]
+        return Q_all.view(world, n_q, D)[:, lo_ : lo_ + B].reshape(world * B, D).contiguous()
+
+    batches = [global_batch(w) for w in range(W + K)]
     out_labels = []
     for w in range(W):
-        _, l = idx.search_device(Q[w * B : (w + 1) * B], 10, prm)
+        ps.search(batches[w], 10)
     agg = {"ndis": 0, "nunique": 0, "nrounds": 0, "update_launches": 0}
     provider.chunks = 0
     barrier()
     t0 = time.perf_counter()
     for s in range(K):
-        lo = (W + s) * B
-        _, l = idx.search_device(Q[lo : lo + B], 10, prm)
-        out_labels.append(l)
+        _, l = ps.search(batches[W + s], 10)
+        out_labels.append(l[rank * B : (rank + 1) * B])
         st = idx.stats()
         for k_ in agg:
             agg[k_] += st[k_]
     barrier()
     elapsed = time.perf_counter() - t0
+    del batches
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,6 +328,22 @@ def main():
                          "pq_train_encode_s": round(t_pq, 1), "steps": 1}
         except Exception as ex:  # noqa: BLE001
             extras_errors["with_two_level_search"] = repr(ex)[:300]
+    # ---- small-batch latency (B = 1, 16, 64, 256) and the parity check on this very index: untimed extras, rank 0 / N = 1 ----
+    latency_rows = parity = None
+    next_row = B * (K + W + 5)
+    if world == 1 and not args.no_latency_rows:
+        try:
+            latency_rows, next_row = small_batch_latency(
+                idx, Q, lambda b: idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b), recall, next_row)
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["small_batch_latency"] = repr(ex)[:300]
+    if world == 1 and not args.no_parity_check:
+        try:
+            t1 = time.time()
+            parity = parity_check(idx, g, X, Q[min(next_row, n_q - 272):], provider, ef, args.beam, D)
+            parity["seconds"] = round(time.time() - t1, 1)
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["parity_check"] = repr(ex)[:300]
     labels_np = torch.cat(out_labels).cpu().numpy() if out_labels else np.zeros((0, 10), np.int64)
     rec = recall(labels_np, range(W * B, (W + K) * B)) if K else 0.0
     if world > 1:
@@ -332,15 +387,17 @@ def main():
                         "whole_step_TFLOPs": round(agg["nunique"] * mean_flops / max(elapsed, 1e-9) / 1e12, 2)}
 
     result = {
-        "metric": "queries/sec at recall@10>=0.9, 1M-chunk HNSW, MiniLM-L6 recompute",
+        "metric": ("queries/sec at recall@10>=0.9, 1M-chunk HNSW, MiniLM-L6 recompute" if args.config == "c2" else
+                   f"queries/sec at recall@10>=0.9, {args.chunks}-chunk HNSW, {args.model} fp16 recompute (BASELINE.json configs[4])"),
         "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * elapsed / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "encoder_dtype": "fp16 (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"{args.chunks} synthetic chunks (topic model, len~N(180,50)), HNSW M={args.M} GPU-built, "
                                f"{args.model} shape (random init), ef_search={ef}, beam={args.beam}, top-10, "
                                f"{B} queries/step/GPU, queries partitioned over {world} GPU(s), graph replicated",
-                   "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
-                   "parallelism": f"queries-dp{world}"},
+                   "baseline_config": args.config, "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
+                   "parallelism": f"queries-dp{world}", "rccl_ranks": world,
+                   "multi_gpu_path": "leann_amd.distributed.PartitionedSearch (index built on rank 0 and broadcast; per-step all_gather of the results)"},
         "recall_at_10": round(rec, 4),
         "encoder_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LEANN_MI355X_")},  # kernels in effect
         "encoder_autotune": autotune_report,
@@ -358,6 +415,10 @@ def main():
         result["with_hub_cache"] = with_hub
     if two_level:
         result["with_two_level_search"] = two_level
+    if latency_rows:
+        result["small_batch_latency"] = latency_rows
+    if parity:
+        result["parity_check"] = parity
     if table_roof:
         result["roofline_table_mode"] = table_roof
     if extras_errors:
@@ -373,6 +434,104 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def parity_check(idx, g, X, Q, provider, ef, beam, dim, n_table=256, n_recompute=16):
+    """GPU path vs the CPU oracle (the checker, untimed) ON THE BENCHMARK'S OWN INDEX AND QUERIES:
+      * stored-embedding mode, n_table queries: labels, distances AND the number of distance evaluations must be identical
+        (one-launch persistent kernel and lock-step rounds); for beam 1 the independent heap-based faiss transcription
+        (oracle/lm_oracle_faiss.c) must return the same labels / distances as well;
+      * recompute mode, n_recompute queries: the oracle replays the GPU encoder's own per-round outputs (its provider
+        must be asked for exactly the same sorted unique ids, round by round) -> labels and distances identical."""
+    import torch
+
+    from leann_amd.devmem import as_tensor
+    from oracle import oracle as orc
+
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, dim)
+    Xn = X.cpu().numpy()
+    qn = Q[:n_table].cpu().numpy()
+    oi, od, ost = orc.search(og, qn, 10, ef=ef, beam=beam, table=Xn)
+    out = {"n": int(qn.shape[0]), "config": f"stored embeddings, N={Xn.shape[0]}, ef={ef}, beam={beam}, top-10"}
+    ids_exact, max_abs, ndis_ok = True, 0.0, True
+    for persistent in (1, 0):
+        idx.set_option("persistent_table", persistent)
+        d, l = idx.search_device(Q[:n_table].contiguous(), 10, idx.make_params(ef=ef, beam=beam, recompute=False))
+        st = idx.stats()
+        ids_exact &= bool(np.array_equal(l.cpu().numpy(), oi))
+        max_abs = max(max_abs, float(np.abs(d.cpu().numpy() - od).max()))
+        ndis_ok &= int(st["ndis"]) == int(ost["ndis"])
+    idx.set_option("persistent_table", 1)
+    out.update({"ids_exact": ids_exact, "max_abs_dist": max_abs, "ndis_equal": ndis_ok})
+    if beam == 1:
+        fi, fd, _ = orc.faiss_search(og, qn, 10, ef=ef, table=Xn)
+        out["faiss_transcription_agrees"] = bool(np.array_equal(fi, oi) and np.array_equal(fd, od))
+    # recompute mode: replay
+    rounds = []
+
+    def recording(d_ids, cnt, stream):
+        ptr = provider(d_ids, cnt, stream)
+        torch.cuda.synchronize()
+        rounds.append((as_tensor(d_ids, (cnt,), "int32").cpu().numpy().copy(),
+                       as_tensor(ptr, (cnt, provider.dp), "float32").cpu().numpy()[:, :dim].copy()))
+        return ptr
+
+    idx.set_provider(recording)
+    qr = Q[n_table : n_table + n_recompute].contiguous()
+    d, l = idx.search_device(qr, 10, idx.make_params(ef=ef, beam=beam, recompute=True))
+    torch.cuda.synchronize()
+    idx.set_provider(provider)
+    it = iter(rounds)
+    asked_same = [True]
+
+    def replay(idv):
+        ids, emb = next(it)
+        asked_same[0] &= bool(np.array_equal(ids, idv))
+        return emb
+
+    try:
+        ri, rd, _ = orc.search(og, qr.cpu().numpy(), 10, ef=ef, beam=beam, provider=replay)
+        out["recompute"] = {"n": int(qr.shape[0]), "rounds": len(rounds), "same_ids_requested_every_round": asked_same[0],
+                            "ids_exact": bool(np.array_equal(l.cpu().numpy(), ri)),
+                            "max_abs_dist": float(np.abs(d.cpu().numpy() - rd).max())}
+    except (StopIteration, AssertionError) as ex:  # the oracle asked for more / different rounds than the GPU ran
+        out["recompute"] = {"n": int(qr.shape[0]), "rounds": len(rounds), "same_ids_requested_every_round": False, "ids_exact": False,
+                            "error": repr(ex)[:200]}
+    return out
+
+
+def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 256), budget_s=25.0):
+    """LEANN's real call is one query at a time (leann/api.py:644-796 consumes labels[0]; the reference reports
+    0.818 s per query for this configuration, docs/configuration-guide.md:357-364).  Per batch size: repeated searches on
+    fresh queries, synchronised after each; p50 / mean latency and the resulting queries per second."""
+    import torch
+
+    rows, lo = [], first_row
+    for b in batches:
+        prm = prm_of(b)
+        idx.search_device(Q[lo : lo + b].contiguous(), 10, prm)  # warm-up (workspace sizing for this batch size)
+        lo += b
+        lat, labels, used = [], [], []
+        t_all = time.perf_counter()
+        reps = 0
+        while reps < (24 if b == 1 else 8) and time.perf_counter() - t_all < budget_s / len(batches) and lo + b <= Q.shape[0]:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, l = idx.search_device(Q[lo : lo + b].contiguous(), 10, prm)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+            labels.append(l)
+            used.append(range(lo, lo + b))
+            lo += b
+            reps += 1
+        if not lat:
+            continue
+        lat_ms = np.array(lat) * 1e3
+        rec = float(np.mean([recall(l.cpu().numpy(), r) for l, r in zip(labels, used)]))
+        rows.append({"batch": b, "reps": len(lat), "p50_ms": round(float(np.median(lat_ms)), 2), "mean_ms": round(float(lat_ms.mean()), 2),
+                     "max_ms": round(float(lat_ms.max()), 2), "queries_per_s": round(b / float(lat_ms.mean()) * 1e3, 2),
+                     "recall_at_10": round(rec, 4)})
+    return rows, lo
 
 
 def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):

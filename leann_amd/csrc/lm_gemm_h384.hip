@@ -138,11 +138,22 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_gemm_h384(
     xb[0] = *b_ptr(0);
 
     for (int p = 0; p < P; ++p) {
+        // accumulators start from the bias (register 4q + i of tile j <-> feature 192 fh + 32 j + 8 q + 4 g + i): no epilogue add
         float16v o[2][6];
+        {
+            int g_b = g;
+            LM_KEEP_LOCAL(g_b);  // keep these 24 loads inside the pass (see the note at the epilogue)
+            const float* bq = bias + ML_H * p + 192 * fh + 4 * g_b;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) o[nt][j] = (float16v){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int q = 0; q < 4; ++q) {
+                    float4v bb = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == 0) bb = *(const float4v*)(bq + 32 * j + 8 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[0][j][4 * q + i] = o[1][j][4 * q + i] = bb[i];
+                }
+        }
 #pragma unroll
         for (int s = 0; s < G2_SLABS; ++s) {  // unrolled: xf is indexed by 2s + u, the stage of slab s is s % 4
             const int t = G2_SLABS * p + s;
@@ -254,37 +265,27 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_gemm_h384(
             }
         }
         // ---- store.  Lanes l and l ^ 32 (same token, g = 0 / 1) hold features [8q, 8q+4) / [8q+4, 8q+8) of every group q:
-        //      for a pair of groups (q, q+1) the g = 0 lane hands its q+1 half to its partner and takes the partner's q half,
-        //      so that it owns features [8q, 8q+8) and the partner [8q+8, 8q+16): 16 contiguous bytes per lane ----
+        //      for a pair of groups (q, q+1) one v_permlane32_swap per dword gives the g = 0 lane features [8q, 8q+8) and the
+        //      g = 1 lane [8q+8, 8q+16): 16 contiguous bytes per lane, 32 rows x 32 B per wave store (guide T21) ----
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int token = tok0 + 32 * nt + r31;
-            _Float16* yr = (_Float16*)out + (int64_t)token * N + ML_H * p + 192 * fh;
+            _Float16* yr = (_Float16*)out + (int64_t)token * N + ML_H * p + 192 * fh + 8 * g;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
                 for (int qp = 0; qp < 2; ++qp) {
-                    half4 h[2];  // groups q = 2 qp, 2 qp + 1
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int q = 2 * qp + e;
-                        float4v bb = {0.f, 0.f, 0.f, 0.f};
-                        if (MODE == 0) bb = *(const float4v*)(bp + 32 * j + 8 * q);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) h[e][i] = (_Float16)(o[nt][j][4 * q + i] + bb[i]);
-                    }
-                    // send: g = 0 sends h[1], g = 1 sends h[0]; keep the other
-                    const half4 send = g ? h[0] : h[1], keep = g ? h[1] : h[0];
-                    uint64_t sb = __builtin_bit_cast(uint64_t, send);
-                    uint64_t rb = __shfl_xor((unsigned long long)sb, 32);
-                    const half4 recv = __builtin_bit_cast(half4, rb);
-                    half8 y;
+                    half4 h0, h1;  // groups q = 2 qp, 2 qp + 1
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        y[i] = g ? recv[i] : keep[i];      // g = 0: own q half first;  g = 1: partner's q+1 half first
-                        y[4 + i] = g ? keep[i] : recv[i];
+                        h0[i] = (_Float16)o[nt][j][8 * qp + i];
+                        h1[i] = (_Float16)o[nt][j][8 * qp + 4 + i];
                     }
-                    if (token < T) *(half8*)(yr + 32 * j + 16 * qp + 8 * g) = y;
+                    uint2 a = __builtin_bit_cast(uint2, h0), b = __builtin_bit_cast(uint2, h1);
+                    lane32_swap(a.x, b.x);
+                    lane32_swap(a.y, b.y);
+                    const uint4 y = {a.x, a.y, b.x, b.y};
+                    if (token < T) *(uint4*)(yr + 32 * j + 16 * qp) = y;
                 }
         }
     }

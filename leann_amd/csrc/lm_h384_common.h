@@ -14,6 +14,23 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// v_permlane32_swap_b32: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (one instruction, no LDS).  With a = the
+// value a lane pair (l, l ^ 32) wants to keep in its lower half and b = the one it wants to keep in its upper half, the pair
+// ends up with (a_lo, b_lo) in lane l and (a_hi, b_hi) in lane l ^ 32.
+__device__ __forceinline__ void lane32_swap(uint32_t& a, uint32_t& b) {
+#ifdef LM_EMULATED_DEVICE
+    const bool hi = (threadIdx.x & 63) >= 32;
+    const uint32_t pa = __shfl_xor(a, 32), pb = __shfl_xor(b, 32);
+    const uint32_t na = hi ? pb : a, nb = hi ? b : pa;
+    a = na;
+    b = nb;
+#else
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+#endif
+}
+
 constexpr int ML_H = 384;                 // hidden size
 constexpr int ML_KS = ML_H / 16;          // 24 k-steps of the first product
 constexpr int ML_NJ = ML_H / 32;          // 12 row tiles of out^T

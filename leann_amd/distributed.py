@@ -110,3 +110,39 @@ class ShardedSearch:
 def shard_bounds(n: int, world: int):
     """Node ranges of the shards: [(lo, hi)] * world."""
     return [partition(n, world, r) for r in range(world)]
+
+
+def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, group: Optional[dist.ProcessGroup] = None):
+    """Rank `src` built the compact-CSR graph; every other rank passes ``g=None`` and receives a copy (the index is
+    built ONCE per job and replicated, not rebuilt per rank).  Arrays travel as int64 tensors on `device` (RCCL
+    over xGMI when it is a GPU, gloo on the CPU tests); scalars in one header tensor."""
+    from .csr_format import HnswCsr
+
+    import numpy as np
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return g
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    names = ("levels", "level_ptr", "node_offsets", "neighbors", "cum_nneighbor_per_level")
+    dtypes = {"levels": np.int32, "level_ptr": np.uint64, "node_offsets": np.uint64, "neighbors": np.int32, "cum_nneighbor_per_level": np.int32}
+    if rank == src:
+        arrs = [np.ascontiguousarray(getattr(g, n)) for n in names]
+        hdr = torch.tensor([g.d, g.ntotal, g.metric_type, g.entry_point, g.max_level, g.ef_construction] + [a.shape[0] for a in arrs],
+                           dtype=torch.int64, device=dev)
+    else:
+        hdr = torch.zeros(6 + len(names), dtype=torch.int64, device=dev)
+    dist.broadcast(hdr, src, group=group)
+    h = [int(v) for v in hdr.cpu().tolist()]
+    out = []
+    for i, n in enumerate(names):
+        if rank == src:
+            t = torch.from_numpy(arrs[i].astype(np.int64)).to(dev)
+        else:
+            t = torch.empty(h[6 + i], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src, group=group)
+        out.append(t.cpu().numpy().astype(dtypes[n]))
+    if rank == src:
+        return g
+    return HnswCsr(d=h[0], ntotal=h[1], metric_type=h[2], levels=out[0], level_ptr=out[1], node_offsets=out[2], neighbors=out[3],
+                   entry_point=h[3], max_level=h[4], ef_construction=h[5], cum_nneighbor_per_level=out[4])

@@ -246,11 +246,11 @@ int main(int argc, char** argv) {
                 const double err = max_err_rows(out.host(), N, 0, N, rows, ref);
                 const float us = time_us(st, reps, run);
                 printf("{\"kernel\": \"%s\", \"mode\": \"%s\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
-                       gen == 1 ? "lm_linear_h384_f16" : "lm_gemm_h384_f16", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us * 1e-3, err);
+                       gen == 1 ? "lm_linear_h384_f16" : "lm_gemm_h384_f16", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us, err);
                 fflush(stdout);
             }
             const float us = time_us(st, reps, [&] { lib_gemm(w.p, N, H, x.p, out.p); });
-            printf("{\"kernel\": \"rocblas_gemm_ex f16 (no bias / LN)\", \"mode\": \"N=%d K=384\", \"us\": %.1f, \"TFLOPs\": %.1f}\n", N, us, gflop / us * 1e-3);
+            printf("{\"kernel\": \"rocblas_gemm_ex f16 (no bias / LN)\", \"mode\": \"N=%d K=384\", \"us\": %.1f, \"TFLOPs\": %.1f}\n", N, us, gflop / us);
             fflush(stdout);
         }
     }
@@ -276,14 +276,14 @@ int main(int argc, char** argv) {
             const double err = max_err_rows(out.host(), H, 0, H, rows, ref);
             const float us = time_us(st, reps, run);
             printf("{\"kernel\": \"lm_mlp_fused_h384_f16\", \"mode\": \"variant %s, ffn 1536 (fc1+GELU+fc2+res+LN)\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
-                   var, us, gflop / us * 1e-3, err);
+                   var, us, gflop / us, err);
             fflush(stdout);
         }
         unsetenv("LEANN_MI355X_MLP_VARIANT");
         const float us1 = time_us(st, reps, [&] { lib_gemm(w1.p, F, H, x.p, hid16.p); });
         const float us2 = time_us(st, reps, [&] { lib_gemm(w2.p, H, F, hid16.p, out.p); });
         printf("{\"kernel\": \"rocblas_gemm_ex f16 fc1 + fc2 (no GELU / LN)\", \"us\": %.1f, \"fc1_us\": %.1f, \"fc2_us\": %.1f, \"TFLOPs\": %.1f}\n", us1 + us2, us1, us2,
-               gflop / (us1 + us2) * 1e-3);
+               gflop / (us1 + us2));
         fflush(stdout);
     }
     if (want("attn")) {

@@ -48,8 +48,18 @@ def _worker(rank, world, port, mode, out):
     torch.set_num_threads(1)
     x = clustered(3000, 64, 5)
     q = torch.from_numpy(queries_near(x, 33, 6))
-    if mode == "partitioned":
-        g = build_hnsw(x, "mips", M=8, ef_construction=40, num_threads=1)
+    if mode in ("partitioned", "broadcast"):
+        if mode == "broadcast":  # the index is built once, on rank 0, and replicated (bench.py's N > 1 path)
+            from leann_amd.distributed import broadcast_graph
+
+            g0 = build_hnsw(x, "mips", M=8, ef_construction=40, num_threads=1) if rank == 0 else None
+            g = broadcast_graph(g0, 0)
+            g.validate()
+            ref = build_hnsw(x, "mips", M=8, ef_construction=40, num_threads=1)
+            assert all(np.array_equal(getattr(g, n), getattr(ref, n)) for n in ("levels", "level_ptr", "node_offsets", "neighbors"))
+            assert (g.entry_point, g.max_level, g.ntotal, g.d, g.metric_type) == (ref.entry_point, ref.max_level, ref.ntotal, ref.d, ref.metric_type)
+        else:
+            g = build_hnsw(x, "mips", M=8, ef_construction=40, num_threads=1)
         og = oracle_graph(g, 64)
 
         def search_fn(qq, k):
@@ -81,7 +91,7 @@ def _worker(rank, world, port, mode, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["partitioned", "sharded"])
+@pytest.mark.parametrize("mode", ["partitioned", "broadcast", "sharded"])
 def test_two_rank_gloo(mode, built_libs):
     world = 2
     mgr = mp.Manager()
