@@ -260,6 +260,13 @@ int lm_linear_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, i
 int lm_gemm_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
                      const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
 
+/* Weight-stationary form of the 384-input linear layer (csrc/lm_gemm_ws_h384.hip): d_out[tokens][n_out] = x W^T + b with
+ * d_w = the nn.Linear weight itself, [n_out][384] fp16 row major (no packing), n_out a multiple of 192 (<= 6144).  A
+ * workgroup keeps its 192 x 384 weight block resident in LDS and streams token tiles past it (no per-slab barriers, two
+ * waves per SIMD).  Host switch: LEANN_MI355X_LINEAR=3 (QKV projection; output projection followed by lm_add_layernorm_f16). */
+int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, int32_t n_out, void *d_out, int64_t tokens,
+                        void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

@@ -66,7 +66,9 @@ __device__ __forceinline__ void g2_issue_slab(const unsigned char* slab, unsigne
     for (int i = 0; i < 6; ++i) g2_dma16(src + i * 4096, stage + (256 * i + 64 * wv) * 16);
 }
 
-template <int MODE>
+// ABL: ablation bits for on-hardware diagnosis (LEANN_MI355X_ABLATE; 0 = the product kernel): 1 = no weight DMA in the main
+// loop (stale LDS), 2 = no counted wait / barrier per slab, 4 = no epilogue stores.  Wrong results by construction.
+template <int MODE, int ABL>
 __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_gemm_h384(
     const __half* __restrict__ x, const __half* __restrict__ wp, const float* __restrict__ bias, const __half* __restrict__ res,
     const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T, int P_arg, float eps) {
@@ -157,13 +159,13 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_gemm_h384(
 #pragma unroll
         for (int s = 0; s < G2_SLABS; ++s) {  // unrolled: xf is indexed by 2s + u, the stage of slab s is s % 4
             const int t = G2_SLABS * p + s;
-            if (t > 0) {
+            if (t > 0 && !(ABL & 2)) {
                 // slab t+1 (its head is prefetched at the tail of this slab) must have landed; slab t+2 may be in flight
                 if (t + 2 < nslab) G2_WAIT_VM(6);
                 else G2_WAIT_VM(0);
                 G2_BARRIER();  // ... for every wave; and every wave is done reading slab t-1, whose stage slab t+3 takes
             }
-            if (t + 3 < nslab) g2_issue_slab(wbytes + (int64_t)(t + 3) * G2_SLAB_BYTES, smem + ((s + 3) % G2_STAGES) * G2_SLAB_BYTES, tid);
+            if (!(ABL & 1) && t + 3 < nslab) g2_issue_slab(wbytes + (int64_t)(t + 3) * G2_SLAB_BYTES, smem + ((s + 3) % G2_STAGES) * G2_SLAB_BYTES, tid);
 #pragma unroll
             for (int n = 0; n < 12; ++n) {
                 const int m = 12 * s + n, u = n / 6, j = n % 6, ks = 2 * s + u;
@@ -285,7 +287,8 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_gemm_h384(
                     lane32_swap(a.x, b.x);
                     lane32_swap(a.y, b.y);
                     const uint4 y = {a.x, a.y, b.x, b.y};
-                    if (token < T) *(uint4*)(yr + 32 * j + 16 * qp) = y;
+                    if (ABL & 4) asm volatile("" ::"v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w));
+                    else if (token < T) *(uint4*)(yr + 32 * j + 16 * qp) = y;
                 }
         }
     }
@@ -306,13 +309,23 @@ extern "C" int lm_gemm_h384_f16(const void* d_x, const void* d_wp, const float* 
     hipStream_t st = (hipStream_t)stream;
     const __half *x = (const __half*)d_x, *w = (const __half*)d_wp, *r = (const __half*)d_residual;
     const __half *gm = (const __half*)d_gamma, *bt = (const __half*)d_beta;
+    const char* ab = getenv("LEANN_MI355X_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
     if (ln) {
-        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_h384<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL));
-        hipLaunchKernelGGL((k_gemm_h384<1>), grid, block, G2_LDS_TOTAL, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, 1, eps);
+        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_h384<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL));
+        hipLaunchKernelGGL((k_gemm_h384<1, 0>), grid, block, G2_LDS_TOTAL, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens, 1, eps);
     } else {
-        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_h384<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL));
-        hipLaunchKernelGGL((k_gemm_h384<0>), grid, block, G2_LDS_TOTAL, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens,
-                           n_out / ML_H, eps);
+#define G2_GO(A)                                                                                                                          \
+    case A:                                                                                                                                \
+        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_h384<0, A>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_TOTAL));             \
+        hipLaunchKernelGGL((k_gemm_h384<0, A>), grid, block, G2_LDS_TOTAL, st, x, w, d_bias, r, gm, bt, (__half*)d_out, (int)tokens,       \
+                           n_out / ML_H, eps);                                                                                             \
+        break
+        switch (abl) {
+            G2_GO(0); G2_GO(1); G2_GO(2); G2_GO(3); G2_GO(4); G2_GO(7);
+            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE must be 0, 1, 2, 3, 4 or 7");
+        }
+#undef G2_GO
     }
     LM_HIP(hipGetLastError());
     return LM_OK;

@@ -276,6 +276,8 @@ def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.
     import os
 
     gen = os.environ.get("LEANN_MI355X_LINEAR", "0")
+    if gen == "3":  # weight-stationary GEMM (csrc/lm_gemm_ws_h384.hip) + the add+LayerNorm kernel for the output projection
+        return _linear_ws_h384(x, lin, residual, ln)
     if gen not in ("1", "2"):
         return None
     n, k = lin.weight.shape
@@ -300,6 +302,27 @@ def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.
         float(ln.eps) if ln is not None else 0.0, C.c_void_p(out.data_ptr()), x.shape[0],
         C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_linear_h384_f16")
     return out
+
+
+def _linear_ws_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor], ln: Optional[nn.LayerNorm]) -> Optional[torch.Tensor]:
+    n, k = lin.weight.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n % 192 == 0 and n <= 6144 and lin.bias is not None):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    pk = getattr(lin, "_ws_pack", None)
+    if pk is None or pk[0].device != x.device:
+        pk = (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous())
+        lin._ws_pack = pk
+    out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().lm_gemm_ws_h384_f16(C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), n,
+                                               C.c_void_p(out.data_ptr()), x.shape[0], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+               "lm_gemm_ws_h384_f16")
+    if ln is None:
+        return out
+    return fused_add_layernorm(out, residual, ln)
 
 
 class _Layer(nn.Module):

@@ -249,6 +249,33 @@ int main(int argc, char** argv) {
                        gen == 1 ? "lm_linear_h384_f16" : "lm_gemm_h384_f16", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us, err);
                 fflush(stdout);
             }
+            {   // weight-stationary form (plain weight layout); the LN variant is GEMM + lm_add_layernorm_f16
+                Dev<__half> tmp((size_t)T * N);
+                CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
+                auto run = [&] {
+                    if (mode == 0) LM(lm_gemm_ws_h384_f16(x.p, w.p, b.p, N, out.p, T, st));
+                    else {
+                        LM(lm_gemm_ws_h384_f16(x.p, w.p, b.p, N, tmp.p, T, st));
+                        LM(lm_add_layernorm_f16(tmp.p, res.p, gamma.p, beta.p, out.p, T, H, 1e-12f, st));
+                    }
+                };
+                run();
+                CK(hipStreamSynchronize(st));
+                const double err = max_err_rows(out.host(), N, 0, N, rows, ref);
+                const float us = time_us(st, reps, run);
+                printf("{\"kernel\": \"lm_gemm_ws_h384_f16%s\", \"mode\": \"%s\", \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g}\n",
+                       mode ? " + lm_add_layernorm_f16" : "", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us, err);
+                fflush(stdout);
+            }
+            if (mode == 0 && want("ablate")) {
+                for (const char* ab : {"1", "2", "3", "4", "7"}) {
+                    setenv("LEANN_MI355X_ABLATE", ab, 1);
+                    const float usa = time_us(st, reps, [&] { LM(lm_gemm_h384_f16(x.p, wp.p, b.p, N, nullptr, nullptr, nullptr, 1e-12f, out.p, T, st)); });
+                    printf("{\"kernel\": \"lm_gemm_h384_f16 QKV\", \"ablate\": \"%s (1 no DMA, 2 no wait/barrier, 4 no stores)\", \"us\": %.1f}\n", ab, usa);
+                    fflush(stdout);
+                }
+                unsetenv("LEANN_MI355X_ABLATE");
+            }
             const float us = time_us(st, reps, [&] { lib_gemm(w.p, N, H, x.p, out.p); });
             printf("{\"kernel\": \"rocblas_gemm_ex f16 (no bias / LN)\", \"mode\": \"N=%d K=384\", \"us\": %.1f, \"TFLOPs\": %.1f}\n", N, us, gflop / us);
             fflush(stdout);
@@ -267,7 +294,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         auto ref = lref.host();
         const double gflop = 4.0 * T * (double)F * H * 1e-9;
-        for (const char* var : {"1", "2"}) {
+        for (const char* var : {"1", "2", "3"}) {
             setenv("LEANN_MI355X_MLP_VARIANT", var, 1);
             CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
             auto run = [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); };
@@ -278,6 +305,16 @@ int main(int argc, char** argv) {
             printf("{\"kernel\": \"lm_mlp_fused_h384_f16\", \"mode\": \"variant %s, ffn 1536 (fc1+GELU+fc2+res+LN)\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
                    var, us, gflop / us, err);
             fflush(stdout);
+        }
+        if (want("ablate")) {  // diagnosis: variant 3 with pieces switched off (results wrong by construction)
+            setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
+            for (const char* ab : {"1", "2", "3", "4", "7"}) {
+                setenv("LEANN_MI355X_ABLATE", ab, 1);
+                const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
+                printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"ablate\": \"%s (1 no DMA, 2 no wait/barrier, 4 no GELU)\", \"us\": %.1f}\n", ab, us);
+                fflush(stdout);
+            }
+            unsetenv("LEANN_MI355X_ABLATE");
         }
         unsetenv("LEANN_MI355X_MLP_VARIANT");
         const float us1 = time_us(st, reps, [&] { lib_gemm(w1.p, F, H, x.p, hid16.p); });

@@ -321,6 +321,23 @@ def case_encoder_abi():
         out = np.zeros((T, H), np.float16)
         _lib.check(lib.lm_mlp_fused_h384_f16(vp(x), vp(w1), vp(b1), vp(w2p), vp(b2), vp(gamma), vp(beta), vp(out), T, F, 1e-12, None), "mlp")
         assert np.abs(out.astype(np.float64) - ref).max() < 8e-3, variant
+    # variant 3 (lm_mlp_fused_v3.hip: DMA weight pipeline, GELU spread over the MFMA gaps, two-slab skew) needs >= 4 slabs
+    for F3 in (128, 224):
+        w1b = (rng.standard_normal((F3, H)) / np.sqrt(H)).astype(np.float16)
+        w2b = (rng.standard_normal((H, F3)) / np.sqrt(F3)).astype(np.float16)
+        b1b = (0.2 * rng.standard_normal(F3)).astype(np.float32)
+        w2pb = pack_w2_fused_mlp(torch.from_numpy(w2b)).numpy()
+        hidb = x.astype(np.float64) @ w1b.astype(np.float64).T + b1b
+        p16b = (0.5 * hidb * (1 + erf(hidb / np.sqrt(2)))).astype(np.float16).astype(np.float64)
+        refb = ln(p16b @ w2b.astype(np.float64).T + b2 + x.astype(np.float64))
+        got = {}
+        for variant in ("2", "3"):
+            os.environ["LEANN_MI355X_MLP_VARIANT"] = variant
+            ob = np.zeros((T, H), np.float16)
+            _lib.check(lib.lm_mlp_fused_h384_f16(vp(x), vp(w1b), vp(b1b), vp(w2pb), vp(b2), vp(gamma), vp(beta), vp(ob), T, F3, 1e-12, None), "mlp3")
+            assert np.abs(ob.astype(np.float64) - refb).max() < 8e-3, (variant, F3)
+            got[variant] = ob
+        assert np.abs(got["2"].astype(np.float64) - got["3"].astype(np.float64)).max() < 2e-3, F3  # same arithmetic, scalar vs packed GELU
     os.environ.pop("LEANN_MI355X_MLP_VARIANT")
     assert lib.lm_mlp_fused_h384_f16(vp(x), vp(w1), vp(b1), vp(w2p), vp(b2), vp(gamma), vp(beta), vp(out), T, 48, 1e-12, None) == -1  # ffn % 32
     # linear: QKV shape and out-projection + residual + LayerNorm
@@ -345,6 +362,14 @@ def case_encoder_abi():
     _lib.check(lib.lm_gemm_h384_f16(vp(x), vp(wop), vp(bo), H, vp(res), vp(gamma), vp(beta), 1e-12, vp(out1b), T, None), "gemm+ln")
     assert np.abs(out1b.astype(np.float64) - ln(res.astype(np.float64) + x.astype(np.float64) @ wo.astype(np.float64).T + bo)).max() < 6e-3
     assert lib.lm_gemm_h384_f16(vp(x), vp(wop), vp(bo), 400, None, None, None, 0.0, vp(out1), T, None) == -1
+    # weight-stationary form (lm_gemm_ws_h384.hip): plain nn.Linear weight layout, 8 waves per workgroup; ragged token count
+    Tw = 300
+    xw = rng.standard_normal((Tw, H)).astype(np.float16)
+    for wmat, bvec in ((w, b), (wo, bo)):
+        ow = np.zeros((Tw, wmat.shape[0]), np.float16)
+        _lib.check(lib.lm_gemm_ws_h384_f16(vp(xw), vp(np.ascontiguousarray(wmat)), vp(bvec), wmat.shape[0], vp(ow), Tw, None), "gemm_ws")
+        assert np.abs(ow.astype(np.float64) - (xw.astype(np.float64) @ wmat.astype(np.float64).T + bvec)).max() < 6e-3, wmat.shape
+    assert lib.lm_gemm_ws_h384_f16(vp(xw), vp(w), vp(b), 200, vp(ow), Tw, None) == -1  # n_out % 192
     # add + LayerNorm: both generations through the same entry point
     for gen in ("1", "2"):
         os.environ["LEANN_MI355X_LN"] = gen

@@ -100,6 +100,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 #define LM_EMULATED_DEVICE 1  // kernels with DMA / counted waits select their host form on this
 #define LM_KEEP_LOCAL(v) ((void)0)
 #define LM_ONE_WAVE_PER_SIMD
+#define LM_TWO_WAVES_PER_SIMD
 #define LM_WAVE_SYNC() emul::wave_sync()
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 #define threadIdx emul::tls.thread
