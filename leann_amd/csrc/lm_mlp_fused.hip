@@ -430,8 +430,8 @@ extern "C" int lm_mlp_fused_h384_f16(const void* d_x, const void* d_w1, const fl
     const size_t shmem = (size_t)2 * ML_BUF + (size_t)ffn * 4;
     if (shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "ffn size too large for the LDS-resident bias (<= 13056)");
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
-    const char* var = getenv("LEANN_MI355X_MLP_VARIANT");  // default: cross-slab software pipelining (k_mlp_fused_h384_p); "1" = plain (A/B)
-    if (var && var[0] == '3' && var[1] == 0) {  // DMA weight pipeline + scalar GELU spread over every MFMA gap (lm_mlp_fused_v3.hip)
+    const char* var = getenv("LEANN_MI355X_MLP_VARIANT");  // default "3"; "2" = cross-slab pipelining (k_mlp_fused_h384_p), "1" = plain (A/B)
+    if (!var || (var[0] == '3' && var[1] == 0)) {  // DMA weight pipeline + scalar GELU spread over every MFMA gap (lm_mlp_fused_v3.hip)
         const int rc3 = lm_mlp_fused_v3_launch(d_x, d_w1, d_b1, d_w2p, d_b2, d_gamma, d_beta, d_out, tokens, ffn, eps, stream);
         if (rc3 != 1) return rc3;  // 1 = shape outside its envelope (ffn < 128): variant 2 below
     }

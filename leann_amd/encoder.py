@@ -271,11 +271,12 @@ def pack_w_linear_h384(w: torch.Tensor) -> torch.Tensor:
 def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor] = None,
                       ln: Optional[nn.LayerNorm] = None) -> Optional[torch.Tensor]:
     """x W^T + b (and, with residual + ln, LayerNorm(residual + x W^T + b)) for 384 input features through the
-    hand-written MFMA kernels: LEANN_MI355X_LINEAR=1 the first generation (csrc/lm_linear_h384.hip, lost to hipBLASLt in
-    round 1), =2 the second (csrc/lm_gemm_h384.hip).  None = the caller takes the hipBLASLt path."""
+    hand-written MFMA kernels: LEANN_MI355X_LINEAR=3 (default) the weight-stationary GEMM (csrc/lm_gemm_ws_h384.hip, + the
+    add+LayerNorm kernel for the output projection), =2 the streaming second generation (csrc/lm_gemm_h384.hip), =1 the first
+    (csrc/lm_linear_h384.hip), =0 the library path (A/B).  None = the caller takes the hipBLASLt path."""
     import os
 
-    gen = os.environ.get("LEANN_MI355X_LINEAR", "0")
+    gen = os.environ.get("LEANN_MI355X_LINEAR", "3")  # default since round 2: measured 381 / 240 us vs 405 / ~225 us (library) per 262k tokens
     if gen == "3":  # weight-stationary GEMM (csrc/lm_gemm_ws_h384.hip) + the add+LayerNorm kernel for the output projection
         return _linear_ws_h384(x, lin, residual, ln)
     if gen not in ("1", "2"):

@@ -189,6 +189,33 @@ static std::vector<__half> pack_w2(const std::vector<__half>& w2, int F) {
     return p;
 }
 
+// ---- raw HBM bandwidth probes (what bounds a kernel whose output is 3x its input) ----
+__global__ void bw_write(uint4* p, size_t n) {
+    const uint4 v = {1u, 2u, 3u, (unsigned)threadIdx.x};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void bw_read(const uint4* p, size_t n, unsigned* sink) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345u) *sink = acc;
+}
+__global__ void bw_copy(const uint4* a, uint4* b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+// the GEMM epilogue's pattern: a wave writes 32 rows x 32 B (row stride `stride` bytes)
+__global__ void bw_write_rows32(unsigned char* p, int rows, int stride, int width) {
+    const int lane = threadIdx.x & 63, wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const uint4 v = {1u, 2u, 3u, 4u};
+    for (int r0 = wv * 32; r0 < rows; r0 += nw * 32)
+        for (int c = 0; c < width; c += 32) {
+            const int row = r0 + (lane & 31);
+            if (row < rows) *(uint4*)(p + (size_t)row * stride + c + 16 * (lane >> 5)) = v;
+        }
+}
+
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 262144 - 37;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -223,6 +250,25 @@ int main(int argc, char** argv) {
                         rocblas_gemm_algo_standard, 0, 0);
     };
 
+    if (want("bw")) {
+        const size_t bytes = (size_t)T * 1152 * 2, n16 = bytes / 16;
+        Dev<unsigned char> A(bytes), B(bytes);
+        Dev<unsigned> sink(1);
+        CK(hipMemset(A.p, 1, bytes));
+        for (int blocks : {1024, 4096, 16384}) {
+            float us = time_us(st, reps, [&] { hipLaunchKernelGGL(bw_write, dim3(blocks), dim3(256), 0, st, (uint4*)A.p, n16); });
+            printf("{\"probe\": \"write %zu MB, 16 B/lane coalesced, %d blocks\", \"us\": %.1f, \"GBps\": %.0f}\n", bytes >> 20, blocks, us, bytes / us * 1e-3);
+            us = time_us(st, reps, [&] { hipLaunchKernelGGL(bw_read, dim3(blocks), dim3(256), 0, st, (const uint4*)A.p, n16, sink.p); });
+            printf("{\"probe\": \"read  %zu MB, 16 B/lane coalesced, %d blocks\", \"us\": %.1f, \"GBps\": %.0f}\n", bytes >> 20, blocks, us, bytes / us * 1e-3);
+            us = time_us(st, reps, [&] { hipLaunchKernelGGL(bw_copy, dim3(blocks), dim3(256), 0, st, (const uint4*)A.p, (uint4*)B.p, n16); });
+            printf("{\"probe\": \"copy  %zu MB -> %zu MB, %d blocks\", \"us\": %.1f, \"GBps_read_plus_write\": %.0f}\n", bytes >> 20, bytes >> 20, blocks, us, 2.0 * bytes / us * 1e-3);
+        }
+        float us = time_us(st, reps, [&] { hipLaunchKernelGGL(bw_write_rows32, dim3(2048), dim3(256), 0, st, A.p, T, 2304, 2304); });
+        printf("{\"probe\": \"write %zu MB as 32 rows x 32 B per wave store (the GEMM epilogue pattern)\", \"us\": %.1f, \"GBps\": %.0f}\n", bytes >> 20, us, bytes / us * 1e-3);
+        us = time_us(st, reps, [&] { CK(hipMemsetAsync(A.p, 0, bytes, st)); });
+        printf("{\"probe\": \"hipMemsetAsync %zu MB\", \"us\": %.1f, \"GBps\": %.0f}\n", bytes >> 20, us, bytes / us * 1e-3);
+        fflush(stdout);
+    }
     if (want("linear")) {
         for (int mode = 0; mode < 2; ++mode) {
             const int N = mode == 0 ? 3 * H : H;

@@ -170,14 +170,14 @@ def test_encoder_forward_default_and_every_kernel_vs_first_generation(monkeypatc
     d = enc.encode_tokens_packed(ti, tl)  # the default path = what bench.py and the searchers run
     assert (d - b).abs().max() < 3e-3
     for k, v in (("LEANN_MI355X_ATTN", "2"), ("LEANN_MI355X_LN", "2"), ("LEANN_MI355X_POOL", "1"), ("LEANN_MI355X_EMBED", "1"),
-                 ("LEANN_MI355X_MLP", "1"), ("LEANN_MI355X_MLP_VARIANT", "2"), ("LEANN_MI355X_LINEAR", "1")):
+                 ("LEANN_MI355X_MLP", "1"), ("LEANN_MI355X_MLP_VARIANT", "2"), ("LEANN_MI355X_LINEAR", "2")):
         monkeypatch.setenv(k, v)
     a = enc.encode_tokens_packed(ti, tl)
     assert (a - b).abs().max() < 3e-3
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 32), (300, 64), (300, 3072)])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 32), (300, 64), (300, 128), (300, 3072)])
 def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):
     """lm_mlp_fused_h384_f16 (LEANN_MI355X_MLP=1) vs a plain PyTorch fp32 reference of the same block and vs the
     default path (hipBLASLt GEMMs + GELU kernel + lm_add_layernorm_f16)."""
@@ -196,7 +196,7 @@ def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):
         layer.fc2.bias.copy_(0.2 * torch.randn(384))
     x = torch.randn((tokens, 384), device="cuda").half()
     monkeypatch.setenv("LEANN_MI355X_MLP", "1")
-    monkeypatch.setenv("LEANN_MI355X_MLP_VARIANT", variant)  # 2: cross-slab software pipelining
+    monkeypatch.setenv("LEANN_MI355X_MLP_VARIANT", variant)  # 3 (default): DMA pipeline + GELU micro-op stream (ffn >= 128, else it runs 2)
     with torch.no_grad():
         got = fused_mlp(x, layer)
         assert got is not None and got.shape == x.shape and got.dtype == torch.float16
@@ -213,9 +213,11 @@ def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):
     assert (got.float() - dflt.float()).abs().max().item() <= 1.2e-2 * scale
 
 
-@pytest.mark.parametrize("tokens", [1, 128, 129, 5000])
-def test_linear_h384_qkv_and_out_projection(tokens, monkeypatch):
-    """lm_linear_h384_f16 (LEANN_MI355X_LINEAR=1): QKV projection (n_out = 1152) and output projection with the
+@pytest.mark.parametrize("gen", ["1", "2", "3"])
+@pytest.mark.parametrize("tokens", [1, 128, 129, 257, 5000])
+def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
+    """The three hand-written 384-input linear kernels -- LEANN_MI355X_LINEAR=3 (default: weight-stationary lm_gemm_ws_h384_f16 +
+    add/LayerNorm), 2 (lm_gemm_h384_f16), 1 (lm_linear_h384_f16): QKV projection (n_out = 1152) and output projection with the
     residual + LayerNorm epilogue, vs plain PyTorch fp32 references of the same ops."""
     import torch
     import torch.nn as nn
@@ -232,7 +234,7 @@ def test_linear_h384_qkv_and_out_projection(tokens, monkeypatch):
         ln.bias.copy_(0.1 * torch.randn(384))
     x = torch.randn((tokens, 384), device="cuda").half()
     res = torch.randn((tokens, 384), device="cuda").half()
-    monkeypatch.setenv("LEANN_MI355X_LINEAR", "1")
+    monkeypatch.setenv("LEANN_MI355X_LINEAR", gen)
     with torch.no_grad():
         got = fused_linear_h384(x, qkv)
         assert got is not None and got.shape == (tokens, 1152)
