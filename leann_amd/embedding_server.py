@@ -24,6 +24,7 @@ import argparse
 import json
 import logging
 import os
+import sys
 import threading
 from pathlib import Path
 from typing import Optional
@@ -276,19 +277,38 @@ class Mi355xEmbeddingService:
             return encode_node_embedding_response(b"", [], [])
 
     # ---- transport ------------------------------------------------------------------------------------
-    def serve(self, zmq_port: int, protocol: str = "hnsw", shutdown_event: Optional[threading.Event] = None) -> None:
+    def serve(self, zmq_port: int, protocol: str = "hnsw", shutdown_event: Optional[threading.Event] = None,
+              ready_event: Optional[threading.Event] = None) -> None:
+        """The REP loop of the reference servers (hnsw_embedding_server.py:97-324, diskann_embedding_server.py:223-364): bind
+        tcp://*:port, one request -> one reply, poll with a 1 s timeout so that a shutdown request is noticed.  With pyzmq
+        installed this is a zmq.REP socket; without it (this image, the GPU box) the same wire protocol is spoken directly by
+        leann_amd/zmtp.py -- REQ clients (the faiss / DiskANN forks, searcher_base.py:130-160) cannot tell the difference."""
+        shutdown_event = shutdown_event or threading.Event()
+        handler = self.handle_msgpack if protocol == "hnsw" else self.handle_diskann
         try:
             import zmq
-        except ImportError as e:  # pragma: no cover - pyzmq absent in the build image
-            raise RuntimeError("pyzmq is required to serve over ZeroMQ (pip install pyzmq)") from e
-        shutdown_event = shutdown_event or threading.Event()
+        except ImportError:
+            zmq = None
+        if zmq is None:
+            from .zmtp import RepServer
+
+            srv = RepServer(zmq_port)
+            logger.info(f"embedding server (native ZMTP REP) listening on tcp://*:{srv.port}")
+            if ready_event is not None:
+                ready_event.set()
+            try:
+                srv.serve(handler, shutdown_event)
+            finally:
+                srv.close()
+            return
         ctx = zmq.Context()
         sock = ctx.socket(zmq.REP)
         sock.bind(f"tcp://*:{zmq_port}")
         sock.setsockopt(zmq.RCVTIMEO, 1000)
         sock.setsockopt(zmq.SNDTIMEO, 1000)
         sock.setsockopt(zmq.LINGER, 0)
-        handler = self.handle_msgpack if protocol == "hnsw" else self.handle_diskann
+        if ready_event is not None:
+            ready_event.set()
         try:
             while not shutdown_event.is_set():
                 try:
@@ -329,20 +349,53 @@ def service_from_meta(passages_file: str, model_name: str, distance_metric: str 
     return Mi355xEmbeddingService(model_name, enc, tokens, tok, distance_metric, dev)
 
 
-def main(argv=None):
-    """Same flags as the reference servers (hnsw_embedding_server.py:395-417)."""
-    ap = argparse.ArgumentParser(description="MI355X embedding server (LEANN wire compatible)")
-    ap.add_argument("--zmq-port", type=int, default=5555)
-    ap.add_argument("--passages-file", type=str, required=True, help="<index>.meta.json")
-    ap.add_argument("--model-name", type=str, default="sentence-transformers/all-mpnet-base-v2")
-    ap.add_argument("--distance-metric", type=str, default="mips", choices=["l2", "mips", "cosine"])
-    ap.add_argument("--embedding-mode", type=str, default="sentence-transformers", choices=["sentence-transformers"])
-    ap.add_argument("--protocol", type=str, default="hnsw", choices=["hnsw", "diskann"])
+EMBEDDING_MODES = ["sentence-transformers", "openai", "mlx", "ollama"]  # the reference parsers' choices
+
+
+def build_parser(flavour: str = "hnsw") -> argparse.ArgumentParser:
+    """EXACTLY the command line of the reference servers -- the stock EmbeddingServerManager builds
+    ``python -m <backend module> --zmq-port P --model-name M [--passages-file F] [--embedding-mode E] [--distance-metric D]``
+    (embedding_server_manager.py:151-174).  hnsw_embedding_server.py:395-417: --distance-metric is free-form, default "mips";
+    diskann_embedding_server.py:435-462: choices l2 / mips / cosine, default "l2"."""
+    ap = argparse.ArgumentParser(description=f"{'HNSW' if flavour == 'hnsw' else 'DiskANN'} Embedding service (MI355X)")
+    ap.add_argument("--zmq-port", type=int, default=5555, help="ZMQ port to run on")
+    ap.add_argument("--passages-file", type=str, help="Metadata JSON file containing passage sources (<index>.meta.json)")
+    ap.add_argument("--model-name", type=str, default="sentence-transformers/all-mpnet-base-v2", help="Embedding model name")
+    if flavour == "hnsw":
+        ap.add_argument("--distance-metric", type=str, default="mips", help="Distance metric to use")
+    else:
+        ap.add_argument("--distance-metric", type=str, default="l2", choices=["l2", "mips", "cosine"],
+                        help="Distance metric for similarity computation")
+    ap.add_argument("--embedding-mode", type=str, default="sentence-transformers", choices=EMBEDDING_MODES, help="Embedding backend mode")
+    return ap
+
+
+def main(argv=None, flavour: str = "hnsw"):
+    """Entry point of the launch shims (server_overlay/leann_backend_hnsw/hnsw_embedding_server.py and
+    server_overlay/leann_backend_diskann/diskann_embedding_server.py) and of ``python -m leann_amd.embedding_server``."""
+    import signal
+
+    ap = build_parser(flavour)
+    if flavour == "hnsw" and argv is None and "--protocol" in sys.argv:  # our own module entry: allow choosing the wire protocol
+        ap.add_argument("--protocol", type=str, default="hnsw", choices=["hnsw", "diskann"])
     args = ap.parse_args(argv)
+    if args.embedding_mode != "sentence-transformers":
+        # openai / ollama are remote HTTP services and mlx is Apple-silicon only (embedding_compute.py:25-68): nothing for a GPU
+        # to recompute.  Fail loudly instead of serving embeddings from a different model.
+        raise SystemExit(f"--embedding-mode {args.embedding_mode}: only 'sentence-transformers' models are served by the MI355X server")
+    if not args.passages_file:
+        raise SystemExit("--passages-file <index>.meta.json is required")
+    logging.basicConfig(level=os.environ.get("LEANN_LOG_LEVEL", "WARNING"))
     # random weights only on explicit request (synthetic corpora): the reference CLI has no such flag, hence the environment
     svc = service_from_meta(args.passages_file, args.model_name, args.distance_metric,
                             allow_random=os.environ.get("LEANN_MI355X_ALLOW_RANDOM_WEIGHTS", "0") == "1")
-    svc.serve(args.zmq_port, args.protocol)
+    stop = threading.Event()
+    for sig in (signal.SIGTERM, signal.SIGINT):  # EmbeddingServerManager.stop_server() terminates the process (SIGTERM)
+        try:
+            signal.signal(sig, lambda *_: stop.set())
+        except ValueError:  # not the main thread (tests)
+            pass
+    svc.serve(args.zmq_port, getattr(args, "protocol", "diskann" if flavour == "diskann" else "hnsw"), stop)
 
 
 if __name__ == "__main__":
