@@ -86,8 +86,6 @@ class Mi355xBuilder(LeannBackendBuilderInterface):
             self.build_params["is_compact"] = False
 
     def build(self, data: np.ndarray, ids: list, index_path: str, **kwargs) -> None:
-        from .hnsw_builder import build_hnsw
-
         path = Path(index_path)
         path.parent.mkdir(parents=True, exist_ok=True)
         if data.dtype != np.float32:
@@ -98,7 +96,7 @@ class Mi355xBuilder(LeannBackendBuilderInterface):
             raise ValueError(f"Unsupported distance_metric '{self.distance_metric}'.")
         if metric == "cosine":
             data = normalize_l2(data)
-        g = build_hnsw(data, metric, M=self.M, ef_construction=self.efConstruction)
+        g = self._build_graph(data, metric)
         g.storage = np.ascontiguousarray(data, dtype=np.float32)
         # the file always uses the CSR layout; "non-compact" in the reference == embeddings kept
         write_index(path.parent / f"{path.stem}.index", g, prune_embeddings=bool(self.is_recompute))
@@ -111,6 +109,35 @@ class Mi355xBuilder(LeannBackendBuilderInterface):
             x = torch.from_numpy(np.ascontiguousarray(data))
             cb = train_pq(x, pq_bytes, seed=0)
             np.savez(path.parent / f"{path.stem}_pq.npz", codebooks=cb.numpy(), codes=encode_pq(x, cb).numpy())
+
+
+    def _build_graph(self, data: np.ndarray, metric: str):
+        """HNSW construction.  Small corpora: the sequential host builder (csrc/hnsw_build.cpp, the role of faiss' index.add in
+        hnsw_backend.py:83-90).  From ``gpu_build_threshold`` vectors on (default 100 000) and with a HIP device present: the
+        batched GPU builder driven by the HIP search kernel (gpu_graph_build.py) -- minutes instead of hours at 1M-60M chunks.
+        ``hub_preserving_m`` > 0 additionally applies the paper's high-degree-preserving pruning (Algorithm 3): ~m links per
+        node, full lists for the 2 % hub nodes -- the storage side of a recompute (pruned) index."""
+        from .hnsw_builder import build_hnsw
+
+        bp = self.build_params
+        thr = int(bp.get("gpu_build_threshold", 100_000))
+        m_low = int(bp.get("hub_preserving_m", 0) or 0)
+        use_gpu = data.shape[0] >= thr and _lib.device_count() > 0
+        if not use_gpu and m_low <= 0:
+            return build_hnsw(data, metric, M=self.M, ef_construction=self.efConstruction)
+        import torch
+
+        from .gpu_graph_build import build_graph_gpu, prune_preserving_hubs
+
+        if use_gpu:
+            x = torch.from_numpy(np.ascontiguousarray(data)).to(torch.device("cuda", int(bp.get("device", 0))))
+            g = build_graph_gpu(x, metric, M=self.M, ef_construction=self.efConstruction)
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(data))
+            g = build_hnsw(data, metric, M=self.M, ef_construction=self.efConstruction)
+        if m_low > 0:
+            g = prune_preserving_hubs(g, x, self.M, m_low, float(bp.get("hub_fraction", 0.02)))
+        return g
 
 
 class _NoServer:

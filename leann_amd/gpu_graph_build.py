@@ -338,3 +338,82 @@ def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, ef_const
     graphs = [(f.sub.cpu().numpy(), f.adj.cpu().numpy()) for f in finished]
     all_ids = np.arange(n, dtype=np.int64)
     return _assemble_csr(lv_np, graphs, all_ids, d, mt, entry_global, M, ef_construction)
+
+
+@torch.no_grad()
+def prune_preserving_hubs(g: HnswCsr, x: torch.Tensor, M: int, m_low: int, hub_fraction: float = 0.02) -> HnswCsr:
+    """High-degree-preserving pruning of the level-0 graph (LEANN paper, Algorithm 3, p. 6): storage drops from ~2M links per node
+    to ~m_low while the few hub nodes that most searches pass through keep their full lists.
+
+      * V* = the ``hub_fraction`` (paper: 2 %) nodes of highest degree -- in-degree here: how many lists a node appears in;
+      * every node re-selects its out-links from its candidate list W(v) in the original (heuristic) order: up to 2M (the
+        level-0 cap of the unpruned graph) for v in V*, up to ``m_low`` < M otherwise.  W(v) is v's list in the input graph:
+        the builder produced it with the select-neighbours heuristic from an ef_construction-sized candidate set, so this
+        is the paper's re-selection without repeating the N searches;
+      * for every kept link v -> u the reverse link u -> v is offered as well and every node may hold up to 2M links in
+        total, overflowing lists being shrunk with the same heuristic (paper: "all nodes establish bidirectional edges up
+        to the maximum threshold M; only the number of outgoing selections of low-degree nodes is restricted").
+    Upper levels are untouched (they hold ~N/M nodes).  Returns a new graph; ``x`` = the [N, D] embeddings on any device."""
+    n = g.ntotal
+    if n == 0 or m_low >= 2 * M:
+        return g
+    dev = x.device
+    mt = g.metric_type
+    p0 = g.node_offsets[:-1].astype(np.int64)
+    beg = g.level_ptr[p0].astype(np.int64)
+    deg = (g.level_ptr[p0 + 1].astype(np.int64) - beg)
+    cap = 2 * M
+    # dense level-0 adjacency [n, cap] in stored order (-1 padded)
+    adj = np.full((n, cap), -1, np.int64)
+    col = np.arange(cap)[None, :]
+    m = col < np.minimum(deg, cap)[:, None]
+    adj[m] = g.neighbors[(beg[:, None] + col)[m]]
+    indeg = np.bincount(adj[m], minlength=n)  # in how many level-0 lists a node appears
+    nh = max(1, int(round(hub_fraction * n)))
+    hubs = np.argpartition(-indeg, min(nh, n - 1))[:nh]
+    quota = np.full(n, m_low, np.int64)
+    quota[hubs] = cap
+    keep = (col < quota[:, None]) & (adj >= 0)
+    src = torch.from_numpy(np.broadcast_to(np.arange(n)[:, None], adj.shape)[keep].copy()).to(dev)
+    dst = torch.from_numpy(adj[keep]).to(dev)
+    # similarities of the kept links (larger = closer), in blocks
+    w = torch.empty(src.shape[0], dtype=torch.float32, device=dev)
+    for b0 in range(0, src.shape[0], 1 << 20):
+        a, b = x[src[b0 : b0 + (1 << 20)]].float(), x[dst[b0 : b0 + (1 << 20)]].float()
+        w[b0 : b0 + (1 << 20)] = (a * b).sum(1) if mt == METRIC_INNER_PRODUCT else -((a - b) ** 2).sum(1)
+    G = _LevelGraph(torch.arange(n, device=dev), cap)
+    step = 1 << 21  # bound the temporaries of add_links
+    for b0 in range(0, src.shape[0], step):
+        s_, d_, w_ = src[b0 : b0 + step], dst[b0 : b0 + step], w[b0 : b0 + step]
+        G.add_links(x, torch.cat([s_, d_]), torch.cat([d_, s_]), torch.cat([w_, w_]), mt)
+    new0 = G.adj.cpu().numpy()
+    # reassemble: level 0 replaced, upper levels copied
+    nlev = g.levels.astype(np.int64)
+    nptr = int(g.node_offsets[-1])
+    old_deg = np.diff(np.concatenate([g.level_ptr.astype(np.int64), [g.neighbors.shape[0]]]))[:nptr] if nptr else np.zeros(0, np.int64)
+    new_deg = old_deg.copy()
+    m0 = new0 >= 0
+    new_deg[p0] = m0.sum(1)
+    # the sentinel slot (last pointer of every node) holds no list
+    new_deg[(g.node_offsets[1:].astype(np.int64) - 1)] = 0
+    level_ptr = np.zeros(nptr, np.uint64)
+    if nptr:
+        level_ptr[1:] = np.cumsum(new_deg)[:-1]
+    neighbors = np.empty(int(new_deg.sum()), np.int32)
+    # level 0
+    pos = np.cumsum(m0, axis=1) - 1
+    rows = np.nonzero(m0)
+    neighbors[level_ptr[p0].astype(np.int64)[rows[0]] + pos[rows]] = new0[rows]
+    # upper levels: copy list by list (few nodes)
+    up = np.nonzero(nlev > 1)[0]
+    for i in up:
+        for l in range(1, int(nlev[i])):
+            p = int(g.node_offsets[i]) + l
+            b, e = int(g.level_ptr[p]), int(g.level_ptr[p + 1])
+            nb = int(level_ptr[p])
+            neighbors[nb : nb + (e - b)] = g.neighbors[b:e]
+    out = HnswCsr(d=g.d, ntotal=n, metric_type=mt, levels=g.levels.copy(), level_ptr=level_ptr, node_offsets=g.node_offsets.copy(),
+                  neighbors=neighbors, entry_point=g.entry_point, max_level=g.max_level, ef_construction=g.ef_construction,
+                  cum_nneighbor_per_level=g.cum_nneighbor_per_level)
+    out.validate()
+    return out

@@ -1,0 +1,116 @@
+"""The plugin boundary exercised on the GPU the way LEANN's callers use it:
+  * a9  -- an `mi355x_diskann` bundle searched through `Mi355xDiskannSearcher.search` (diskann_backend.py:383-471), stored
+           embeddings and recompute (deferred exact rerank through the in-process encoder), against the PQ oracle;
+  * a12 -- the REAL `leann.api.LeannSearcher` (api.py:644-796) on top of our backend, when leann-core is importable
+           (it is not shipped to the GPU box: /root/reference never travels; the test then skips and says so)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import clustered, oracle_graph, queries_near
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        return False
+
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _has_gpu(), reason="needs an MI355X")]
+
+
+def test_diskann_searcher_plugin_against_the_pq_oracle(tmp_path, built_libs):
+    import torch
+
+    from leann_amd import csr_format as cf
+    from leann_amd._compat import BACKEND_REGISTRY
+    from leann_amd.backend import write_leann_bundle
+    from leann_amd.encoder import BertEncoder
+    from leann_amd.tokenizer import load_tokenizer
+    from oracle import oracle as orc
+
+    model = "sentence-transformers/all-MiniLM-L6-v2"
+    texts = [f"passage {i} " + " ".join(f"w{(i * 11 + j * 3) % 90}" for j in range(14)) for i in range(600)]
+    # (1) stored embeddings: an index that keeps its vectors, traversal on PQ codes, rerank from the table
+    x = clustered(600, 384, 9)
+    p = str(tmp_path / "full.leann")
+    write_leann_bundle(p, texts, x, model, backend_name="mi355x_diskann", distance_metric="l2", graph_degree=16, complexity=48, pq_bytes=48)
+    s = BACKEND_REGISTRY["mi355x_diskann"].searcher(p)
+    q = queries_near(x, 12, 10)
+    r = s.search(q, 5, complexity=40, beam_width=4, recompute_embeddings=False)
+    g = cf.read_index(tmp_path / "full.index")
+    z = np.load(tmp_path / "full_pq.npz")
+    oi, od, _ = orc.pq_search(oracle_graph(g, 384), z["codebooks"], z["codes"], q, 5, L=40, W=4, table=x)
+    assert r["labels"] == [[str(int(v)) for v in row] for row in oi]
+    assert np.array_equal(r["distances"].view(np.uint32), od.view(np.uint32))
+    assert np.all(np.diff(r["distances"], axis=1) >= 0)  # squared L2, best first
+    s.cleanup()
+    # (2) recompute: pruned index (no vectors), PQ traversal + ONE deferred exact rerank through the in-process encoder
+    enc = BertEncoder.load(model, allow_random=True).to("cuda", dtype=torch.float16)
+    p2 = str(tmp_path / "pruned.leann")
+    tok = load_tokenizer(model, 256, p2, texts, enc.cfg.vocab_size, allow_stand_in=enc.weights_source == "random")
+    seqs = tok.encode_batch(texts)
+    T = max(len(t) for t in seqs)
+    ids = torch.zeros((len(seqs), T), dtype=torch.int32)
+    for i, t in enumerate(seqs):
+        ids[i, : len(t)] = torch.tensor(t, dtype=torch.int32)
+    emb = enc.encode_tokens(ids.cuda(), torch.tensor([len(t) for t in seqs], dtype=torch.int32).cuda()).cpu().numpy()
+    write_leann_bundle(p2, texts, emb, model, backend_name="mi355x_diskann", distance_metric="mips", graph_degree=16, complexity=48,
+                       pq_bytes=48, is_recompute=True)
+    s2 = BACKEND_REGISTRY["mi355x_diskann"].searcher(p2, allow_random_weights=True)
+    with pytest.raises(ValueError, match="zmq_port must be provided"):
+        s2.search(emb[:1], 3, recompute_embeddings=True)
+    r2 = s2.search(emb[:9], 4, complexity=48, beam_width=8, recompute_embeddings=True, zmq_port=5557)
+    g2 = cf.read_index(tmp_path / "pruned.index")
+    z2 = np.load(tmp_path / "pruned_pq.npz")
+    oi2, od2, ost = orc.pq_search(oracle_graph(g2, 384), z2["codebooks"], z2["codes"], emb[:9], 4, L=48, W=8, provider=lambda idv: emb[idv],
+                                  use_deferred_fetch=True)
+    assert [row[0] for row in r2["labels"]] == [str(i) for i in range(9)]  # every query IS a passage
+    assert r2["labels"] == [[str(int(v)) for v in row] for row in oi2]     # same candidates, same exact-rerank order
+    assert np.allclose(r2["distances"], od2, atol=5e-3)                    # GPU fp16 encoder vs the embeddings it produced at build time
+    assert np.all(np.diff(r2["distances"], axis=1) <= 0)                   # +IP, best first
+    assert s2.last_stats()["nunique"] == ost["n_rerank_unique"]            # one deferred fetch of the unique candidates
+    s2.cleanup()
+
+
+def test_real_leann_searcher_on_top_of_the_backend(tmp_path, built_libs):
+    """leann.api.LeannSearcher(index).search("...") end to end (a12).  Needs leann-core importable: PYTHONPATH pointing at a
+    LEANN checkout (in this repo's dev container: /root/reference/packages/leann-core/src)."""
+    import sys
+
+    ref = Path("/root/reference/packages/leann-core/src")
+    if ref.is_dir() and str(ref) not in sys.path:
+        sys.path.insert(0, str(ref))
+    try:
+        from leann.api import LeannSearcher
+    except Exception as ex:  # noqa: BLE001
+        pytest.skip(f"leann-core is not importable on this box ({type(ex).__name__}): the reference tree does not travel to the GPU box")
+    import torch
+
+    import leann_backend_mi355x  # noqa: F401 - registers the backend with leann's registry
+    from leann_amd.backend import write_leann_bundle
+    from leann_amd.encoder import BertEncoder
+    from leann_amd.tokenizer import load_tokenizer
+
+    model = "sentence-transformers/all-MiniLM-L6-v2"
+    texts = [f"the {w} sat on the mat number {i}" for i, w in enumerate(["cat", "dog", "crocodile", "banana", "robot"] * 40)]
+    p = str(tmp_path / "real.leann")
+    enc = BertEncoder.load(model, allow_random=True).to("cuda", dtype=torch.float16)
+    tok = load_tokenizer(model, 256, p, texts, enc.cfg.vocab_size, allow_stand_in=True)
+    seqs = tok.encode_batch(texts)
+    T = max(len(t) for t in seqs)
+    ids = torch.zeros((len(seqs), T), dtype=torch.int32)
+    for i, t in enumerate(seqs):
+        ids[i, : len(t)] = torch.tensor(t, dtype=torch.int32)
+    emb = enc.encode_tokens(ids.cuda(), torch.tensor([len(t) for t in seqs], dtype=torch.int32).cuda()).cpu().numpy()
+    write_leann_bundle(p, texts, emb, model, distance_metric="mips", M=8, efConstruction=40)
+    searcher = LeannSearcher(p, allow_random_weights=True)
+    res = searcher.search(texts[17], top_k=3, complexity=32, recompute_embeddings=True)
+    assert len(res) == 3 and res[0].id == "17" and res[0].text == texts[17]
+    assert res[0].score >= res[1].score >= res[2].score
+    searcher.cleanup()

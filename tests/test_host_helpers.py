@@ -100,3 +100,42 @@ def test_encoder_autotune_falls_back_to_the_default_path_when_the_probe_process_
     assert any("child_exit" in e for e in r["log"])
     keys = {k for c, _ in autotune.CANDIDATES for k in c}
     assert keys == set(autotune.ALL_KEYS) and all(k.startswith("LEANN_MI355X_") for k in keys)
+
+
+def test_high_degree_preserving_pruning_alg3(built_libs):
+    """LEANN paper Algorithm 3 (gpu_graph_build.prune_preserving_hubs): fewer links, hubs keep theirs, the graph stays valid and
+    searchable (recall within 1 % of the unpruned graph at the same ef), fewer distance evaluations per query."""
+    import torch
+
+    from leann_amd.gpu_graph_build import prune_preserving_hubs
+    from leann_amd.hnsw_builder import build_hnsw
+    from oracle import oracle as orc
+    from tests.util import clustered, oracle_graph, queries_near, recall_at_k
+
+    x = clustered(5000, 48, 3)
+    g = build_hnsw(x, "mips", M=16, ef_construction=100)
+    g2 = prune_preserving_hubs(g, torch.from_numpy(x), M=16, m_low=6, hub_fraction=0.02)
+    g2.validate()
+    d1, d2 = g.level0_degrees(), g2.level0_degrees()
+    assert g2.neighbors.shape[0] < g.neighbors.shape[0] and d2.mean() < d1.mean() and d2.max() <= 32
+    indeg = np.bincount(g.neighbors[: int(d1.sum())] if g.max_level == 0 else np.concatenate([g.neighbors_of(i, 0) for i in range(5000)]), minlength=5000)
+    hubs = np.argsort(-indeg)[:100]
+    assert d2[hubs].mean() > 1.3 * d2.mean()  # the hubs are the well-connected nodes of the pruned graph
+    # upper levels untouched
+    for i in np.nonzero(g.levels > 1)[0][:50]:
+        for l in range(1, int(g.levels[i])):
+            assert np.array_equal(g.neighbors_of(int(i), l), g2.neighbors_of(int(i), l))
+    q = queries_near(x, 150, 5)
+    gt, _ = orc.bruteforce_topk(x, q, 10, 0)
+    i1, _, s1 = orc.search(oracle_graph(g, 48), q, 10, ef=64, table=x)
+    i2, _, s2 = orc.search(oracle_graph(g2, 48), q, 10, ef=64, table=x)
+    assert recall_at_k(i2, gt) >= recall_at_k(i1, gt) - 0.01 and s2["ndis"] < s1["ndis"]
+    # the builder applies it on request (host builder below the GPU threshold)
+    from leann_amd import csr_format as cf
+    from leann_amd.backend import Mi355xBuilder
+    import tempfile, pathlib
+
+    with tempfile.TemporaryDirectory() as td:
+        Mi355xBuilder(M=16, efConstruction=100, hub_preserving_m=6).build(x, [str(i) for i in range(5000)], str(pathlib.Path(td) / "p.leann"))
+        Mi355xBuilder(M=16, efConstruction=100).build(x, [str(i) for i in range(5000)], str(pathlib.Path(td) / "f.leann"))
+        assert cf.read_index(pathlib.Path(td) / "p.index").neighbors.shape[0] < cf.read_index(pathlib.Path(td) / "f.index").neighbors.shape[0]
