@@ -20,13 +20,17 @@ struct PersistArgs {
     int32_t* rounds_q;
 };
 
-template <int NCH, bool L2, bool F16>
-__global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, PersistArgs a) {
+// NT = threads per query: 256 (a workgroup of 4 waves; long new-lists: high degree x beam) or 64 (ONE wave per query: the
+// traversal of a query is a chain of dependent memory round trips -- pop -> neighbour range -> ids -> visited bits -> rows --
+// so throughput is queries in flight / chain latency, and a wave per query puts 4x as many queries on a CU; at beam 1 on a
+// pruned graph (~9 neighbours per hop) a wave's 4 row groups x 2 rows in flight cover a hop's new-list in one pass).
+template <int NCH, bool L2, bool F16, int NT>
+__global__ __launch_bounds__(NT) void k_search_table(GraphDev g, WsDev ws, PersistArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_off[65];
     __shared__ uint64_t s_b[64];
     __shared__ int32_t s_pop[64];
-    __shared__ int s_npop, s_wcnt[4];
+    __shared__ int s_npop, s_wcnt[NT / 64];
     __shared__ unsigned long long s_best;
     const int ef = ws.ef;
     uint64_t* lpool = (uint64_t*)smem;
@@ -43,8 +47,8 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
 
     // distances of s_new[0..n) -> newk[0..n)   (two rows in flight per 16-lane group, canonical reduction)
     auto eval_new = [&](int n) {
-        for (int i = sg; i < n; i += 32) {
-            const int i2 = i + 16;
+        for (int i = sg; i < n; i += NT / 8) {
+            const int i2 = i + NT / 16;
             const bool has2 = i2 < n;
             const int32_t v0 = s_new[i];
             const int32_t v1 = has2 ? s_new[i2] : v0;
@@ -76,12 +80,12 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
         uint64_t b;
         uint32_t cnt;
         nbr_range(g, key_id(cur), level, b, cnt);
-        for (uint32_t j = tid; j < cnt; j += 256) s_new[j] = g.neighbors[b + j];
+        for (uint32_t j = tid; j < cnt; j += NT) s_new[j] = g.neighbors[b + j];
         if (tid == 0) s_best = KEY_NONE;
         __syncthreads();
         eval_new((int)cnt);
         __syncthreads();
-        for (int i = tid; i < (int)cnt; i += 256) atomicMin(&s_best, (unsigned long long)newk[i]);
+        for (int i = tid; i < (int)cnt; i += NT) atomicMin(&s_best, (unsigned long long)newk[i]);
         __syncthreads();
         const uint64_t best = s_best;
         ndis += cnt;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
         rounds++;
         const uint32_t totalc = s_off[np];
         int total = 0;
-        for (uint32_t f0 = 0; f0 < totalc; f0 += 256) {
+        for (uint32_t f0 = 0; f0 < totalc; f0 += NT) {
             const uint32_t f = f0 + tid;
             bool fresh = false;
             int32_t v = -1;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
             int woff = 0;
             for (int i = 0; i < wv; ++i) woff += s_wcnt[i];
             if (fresh) s_new[total + woff + __popcll(m & ((1ull << lane) - 1ull))] = v;
-            total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            for (int i = 0; i < NT / 64; ++i) total += s_wcnt[i];
             __syncthreads();
         }
         const int n = total;
@@ -155,18 +159,18 @@ __global__ __launch_bounds__(256) void k_search_table(GraphDev g, WsDev ws, Pers
         int Pn = 1;
         while (Pn < n) Pn <<= 1;
         eval_new(n);
-        for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+        for (int i = n + tid; i < Pn; i += NT) newk[i] = KEY_NONE;
         __syncthreads();
         if (n > 0) {
-            sort_keys<256>(newk, Pn, tid);
-            rank_merge<256>(lpool, npool, newk, n, outp, ef, tid);
+            sort_keys<NT>(newk, Pn, tid);
+            rank_merge<NT>(lpool, npool, newk, n, outp, ef, tid);
             npool = min(ef, npool + n);
-            for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
+            for (int i = tid; i < npool; i += NT) lpool[i] = outp[i];
             __syncthreads();
         }
     }
     // ---- results (same as k_finalize) + per-query statistics ----
-    for (int i = tid; i < a.k; i += 256) {
+    for (int i = tid; i < a.k; i += NT) {
         const size_t t = (size_t)q * a.k + i;
         if (i < npool) {
             const float d = key_dist(lpool[i]);

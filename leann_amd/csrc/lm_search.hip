@@ -92,6 +92,7 @@ struct lm_index {
     bool profiling = false;
     int update_variant = 0;  // 0: auto, 3: wave (64 lanes) per query, 4: workgroup (256 threads) per query   (1, 2: removed A/B forms)
     int persistent_table = 1;  // stored-embedding mode: one persistent launch per batch (0: lock-step rounds, for A/B)
+    int persistent_wave = -1;  // persistent search: 1 = one wave per query, 0 = one 256-thread workgroup per query, -1 = auto
     int wave_maxnew = 0;     // auto rule threshold on beam x mean level-0 degree; 0 = never: on the 1M-chunk HNSW graph
                              // (max degree 64, mean 9.3) the workgroup form is 1.5x faster (profiles/r1_bench_default_1M_b2048.json
                              // vs r1_bench_default_1M.json), although the wave form wins on uniform-degree graphs
@@ -227,14 +228,28 @@ static int launch_update(lm_index* ix, const UpdateArgs& a, bool f16) {
     return f16 ? launch_update_nch<false, true>(ix, a, shmem) : launch_update_nch<false, false>(ix, a, shmem);
 }
 
+// wave (64 threads) or workgroup (256 threads) per query for the persistent stored-embedding search: option "persistent_wave"
+// 1 / 0 forces either, -1 (default) = wave when the expected new-list per hop (beam x mean level-0 degree) fits one pass of a
+// wave's row groups comfortably (<= 24) and there are enough queries to fill the chip with waves (B >= 2048)
+static bool persist_wave_form(const lm_index* ix) {
+    if (ix->persistent_wave >= 0) return ix->persistent_wave != 0;
+    return ix->ws.B >= 2048 && ix->ws.W * ix->avg_degree0 <= 24.0;
+}
+
 template <bool L2, bool F16>
 static int launch_persist_nch(lm_index* ix, const PersistArgs& a, const GraphDev& g, size_t shmem) {
-    dim3 grid(ix->ws.B), block(256);
+    dim3 grid(ix->ws.B);
+    const bool wave = persist_wave_form(ix);
     switch (ix->Dp / 64) {
 #define CASEP(n)                                                                                                         \
     case n:                                                                                                              \
-        LM_HIP(hipFuncSetAttribute((const void*)k_search_table<n, L2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-        hipLaunchKernelGGL((k_search_table<n, L2, F16>), grid, block, shmem, ix->stream, g, ix->ws, a);                   \
+        if (wave) {                                                                                                      \
+            LM_HIP(hipFuncSetAttribute((const void*)k_search_table<n, L2, F16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+            hipLaunchKernelGGL((k_search_table<n, L2, F16, 64>), grid, dim3(64), shmem, ix->stream, g, ix->ws, a);        \
+        } else {                                                                                                         \
+            LM_HIP(hipFuncSetAttribute((const void*)k_search_table<n, L2, F16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+            hipLaunchKernelGGL((k_search_table<n, L2, F16, 256>), grid, dim3(256), shmem, ix->stream, g, ix->ws, a);      \
+        }                                                                                                                \
         break
         CASEP(1); CASEP(2); CASEP(3); CASEP(4); CASEP(5); CASEP(6); CASEP(8); CASEP(12); CASEP(16);
 #undef CASEP
@@ -784,6 +799,11 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     }
     if (!std::strcmp(name, "persistent_table")) {
         ix->persistent_table = value != 0;
+        return LM_OK;
+    }
+    if (!std::strcmp(name, "persistent_wave")) {
+        if (value < -1 || value > 1) LM_FAIL(LM_EINVAL, "persistent_wave must be -1 (auto), 0 or 1");
+        ix->persistent_wave = (int)value;
         return LM_OK;
     }
     if (!std::strcmp(name, "wave_maxnew")) {

@@ -30,6 +30,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--provider", action="store_true", help="recompute mode: embeddings served by a provider (index_select of the table)")
 ap.add_argument("--memo", action="store_true")
+ap.add_argument("--wave", type=int, default=-1, help="persistent kernel: 1 = wave per query, 0 = workgroup per query, -1 = auto")
 ap.add_argument("--lockstep", action="store_true", help="stored-embedding mode with lock-step rounds instead of the persistent kernel")
 args = ap.parse_args()
 
@@ -80,6 +81,7 @@ idx.attach_table(X)
 idx.set_profiling(True)
 idx.set_option("update_variant", args.variant)
 idx.set_option("persistent_table", 0 if args.lockstep else 1)
+idx.set_option("persistent_wave", args.wave)
 keep = {}
 if args.provider:
     from leann_amd.devmem import as_tensor
@@ -93,7 +95,7 @@ prm = idx.make_params(ef=args.ef, beam=args.beam, recompute=args.provider, max_b
 for r in range(args.reps):
     idx.search_device(Q, 10, prm)
     s = idx.stats()
-out["search"] = {"batch": args.batch, "ef": args.ef, "beam": args.beam, "variant": args.variant, "lockstep": args.lockstep, "provider": args.provider, "memo": args.memo, "nunique": s["nunique"], "ndis": s["ndis"],
+out["search"] = {"batch": args.batch, "ef": args.ef, "beam": args.beam, "variant": args.variant, "wave": args.wave, "lockstep": args.lockstep, "provider": args.provider, "memo": args.memo, "nunique": s["nunique"], "ndis": s["ndis"],
                  "launches": s["update_launches"], "update_ms": round(s["update_ms"], 3), "update_span_ms": round(s["update_span_ms"], 3), "expand_ms": round(s["expand_ms"], 3),
                  "evals_per_launch": round(s["ndis"] / s["update_launches"], 1),
                  "update_GBps_algorithmic": round(s["ndis"] * (D * 4 + 4) / s["update_ms"] / 1e6, 1),

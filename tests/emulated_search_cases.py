@@ -64,12 +64,13 @@ def case_table(metric="mips", d=64, f16=False):
     tab = x.astype(np.float16) if f16 else x
     idx.attach_table(tab)
     ref_tab = tab.astype(np.float32)
-    for persistent in (1, 0):
+    for persistent, wave in ((1, 0), (1, 1), (0, 0)):  # persistent kernel: workgroup / wave per query; lock-step rounds
         idx.set_option("persistent_table", persistent)
+        idx.set_option("persistent_wave", wave)
         for beam, ef in ((1, 12), (3, 20)):
             got = idx.search(q, 5, idx.make_params(ef=ef, beam=beam, recompute=False))
             exp = orc.search(og, q, 5, ef=ef, beam=beam, table=ref_tab)
-            _check(f"table {metric} d={d} f16={f16} persistent={persistent} beam={beam}", got, exp[:2], idx.stats(), exp[2])
+            _check(f"table {metric} d={d} f16={f16} persistent={persistent} wave={wave} beam={beam}", got, exp[:2], idx.stats(), exp[2])
     idx.close()
 
 
