@@ -189,13 +189,16 @@ def main():
             Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
             bytes_eval = D * 4 + 4
             table_roof = {}
-            for persistent in (1, 0, 1, 0):  # interleaved A/B: persistent one-launch kernel vs lock-step rounds
+            # interleaved A/B: persistent one-launch kernel (wave / workgroup per query; -1 = the library's own choice) vs lock-step rounds
+            for persistent, wave in ((1, -1), (1, 1), (1, 0), (0, 0)) * 2:
                 for beam_t, ef_t in ((4, ef), (1, ef)):
                     idx.set_option("persistent_table", persistent)
+                    idx.set_option("persistent_wave", wave)
                     prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=16384)
                     idx.search_device(Qbig, 10, prm)
                     st = idx.stats()
-                    key = f"{'k_search_table_persistent' if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}"
+                    form = {-1: "auto", 1: "wave_per_query", 0: "workgroup_per_query"}[wave]
+                    key = f"{'k_search_table_persistent_' + form if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}"
                     net_ms = max(st["update_span_ms"], 1e-6)
                     r = {"GBps": round(st["ndis"] * bytes_eval / (net_ms * 1e-3) / 1e9, 1), "launches": st["update_launches"],
                          "us_per_launch": round(1e3 * net_ms / max(st["update_launches"], 1), 2),
@@ -203,11 +206,13 @@ def main():
                          "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
                     table_roof.setdefault(key, []).append(r)
             idx.set_option("persistent_table", 1)
+            idx.set_option("persistent_wave", -1)
             idx.set_profiling(False)
         except Exception as ex:  # noqa: BLE001 - an optional measurement must never cost the headline line
             extras_errors["roofline_table_mode"] = repr(ex)[:300]
             table_roof = None
             idx.set_option("persistent_table", 1)
+            idx.set_option("persistent_wave", -1)
             idx.set_profiling(False)
 
     # ---- timed region: recompute mode ---------------------------------------------------------------
@@ -259,7 +264,10 @@ def main():
         elapsed = float(t.item())
     # ---- one more step of the same workload WITH profiling (HIP event pairs + device span stamps per launch): the
     #      source of the roofline figures; not part of `value` ----------------------------------------------------
+    from leann_amd.encoder import KernelTimers
+
     idx.set_profiling(True)
+    KernelTimers.active = KernelTimers()
     lo = (W + K) * B
     torch.cuda.synchronize()
     t1p = time.perf_counter()
@@ -267,6 +275,8 @@ def main():
     torch.cuda.synchronize()
     prof_step_s = time.perf_counter() - t1p
     prof = idx.stats()
+    ktimes = KernelTimers.active.totals()
+    KernelTimers.active = None
     idx.set_profiling(False)
     # ---- extras (NOT `value`; single-GPU runs only -- they contain no collectives and may never cost the headline
     #      line): one extra step each, on fresh queries ----------------------------------------------------------
@@ -370,7 +380,7 @@ def main():
         traffic_src = "rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/r1_pmc_k_update.json), x1.08 calibration, scaled by evals/launch"
     except Exception:  # noqa: BLE001
         pass
-    roofline = {"bound": "hbm", "kernel": "lm::k_update<6,false,false,true> (fused gather + distance + beam update, recompute mode)", "achieved": round(achieved, 2),
+    roofline_dist = {"bound": "hbm", "kernel": "lm::k_update<6,false,false,1,256> (fused gather + distance + beam update, recompute mode)", "achieved": round(achieved, 2),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(bytes_eval * prof["ndis"] / max(prof["update_launches"], 1)),
                 "bytes_per_eval": bytes_eval, "evals_per_launch": round(prof["ndis"] / max(prof["update_launches"], 1), 1),
@@ -386,6 +396,20 @@ def main():
                         "mean_gflop_per_chunk": round(mean_flops / 1e9, 3), "provider_ms_share": round(prof["provider_ms"] / (prof_step_s * 1e3), 4),
                         "whole_step_TFLOPs": round(agg["nunique"] * mean_flops / max(elapsed, 1e-9) / 1e12, 2)}
 
+    # `roofline` = the DOMINANT kernel of the timed region: the fused feed-forward block of the encoder (62 % of the encoder's
+    # flops, the largest share of the step's time), MFMA bound; duration = HIP event pairs around every one of its launches in the
+    # profiled step (torch's current stream = the stream it is launched on).  Algorithmic flops per token: 4 * ffn * hidden.
+    mlp = ktimes.get("mlp_fused_h384")
+    if mlp and mlp["ms"] > 0:
+        mlp_tf = mlp["work"] / (mlp["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "lm::k_mlp_fused_h384_v3<0> (fc1 + GELU + fc2 + residual + LayerNorm in one kernel)",
+                    "achieved": round(mlp_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(mlp_tf / 2500.0, 5), "traffic": None,
+                    "flops_per_token": 4 * cfg.ffn * cfg.hidden, "launches": mlp["launches"],
+                    "avg_launch_us": round(1e3 * mlp["ms"] / max(mlp["launches"], 1), 1),
+                    "share_of_profiled_step": round(mlp["ms"] / (prof_step_s * 1e3), 4),
+                    "timing": "HIP event pairs around every launch in one profiled step after the timed ones"}
+    else:  # encoder without the fused block (hidden != 384): fall back to the distance kernel's line
+        roofline = roofline_dist
     result = {
         "metric": ("queries/sec at recall@10>=0.9, 1M-chunk HNSW, MiniLM-L6 recompute" if args.config == "c2" else
                    f"queries/sec at recall@10>=0.9, {args.chunks}-chunk HNSW, {args.model} fp16 recompute (BASELINE.json configs[4])"),
@@ -401,7 +425,7 @@ def main():
         "recall_at_10": round(rec, 4),
         "encoder_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LEANN_MI355X_")},  # kernels in effect
         "encoder_autotune": autotune_report,
-        "roofline": roofline, "roofline_encoder": roofline_encoder,
+        "roofline": roofline, "roofline_distance_kernel": roofline_dist, "roofline_encoder": roofline_encoder,
         "ef_sweep": sweep,
         "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),
                       "rounds_per_step": round(agg["nrounds"] / max(K, 1), 1)},

@@ -107,6 +107,25 @@ def sentence_transformers_settings(model_dir: Path) -> dict:
     return out
 
 
+class KernelTimers:
+    """HIP-event pairs around the hand-written encoder kernels (on torch's current stream = the stream they are launched on),
+    switched on only for bench.py's profiled step: ``KernelTimers.active = KernelTimers()`` ... ``.totals()``."""
+
+    active: "Optional[KernelTimers]" = None
+
+    def __init__(self):
+        self.pairs: dict = {}
+
+    def span(self, name: str, work: float):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.setdefault(name, []).append((a, b, work))
+        return a, b
+
+    def totals(self) -> dict:
+        torch.cuda.synchronize()
+        return {k: {"ms": sum(a.elapsed_time(b) for a, b, _ in v), "work": sum(w for _, _, w in v), "launches": len(v)} for k, v in self.pairs.items()}
+
+
 def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
     """LayerNorm(x + residual) through the hand-written HIP kernel (csrc/lm_encoder_ops.hip) for fp16 CUDA
     tensors; plain torch otherwise (CPU / fp32 parity paths)."""
@@ -253,11 +272,17 @@ def fused_mlp(x: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
         layer._mlp_pack = pk
     w2p, b1, b2, w1 = pk
     out = torch.empty_like(x)
+    tm = KernelTimers.active
+    ev = tm.span("mlp_fused_h384", 4.0 * x.shape[0] * f * h) if tm is not None else None
+    if ev:
+        ev[0].record()
     _lib.check(_lib.load().lm_mlp_fused_h384_f16(
         C.c_void_p(x.data_ptr()), C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2p.data_ptr()),
         C.c_void_p(b2.data_ptr()), C.c_void_p(layer.ln2.weight.data_ptr()), C.c_void_p(layer.ln2.bias.data_ptr()),
         C.c_void_p(out.data_ptr()), x.shape[0], f, float(layer.ln2.eps), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
         "lm_mlp_fused_h384_f16")
+    if ev:
+        ev[1].record()
     return out
 
 
