@@ -53,9 +53,10 @@ def encode_pq(x: torch.Tensor, codebooks: torch.Tensor, block: int = 65536) -> t
     return out
 
 
-def flat_graph(g: HnswCsr, x: np.ndarray) -> HnswCsr:
+def flat_graph(g: HnswCsr, x) -> HnswCsr:
     """Single-level (Vamana-style) graph from the level-0 lists of ``g``, entered at the medoid
-    (the node closest to the mean; DiskANN's `<prefix>_disk.index_medoids.bin`)."""
+    (the node closest to the mean; DiskANN's `<prefix>_disk.index_medoids.bin`).  ``x``: [N, D] numpy array or torch tensor
+    (any device; the 10M-chunk configuration passes the HBM-resident table)."""
     n = g.ntotal
     p0 = g.node_offsets[:-1].astype(np.int64)
     beg = g.level_ptr[p0].astype(np.int64)
@@ -65,10 +66,23 @@ def flat_graph(g: HnswCsr, x: np.ndarray) -> HnswCsr:
     cs = np.cumsum(deg)
     level_ptr[0::2] = cs - deg
     level_ptr[1::2] = cs
-    idx = np.concatenate([np.arange(b, e) for b, e in zip(beg, end)]) if n else np.zeros(0, np.int64)
+    total = int(cs[-1]) if n else 0
+    # position of every level-0 entry inside g.neighbors: beg[i] + (k - start[i]) for k in [start[i], start[i] + deg[i])
+    idx = np.repeat(beg - (cs - deg), deg) + np.arange(total, dtype=np.int64)
     neighbors = g.neighbors[idx].astype(np.int32)
-    mean = x.mean(0, keepdims=True)
-    medoid = int(np.argmin(((x - mean) ** 2).sum(1))) if n else -1
+    medoid = -1
+    if n:
+        xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+        mean = torch.zeros(xt.shape[1], dtype=torch.float64, device=xt.device)
+        for b0 in range(0, n, 1 << 20):
+            mean += xt[b0 : b0 + (1 << 20)].double().sum(0)
+        mean = (mean / n).float()
+        best, medoid = float("inf"), 0
+        for b0 in range(0, n, 1 << 20):
+            d2 = ((xt[b0 : b0 + (1 << 20)].float() - mean) ** 2).sum(1)
+            v, i = torch.min(d2, 0)
+            if float(v) < best:
+                best, medoid = float(v), b0 + int(i)
     return HnswCsr(d=g.d, ntotal=n, metric_type=g.metric_type, levels=np.ones(n, np.int32), level_ptr=level_ptr,
                    node_offsets=np.arange(n + 1, dtype=np.uint64) * 2, neighbors=neighbors, entry_point=medoid,
                    max_level=0 if n else -1, ef_construction=g.ef_construction,

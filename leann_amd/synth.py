@@ -99,6 +99,56 @@ class SyntheticCorpus:
             base += int(o[-1])
         return np.concatenate(toks), np.concatenate(offs)
 
+    def chunks_torch(self, device, block: int = 1 << 20):
+        """The same generative model evaluated with torch ops on ``device`` (10M-60M chunk configurations: the numpy path above
+        takes ~20 s per million chunks on the host).  Same topic tables and per-document vocabularies, the random draws come
+        from torch's generator (seeded per block), so the corpus is deterministic but NOT bit-identical to ``chunks()``.
+        Returns (tokens u16[total], offsets u64[n+1]) as numpy arrays."""
+        import torch
+
+        s = self.spec
+        dev = torch.device(device)
+        tw = torch.from_numpy(self.topic_words).to(dev)
+        dt = torch.from_numpy(self.doc_topic).to(dev).long()
+        ds = torch.from_numpy(self.doc_seed).to(dev)
+
+        def cdf(size):
+            w = 1.0 / torch.arange(1, size + 1, dtype=torch.float64, device=dev) ** s.zipf_a
+            c = torch.cumsum(w, 0)
+            return (c / c[-1]).float()
+
+        c_t, c_d, c_b = cdf(s.topic_vocab), cdf(s.doc_vocab), cdf(s.vocab_size - 1000)
+        toks, lens_all = [], []
+        for b0 in range(0, s.n_chunks, block):
+            b1 = min(s.n_chunks, b0 + block)
+            g = torch.Generator(device=dev).manual_seed(int(s.seed) * 1_000_003 + b0)
+            docs = torch.arange(b0, b1, device=dev) // s.chunks_per_doc
+            lens = torch.clamp(torch.round(torch.randn(b1 - b0, generator=g, device=dev) * s.len_std + s.len_mean), s.len_min, s.len_max).long()
+            off = torch.zeros(b1 - b0 + 1, dtype=torch.int64, device=dev)
+            off[1:] = torch.cumsum(lens, 0)
+            total = int(off[-1])
+            chunk_of = torch.repeat_interleave(torch.arange(b1 - b0, device=dev), lens, output_size=total)
+            u = torch.rand(total, generator=g, device=dev)
+            rt = torch.searchsorted(c_t, torch.rand(total, generator=g, device=dev)).clamp(max=s.topic_vocab - 1)
+            rd = torch.searchsorted(c_d, torch.rand(total, generator=g, device=dev)).clamp(max=s.doc_vocab - 1)
+            rb = torch.searchsorted(c_b, torch.rand(total, generator=g, device=dev)).clamp(max=s.vocab_size - 1001) + 1000
+            d_of = docs[chunk_of]
+            # per-document private word (same hash as _doc_words, evaluated per token)
+            x = ds[d_of] * 6364136223846793005 + rd * 1442695040888963407
+            x = x ^ (x >> 29)
+            x = x * (0xBF58476D1CE4E5B9 & 0x7FFFFFFFFFFFFFFF)
+            x = x ^ (x >> 32)
+            dw = 1000 + (x.abs() % (s.vocab_size - 1000))
+            t = torch.where(u < s.p_topic, tw[dt[d_of], rt].long(), torch.where(u < s.p_topic + s.p_doc, dw, rb))
+            t[off[:-1]] = CLS_ID
+            t[off[1:] - 1] = SEP_ID
+            toks.append(t.to(torch.int32).cpu().numpy().astype(np.uint16))
+            lens_all.append(lens.cpu().numpy())
+        lens_np = np.concatenate(lens_all)
+        offs = np.zeros(s.n_chunks + 1, np.uint64)
+        offs[1:] = np.cumsum(lens_np)
+        return np.concatenate(toks), offs
+
     def queries(self, n: int, seed: int = 4321):
         """Held-out chunks of randomly chosen existing documents."""
         rng = np.random.default_rng([self.spec.seed, 2, seed])

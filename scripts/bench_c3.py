@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[2] (C3): 10M chunks, DiskANN-style search -- PQ-ADC traversal (complexity L = 64, beam width W = 64) on
+an HBM-resident graph + PQ codes, then ONE deferred exact rerank of the <= L candidates per query through the recompute
+provider (HBM token store -> bge-small-en-v1.5 shaped encoder, CLS pooling) -- 1 x MI355X.  The call this replaces:
+StaticDiskFloatIndex.batch_search(query, B, k, L, W, threads, USE_DEFERRED_FETCH, ...) (diskann_backend.py:453-467).
+
+    python scripts/bench_c3.py [--chunks 10000000] [--steps 5] [--warmup 2] [--batch 1024]
+
+Prints ONE JSON line with the same keys as bench.py (value = queries/s, roofline of the traversal kernel, cpu_baseline).
+Set-up at 10M chunks: corpus on the GPU (~40 s), 10M encoder forwards (~3 min), GPU graph build (~5 min), PQ (~30 s)."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+
+
+def log(*a):
+    print("[c3]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=10_000_000)
+    ap.add_argument("--model", default="BAAI/bge-small-en-v1.5")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--complexity", type=int, default=64)
+    ap.add_argument("--beam", type=int, default=64)
+    ap.add_argument("--pq-bytes", type=int, default=96)
+    ap.add_argument("--M", type=int, default=16, help="graph degree / 2 of the Vamana-style flat graph (degree 32)")
+    ap.add_argument("--efc", type=int, default=128)
+    ap.add_argument("--cpu-baseline-queries", type=int, default=8)
+    args = ap.parse_args()
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.pq import encode_pq, flat_graph, train_pq
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus
+    from leann_amd.token_store import TokenStore
+
+    _lib.require_gpu()
+    dev = torch.device("cuda", 0)
+    n, B, K, W = args.chunks, args.batch, args.steps, args.warmup
+    t_all = time.time()
+    corpus = SyntheticCorpus(CorpusSpec(n_chunks=n, seed=1234))
+    tok, off = corpus.chunks_torch(dev)
+    tokens = TokenStore(tok, off)
+    log(f"corpus: {n} chunks, {int(off[-1])} tokens ({time.time() - t_all:.0f}s)")
+    cfg = config_for(args.model)
+    enc = BertEncoder.load(args.model, allow_random=True).to(dev, dtype=torch.float16).eval()
+    D = cfg.hidden
+    provider = RecomputeProvider(enc, tokens, (D + 63) // 64 * 64, dev)
+    t0 = time.time()
+    X = torch.empty((n, D), dtype=torch.float32, device=dev)
+    for b0 in range(0, n, 32768):
+        ids = torch.arange(b0, min(n, b0 + 32768), dtype=torch.int32, device=dev)
+        X[b0 : b0 + ids.shape[0]] = provider.embed_ids(ids)
+    torch.cuda.synchronize()
+    t_embed = time.time() - t0
+    log(f"embedded in {t_embed:.0f}s ({n / t_embed:.0f} chunks/s)")
+    t0 = time.time()
+    g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc)
+    fg = flat_graph(g, X)
+    t_graph = time.time() - t0
+    log(f"flat graph (degree <= {2 * args.M}) in {t_graph:.0f}s, mean degree {fg.level0_degrees().mean():.1f}")
+    t0 = time.time()
+    cb = train_pq(X, args.pq_bytes, iters=10)
+    codes = encode_pq(X, cb)
+    torch.cuda.synchronize()
+    t_pq = time.time() - t0
+    idx = Mi355xIndex.from_csr(fg)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.attach_pq(cb.cpu().numpy(), codes.cpu().numpy())
+    idx.set_provider(provider)
+    nq = B * (K + W + 1)
+    qt, qo, _ = corpus.queries(nq, seed=4321)
+    Q = RecomputeProvider(enc, TokenStore(qt, qo), provider.dp, dev).embed_ids(torch.arange(nq, dtype=torch.int32, device=dev)).contiguous()
+    gt = torch.empty((nq, 10), dtype=torch.int64, device=dev)
+    for b0 in range(0, nq, 256):
+        gt[b0 : b0 + 256] = torch.topk(Q[b0 : b0 + 256] @ X.T, 10, dim=1).indices
+    gt = gt.cpu().numpy()
+    prm = idx.make_pq_params(args.complexity, args.beam, use_deferred_fetch=True)
+    setup_s = time.time() - t_all
+    log(f"setup {setup_s:.0f}s; timing {K} steps x {B} queries")
+    for w in range(W):
+        idx.pq_search_device(Q[w * B : (w + 1) * B], 10, prm)
+    agg = {"ndis": 0, "nunique": 0}
+    labels = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        lo = (W + s) * B
+        l, _ = idx.pq_search_device(Q[lo : lo + B], 10, prm)
+        labels.append(l)
+        st = idx.stats()
+        agg["ndis"] += st["ndis"]
+        agg["nunique"] += st["nunique"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lab = torch.cat(labels).cpu().numpy()
+    rec = float(np.mean([len(set(lab[i]) & set(gt[W * B + i])) / 10 for i in range(K * B)]))
+    # profiled step: traversal kernel duration (HIP event pair around the one persistent launch per batch)
+    idx.set_profiling(True)
+    lo = (W + K) * B
+    idx.pq_search_device(Q[lo : lo + B], 10, prm)
+    torch.cuda.synchronize()
+    pst = idx.stats()
+    idx.set_profiling(False)
+    bytes_eval = args.pq_bytes + 4  # SURVEY 8(d) PQ unit: m code bytes + the id
+    trav_ms = max(pst["update_ms"], 1e-9)
+    ach = pst["ndis"] * bytes_eval / (trav_ms * 1e-3) / 1e9
+    result = {
+        "metric": f"queries/sec, {n}-chunk DiskANN-style PQ traversal (L={args.complexity}, W={args.beam}) + deferred recompute rerank, {args.model} shape",
+        "value": round(K * B / elapsed, 3), "unit": "queries/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 codes / f32 LUT; fp16 encoder", "data": "synthetic",
+        "config": {"workload": f"{n} synthetic chunks, flat graph degree<={2 * args.M} (GPU-built), PQ {args.pq_bytes} B/vector, complexity {args.complexity}, "
+                               f"beam_width {args.beam}, top-10, {B} queries/step, one deferred rerank through the recompute provider",
+                   "baseline_config": "c3", "n_chunks": n, "queries_per_step": B},
+        "recall_at_10": round(rec, 4),
+        "roofline": {"bound": "hbm", "kernel": "lm::k_pq_traverse (persistent PQ-ADC traversal, one launch per batch; codes gathered from HBM, LUT in LDS)",
+                     "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
+                     "bytes_per_adc_eval": bytes_eval, "adc_evals_per_launch": pst["ndis"], "us_per_launch": round(1e3 * trav_ms, 1)},
+        "per_query": {"adc_evals": round(agg["ndis"] / (K * B), 1), "reranked_unique_chunks": round(agg["nunique"] / (K * B), 1)},
+        "setup_s": {"total": round(setup_s), "embed_corpus": round(t_embed), "build_graph": round(t_graph), "pq": round(t_pq)},
+    }
+    # CPU baseline: the PQ oracle (traversal + deferred rerank through the fp32 CPU encoder) on a few queries
+    try:
+        from oracle import oracle as orc
+
+        ncores = orc.usable_cores()
+        torch.set_num_threads(ncores)
+        cenc = BertEncoder.load(args.model, allow_random=True).float().eval()
+        lens_all = np.diff(off.astype(np.int64))
+
+        def cpu_provider(idv):
+            T = int(lens_all[idv].max())
+            ids = np.zeros((idv.shape[0], T), np.int32)
+            for i, v in enumerate(idv):
+                ids[i, : lens_all[v]] = tok[int(off[v]) : int(off[v]) + lens_all[v]]
+            with torch.no_grad():
+                return cenc.encode_tokens(torch.from_numpy(ids), torch.from_numpy(lens_all[idv].astype(np.int32)), batch_size=64).numpy()
+
+        og = orc.OracleGraph(fg.node_offsets, fg.level_ptr, fg.neighbors, fg.levels, fg.entry_point, fg.max_level, fg.metric_type, D)
+        qn = Q[: args.cpu_baseline_queries].cpu().numpy()
+        t0 = time.perf_counter()
+        orc.pq_search(og, cb.cpu().numpy(), codes.cpu().numpy(), qn, 10, L=args.complexity, W=args.beam, provider=cpu_provider, use_deferred_fetch=True)
+        el = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(qn.shape[0] / el, 4), "unit": "queries/s", "cores": ncores, "kind": "port",
+                                  "sample": f"{qn.shape[0]} queries: oracle PQ traversal + fp32 CPU encoder rerank in {el:.1f}s"}
+    except Exception as ex:  # noqa: BLE001
+        result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+    print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[3] (C4): 60M chunks (DPR-Wikipedia scale), HNSW graph sharded 8-way, query batch 256, per-shard top-k
+merged over RCCL/xGMI.  One process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 scripts/bench_c4.py
+    python scripts/bench_c4.py --chunks 7500000          # one rank = one shard of the 8 (what a single GPU can measure)
+
+Every rank builds ITS shard (chunks [rank * n/W, (rank + 1) * n/W): own token store, own embeddings, own HNSW graph with local
+ids) and holds the same 256 queries; a step = leann_amd.distributed.ShardedSearch.search: recompute search of all queries on
+the local shard, ONE all_gather of the (B, k) x {f32, i64} lists (30 KB per rank at B = 256), per-query merge by the
+lm_topk_merge kernel -- all inside the timed region.  Prints ONE JSON line on rank 0 (bench.py's keys + "rccl_ranks")."""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=60_000_000, help="TOTAL chunks over all ranks")
+    ap.add_argument("--model", default="sentence-transformers/all-MiniLM-L6-v2")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ef", type=int, default=64)
+    ap.add_argument("--M", type=int, default=32)
+    ap.add_argument("--efc", type=int, default=200)
+    args = ap.parse_args()
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+    from leann_amd import _lib
+    from leann_amd.distributed import ShardedSearch, shard_bounds
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus
+    from leann_amd.token_store import TokenStore
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def log(*a):
+        if rank == 0:
+            print("[c4]", *a, file=sys.stderr, flush=True)
+
+    B, K, W = args.batch, args.steps, args.warmup
+    lo, hi = shard_bounds(args.chunks, world)[rank]
+    ns = hi - lo
+    t_all = time.time()
+    # the shard's chunks: an independent corpus per shard (seed = 1234 + rank), ids local to the shard + id_base = lo
+    corpus = SyntheticCorpus(CorpusSpec(n_chunks=ns, seed=1234 + rank))
+    tok, off = corpus.chunks_torch(dev)
+    tokens = TokenStore(tok, off, device=local)
+    cfg = config_for(args.model)
+    enc = BertEncoder.load(args.model, allow_random=True).to(dev, dtype=torch.float16).eval()
+    D = cfg.hidden
+    provider = RecomputeProvider(enc, tokens, (D + 63) // 64 * 64, dev)
+    X = torch.empty((ns, D), dtype=torch.float32, device=dev)  # build time only: dropped below (60M x 384 x 4 B would be 92 GB in total)
+    for b0 in range(0, ns, 32768):
+        ids = torch.arange(b0, min(ns, b0 + 32768), dtype=torch.int32, device=dev)
+        X[b0 : b0 + ids.shape[0]] = provider.embed_ids(ids)
+    g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc)
+    log(f"shard of {ns} chunks ready in {time.time() - t_all:.0f}s (mean level-0 degree {g.level0_degrees().mean():.1f})")
+    idx = Mi355xIndex.from_csr(g, device=local)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_provider(provider)
+    # queries: identical on every rank (drawn from shard 0's documents; broadcast from rank 0)
+    nq = B * (K + W)
+    if rank == 0:
+        qt, qo, _ = corpus.queries(nq, seed=4321)
+        Q = RecomputeProvider(enc, TokenStore(qt, qo, device=local), provider.dp, dev).embed_ids(torch.arange(nq, dtype=torch.int32, device=dev)).contiguous()
+    else:
+        Q = torch.empty((nq, D), dtype=torch.float32, device=dev)
+    if world > 1:
+        dist.broadcast(Q, 0)
+    # exact ground truth over ALL shards: local exact top-10, gathered and merged on the host
+    s = Q @ X.T
+    ld, li = torch.topk(s, 10, dim=1)
+    li = li + lo
+    if world > 1:
+        gd = [torch.empty_like(ld) for _ in range(world)]
+        gi = [torch.empty_like(li) for _ in range(world)]
+        dist.all_gather(gd, ld)
+        dist.all_gather(gi, li)
+        ad, ai = torch.cat(gd, 1), torch.cat(gi, 1)
+        top = torch.topk(ad, 10, dim=1).indices
+        gt = torch.gather(ai, 1, top).cpu().numpy()
+    else:
+        gt = li.cpu().numpy()
+    del X, s
+    torch.cuda.empty_cache()
+    prm = idx.make_params(ef=args.ef, beam=1, recompute=True, max_batch=B)
+    ss = ShardedSearch(lambda qq, k: idx.search_device(qq, k, prm), id_base=lo, metric=g.metric_type)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(W):
+        ss.search(Q[w * B : (w + 1) * B].contiguous(), 10)
+    labels = []
+    barrier()
+    t0 = time.perf_counter()
+    for st in range(K):
+        _, l = ss.search(Q[(W + st) * B : (W + st + 1) * B].contiguous(), 10)
+        labels.append(l)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lab = torch.cat(labels).cpu().numpy()
+    rec = float(np.mean([len(set(lab[i]) & set(gt[W * B + i])) / 10 for i in range(K * B)]))
+    # the collective step alone (all_gather + merge of B x k lists), timed separately
+    d0, i0 = idx.search_device(Q[:B].contiguous(), 10, prm)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        if world > 1:
+            gd = [torch.empty_like(d0) for _ in range(world)]
+            gi = [torch.empty_like(i0) for _ in range(world)]
+            dist.all_gather(gd, d0)
+            dist.all_gather(gi, i0)
+            ss.merge_fn(torch.stack(gi), torch.stack(gd), g.metric_type)
+        else:
+            ss.merge_fn(i0[None].contiguous(), d0[None].contiguous(), g.metric_type)
+    barrier()
+    coll_us = (time.perf_counter() - t0) / 20 * 1e6
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"queries/sec, {args.chunks}-chunk HNSW sharded {world}-way, query batch {B}, RCCL all_gather of per-shard top-k + merge",
+            "value": round(K * B / elapsed, 3), "unit": "queries/s", "n_gpus": world, "rccl_ranks": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "encoder_dtype": "fp16 (fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"{args.chunks} synthetic chunks in {world} shard(s) of {ns}, HNSW M={args.M} per shard (GPU-built), {args.model} shape, "
+                                   f"ef_search={args.ef}, beam=1, top-10, {B} queries per step searched on EVERY shard, all_gather + lm_topk_merge in the timed region",
+                       "baseline_config": "c4", "n_chunks": args.chunks, "shard_chunks": ns, "queries_per_step": B,
+                       "multi_gpu_path": "leann_amd.distributed.ShardedSearch"},
+            "recall_at_10": round(rec, 4), "allgather_plus_merge_us": round(coll_us, 1),
+            "exchange_bytes_per_rank": B * 10 * 12, "setup_s": round(time.time() - t_all)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,34 @@
+"""The C3 / C4 bench scripts (BASELINE.json configs[2], configs[3]) at a size that runs in seconds: the JSON contract, a sane
+recall, and -- for C4 -- the sharded path's merge in the timed region.  The full-size lines are recorded in DESIGN.md."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _run(script, *args):
+    out = subprocess.run([sys.executable, str(ROOT / "scripts" / script), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_c3_small():
+    r = _run("bench_c3.py", "--chunks", "30000", "--batch", "128", "--steps", "2", "--warmup", "1", "--cpu-baseline-queries", "2")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r
+    assert r["config"]["baseline_config"] == "c3" and r["value"] > 0
+    assert r["recall_at_10"] >= 0.8
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0
+    assert r["cpu_baseline"]["value"] and r["cpu_baseline"]["value"] > 0
+
+
+def test_bench_c4_one_shard_small():
+    r = _run("bench_c4.py", "--chunks", "30000", "--batch", "64", "--steps", "2", "--warmup", "1")
+    assert r["config"]["baseline_config"] == "c4" and r["rccl_ranks"] == 1 and r["value"] > 0
+    assert r["recall_at_10"] >= 0.9
+    assert r["allgather_plus_merge_us"] > 0
