@@ -55,14 +55,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-roofline", action="store_true", default=True, help="also time the stored-embedding (HBM gather) mode (default on)")
     ap.add_argument("--no-table-roofline", dest="table_roofline", action="store_false")
-    ap.add_argument("--config", default="c2", choices=["c2", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, BASELINE.json configs[1]): 1M chunks, MiniLM-L6; c5 (configs[4]): 10M chunks, bge-base-en-v1.5 768-d fp16, "
-                         "query batch 1024 split over the ranks.  The DiskANN-style (c3) and sharded (c4) configurations have their own "
-                         "entry points: scripts/bench_c3.py, scripts/bench_c4.py")
+                         "query batch 1024 split over the ranks; c3 (configs[2], 10M DiskANN-style) and c4 (configs[3], 60M sharded over the "
+                         "ranks, all_gather + merge timed) run scripts/bench_c3.py / scripts/bench_c4.py with this command's --steps/--warmup")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
     ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows")
     ap.add_argument("--autotune", action="store_true", help="A/B the switchable encoder kernels at start-up (leann_amd.autotune); default: the tested default set")
     args = ap.parse_args()
+    if args.config in ("c3", "c4"):  # own entry points (different index type / sharded index); same JSON contract
+        import runpy
+
+        defaults = {a.dest: a.default for a in ap._actions}
+        argv = ["--steps", str(args.steps), "--warmup", str(args.warmup)]
+        if args.chunks != defaults["chunks"]:
+            argv += ["--chunks", str(args.chunks)]
+        if args.batch != defaults["batch"]:
+            argv += ["--batch", str(args.batch)]
+        script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", f"bench_{args.config}.py")
+        sys.argv = [script] + argv
+        runpy.run_path(script, run_name="__main__")
+        return
     if args.config == "c5":  # BASELINE.json configs[4]; explicit --chunks / --model / --batch still win
         defaults = {a.dest: a.default for a in ap._actions}
         if args.chunks == defaults["chunks"]:
@@ -579,13 +592,18 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     def provider(idv):
         t0 = time.perf_counter()
         n = idv.shape[0]
-        ids = np.zeros((n, T), np.int32)
         ln = lens_all[idv].astype(np.int32)
-        for i, v in enumerate(idv):
-            b = int(off[v])
-            ids[i, : ln[i]] = tok[b : b + ln[i]]
+        order = np.argsort(ln, kind="stable")  # length-sorted mini-batches padded to their own maximum, as a careful CPU
+        e = np.empty((n, cfg.hidden), np.float32)  # implementation would (the reference pads a batch to its longest member)
         with torch.no_grad():
-            e = enc.encode_tokens(torch.from_numpy(ids), torch.from_numpy(ln), batch_size=64).numpy()
+            for b0 in range(0, n, 64):
+                sel = order[b0 : b0 + 64]
+                Tb = int(ln[sel].max())
+                ids = np.zeros((sel.shape[0], Tb), np.int32)
+                for i, j in enumerate(sel):
+                    b = int(off[idv[j]])
+                    ids[i, : ln[j]] = tok[b : b + ln[j]]
+                e[sel] = enc.encode_tokens(torch.from_numpy(ids), torch.from_numpy(ln[sel]), batch_size=64).numpy()
         stat["chunks"] += n
         stat["enc_s"] += time.perf_counter() - t0
         return e
@@ -595,7 +613,7 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     t0 = time.perf_counter()
     orc.search(og, q[:1], 10, ef=ef, beam=beam, provider=provider)
     one = time.perf_counter() - t0
-    nq = int(max(1, min(63, args.cpu_baseline_seconds // max(one, 1e-3))))
+    nq = int(max(16, min(63, args.cpu_baseline_seconds // max(one, 1e-3))))  # never fewer than 16 queries in the sample
     stat = {"chunks": 0, "enc_s": 0.0}
     t0 = time.perf_counter()
     _, _, st = orc.search(og, q[1 : 1 + nq], 10, ef=ef, beam=beam, provider=provider)

@@ -18,6 +18,8 @@
 // Role in the reference: part of compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "lm_internal.h"
 
 namespace lm {
@@ -33,9 +35,19 @@ constexpr int A2_KSTRIDE = 40;  // halfs per K row in LDS (80 B): conflict-free 
 
 template <int NT>  // NT = number of 32-key tiles (max_len <= 32*NT), 1..8
 __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                             __half* __restrict__ out, int heads, float scale_log2e) {
+                                                             __half* __restrict__ out, int heads, float scale_log2e, int n_units) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
+    // XCD-aware unit order.  Workgroup b runs on XCD b % 8 and every XCD has its own L2; a (sequence, head) unit reads 64-byte
+    // row segments of the [T][3H] activations, i.e. HALF of each 128-byte line -- the other half belongs to the neighbouring
+    // head.  With the plain order (unit = b) neighbouring heads sit on different XCDs and every line is fetched from HBM twice
+    // (round-2 counters: 805 MB fetched for 403 MB of operands at 131k tokens, the kernel ran AT the HBM read rate).  So the
+    // units are dealt out in contiguous runs per XCD: XCD x works through units [x * per, (x + 1) * per) in dispatch order, and
+    // the twelve heads of a sequence are resident on one XCD at about the same time.  (grid = 8 * per >= n_units.)
+    // n_units < 0: plain order over -n_units units (LEANN_MI355X_ATTN_XCD=0, kept for A/B timing).
+    const int per = gridDim.x >> 3;
+    const int unit = n_units < 0 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * per + (blockIdx.x >> 3));
+    if (unit >= (n_units < 0 ? -n_units : n_units)) return;
+    const int seq = unit / heads, h = unit % heads;
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
     const int H = heads * A2_HD;
@@ -204,12 +216,14 @@ int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_
     const int nt = (max_len + 31) / 32;
     const size_t shmem = ((size_t)32 * nt * A2_KSTRIDE + (size_t)32 * (32 * nt + 4)) * 2;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)A2_HD);
-    dim3 grid((unsigned)(n_seqs * heads)), block(256);
+    const char* xo = getenv("LEANN_MI355X_ATTN_XCD");
+    const int n_units = (xo && xo[0] == '0') ? -(n_seqs * heads) : n_seqs * heads;
+    dim3 grid((unsigned)((n_seqs * heads + 7) / 8 * 8)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const __half* q = (const __half*)d_qkv;
     __half* o = (__half*)d_out;
     switch (nt) {
-#define CASEA(n) case n: hipLaunchKernelGGL((k_attn_varlen_hd32_v2<n>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e); break
+#define CASEA(n) case n: hipLaunchKernelGGL((k_attn_varlen_hd32_v2<n>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
         CASEA(1); CASEA(2); CASEA(3); CASEA(4); CASEA(5); CASEA(6); CASEA(7); CASEA(8);
 #undef CASEA
         default: LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");

@@ -41,18 +41,11 @@ constexpr int G2_LDS_X = 2 * 32 * G2_XROW;            // 49152: second 32-token 
 constexpr int G2_LDS_RED = 4 * 64 * 4;                // LayerNorm partial sums: [wave][token] floats
 constexpr int G2_LDS_TOTAL = G2_LDS_W + G2_LDS_X + G2_LDS_RED;  // 148480
 
+#define g2_dma16 lm_dma16  // lm_h384_common.h (inline assembly form: see there why)
 #ifdef LM_EMULATED_DEVICE
-// the host emulation (tests/hip_emul) has no DMA engine: lane-wise copy to (wave-uniform base + 16 lane)
-__device__ inline void g2_dma16(const void* gsrc, unsigned char* lds_wave_base) {
-    std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16);
-}
 #define G2_WAIT_VM(n) ((void)0)
 #define G2_BARRIER() __syncthreads()
 #else
-__device__ __forceinline__ void g2_dma16(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 #define G2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define G2_BARRIER() __builtin_amdgcn_s_barrier()  // raw: fragment reads of the next slab stay in flight across it
 #endif

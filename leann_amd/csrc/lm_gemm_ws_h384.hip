@@ -26,14 +26,10 @@ constexpr int WS_ROWS = 192;                       // output features per workgr
 constexpr int WS_W_BYTES = WS_ROWS * ML_H * 2;      // 147456
 constexpr int WS_LDS_TOTAL = WS_W_BYTES + WS_ROWS * 4;  // + the bias slice as floats
 
+#define ws_dma16 lm_dma16  // lm_h384_common.h (inline assembly form: see there why)
 #ifdef LM_EMULATED_DEVICE
-__device__ inline void ws_dma16(const void* gsrc, unsigned char* lds_wave_base) { std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16); }
 #define WS_WAIT_VM0() ((void)0)
 #else
-__device__ __forceinline__ void ws_dma16(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 #define WS_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_fp16.h>
 
+#include <cstring>
+
 #include "lm_internal.h"
 
 namespace lm {
@@ -30,6 +32,29 @@ __device__ __forceinline__ void lane32_swap(uint32_t& a, uint32_t& b) {
     b = r[1];
 #endif
 }
+
+// One LDS-DMA piece: 64 lanes x 16 B, lane l from gsrc (its own address) to LDS byte lds_wave_base (wave uniform) + 16 l.
+// Inline assembly ON PURPOSE.  The compiler models global_load_lds (the __builtin_amdgcn_global_load_lds form) as a FLAT access
+// that may touch LDS, and from then on every wait it inserts for an LDS read in the same loop is s_waitcnt lgkmcnt(0) -- also for
+// a fragment read four MFMAs ago, i.e. right behind the NEXT fragment read: every group of four MFMAs paid a full LDS round
+// trip (s_memtime stamps of the fused MLP with the builtin: 3200 cycles per 48-MFMA iteration against a 1536-cycle matrix-pipe
+// floor; the same loop without a DMA gets counted lgkmcnt(3) waits).  The asm form is invisible to that bookkeeping; what orders
+// the pieces is each kernel's own counted s_waitcnt vmcnt + barrier protocol, exactly as before.
+#ifdef LM_EMULATED_DEVICE
+__device__ inline void lm_dma16(const void* gsrc, unsigned char* lds_wave_base) { std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16); }
+__device__ inline void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) { lm_dma16((const unsigned char*)sbase + voff, lds_wave_base); }
+#else
+__device__ __forceinline__ void lm_dma16(const void* gsrc, unsigned char* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);  // low half of the flat address = LDS offset
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
+}
+// The same piece with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): no 64-bit VALU add per
+// piece; with a wave-uniform lds_wave_base the M0 value is SALU arithmetic as well (the readfirstlane folds away).
+__device__ __forceinline__ void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+}
+#endif
 
 constexpr int ML_H = 384;                 // hidden size
 constexpr int ML_KS = ML_H / 16;          // 24 k-steps of the first product

@@ -14,8 +14,9 @@
 //   * streams W1 / W2 slabs L2 -> LDS with global_load_lds_dwordx4 (no registers, no ds_write), three stages per matrix,
 //     counted vmcnt + one raw s_barrier per slab; LDS images are lane-linear per DMA instruction, made bank-conflict
 //     free by an XOR swizzle of the SOURCE chunk and of the fragment READ (same scheme as lm_gemm_h384.hip);
-//   * evaluates GELU in SCALAR fp32 (no packed ops) as a stream of 256 micro-operations per slab, four values in flight so
-//     that neighbouring instructions are independent, 5-6 of them behind EACH of the 48 MFMAs of an iteration; to have 48
+//   * evaluates GELU in SCALAR fp32 (no packed ops) as a stream of micro-operations (144 per slab: 8.5 instructions per value,
+//     one transcendental -- see gelu_uop), four values in flight so that neighbouring instructions are independent, 3 of
+//     them behind EACH of the 48 MFMAs of an iteration; to have 48
 //     gaps for them the pipeline is skewed by two slabs:
 //         iteration s = { first product of slab s+1 | GELU of slab s | second product of slab s-1 };
 //   * fragment reads run four MFMAs ahead, across the boundary between the two products.
@@ -28,21 +29,19 @@
 
 namespace lm {
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
 constexpr int M3_SLAB = 24576;                 // bytes of a W1 slab (32 hidden x 384 k) and of a W2 slab (384 rows x 32 hidden)
 constexpr int M3_STAGES = 3;
 constexpr int M3_W1_OFF = 0;
 constexpr int M3_W2_OFF = M3_STAGES * M3_SLAB;  // 73728
 constexpr int M3_B1_OFF = 2 * M3_STAGES * M3_SLAB;  // 147456: b1 as floats behind the six stages
 
+#define m3_dma16 lm_dma16  // lm_h384_common.h
 #ifdef LM_EMULATED_DEVICE
-__device__ inline void m3_dma16(const void* gsrc, unsigned char* lds_wave_base) { std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16); }
 #define M3_WAIT_VM(n) ((void)0)
 #define M3_BARRIER() __syncthreads()
 #else
-__device__ __forceinline__ void m3_dma16(const void* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 #define M3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define M3_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
@@ -56,59 +55,147 @@ __device__ __forceinline__ void m3_w1_offsets(int tid, int (&off)[6]) {  // per-
         off[i] = row * 768 + (((pos & ~15) | ((pos ^ row) & 15)) << 4);
     }
 }
-__device__ __forceinline__ void m3_issue_w1(const unsigned char* slab, unsigned char* stage, int tid, const int (&off)[6]) {
-    const int wv = tid >> 6;
+// slab, stage and wv are wave uniform (wv comes out of a readfirstlane): base and M0 arithmetic stay on the scalar unit
+__device__ __forceinline__ void m3_issue_w1(const unsigned char* slab, unsigned char* stage, int wv, const int (&off)[6]) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m3_dma16(slab + off[i], stage + (256 * i + 64 * wv) * 16);
+    for (int i = 0; i < 6; ++i) lm_dma16_sv(slab, (unsigned)off[i], stage + (256 * i + 64 * wv) * 16);
 }
 // W2 slab [384 rows][4 chunks] -> stage: LDS chunk L = (row = L >> 2, pos = L & 3) holds source chunk pos ^ ((row >> 2) & 3)
-__device__ __forceinline__ void m3_issue_w2(const unsigned char* slab, unsigned char* stage, int tid) {
-    const int wv = tid >> 6;
-    const unsigned char* src = slab + (tid >> 2) * 64 + (((tid & 3) ^ ((tid >> 4) & 3)) << 4);
+__device__ __forceinline__ void m3_issue_w2(const unsigned char* slab, unsigned char* stage, int wv, int tid) {
+    const unsigned off = (unsigned)((tid >> 2) * 64 + (((tid & 3) ^ ((tid >> 4) & 3)) << 4));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) m3_dma16(src + i * 4096, stage + (256 * i + 64 * wv) * 16);
+    for (int i = 0; i < 6; ++i) lm_dma16_sv(slab + i * 4096, off, stage + (256 * i + 64 * wv) * 16);
 }
 
-// exact (erf) GELU in scalar fp32 (Abramowitz-Stegun 7.1.26, |abs err| < 3.4e-7):
-//   gelu(x) = max(x,0) - 0.5|x| t P(t) exp(-x^2/2),   t = 1 / (1 + p|x|/sqrt2)
-// With ONE wave per SIMD nothing hides the latency of a dependent VALU chain (first hardware run of this kernel: one value at a
-// time, 4-6 dependent instructions per MFMA gap, cost ~53 cycles per gap on top of the 32 of the MFMA).  So the 16 values of a
-// slab are processed FOUR AT A TIME, one micro-operation per value in turn: consecutive instructions belong to different values
-// and are independent; the same value comes round again four issue slots later.  A slab is 4 groups x 16 rows x 4 values = 256
-// micro-operations, numbered idx = 64 group + 4 row + value; an iteration spreads them evenly over its 48 MFMA gaps.
+// exact (erf) GELU in scalar fp32.  With ONE wave per SIMD nothing hides the latency of a dependent VALU chain (first hardware
+// run of this kernel: one value at a time, 4-6 dependent instructions per MFMA gap, cost ~53 cycles per gap on top of the 32 of
+// the MFMA).  So the 16 values of a slab are processed FOUR AT A TIME, one micro-operation per value in turn: consecutive
+// instructions belong to different values and are independent; the same value comes round again four issue slots later.  A slab
+// is 4 groups x ROWS rows x 4 values micro-operations, numbered idx = 4 ROWS group + 4 row + value; an iteration spreads them
+// evenly over its 48 MFMA gaps.
+//
+// FORM 1 (the product kernel): 8.5 instructions per value, ONE transcendental.
+//     gelu(x) = x Phi(x) = max(x, 0) - |x| * 0.5 erfc(|x| / sqrt2),      0.5 erfc(u / sqrt2) = 2^(-1 - u q(u)),
+//   q = degree-4 polynomial fitted (weighted minimax on the error of the RESULT, u in [0, 9]) to -log2(erfc(u / sqrt2)) / u, which
+//   is smooth and nearly linear; its leading coefficient is positive, so 2^(...) underflows to 0 for any larger |x| without a
+//   clamp.  |error| < 1e-6 absolute over all x in fp32 (fp16 output: <= 1 ulp for x > -3, absolute < 6e-7 below);  |x| and -|x|
+//   are source modifiers; two results are converted by one v_cvt_pk_f16_f32.
+// FORM 2 (LEANN_MI355X_ABLATE=8, kept for A/B): Abramowitz-Stegun 7.1.26, 14.5 instructions per value, TWO transcendentals
+//     gelu(x) = max(x,0) - 0.5|x| t P(t) exp(-x^2/2),   t = 1 / (1 + p|x|/sqrt2)          (|abs err| < 3.4e-7)
+//   the round-2 hardware sessions measured this GELU at ~435 us of the kernel's 910 us (262k tokens).
+// FORMS 3, 4, 5 (LEANN_MI355X_ABLATE=16 / 32 / 48): FORM 1's arithmetic written as `asm volatile` micro-operations, which pins
+//   the interleaved order (the compiler's instruction selection is free to move plain arithmetic between the scheduling
+//   barriers of the slots: in FORM 1's steady-state loop the first gaps carry 3, 5, 6, 4 operations and a value's consecutive
+//   stages end up two instructions apart).  3: VOP2 forms with literal constants (v_fmaak_f32, |x| in a register, 9.5
+//   instructions per value); 4: FORM 1's VOP3 forms with source modifiers (8.5); 5: as 4 with EIGHT values in flight.
 struct GeluQuad {
-    float x[4], a[4], t[4], w[4], p[4];
+    float x[8], a[8], t[8], w[8], p[8];
 };
-template <int IDX>  // every index is a constant expression: the arrays stay in registers
-__device__ __forceinline__ void gelu_uop(const float (&acc)[16], GeluQuad& q, half8 (&pf)[2]) {
-    constexpr int grp = IDX >> 6, row = (IDX >> 2) & 15, k = IDX & 3, v = 4 * grp + k;
-    // 14 instructions per value (|x| is a source modifier; the 0.5 of 0.5|x| lives in the polynomial coefficients);
-    // rows 14, 15 are empty so that a group stays 64 slots long
-    if constexpr (row == 0) {
-        q.x[k] = acc[v];
-        q.t[k] = __builtin_fmaf(__builtin_fabsf(acc[v]), 0.3275911f * 0.70710678f, 1.0f);
-    } else if constexpr (row == 1) q.t[k] = __builtin_amdgcn_rcpf(q.t[k]);
-    else if constexpr (row == 2) q.w[k] = q.x[k] * -0.72134752f;  // -0.5 log2(e) x
-    else if constexpr (row == 3) q.w[k] = q.w[k] * q.x[k];          // -0.5 log2(e) x^2
-    else if constexpr (row == 4) q.p[k] = __builtin_fmaf(q.t[k], 0.5f * 1.061405429f, 0.5f * -1.453152027f);
-    else if constexpr (row == 5) q.p[k] = __builtin_fmaf(q.p[k], q.t[k], 0.5f * 1.421413741f);
-    else if constexpr (row == 6) q.p[k] = __builtin_fmaf(q.p[k], q.t[k], 0.5f * -0.284496736f);
-    else if constexpr (row == 7) q.p[k] = __builtin_fmaf(q.p[k], q.t[k], 0.5f * 0.254829592f);
-    else if constexpr (row == 8) q.a[k] = __builtin_fabsf(q.x[k]) * q.t[k];
-    else if constexpr (row == 9) q.p[k] = q.p[k] * q.a[k];  // 0.5 |x| t P(t)
-    else if constexpr (row == 10) q.w[k] = __builtin_amdgcn_exp2f(q.w[k]);
-    else if constexpr (row == 11) q.a[k] = __builtin_amdgcn_fmed3f(q.x[k], 0.0f, __builtin_inff());  // max(x, 0)
-    else if constexpr (row == 12) q.p[k] = __builtin_fmaf(-q.p[k], q.w[k], q.a[k]);
-    else if constexpr (row == 13) pf[v >> 3][v & 7] = (_Float16)q.p[k];  // fp16 into the B fragment of the second product
+template <int FORM>
+constexpr int gelu_rows() { return (FORM == 1 || FORM == 4 || FORM == 5) ? 9 : (FORM == 3 ? 10 : 16); }
+template <int FORM>
+constexpr int gelu_flight() { return FORM == 5 ? 8 : 4; }
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gelu_put_pair(half8 (&pf)[2], int v, unsigned two_halfs) {  // v even: fp16 elements v, v + 1 of the 16
+    uint4v u = __builtin_bit_cast(uint4v, pf[v >> 3]);
+    u[(v & 7) >> 1] = two_halfs;
+    pf[v >> 3] = __builtin_bit_cast(half8, u);
 }
-template <int LO, int... E>
+template <int FORM, int IDX>  // every index is a constant expression: the arrays stay in registers
+__device__ __forceinline__ void gelu_uop(const float (&acc)[16], GeluQuad& q, half8 (&pf)[2]) {
+    constexpr int R = gelu_rows<FORM>(), NF = gelu_flight<FORM>();
+    constexpr int grp = IDX / (NF * R), row = (IDX % (NF * R)) / NF, k = IDX % NF, v = NF * grp + k;
+#ifndef LM_EMULATED_DEVICE
+    if constexpr (FORM == 3) {
+        if constexpr (row == 0) {
+            q.x[k] = acc[v];
+            asm volatile("v_and_b32 %0, 0x7fffffff, %1" : "=v"(q.a[k]) : "v"(acc[v]));
+        } else if constexpr (row == 1) asm volatile("v_fmaak_f32 %0, %1, %2, 0x3bebe3f5" : "=v"(q.p[k]) : "v"(-0.0004881171917077154f), "v"(q.a[k]));
+        else if constexpr (row == 2) asm volatile("v_fmaak_f32 %0, %1, %2, 0xbd5597e3" : "=v"(q.p[k]) : "v"(q.p[k]), "v"(q.a[k]));
+        else if constexpr (row == 3) asm volatile("v_fmaak_f32 %0, %1, %2, 0xbeeb5021" : "=v"(q.p[k]) : "v"(q.p[k]), "v"(q.a[k]));
+        else if constexpr (row == 4) asm volatile("v_fmaak_f32 %0, %1, %2, 0xbf9353fd" : "=v"(q.p[k]) : "v"(q.p[k]), "v"(q.a[k]));
+        else if constexpr (row == 5) asm volatile("v_fmaak_f32 %0, %1, %2, 0xbf800000" : "=v"(q.w[k]) : "v"(q.p[k]), "v"(q.a[k]));
+        else if constexpr (row == 6) asm volatile("v_exp_f32 %0, %1" : "=v"(q.w[k]) : "v"(q.w[k]));
+        else if constexpr (row == 7) asm volatile("v_max_f32 %0, 0, %1" : "=v"(q.t[k]) : "v"(q.x[k]));
+        else if constexpr (row == 8) asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(q.p[k]) : "v"(q.a[k]), "v"(q.w[k]), "v"(q.t[k]));
+        else if constexpr (row == 9 && (k & 1) == 0) {
+            unsigned r;
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(q.p[k]), "v"(q.p[k + 1]));
+            gelu_put_pair(pf, v, r);
+        }
+        return;
+    }
+    if constexpr (FORM == 4 || FORM == 5) {
+        if constexpr (row == 0) {
+            q.x[k] = acc[v];
+            asm volatile("v_fma_f32 %0, |%1|, %2, %3" : "=v"(q.p[k]) : "v"(acc[v]), "s"(-0.0004881171917077154f), "v"(0.007198805455118418f));
+        } else if constexpr (row == 1) asm volatile("v_fma_f32 %0, %1, |%2|, %3" : "=v"(q.p[k]) : "v"(q.p[k]), "v"(q.x[k]), "s"(-0.052146803587675095f));
+        else if constexpr (row == 2) asm volatile("v_fma_f32 %0, %1, |%2|, %3" : "=v"(q.p[k]) : "v"(q.p[k]), "v"(q.x[k]), "s"(-0.4595957100391388f));
+        else if constexpr (row == 3) asm volatile("v_fma_f32 %0, %1, |%2|, %3" : "=v"(q.p[k]) : "v"(q.p[k]), "v"(q.x[k]), "s"(-1.1510006189346313f));
+        else if constexpr (row == 4) asm volatile("v_fma_f32 %0, %1, |%2|, -1.0" : "=v"(q.w[k]) : "v"(q.p[k]), "v"(q.x[k]));
+        else if constexpr (row == 5) asm volatile("v_exp_f32 %0, %1" : "=v"(q.w[k]) : "v"(q.w[k]));
+        else if constexpr (row == 6) asm volatile("v_max_f32 %0, 0, %1" : "=v"(q.t[k]) : "v"(q.x[k]));
+        else if constexpr (row == 7) asm volatile("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(q.p[k]) : "v"(q.x[k]), "v"(q.w[k]), "v"(q.t[k]));
+        else if constexpr (row == 8 && (k & 1) == 0) {
+            unsigned r;
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(q.p[k]), "v"(q.p[k + 1]));
+            gelu_put_pair(pf, v, r);
+        }
+        return;
+    }
+#endif
+    if constexpr (FORM != 2) {  // FORM 1 (and the host-emulated build of 3 / 4 / 5, which has no GCN assembler: same arithmetic in C)
+        constexpr int last = R - 1;
+        if constexpr (row == last) {
+            if constexpr ((k & 1) == 0) {  // values k, k + 1 -> two fp16 of the B fragment of the second product
+                const float2v pr = {q.p[k], q.p[k + 1]};
+                const half2v h = __builtin_convertvector(pr, half2v);
+                pf[v >> 3][v & 7] = h[0];
+                pf[v >> 3][(v & 7) + 1] = h[1];
+            }
+        } else if constexpr (FORM == 3 && row == 0) q.x[k] = acc[v];
+        else if constexpr (row - (FORM == 3) == 0) {
+            if constexpr (FORM != 3) q.x[k] = acc[v];
+            q.p[k] = __builtin_fmaf(__builtin_fabsf(q.x[k]), -0.0004881171917077154f, 0.007198805455118418f);
+        } else {
+            constexpr int r = row - (FORM == 3);
+            if constexpr (r == 1) q.p[k] = __builtin_fmaf(q.p[k], __builtin_fabsf(q.x[k]), -0.052146803587675095f);
+            else if constexpr (r == 2) q.p[k] = __builtin_fmaf(q.p[k], __builtin_fabsf(q.x[k]), -0.4595957100391388f);
+            else if constexpr (r == 3) q.p[k] = __builtin_fmaf(q.p[k], __builtin_fabsf(q.x[k]), -1.1510006189346313f);
+            else if constexpr (r == 4) q.w[k] = __builtin_fmaf(q.p[k], __builtin_fabsf(q.x[k]), -1.0f);  // -1 - u q(u)
+            else if constexpr (r == 5) q.w[k] = __builtin_amdgcn_exp2f(q.w[k]);
+            else if constexpr (r == 6) q.a[k] = __builtin_amdgcn_fmed3f(q.x[k], 0.0f, __builtin_inff());  // max(x, 0)
+            else if constexpr (r == 7) q.p[k] = __builtin_fmaf(-__builtin_fabsf(q.x[k]), q.w[k], q.a[k]);
+        }
+    } else {
+        // 14 instructions per value (|x| is a source modifier; the 0.5 of 0.5|x| lives in the polynomial coefficients);
+        // rows 14, 15 are empty so that a group stays 64 slots long
+        if constexpr (row == 0) {
+            q.x[k] = acc[v];
+            q.t[k] = __builtin_fmaf(__builtin_fabsf(acc[v]), 0.3275911f * 0.70710678f, 1.0f);
+        } else if constexpr (row == 1) q.t[k] = __builtin_amdgcn_rcpf(q.t[k]);
+        else if constexpr (row == 2) q.w[k] = q.x[k] * -0.72134752f;  // -0.5 log2(e) x
+        else if constexpr (row == 3) q.w[k] = q.w[k] * q.x[k];          // -0.5 log2(e) x^2
+        else if constexpr (row == 4) q.p[k] = __builtin_fmaf(q.t[k], 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+        else if constexpr (row == 5) q.p[k] = __builtin_fmaf(q.p[k], q.t[k], 0.5f * 1.421413741f);
+        else if constexpr (row == 6) q.p[k] = __builtin_fmaf(q.p[k], q.t[k], 0.5f * -0.284496736f);
+        else if constexpr (row == 7) q.p[k] = __builtin_fmaf(q.p[k], q.t[k], 0.5f * 0.254829592f);
+        else if constexpr (row == 8) q.a[k] = __builtin_fabsf(q.x[k]) * q.t[k];
+        else if constexpr (row == 9) q.p[k] = q.p[k] * q.a[k];  // 0.5 |x| t P(t)
+        else if constexpr (row == 10) q.w[k] = __builtin_amdgcn_exp2f(q.w[k]);
+        else if constexpr (row == 11) q.a[k] = __builtin_amdgcn_fmed3f(q.x[k], 0.0f, __builtin_inff());  // max(x, 0)
+        else if constexpr (row == 12) q.p[k] = __builtin_fmaf(-q.p[k], q.w[k], q.a[k]);
+        else if constexpr (row == 13) pf[v >> 3][v & 7] = (_Float16)q.p[k];  // fp16 into the B fragment of the second product
+    }
+}
+template <int FORM, int LO, int... E>
 __device__ __forceinline__ void gelu_range(std::integer_sequence<int, E...>, const float (&acc)[16], GeluQuad& q, half8 (&pf)[2]) {
-    (gelu_uop<LO + E>(acc, q, pf), ...);
+    (gelu_uop<FORM, LO + E>(acc, q, pf), ...);
 }
 
 // One iteration of the skewed pipeline.  FC1: first product of the slab in stage w1s (bias bs) -> accn;  GEL: GELU of acc[0..16)
 // -> pfcur;  FC2: second product of the slab in stage w2s with pfprev -> o.  48 slots, slot i = MFMA i (24 of FC1 then 24 of
-// FC2) followed by GELU stage i (value i / 3, stage i % 3) and the fragment read of slot i + 4.
+// FC2) followed by its share of the GELU micro-operations and the fragment read of slot i + 4.
 struct M3Ctx {
     const unsigned char* w1s;
     const unsigned char* w2s;
@@ -125,37 +212,37 @@ __device__ __forceinline__ half8 m3_frag(const M3Ctx& c) {
 template <bool FC1, bool FC2, int SLOT>
 constexpr bool m3_live() { return SLOT < 24 ? FC1 : (SLOT < 48 ? FC2 : false); }
 
-template <bool FC1, bool FC2, bool GEL, int I>
+template <bool FC1, bool FC2, int GEL, int RD, int I>
 __device__ __forceinline__ void m3_slot(const M3Ctx& c, const half8 (&xf)[ML_KS], float16v (&accn)[2], const float (&acc)[16],
-                                        const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[4], GeluQuad& gq) {
+                                        const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[RD], GeluQuad& gq) {
     if constexpr (m3_live<FC1, FC2, I>()) {
         if constexpr (I < 24) {
             // two accumulators in turn: an instruction issued between two MFMAs on the SAME accumulator costs ~43 cycles
             // (MI355X_MICROARCH.md, per-instruction constants) -- and every gap here carries GELU micro-operations
-            accn[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & 3], xf[I], accn[I & 1], 0, 0, 0);
+            accn[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], xf[I], accn[I & 1], 0, 0, 0);
         } else {
             constexpr int n = I - 24, u = n / ML_NJ, j = n % ML_NJ;
-            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & 3], pfprev[u], o[j], 0, 0, 0);
+            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], pfprev[u], o[j], 0, 0, 0);
         }
-        if constexpr (m3_live<FC1, FC2, I + 4>()) ring[I & 3] = m3_frag<I + 4>(c);
+        if constexpr (m3_live<FC1, FC2, I + RD>()) ring[I & (RD - 1)] = m3_frag<I + RD>(c);
     }
-    if constexpr (GEL) {
-        constexpr int lo = (256 * I) / 48, hi = (256 * (I + 1)) / 48;
-        gelu_range<lo>(std::make_integer_sequence<int, hi - lo>{}, acc, gq, pfcur);
+    if constexpr (GEL != 0) {
+        constexpr int n = 16 * gelu_rows<GEL>(), lo = (n * I) / 48, hi = (n * (I + 1)) / 48;
+        gelu_range<GEL, lo>(std::make_integer_sequence<int, hi - lo>{}, acc, gq, pfcur);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <bool FC1, bool FC2, bool GEL, int... I>
+template <bool FC1, bool FC2, int GEL, int RD, int... I>
 __device__ __forceinline__ void m3_slots(std::integer_sequence<int, I...>, const M3Ctx& c, const half8 (&xf)[ML_KS], float16v (&accn)[2],
-                                         const float (&acc)[16], const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[4],
+                                         const float (&acc)[16], const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[RD],
                                          GeluQuad& gq) {
-    (m3_slot<FC1, FC2, GEL, I>(c, xf, accn, acc, pfprev, pfcur, o, ring, gq), ...);
+    (m3_slot<FC1, FC2, GEL, RD, I>(c, xf, accn, acc, pfprev, pfcur, o, ring, gq), ...);
 }
 
 // One iteration of the skewed pipeline.  FC1: first product of the slab in stage w1s (bias bs) -> accn;  GEL: GELU of acc[0..16)
 // -> pfcur;  FC2: second product of the slab in stage w2s with pfprev -> o.  48 slots, slot i = MFMA i (24 of FC1 then 24 of
 // FC2), the fragment read of slot i + 4 and GELU micro-operations [256 i / 48, 256 (i + 1) / 48).
-template <bool FC1, bool FC2, bool GEL>
+template <bool FC1, bool FC2, int GEL, int RD>
 __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const unsigned char* w2s, const int (&a1)[8], int b20, int b21,
                                              const float* bs, const half8 (&xf)[ML_KS], float16v (&accn)[2], const float (&acc)[16],
                                              const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ]) {
@@ -177,31 +264,180 @@ __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const uns
             }
         }
     }
-    half8 ring[4];
+    half8 ring[RD];  // fragment reads run RD MFMAs ahead
     constexpr int first = FC1 ? 0 : 24;
     if constexpr (m3_live<FC1, FC2, first>()) {
         ring[0] = m3_frag<first>(c);
         ring[1] = m3_frag<first + 1>(c);
         ring[2] = m3_frag<first + 2>(c);
         ring[3] = m3_frag<first + 3>(c);
+        if constexpr (RD == 8) {
+            ring[4] = m3_frag<first + 4>(c);
+            ring[5] = m3_frag<first + 5>(c);
+            ring[6] = m3_frag<first + 6>(c);
+            ring[7] = m3_frag<first + 7>(c);
+        }
     }
     GeluQuad gq;
-    m3_slots<FC1, FC2, GEL>(std::make_integer_sequence<int, 48>{}, c, xf, accn, acc, pfprev, pfcur, o, ring, gq);
+    m3_slots<FC1, FC2, GEL, RD>(std::make_integer_sequence<int, 48>{}, c, xf, accn, acc, pfprev, pfcur, o, ring, gq);
+}
+
+// Epilogue of variant 3:  y = LayerNorm(o + residual) * gamma + beta  (b2 is already in the accumulators), written as fp16.
+// The shared epilogue (lm_h384_common.h: mlp_epilogue) reads the residual, b2, gamma and beta with ~190 row-per-lane loads and
+// writes 48 row-per-lane 8-byte stores per lane; s_memtime stamps on the MI355X put it at 36,000 of a workgroup's 200,000 cycles
+// (and one workgroup per CU means nothing overlaps it).  Here
+//   * the residual comes out of the x^T fragments the wave still holds for the first product: lane (token, g) owns features
+//     16 ks + 8 g + e and needs 32 j + 8 q + 4 g + i, i.e. half of every fragment register pair trades places with the partner lane
+//     (token, g ^ 1) -- 48 v_permlane32_swap, no memory access;
+//   * gamma / beta are read from an LDS copy (two addresses per instruction: a broadcast);
+//   * the fp16 results go through the wave's own 24 KB of the (now idle) weight stages -- [32 tokens][48 chunks of 16 B], chunk c
+//     of row r at position (c & ~15) | ((c ^ r) & 15): conflict-free ds_write_b64 in, ds_read_b128 out -- and leave as 24
+//     fully coalesced 1 KB stores per wave (a wave's 32 token rows are one contiguous 24 KB block of the output).
+__device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
+                                            unsigned char* tile, __half* __restrict__ out, int64_t token0, int T, int r31, int g, int lane,
+                                            float eps) {
+    __builtin_amdgcn_sched_barrier(0);
+    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < ML_KS; ++ks) {
+        u32x4 d = __builtin_bit_cast(u32x4, xf[ks]);
+        uint32_t a0 = d[0], b0 = d[2], a1 = d[1], b1 = d[3];
+        lane32_swap(a0, b0);  // a: features of the even q (i = 0, 1), b: of the odd q
+        lane32_swap(a1, b1);  // the same for i = 2, 3
+        const int j = ks >> 1, qe = 2 * (ks & 1);
+        const half2v ea = __builtin_bit_cast(half2v, a0), eb = __builtin_bit_cast(half2v, a1);
+        const half2v oa = __builtin_bit_cast(half2v, b0), ob = __builtin_bit_cast(half2v, b1);
+        float2v v0 = (float2v){o[j][4 * qe], o[j][4 * qe + 1]} + (float2v){(float)ea[0], (float)ea[1]};
+        float2v v1 = (float2v){o[j][4 * qe + 2], o[j][4 * qe + 3]} + (float2v){(float)eb[0], (float)eb[1]};
+        float2v v2 = (float2v){o[j][4 * qe + 4], o[j][4 * qe + 5]} + (float2v){(float)oa[0], (float)oa[1]};
+        float2v v3 = (float2v){o[j][4 * qe + 6], o[j][4 * qe + 7]} + (float2v){(float)ob[0], (float)ob[1]};
+        o[j][4 * qe] = v0[0];
+        o[j][4 * qe + 1] = v0[1];
+        o[j][4 * qe + 2] = v1[0];
+        o[j][4 * qe + 3] = v1[1];
+        o[j][4 * qe + 4] = v2[0];
+        o[j][4 * qe + 5] = v2[1];
+        o[j][4 * qe + 6] = v3[0];
+        o[j][4 * qe + 7] = v3[1];
+        sa += v0 + v2;
+        sb += v1 + v3;
+    }
+    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / ML_H);
+    const float2v nm = {-mean, -mean};
+    float2v qa = {0.f, 0.f}, qb = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            float2v d0 = (float2v){o[j][r], o[j][r + 1]} + nm, d1 = (float2v){o[j][r + 2], o[j][r + 3]} + nm;
+            qa = __builtin_elementwise_fma(d0, d0, qa);
+            qb = __builtin_elementwise_fma(d1, d1, qb);
+        }
+    float sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
+    const float2v rs = {rstd, rstd};
+    unsigned char* trow = tile + r31 * 768 + 8 * g;
+    // gamma / beta of tile j + 1 are read while tile j is normalised (left to itself the compiler emits read, read, wait, 25
+    // instructions, write -- 48 exposed LDS round trips)
+    half4 gv[4], bv[4], gn[4], bn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        gv[q] = *(const half4*)(gam_s + 8 * q + 4 * g);
+        bv[q] = *(const half4*)(bet_s + 8 * q + 4 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j) {
+        if (j + 1 < ML_NJ) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gn[q] = *(const half4*)(gam_s + 32 * (j + 1) + 8 * q + 4 * g);
+                bn[q] = *(const half4*)(bet_s + 32 * (j + 1) + 8 * q + 4 * g);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * j + q;
+            float2v n0 = ((float2v){o[j][4 * q], o[j][4 * q + 1]} + nm) * rs;
+            float2v n1 = ((float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + nm) * rs;
+            float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[q][0], (float)gv[q][1]}, (float2v){(float)bv[q][0], (float)bv[q][1]});
+            float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[q][2], (float)gv[q][3]}, (float2v){(float)bv[q][2], (float)bv[q][3]});
+            const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
+            const half4 y = {h0[0], h0[1], h1[0], h1[1]};
+            *(half4*)(trow + ((c & ~15) | ((c ^ r31) & 15)) * 16) = y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            gv[q] = gn[q];
+            bv[q] = bn[q];
+        }
+    }
+    LM_WAVE_SYNC();  // the rows were written by other lanes of this wave (lock-step on the GPU: program order is enough)
+    // the wave's tile back out in linear order: chunk L = 64 i + lane = (row L / 48, chunk L % 48) is bytes [16 L, 16 L + 16) of the
+    // wave's 24 KB of output
+    unsigned char* obase = (unsigned char*)out + token0 * (ML_H * 2);
+    const int rows_valid = (int)((int64_t)T - token0 < 32 ? (int64_t)T - token0 : 32);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {  // eight reads in flight, then their eight stores
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
+            v[i] = *(const u32x4*)(tile + row * 768 + ((c & ~15) | ((c ^ row) & 15)) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = 64 * (8 * b + i) + lane;
+            if (L < 48 * rows_valid) *(u32x4*)(obase + 16 * L) = v[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // w1:  [F][384] fp16 (nn.Linear weight; slab s = rows 32s .. 32s+31, contiguous)
 // w2p: [F/32][384][32] fp16 with the k permutation of leann_amd/encoder.py: fused_mlp_k_permutation
 // ABL: ablation bits for on-hardware diagnosis (LEANN_MI355X_ABLATE; 0 = the product kernel): 1 = no weight DMA after the
 // prologue (stale LDS), 2 = no counted wait / barrier per slab, 4 = no GELU stages (second product on stale fragments).
-// Results are wrong by construction with any bit set; only the timing is of interest.
+// Results are wrong by construction with any of these bits set; only the timing is of interest.  8 = the round-2 GELU form
+// (Abramowitz-Stegun, two transcendentals): results are right, for A/B timing of the two forms.
+// ABL & 64: the kernel plus eight s_memtime stamps per workgroup (wave 0), written over the first 64 bytes of the
+// workgroup's first output row when it is done -- where the cycles of a workgroup go (scripts/kbench.cpp "stamps").
+#ifdef LM_EMULATED_DEVICE
+#define M3_STAMP(i) ((void)0)
+#else
+#define M3_STAMP(i)                                                     \
+    if constexpr ((ABL & 64) != 0) {                                    \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        stamp[i] = __builtin_amdgcn_s_memtime();                        \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    }
+#endif
 template <int ABL>
 __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
     int F, float eps) {
     extern __shared__ __align__(16) unsigned char smem[];
+    [[maybe_unused]] unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    M3_STAMP(0);
+    constexpr int AF = ABL & 56;  // GELU form bits
+    constexpr int GEL = (ABL & 4) ? 0 : (AF == 8 ? 2 : (AF == 16 ? 3 : (AF == 32 ? 4 : (AF == 48 ? 5 : 1))));  // GELU form (see gelu_uop)
+    constexpr int RD = (ABL & 128) ? 8 : 4;  // fragment read-ahead distance
     float* b1s = (float*)(smem + M3_B1_OFF);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* b2s = b1s + F;                          // b2 (384 floats), gamma, beta (384 halfs each) behind b1
+    _Float16* gam_s = (_Float16*)(b2s + ML_H);
+    _Float16* bet_s = gam_s + ML_H;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef LM_EMULATED_DEVICE
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave uniform, and known to be
+#endif
     const int r31 = lane & 31, g = lane >> 5;
     const int token = blockIdx.x * 128 + wv * 32 + r31;
     const bool valid = token < T;
@@ -212,10 +448,10 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     // ---- prologue: W1 slabs 0..2 and W2 slab 0 in flight; x^T fragments and b1 meanwhile ----
     int w1off[6];
     m3_w1_offsets(tid, w1off);
-    m3_issue_w1(g1, smem + M3_W1_OFF, tid, w1off);
-    m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, tid, w1off);
-    m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, tid, w1off);
-    m3_issue_w2(g2, smem + M3_W2_OFF, tid);
+    m3_issue_w1(g1, smem + M3_W1_OFF, wv, w1off);
+    m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, wv, w1off);
+    m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
+    m3_issue_w2(g2, smem + M3_W2_OFF, wv, tid);
     half8 xf[ML_KS];
     {
         const _Float16* xr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
@@ -227,6 +463,11 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
         }
     }
     for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
+    for (int i = tid; i < ML_H; i += 256) {
+        b2s[i] = b2[i];
+        gam_s[i] = ((const _Float16*)gamma)[i];
+        bet_s[i] = ((const _Float16*)beta)[i];
+    }
 
     // fragment addresses.  W1: row r31, chunk c = 2 ks + g at position (c & ~15) | ((c ^ r31) & 15): the low part depends on ks & 7
     int a1[8];
@@ -235,18 +476,25 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     // W2: row 32 j + r31, chunk (2u + g) ^ ((r31 >> 2) & 3); u = 1 flips bit 5 of the byte offset
     const int b20 = r31 * 64 + ((g ^ ((r31 >> 2) & 3)) << 4), b21 = b20 ^ 32;
 
-    float16v o[ML_NJ];
-#pragma unroll
-    for (int j = 0; j < ML_NJ; ++j) o[j] = (float16v){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float16v o[ML_NJ];  // second product; starts from b2 (after the prologue barrier: the LDS copy of b2)
     float16v accn[2];  // first product: even / odd k-steps
     float acc[16];
     half8 pfa[2], pfb[2];  // GELU outputs of the slab being activated / of the previous slab
     if (ABL & 4) pfa[0] = pfa[1] = pfb[0] = pfb[1] = xf[0];
     M3_WAIT_VM(0);
     __syncthreads();  // b1s written, every wave's DMA pieces landed (nothing is in flight: a plain barrier is fine here)
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v bv = *(const float4v*)(b2s + 32 * j + 8 * q + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
+        }
+    M3_STAMP(1);
 
     // first product of slab 0, nothing to overlap it with
-    m3_iteration<true, false, false>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<true, false, 0, RD>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
 
     // iteration s: FC1 of slab s+1 (stage (s+1) % 3), GELU of slab s, FC2 of slab s-1 (stage (s-1) % 3).
     // At its top: W1(s+1) and W2(s-1) must have landed; issued after them, one iteration ago: W1(s+2), W2(s).
@@ -254,6 +502,12 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     auto top = [&](int s) {  // everything an iteration does before its 48 slots
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = accn[0][r] + accn[1][r];
+#ifndef LM_EMULATED_DEVICE
+        if constexpr ((ABL & 4) != 0) {  // the "no GELU" ablation must keep the first product alive (round 2 timed it WITHOUT: the
+#pragma unroll                           // compiler had removed the 24 dead MFMAs and their fragment reads)
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+        }
+#endif
         if (s > 0 && !(ABL & 2)) {
             const int pend = (s + 2 < nslab ? 6 : 0) + 6;  // pieces of W1(s+2), W2(s) issued at the top of s-1
             if (pend == 12) M3_WAIT_VM(12);
@@ -261,38 +515,52 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
             M3_BARRIER();
         }
         if (ABL & 1) return;
-        if (s + 3 < nslab) m3_issue_w1(g1 + (int64_t)(s + 3) * M3_SLAB, smem + M3_W1_OFF + ((s + 3) % M3_STAGES) * M3_SLAB, tid, w1off);
-        if (s + 1 < nslab) m3_issue_w2(g2 + (int64_t)(s + 1) * M3_SLAB, smem + M3_W2_OFF + ((s + 1) % M3_STAGES) * M3_SLAB, tid);
+        if (s + 3 < nslab) m3_issue_w1(g1 + (int64_t)(s + 3) * M3_SLAB, smem + M3_W1_OFF + ((s + 3) % M3_STAGES) * M3_SLAB, wv, w1off);
+        if (s + 1 < nslab) m3_issue_w2(g2 + (int64_t)(s + 1) * M3_SLAB, smem + M3_W2_OFF + ((s + 1) % M3_STAGES) * M3_SLAB, wv, tid);
     };
     auto w1_stage = [&](int s) { return (const unsigned char*)smem + M3_W1_OFF + ((s + 1) % M3_STAGES) * M3_SLAB; };
     auto w2_stage = [&](int s) { return (const unsigned char*)smem + M3_W2_OFF + ((s + 2) % M3_STAGES) * M3_SLAB; };  // (s - 1) mod 3
     // s = 0: no second product yet
+    M3_STAMP(2);
     top(0);
-    m3_iteration<true, false, !(ABL & 4)>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<true, false, GEL, RD>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
     pfb[0] = pfa[0];
     pfb[1] = pfa[1];
     // steady state: one basic block per iteration
+    M3_STAMP(3);
     for (int s = 1; s + 1 < nslab; ++s) {
+        if (s == 17) { M3_STAMP(4); }
         top(s);
-        m3_iteration<true, true, !(ABL & 4)>(w1_stage(s), w2_stage(s), a1, b20, b21, b1s + 32 * (s + 1) + 4 * g, xf, accn, acc, pfb, pfa, o);
+        m3_iteration<true, true, GEL, RD>(w1_stage(s), w2_stage(s), a1, b20, b21, b1s + 32 * (s + 1) + 4 * g, xf, accn, acc, pfb, pfa, o);
         pfb[0] = pfa[0];
         pfb[1] = pfa[1];
     }
     // s = nslab - 1: no first product left
+    M3_STAMP(5);
     top(nslab - 1);
-    m3_iteration<false, true, !(ABL & 4)>(nullptr, w2_stage(nslab - 1), a1, b20, b21, nullptr, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<false, true, GEL, RD>(nullptr, w2_stage(nslab - 1), a1, b20, b21, nullptr, xf, accn, acc, pfb, pfa, o);
     pfb[0] = pfa[0];
     pfb[1] = pfa[1];
     // second product of the last slab (its W2 slab was waited for at the top of the last iteration: pend covered it)
     M3_WAIT_VM(0);
     M3_BARRIER();
-    m3_iteration<false, true, false>(nullptr, smem + M3_W2_OFF + ((nslab - 1) % M3_STAGES) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, pfb,
+    m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + ((nslab - 1) % M3_STAGES) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, pfb,
                                      pfa, o);
-    // the epilogue's ~150 read-only loads must not be hoisted above the slab loop (they would be spilled): an opaque copy
-    // of the lane's half index ties their addresses to this point of the program
-    int g_e = g;
-    LM_KEEP_LOCAL(g_e);
-    mlp_epilogue(o, x, b2, gamma, beta, out, token, valid, g_e, eps);
+    M3_STAMP(6);
+    __syncthreads();  // every wave is done with the weight stages: they become the output staging tiles
+    m3_epilogue(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
+#ifndef LM_EMULATED_DEVICE
+    if constexpr ((ABL & 64) != 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp[7] = __builtin_amdgcn_s_memtime();
+        __syncthreads();  // every wave's rows are stored: the stamps go on top
+        if (tid == 0) {
+            unsigned long long* dst = (unsigned long long*)(out + (int64_t)blockIdx.x * 128 * ML_H);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = stamp[i];
+        }
+    }
+#endif
 }
 
 }  // namespace lm
@@ -300,7 +568,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
 int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
                            const void* d_beta, void* d_out, int64_t tokens, int32_t ffn, float eps, void* stream) {
     using namespace lm;
-    const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4;
+    const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 8;  // + b2 (fp32), gamma, beta (fp16)
     if (ffn < 128 || shmem > 160 * 1024) return 1;  // not applicable: the caller takes variant 2
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
     const char* ab = getenv("LEANN_MI355X_ABLATE");
@@ -313,8 +581,8 @@ int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1,
                            (int)tokens, ffn, eps);                                                                                      \
         break
     switch (abl) {
-        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7);
-        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE must be 0, 1, 2, 3, 4 or 7");
+        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7); M3_GO(8); M3_GO(16); M3_GO(32); M3_GO(48); M3_GO(64); M3_GO(65); M3_GO(66); M3_GO(68); M3_GO(71); M3_GO(128); M3_GO(192); M3_GO(96); M3_GO(224);
+        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: unknown combination");
     }
 #undef M3_GO
     LM_HIP(hipGetLastError());

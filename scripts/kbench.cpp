@@ -354,12 +354,52 @@ int main(int argc, char** argv) {
         }
         if (want("ablate")) {  // diagnosis: variant 3 with pieces switched off (results wrong by construction)
             setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
-            for (const char* ab : {"1", "2", "3", "4", "7"}) {
+            for (const char* ab : {"1", "2", "3", "4", "7", "8"}) {
                 setenv("LEANN_MI355X_ABLATE", ab, 1);
                 const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
-                printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"ablate\": \"%s (1 no DMA, 2 no wait/barrier, 4 no GELU)\", \"us\": %.1f}\n", ab, us);
+                printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"ablate\": \"%s (1 no DMA, 2 no wait/barrier, 4 no GELU, 8 = round-2 GELU form, results right)\", \"us\": %.1f}\n", ab, us);
                 fflush(stdout);
             }
+            unsetenv("LEANN_MI355X_ABLATE");
+        }
+        if (want("stamps")) {  // where a workgroup's cycles go: LEANN_MI355X_ABLATE & 64 writes 8 s_memtime stamps per workgroup over its first output row
+            setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
+            const int nwg = (T + 127) / 128;
+            for (const char* ab : {"64", "68", "71", "65", "66", "96", "192", "224"}) {
+                setenv("LEANN_MI355X_ABLATE", ab, 1);
+                for (int rep = 0; rep < 3; ++rep) LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st));
+                CK(hipStreamSynchronize(st));
+                const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
+                auto ho = out.host();
+                double sum[8] = {0};
+                for (int b = 0; b < nwg; ++b) {
+                    unsigned long long t[8];
+                    memcpy(t, (const char*)ho.data() + (size_t)b * 128 * H * 2, 64);
+                    for (int i = 1; i < 8; ++i) sum[i] += (double)(t[i] - t[i - 1]);
+                }
+                printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3 stamps\", \"ablate\": \"%s (64 = product kernel; +4 no GELU, +7 bare MFMA/LDS loop, +1 no DMA, +2 no wait/barrier, +32 asm GELU, +128 fragment ring 8)\", "
+                       "\"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"first product of slab 0\": %.0f, \"iteration 0\": %.0f, \"per steady iteration s = 1..16\": %.0f, "
+                       "\"per steady iteration s = 17..46\": %.0f, \"last iteration + final second product\": %.0f, \"epilogue\": %.0f}}\n",
+                       ab, us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg / 16, sum[5] / nwg / 30, sum[6] / nwg, sum[7] / nwg);
+                fflush(stdout);
+            }
+            unsetenv("LEANN_MI355X_ABLATE");
+        }
+        if (want("gelu")) {  // interleaved A/B of variant 3's two GELU forms (clock / thermal state drifts between back-to-back groups)
+            setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
+            for (int round = 0; round < 3; ++round)
+                for (const char* ab : {"0", "8", "16", "32", "48"}) {
+                    setenv("LEANN_MI355X_ABLATE", ab, 1);
+                    if (round == 0) {  // results of every form against the reference rows
+                        CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
+                        LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st));
+                        CK(hipStreamSynchronize(st));
+                        printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"gelu_form_ablate\": \"%s\", \"max_abs_err\": %.3g}\n", ab, max_err_rows(out.host(), H, 0, H, rows, ref));
+                    }
+                    const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
+                    printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"gelu_form\": \"%s\", \"round\": %d, \"us\": %.1f}\n", !strcmp(ab, "0") ? "1: one transcendental, C" : !strcmp(ab, "8") ? "2: Abramowitz-Stegun" : !strcmp(ab, "16") ? "3: asm, VOP2 literals" : !strcmp(ab, "32") ? "4: asm, VOP3 modifiers" : "5: asm, VOP3, 8 in flight", round, us);
+                    fflush(stdout);
+                }
             unsetenv("LEANN_MI355X_ABLATE");
         }
         unsetenv("LEANN_MI355X_MLP_VARIANT");
@@ -391,8 +431,9 @@ int main(int argc, char** argv) {
         for (int i = 0; i < cu[nchk]; ++i) arows.push_back(i);
         double flops = 0;
         for (int i = 0; i < ns; ++i) flops += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
-        for (const char* rev : {"1", "2"}) {
-            setenv("LEANN_MI355X_ATTN", rev, 1);
+        for (const char* rev : {"1", "2", "2 plain unit order"}) {
+            setenv("LEANN_MI355X_ATTN", rev[0] == '1' ? "1" : "2", 1);
+            setenv("LEANN_MI355X_ATTN_XCD", rev[1] ? "0" : "1", 1);
             auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };
             run();
             CK(hipStreamSynchronize(st));
@@ -403,6 +444,7 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
         unsetenv("LEANN_MI355X_ATTN");
+        unsetenv("LEANN_MI355X_ATTN_XCD");
     }
     if (want("ln")) {
         Dev<__half> out((size_t)T * H);

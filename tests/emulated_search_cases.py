@@ -339,6 +339,13 @@ def case_encoder_abi():
             assert np.abs(ob.astype(np.float64) - refb).max() < 8e-3, (variant, F3)
             got[variant] = ob
         assert np.abs(got["2"].astype(np.float64) - got["3"].astype(np.float64)).max() < 2e-3, F3  # same arithmetic, scalar vs packed GELU
+        # variant 3's two GELU forms (one-transcendental 2^(-1 - u q(u)) product form vs Abramowitz-Stegun, LEANN_MI355X_ABLATE=8)
+        os.environ["LEANN_MI355X_ABLATE"] = "8"
+        oc = np.zeros((T, H), np.float16)
+        _lib.check(lib.lm_mlp_fused_h384_f16(vp(x), vp(w1b), vp(b1b), vp(w2pb), vp(b2), vp(gamma), vp(beta), vp(oc), T, F3, 1e-12, None), "mlp3 A-S")
+        os.environ.pop("LEANN_MI355X_ABLATE")
+        assert np.abs(oc.astype(np.float64) - refb).max() < 8e-3, F3
+        assert np.abs(oc.astype(np.float64) - got["3"].astype(np.float64)).max() < 2e-3, F3
     os.environ.pop("LEANN_MI355X_MLP_VARIANT")
     assert lib.lm_mlp_fused_h384_f16(vp(x), vp(w1), vp(b1), vp(w2p), vp(b2), vp(gamma), vp(beta), vp(out), T, 48, 1e-12, None) == -1  # ffn % 32
     # linear: QKV shape and out-projection + residual + LayerNorm

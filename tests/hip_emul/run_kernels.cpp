@@ -55,14 +55,16 @@ static void test_attention(int heads, const std::vector<int>& lens) {
     fill(qkv, 1.5f);
     const int nt = (maxlen + 31) / 32;
     const float scale_log2e = 1.4426950408889634f / std::sqrt(32.0f);
-    for (int b = 0; b < nseq * heads; ++b) {
-        emul::run_block(b, 256, [&] {
+    {
+        // revision 2 deals the (sequence, head) units out per XCD: its grid is padded to a multiple of 8 workgroups
+        const int n_units = nseq * heads, grid = REV == 1 ? n_units : (n_units + 7) / 8 * 8;
+        emul::launch(dim3((unsigned)grid), dim3(256), 0, [&] {
             const __half* q = (const __half*)qkv.data();
             __half* o = (__half*)out.data();
 #define RUN(n)                                                                                  \
     case n:                                                                                     \
         if (REV == 1) lm::k_attn_varlen_hd32<n>(q, cu.data(), o, heads, scale_log2e);           \
-        else lm::k_attn_varlen_hd32_v2<n>(q, cu.data(), o, heads, scale_log2e);                 \
+        else lm::k_attn_varlen_hd32_v2<n>(q, cu.data(), o, heads, scale_log2e, n_units);        \
         break
             switch (nt) { RUN(1); RUN(2); RUN(3); RUN(4); RUN(5); RUN(6); RUN(7); RUN(8); }
 #undef RUN
