@@ -118,6 +118,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     K, W, B = args.steps, args.warmup, args.batch
+    # HIP-event pairs around every launch of the dominant kernel (the fused feed-forward block) for the WHOLE process, labelled by
+    # phase: the roofline line uses the launches of the timed region; the all-launch average is what a rocprofv3 --kernel-trace
+    # --stats table of this same command reports for the kernel (profiles/r2_bench_c2_kernel_stats.csv).
+    from leann_amd.encoder import KernelTimers
+
+    ktm = KernelTimers.active = KernelTimers()
     EXTRA_ROWS = 4096  # small-batch latency rows + parity-check queries (fresh, after every step's block)
     n_q = B * (K + W + 5) + EXTRA_ROWS  # +5: the profiled step and the extra steps (smallest ef reaching recall 0.9; per-call memo; hub cache; two-level search)
     t_setup = time.time()
@@ -256,11 +262,13 @@ def main():
 
     batches = [global_batch(w) for w in range(W + K)]
     out_labels = []
+    ktm.phase = "warmup"
     for w in range(W):
         ps.search(batches[w], 10)
     agg = {"ndis": 0, "nunique": 0, "nrounds": 0, "update_launches": 0}
     provider.chunks = 0
     barrier()
+    ktm.phase = "timed"
     t0 = time.perf_counter()
     for s in range(K):
         _, l = ps.search(batches[W + s], 10)
@@ -270,6 +278,7 @@ def main():
             agg[k_] += st[k_]
     barrier()
     elapsed = time.perf_counter() - t0
+    ktm.phase = "profiled"
     del batches
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -277,10 +286,7 @@ def main():
         elapsed = float(t.item())
     # ---- one more step of the same workload WITH profiling (HIP event pairs + device span stamps per launch): the
     #      source of the roofline figures; not part of `value` ----------------------------------------------------
-    from leann_amd.encoder import KernelTimers
-
     idx.set_profiling(True)
-    KernelTimers.active = KernelTimers()
     lo = (W + K) * B
     torch.cuda.synchronize()
     t1p = time.perf_counter()
@@ -288,8 +294,7 @@ def main():
     torch.cuda.synchronize()
     prof_step_s = time.perf_counter() - t1p
     prof = idx.stats()
-    ktimes = KernelTimers.active.totals()
-    KernelTimers.active = None
+    ktm.phase = "extras"
     idx.set_profiling(False)
     # ---- extras (NOT `value`; single-GPU runs only -- they contain no collectives and may never cost the headline
     #      line): one extra step each, on fresh queries ----------------------------------------------------------
@@ -412,15 +417,21 @@ def main():
     # `roofline` = the DOMINANT kernel of the timed region: the fused feed-forward block of the encoder (62 % of the encoder's
     # flops, the largest share of the step's time), MFMA bound; duration = HIP event pairs around every one of its launches in the
     # profiled step (torch's current stream = the stream it is launched on).  Algorithmic flops per token: 4 * ffn * hidden.
-    mlp = ktimes.get("mlp_fused_h384")
+    ktimes, kall = ktm.totals("timed"), ktm.totals()
+    KernelTimers.active = None
+    mlp, mlp_all = ktimes.get("mlp_fused_h384"), kall.get("mlp_fused_h384")
     if mlp and mlp["ms"] > 0:
         mlp_tf = mlp["work"] / (mlp["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "lm::k_mlp_fused_h384_v3<0> (fc1 + GELU + fc2 + residual + LayerNorm in one kernel)",
                     "achieved": round(mlp_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(mlp_tf / 2500.0, 5), "traffic": None,
                     "flops_per_token": 4 * cfg.ffn * cfg.hidden, "launches": mlp["launches"],
                     "avg_launch_us": round(1e3 * mlp["ms"] / max(mlp["launches"], 1), 1),
-                    "share_of_profiled_step": round(mlp["ms"] / (prof_step_s * 1e3), 4),
-                    "timing": "HIP event pairs around every launch in one profiled step after the timed ones"}
+                    "tokens_per_launch": round(mlp["work"] / (4 * cfg.ffn * cfg.hidden) / max(mlp["launches"], 1)),
+                    "share_of_timed_region": round(mlp["ms"] / (elapsed * 1e3), 4),
+                    "all_launches_of_the_process": {"launches": mlp_all["launches"], "avg_launch_us": round(1e3 * mlp_all["ms"] / max(mlp_all["launches"], 1), 1),
+                                                    "TFLOPs": round(mlp_all["work"] / (mlp_all["ms"] * 1e-3) / 1e12, 2),
+                                                    "note": "corpus embedding, warm-up, timed, profiled and extra steps together: the population a rocprofv3 --kernel-trace --stats table of this command averages"},
+                    "timing": "HIP event pairs around every launch of the timed region (torch's current stream = the launch stream)"}
     else:  # encoder without the fused block (hidden != 384): fall back to the distance kernel's line
         roofline = roofline_dist
     result = {

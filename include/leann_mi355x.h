@@ -244,6 +244,21 @@ int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, 
                           const void *d_gamma, const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps,
                           void *stream);
 
+/* The second half of a BERT layer with hidden size 384 in one kernel -- attention output projection, residual,
+ * LayerNorm, then the feed-forward block of lm_mlp_fused_h384_f16:
+ *   x     = LayerNorm(resid + attn W_o^T + b_o) * gamma1 + beta1          (never written to HBM)
+ *   d_out = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2) * gamma + beta,    attn / resid / d_out [tokens][384] fp16,
+ * d_wo_p = W_o packed as [12][384][32] fp16 (slab s = input features 32 s .. 32 s + 31, natural order),
+ * d_w1acc = W1 [ffn][384] with its COLUMNS in accumulator order (leann_amd/encoder.py: pack_w1_acc_order),
+ * d_w2p as for lm_mlp_fused_h384_f16; biases fp32; 128 <= ffn <= 2560, ffn % 32 == 0.  Replaces
+ * lm_gemm_ws_h384_f16 (n_out 384) + lm_add_layernorm_f16 + lm_mlp_fused_h384_f16: two launches and three passes
+ * over the activations fewer.  Part of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).
+ * Host switch: LEANN_MI355X_TAIL=1. */
+int lm_attn_out_mlp_fused_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_p, const float *d_bo,
+                                   const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1acc,
+                                   const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
+                                   const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps, void *stream);
+
 /* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
  *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
  *   d_out[tokens][384]   = LayerNorm(residual + x W^T + b) gamma+beta (d_residual != NULL, n_out == 384)

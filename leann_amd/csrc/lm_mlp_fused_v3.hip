@@ -293,13 +293,37 @@ __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const uns
 //   * the fp16 results go through the wave's own 24 KB of the (now idle) weight stages -- [32 tokens][48 chunks of 16 B], chunk c
 //     of row r at position (c & ~15) | ((c ^ r) & 15): conflict-free ds_write_b64 in, ds_read_b128 out -- and leave as 24
 //     fully coalesced 1 KB stores per wave (a wave's 32 token rows are one contiguous 24 KB block of the output).
+// ACCRES (the kernel with the attention output projection in front, below): the x fragments are already in ACCUMULATOR order
+// (fragment 2 j + u, element e = the value that belongs to register 8 u + e of tile j), so the residual needs no lane traffic.
+template <bool ACCRES>
 __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
                                             unsigned char* tile, __half* __restrict__ out, int64_t token0, int T, int r31, int g, int lane,
                                             float eps) {
     __builtin_amdgcn_sched_barrier(0);
     float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+    if constexpr (ACCRES) {
 #pragma unroll
-    for (int ks = 0; ks < ML_KS; ++ks) {
+        for (int ks = 0; ks < ML_KS; ++ks) {
+            const int j = ks >> 1, r0 = 8 * (ks & 1);
+            const half8 d = xf[ks];
+            float2v v0 = (float2v){o[j][r0], o[j][r0 + 1]} + (float2v){(float)d[0], (float)d[1]};
+            float2v v1 = (float2v){o[j][r0 + 2], o[j][r0 + 3]} + (float2v){(float)d[2], (float)d[3]};
+            float2v v2 = (float2v){o[j][r0 + 4], o[j][r0 + 5]} + (float2v){(float)d[4], (float)d[5]};
+            float2v v3 = (float2v){o[j][r0 + 6], o[j][r0 + 7]} + (float2v){(float)d[6], (float)d[7]};
+            o[j][r0] = v0[0];
+            o[j][r0 + 1] = v0[1];
+            o[j][r0 + 2] = v1[0];
+            o[j][r0 + 3] = v1[1];
+            o[j][r0 + 4] = v2[0];
+            o[j][r0 + 5] = v2[1];
+            o[j][r0 + 6] = v3[0];
+            o[j][r0 + 7] = v3[1];
+            sa += v0 + v2;
+            sb += v1 + v3;
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < (ACCRES ? 0 : ML_KS); ++ks) {
         u32x4 d = __builtin_bit_cast(u32x4, xf[ks]);
         uint32_t a0 = d[0], b0 = d[2], a1 = d[1], b1 = d[3];
         lane32_swap(a0, b0);  // a: features of the even q (i = 0, 1), b: of the odd q
@@ -399,6 +423,94 @@ __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&
     }
 }
 
+// The kernel with the attention output projection in front (PRE, below) normalises INSIDE the registers:
+//     x = LayerNorm(o + residual) * gamma1 + beta1,       o = attn W_o^T + b_o in the accumulators
+// and writes x as fp16 straight into the B-fragment registers of the first product, in ACCUMULATOR order: fragment 2 j + u,
+// element e <- register 8 u + e of tile j = feature 32 j + 16 u + 8 (e >> 2) + 4 g + (e & 3).  W1's columns are packed in that
+// k order for this kernel (leann_amd/encoder.py: pack_w1_acc_order), so x never leaves the registers.  The residual (the
+// layer's input rows, fragments in natural order) is brought into accumulator order with the lane swaps of m3_epilogue.
+__device__ __forceinline__ void m3_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[ML_KS], half8 (&xf)[ML_KS], const _Float16* gam_s,
+                                       const _Float16* bet_s, int g, float eps) {
+    __builtin_amdgcn_sched_barrier(0);
+    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < ML_KS; ++ks) {
+        u32x4 d = __builtin_bit_cast(u32x4, rf[ks]);
+        uint32_t a0 = d[0], b0 = d[2], a1 = d[1], b1 = d[3];
+        lane32_swap(a0, b0);
+        lane32_swap(a1, b1);
+        const int j = ks >> 1, qe = 2 * (ks & 1);
+        const half2v ea = __builtin_bit_cast(half2v, a0), eb = __builtin_bit_cast(half2v, a1);
+        const half2v oa = __builtin_bit_cast(half2v, b0), ob = __builtin_bit_cast(half2v, b1);
+        float2v v0 = (float2v){o[j][4 * qe], o[j][4 * qe + 1]} + (float2v){(float)ea[0], (float)ea[1]};
+        float2v v1 = (float2v){o[j][4 * qe + 2], o[j][4 * qe + 3]} + (float2v){(float)eb[0], (float)eb[1]};
+        float2v v2 = (float2v){o[j][4 * qe + 4], o[j][4 * qe + 5]} + (float2v){(float)oa[0], (float)oa[1]};
+        float2v v3 = (float2v){o[j][4 * qe + 6], o[j][4 * qe + 7]} + (float2v){(float)ob[0], (float)ob[1]};
+        o[j][4 * qe] = v0[0];
+        o[j][4 * qe + 1] = v0[1];
+        o[j][4 * qe + 2] = v1[0];
+        o[j][4 * qe + 3] = v1[1];
+        o[j][4 * qe + 4] = v2[0];
+        o[j][4 * qe + 5] = v2[1];
+        o[j][4 * qe + 6] = v3[0];
+        o[j][4 * qe + 7] = v3[1];
+        sa += v0 + v2;
+        sb += v1 + v3;
+    }
+    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / ML_H);
+    const float2v nm = {-mean, -mean};
+    float2v qa = {0.f, 0.f}, qb = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            float2v d0 = (float2v){o[j][r], o[j][r + 1]} + nm, d1 = (float2v){o[j][r + 2], o[j][r + 3]} + nm;
+            qa = __builtin_elementwise_fma(d0, d0, qa);
+            qb = __builtin_elementwise_fma(d1, d1, qb);
+        }
+    float sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
+    const float2v rs = {rstd, rstd};
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            half8 h;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * u + qq;
+                const half4 gv = *(const half4*)(gam_s + 32 * j + 8 * q + 4 * g), bv = *(const half4*)(bet_s + 32 * j + 8 * q + 4 * g);
+                float2v n0 = ((float2v){o[j][4 * q], o[j][4 * q + 1]} + nm) * rs;
+                float2v n1 = ((float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + nm) * rs;
+                float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[0], (float)gv[1]}, (float2v){(float)bv[0], (float)bv[1]});
+                float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[2], (float)gv[3]}, (float2v){(float)bv[2], (float)bv[3]});
+                const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
+                h[4 * qq] = h0[0];
+                h[4 * qq + 1] = h0[1];
+                h[4 * qq + 2] = h1[0];
+                h[4 * qq + 3] = h1[1];
+            }
+            xf[2 * j + u] = h;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Extra operands of the PRE form of the kernel (attention output projection + first LayerNorm in front of the feed-forward block):
+//     x = LayerNorm(residual + attn W_o^T + b_o) * gamma1 + beta1;   y = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2) * gamma + beta
+// attn: [T][384] fp16 (attention output); wo_p: W_o packed as [12][384][32] in NATURAL k order (slab s = input features 32 s .. 32 s + 31);
+// the kernel's `x` argument is then the residual (the layer's input) and `w1` must be in accumulator k order (see m3_ln1).
+struct M3Pre {
+    const __half* attn;
+    const __half* wo_p;
+    const float* bo;
+    const __half* gamma1;
+    const __half* beta1;
+    float eps1;
+};
+
 // w1:  [F][384] fp16 (nn.Linear weight; slab s = rows 32s .. 32s+31, contiguous)
 // w2p: [F/32][384][32] fp16 with the k permutation of leann_amd/encoder.py: fused_mlp_k_permutation
 // ABL: ablation bits for on-hardware diagnosis (LEANN_MI355X_ABLATE; 0 = the product kernel): 1 = no weight DMA after the
@@ -417,13 +529,13 @@ __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&
         __builtin_amdgcn_sched_barrier(0);                              \
     }
 #endif
-template <int ABL>
-__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
+template <int ABL, bool PRE>
+__device__ __forceinline__ void m3_kernel_body(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
-    int F, float eps) {
+    int F, float eps, const M3Pre& pre) {
     extern __shared__ __align__(16) unsigned char smem[];
-    [[maybe_unused]] unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     M3_STAMP(0);
     constexpr int AF = ABL & 56;  // GELU form bits
     constexpr int GEL = (ABL & 4) ? 0 : (AF == 8 ? 2 : (AF == 16 ? 3 : (AF == 32 ? 4 : (AF == 48 ? 5 : 1))));  // GELU form (see gelu_uop)
@@ -432,6 +544,9 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     float* b2s = b1s + F;                          // b2 (384 floats), gamma, beta (384 halfs each) behind b1
     _Float16* gam_s = (_Float16*)(b2s + ML_H);
     _Float16* bet_s = gam_s + ML_H;
+    [[maybe_unused]] float* bos = (float*)(bet_s + ML_H);  // PRE: b_o (384 floats), gamma1, beta1 (384 halfs each) behind them
+    [[maybe_unused]] _Float16* gam1_s = (_Float16*)(bos + ML_H);
+    [[maybe_unused]] _Float16* bet1_s = gam1_s + ML_H;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef LM_EMULATED_DEVICE
     const int wv = tid >> 6;
@@ -448,13 +563,24 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     // ---- prologue: W1 slabs 0..2 and W2 slab 0 in flight; x^T fragments and b1 meanwhile ----
     int w1off[6];
     m3_w1_offsets(tid, w1off);
-    m3_issue_w1(g1, smem + M3_W1_OFF, wv, w1off);
-    m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, wv, w1off);
-    m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
-    m3_issue_w2(g2, smem + M3_W2_OFF, wv, tid);
-    half8 xf[ML_KS];
+    if constexpr (!PRE) {
+        m3_issue_w1(g1, smem + M3_W1_OFF, wv, w1off);
+        m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, wv, w1off);
+        m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
+    }
+    [[maybe_unused]] const unsigned char* go = (const unsigned char*)pre.wo_p;
+    if constexpr (PRE) {  // the three W2 stages start with W_o slabs 0..2; W2 slab 0 follows W_o slab 11 through the same ring.
+        // (W1 slabs 0..2 and the residual rows are requested BEHIND the prologue barrier: the hardware counts at most 63 vector
+        // memory operations in flight per wave, and W_o + attention rows + the LDS fills are 56 already)
+        m3_issue_w2(go, smem + M3_W2_OFF, wv, tid);
+        m3_issue_w2(go + M3_SLAB, smem + M3_W2_OFF + M3_SLAB, wv, tid);
+        m3_issue_w2(go + 2 * M3_SLAB, smem + M3_W2_OFF + 2 * M3_SLAB, wv, tid);
+    } else {
+        m3_issue_w2(g2, smem + M3_W2_OFF, wv, tid);
+    }
+    half8 xf[ML_KS];  // PRE: the attention-output fragments first, the first LayerNorm's output (accumulator order) afterwards
     {
-        const _Float16* xr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
+        const _Float16* xr = (const _Float16*)(PRE ? pre.attn : x) + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < ML_KS; ++ks) {
             half8 v = *(const half8*)(xr + 16 * ks);
@@ -462,11 +588,17 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
             xf[ks] = valid ? v : z;
         }
     }
+    [[maybe_unused]] half8 rf[PRE ? ML_KS : 1];  // PRE: the residual rows (the layer's input), natural fragment order
     for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
     for (int i = tid; i < ML_H; i += 256) {
         b2s[i] = b2[i];
         gam_s[i] = ((const _Float16*)gamma)[i];
         bet_s[i] = ((const _Float16*)beta)[i];
+        if constexpr (PRE) {
+            bos[i] = pre.bo[i];
+            gam1_s[i] = ((const _Float16*)pre.gamma1)[i];
+            bet1_s[i] = ((const _Float16*)pre.beta1)[i];
+        }
     }
 
     // fragment addresses.  W1: row r31, chunk c = 2 ks + g at position (c & ~15) | ((c ^ r31) & 15): the low part depends on ks & 7
@@ -483,6 +615,50 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     if (ABL & 4) pfa[0] = pfa[1] = pfb[0] = pfb[1] = xf[0];
     M3_WAIT_VM(0);
     __syncthreads();  // b1s written, every wave's DMA pieces landed (nothing is in flight: a plain barrier is fine here)
+    M3_STAMP(1);
+    if constexpr (PRE) {
+        // residual rows and the first three W1 slabs: needed after the projection, requested now (42 operations; the first counted
+        // wait below is at slab 3, two slabs of MFMAs later)
+        {
+            const _Float16* rr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < ML_KS; ++ks) {
+                half8 v = *(const half8*)(rr + 16 * ks);
+                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                rf[ks] = valid ? v : z;
+            }
+        }
+        m3_issue_w1(g1, smem + M3_W1_OFF, wv, w1off);
+        m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, wv, w1off);
+        m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
+        // ---- attention output projection: o = attn W_o^T + b_o, twelve 32-wide k slabs through the W2 ring (slab s in stage s % 3).
+        //      Top of slab s >= 1: every wave is done with slab s - 1 (barrier), whose stage takes slab s + 2 -- and "slab 12" is W2
+        //      slab 0, which the feed-forward loop expects in stage 0.  Slabs 0..2 landed in the prologue; from slab 3 on, slab s
+        //      has landed once only slab s + 1 may still be in flight (vmcnt(6): everything older -- the residual rows and W1
+        //      slabs 0..2 included -- is complete). ----
+#pragma unroll
+        for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4v bv = *(const float4v*)(bos + 32 * j + 8 * q + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
+            }
+#pragma unroll
+        for (int s = 0; s < ML_H / 32; ++s) {
+            if (s > 0) {
+                if (s > 2) M3_WAIT_VM(6);
+                M3_BARRIER();
+                const unsigned char* src = s + 2 < ML_H / 32 ? go + (int64_t)(s + 2) * M3_SLAB : g2;
+                if (s + 2 <= ML_H / 32) m3_issue_w2(src, smem + M3_W2_OFF + ((s + 2) % M3_STAGES) * M3_SLAB, wv, tid);
+            }
+            const half8 af[2] = {xf[2 * s], xf[2 * s + 1]};
+            m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (s % M3_STAGES) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, af, pfa, o);
+        }
+        M3_STAMP(8);
+        m3_ln1(o, rf, xf, gam1_s, bet1_s, g, pre.eps1);
+        M3_STAMP(9);
+    }
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
@@ -491,7 +667,6 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
         }
-    M3_STAMP(1);
 
     // first product of slab 0, nothing to overlap it with
     m3_iteration<true, false, 0, RD>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
@@ -522,6 +697,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     auto w2_stage = [&](int s) { return (const unsigned char*)smem + M3_W2_OFF + ((s + 2) % M3_STAGES) * M3_SLAB; };  // (s - 1) mod 3
     // s = 0: no second product yet
     M3_STAMP(2);
+    M3_BARRIER();  // top(0) refills W1 stage 0: every wave must be done with slab 0 first
     top(0);
     m3_iteration<true, false, GEL, RD>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
     pfb[0] = pfa[0];
@@ -548,7 +724,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
                                      pfa, o);
     M3_STAMP(6);
     __syncthreads();  // every wave is done with the weight stages: they become the output staging tiles
-    m3_epilogue(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
+    m3_epilogue<PRE>(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
 #ifndef LM_EMULATED_DEVICE
     if constexpr ((ABL & 64) != 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -557,13 +733,65 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
         if (tid == 0) {
             unsigned long long* dst = (unsigned long long*)(out + (int64_t)blockIdx.x * 128 * ML_H);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dst[i] = stamp[i];
+            for (int i = 0; i < (PRE ? 10 : 8); ++i) dst[i] = stamp[i];
         }
     }
 #endif
 }
 
+template <int ABL>
+__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
+    const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
+    const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
+    int F, float eps) {
+    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
+    m3_kernel_body<ABL, false>(x, w1, b1, w2p, b2, gamma, beta, out, T, F, eps, none);
+}
+
+// The second half of a BERT layer in ONE kernel: attention output projection + residual + LayerNorm, then the feed-forward block
+// (see M3Pre).  Against k_gemm_ws_h384 + k_add_layernorm + k_mlp_fused_h384_v3 it saves two launches and three passes over the
+// [T][384] activations (projection output written and re-read, LayerNorm output written and re-read).
+template <int ABL>
+__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_attn_out_mlp_h384(
+    const __half* __restrict__ resid, M3Pre pre, const __half* __restrict__ w1acc, const float* __restrict__ b1,
+    const __half* __restrict__ w2p, const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta,
+    __half* __restrict__ out, int T, int F, float eps) {
+    m3_kernel_body<ABL, true>(resid, w1acc, b1, w2p, b2, gamma, beta, out, T, F, eps, pre);
+}
+
 }  // namespace lm
+
+extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
+                                              const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
+                                              const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
+                                              int64_t tokens, int32_t ffn, float eps, void* stream) {
+    using namespace lm;
+    if (tokens == 0) return LM_OK;
+    if (!d_attn || !d_resid || !d_wo_p || !d_bo || !d_gamma1 || !d_beta1 || !d_w1acc || !d_b1 || !d_w2p || !d_b2 || !d_gamma || !d_beta || !d_out ||
+        tokens < 0 || tokens > 0x7fffffff)
+        LM_FAIL(LM_EINVAL, "bad fused attention-output + MLP arguments");
+    if (ffn <= 0 || ffn % 32) LM_FAIL(LM_EINVAL, "ffn size must be a positive multiple of 32");
+    const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 16;  // + b2, b_o (fp32), gamma, beta, gamma1, beta1 (fp16)
+    if (ffn < 128 || shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "fused attention-output + MLP kernel: ffn must be in [128, 2560]");
+    dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
+    const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1};
+    const char* ab = getenv("LEANN_MI355X_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+#define M3P_GO(A)                                                                                                                     \
+    case A:                                                                                                                            \
+        LM_HIP(hipFuncSetAttribute((const void*)k_attn_out_mlp_h384<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+        hipLaunchKernelGGL(k_attn_out_mlp_h384<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_resid, pre,               \
+                           (const __half*)d_w1acc, d_b1, (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta,    \
+                           (__half*)d_out, (int)tokens, ffn, eps);                                                                      \
+        break
+    switch (abl) {
+        M3P_GO(0); M3P_GO(64);
+        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0 and 64 (stamps)");
+    }
+#undef M3P_GO
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
 
 int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
                            const void* d_beta, void* d_out, int64_t tokens, int32_t ffn, float eps, void* stream) {

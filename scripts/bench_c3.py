@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """BASELINE.json configs[2] (C3): 10M chunks, DiskANN-style search -- PQ-ADC traversal (complexity L = 64, beam width W = 64) on
 an HBM-resident graph + PQ codes, then ONE deferred exact rerank of the <= L candidates per query through the recompute
-provider (HBM token store -> bge-small-en-v1.5 shaped encoder, CLS pooling) -- 1 x MI355X.  The call this replaces:
+provider (HBM token store -> bge-small-en-v1.5 shaped encoder; pooling of the random-init stand-in: see --pooling) -- 1 x MI355X.  The call this replaces:
 StaticDiskFloatIndex.batch_search(query, B, k, L, W, threads, USE_DEFERRED_FETCH, ...) (diskann_backend.py:453-467).
 
     python scripts/bench_c3.py [--chunks 10000000] [--steps 5] [--warmup 2] [--batch 1024]
@@ -36,6 +36,12 @@ def main():
     ap.add_argument("--M", type=int, default=16, help="graph degree / 2 of the Vamana-style flat graph (degree 32)")
     ap.add_argument("--efc", type=int, default=128)
     ap.add_argument("--cpu-baseline-queries", type=int, default=8)
+    ap.add_argument("--pooling", default="mean", choices=["mean", "cls"],
+                    help="sentence pooling of the RANDOM-INIT stand-in encoder.  bge-small pools the [CLS] row, but with random weights the [CLS] rows of "
+                         "different chunks are nearly parallel (mean pairwise cosine 0.997 on this corpus: attention is ~uniform, so [CLS] sees the same "
+                         "average everywhere) and no 96-byte PQ can rank them -- brute-force ADC top-64 holds only 62 %% of the true top-10.  Mean pooling "
+                         "keeps the per-chunk topic signal (ADC top-64 holds 100 %%), costs the same flops, and is what makes recall@10 of this SYNTHETIC "
+                         "workload meaningful; `cls` reproduces the degenerate case.")
     args = ap.parse_args()
 
     from leann_amd import _lib
@@ -56,7 +62,11 @@ def main():
     tokens = TokenStore(tok, off)
     log(f"corpus: {n} chunks, {int(off[-1])} tokens ({time.time() - t_all:.0f}s)")
     cfg = config_for(args.model)
+    from dataclasses import replace
+
     enc = BertEncoder.load(args.model, allow_random=True).to(dev, dtype=torch.float16).eval()
+    if enc.weights_source == "random":
+        enc.cfg = replace(enc.cfg, pooling=args.pooling)  # see --pooling
     D = cfg.hidden
     provider = RecomputeProvider(enc, tokens, (D + 63) // 64 * 64, dev)
     t0 = time.time()
@@ -123,7 +133,8 @@ def main():
         "value": round(K * B / elapsed, 3), "unit": "queries/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 codes / f32 LUT; fp16 encoder", "data": "synthetic",
         "config": {"workload": f"{n} synthetic chunks, flat graph degree<={2 * args.M} (GPU-built), PQ {args.pq_bytes} B/vector, complexity {args.complexity}, "
-                               f"beam_width {args.beam}, top-10, {B} queries/step, one deferred rerank through the recompute provider",
+                               f"beam_width {args.beam}, top-10, {B} queries/step, one deferred rerank through the recompute provider; "
+                               f"{args.model} shape, random init, {enc.cfg.pooling} pooling",
                    "baseline_config": "c3", "n_chunks": n, "queries_per_step": B},
         "recall_at_10": round(rec, 4),
         "roofline": {"bound": "hbm", "kernel": "lm::k_pq_traverse (persistent PQ-ADC traversal, one launch per batch; codes gathered from HBM, LUT in LDS)",
@@ -139,6 +150,7 @@ def main():
         ncores = orc.usable_cores()
         torch.set_num_threads(ncores)
         cenc = BertEncoder.load(args.model, allow_random=True).float().eval()
+        cenc.cfg = enc.cfg
         lens_all = np.diff(off.astype(np.int64))
 
         def cpu_provider(idv):

@@ -139,6 +139,11 @@ __global__ void ref_attn(const __half* qkv, const int* cu, int heads, float* out
     }
 }
 
+__global__ void f32_to_f16(const float* a, __half* b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = __float2half(a[i]);
+}
+
 static double max_err_rows(const std::vector<__half>& got, int ncols, int col0, int width, const std::vector<int>& rows, const std::vector<float>& ref) {
     double m = 0;
     for (size_t i = 0; i < rows.size(); ++i)
@@ -186,6 +191,28 @@ static std::vector<__half> pack_w2(const std::vector<__half>& w2, int F) {
     for (int s = 0; s < F / 32; ++s)
         for (int f = 0; f < H; ++f)
             for (int pos = 0; pos < 32; ++pos) p[((size_t)s * H + f) * 32 + pos] = w2[(size_t)f * F + s * 32 + perm[pos]];
+    return p;
+}
+
+// W_o [384][384] -> [12][384][32], natural k order (leann_amd/encoder.py: pack_wo_slabs)
+static std::vector<__half> pack_wo(const std::vector<__half>& w) {
+    std::vector<__half> p(w.size());
+    for (int s = 0; s < 12; ++s)
+        for (int f = 0; f < H; ++f)
+            for (int c = 0; c < 32; ++c) p[((size_t)s * H + f) * 32 + c] = w[(size_t)f * H + s * 32 + c];
+    return p;
+}
+// W1 [F][384] with its columns in accumulator order (leann_amd/encoder.py: pack_w1_acc_order)
+static std::vector<__half> pack_w1_acc(const std::vector<__half>& w1, int F) {
+    int perm[32];
+    for (int pos = 0; pos < 32; ++pos) {
+        int u = pos / 16, g = (pos % 16) / 8, e = pos % 8;
+        perm[pos] = e < 4 ? 16 * u + 4 * g + e : 16 * u + 8 + 4 * g + e - 4;
+    }
+    std::vector<__half> p(w1.size());
+    for (int f = 0; f < F; ++f)
+        for (int j = 0; j < H / 32; ++j)
+            for (int pos = 0; pos < 32; ++pos) p[(size_t)f * H + 32 * j + pos] = w1[(size_t)f * H + 32 * j + perm[pos]];
     return p;
 }
 
@@ -407,6 +434,86 @@ int main(int argc, char** argv) {
         const float us2 = time_us(st, reps, [&] { lib_gemm(w2.p, H, F, hid16.p, out.p); });
         printf("{\"kernel\": \"rocblas_gemm_ex f16 fc1 + fc2 (no GELU / LN)\", \"us\": %.1f, \"fc1_us\": %.1f, \"fc2_us\": %.1f, \"TFLOPs\": %.1f}\n", us1 + us2, us1, us2,
                gflop / (us1 + us2));
+        fflush(stdout);
+    }
+    if (want("tail")) {  // second half of a layer: out-projection + LN + feed-forward block + LN -- three kernels vs the fused one
+        const int F = 1536;
+        auto hwo = rand_half((size_t)H * H, 0.05f, 40), hw1 = rand_half((size_t)F * H, 0.05f, 41), hw2 = rand_half((size_t)H * F, 0.03f, 42);
+        Dev<__half> wo(hwo), wop(pack_wo(hwo)), w1(hw1), w1a(pack_w1_acc(hw1, F)), w2(hw2), w2p(pack_w2(hw2, F));
+        Dev<float> bo(rand_float(H, 0.2f, 43)), b1(rand_float(F, 0.2f, 44)), b2(rand_float(H, 0.2f, 45));
+        Dev<__half> gamma1(rand_half(H, 0.1f, 46)), beta1(rand_half(H, 0.1f, 47));
+        {
+            auto g = gamma1.host();
+            for (auto& v : g) v = __float2half(1.0f + __half2float(v));
+            CK(hipMemcpy(gamma1.p, g.data(), H * sizeof(__half), hipMemcpyHostToDevice));
+        }
+        Dev<__half> y0((size_t)T * H), x1((size_t)T * H), out3((size_t)T * H), outf((size_t)T * H), x1h((size_t)nr * H);
+        Dev<float> z0((size_t)nr * H), x1f((size_t)nr * H), hid((size_t)nr * F), z((size_t)nr * H), lref((size_t)nr * H);
+        std::vector<int> ident(nr);
+        for (int i = 0; i < nr; ++i) ident[i] = i;
+        Dev<int> d_ident(ident);
+        // reference on the sampled rows: x = attention output, res = the layer's input
+        hipLaunchKernelGGL(ref_linear, dim3((nr * H + 255) / 256), dim3(256), 0, st, x.p, wo.p, bo.p, d_rows.p, nr, H, z0.p);
+        hipLaunchKernelGGL(ref_add_ln, dim3(nr), dim3(128), 0, st, z0.p, res.p, d_rows.p, nr, gamma1.p, beta1.p, 1e-12f, x1f.p);
+        hipLaunchKernelGGL(f32_to_f16, dim3((nr * H + 255) / 256), dim3(256), 0, st, x1f.p, x1h.p, (size_t)nr * H);
+        hipLaunchKernelGGL(ref_gelu_fc1, dim3((nr * F + 255) / 256), dim3(256), 0, st, x1h.p, w1.p, b1.p, d_ident.p, nr, F, hid.p);
+        hipLaunchKernelGGL(ref_fc2, dim3((nr * H + 255) / 256), dim3(256), 0, st, hid.p, w2.p, b2.p, nr, F, z.p);
+        hipLaunchKernelGGL(ref_add_ln, dim3(nr), dim3(128), 0, st, z.p, x1h.p, d_ident.p, nr, gamma.p, beta.p, 1e-12f, lref.p);
+        CK(hipStreamSynchronize(st));
+        auto ref = lref.host();
+        const double gflop = (4.0 * F * H + 2.0 * H * H) * T * 1e-9;
+        setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
+        auto run3 = [&] {
+            LM(lm_gemm_ws_h384_f16(x.p, wo.p, bo.p, H, y0.p, T, st));
+            LM(lm_add_layernorm_f16(y0.p, res.p, gamma1.p, beta1.p, x1.p, T, H, 1e-12f, st));
+            LM(lm_mlp_fused_h384_f16(x1.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out3.p, T, F, 1e-12f, st));
+        };
+        auto runf = [&] {
+            LM(lm_attn_out_mlp_fused_h384_f16(x.p, res.p, wop.p, bo.p, gamma1.p, beta1.p, 1e-12f, w1a.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, outf.p, T,
+                                              F, 1e-12f, st));
+        };
+        CK(hipMemsetAsync(out3.p, 0xFF, out3.n * sizeof(__half), st));
+        CK(hipMemsetAsync(outf.p, 0xFF, outf.n * sizeof(__half), st));
+        run3();
+        runf();
+        CK(hipStreamSynchronize(st));
+        const double e3 = max_err_rows(out3.host(), H, 0, H, rows, ref), ef = max_err_rows(outf.host(), H, 0, H, rows, ref);
+        double dmax = 0;
+        {
+            auto a = out3.host(), b = outf.host();
+            for (size_t i = 0; i < a.size(); ++i) {
+                double d = fabs((double)__half2float(a[i]) - (double)__half2float(b[i]));
+                if (!(d <= dmax)) dmax = d;
+            }
+        }
+        for (int round = 0; round < 2; ++round) {  // interleaved A/B
+            const float us3 = time_us(st, reps, run3), usf = time_us(st, reps, runf);
+            printf("{\"kernel\": \"lm_gemm_ws_h384_f16 + lm_add_layernorm_f16 + lm_mlp_fused_h384_f16 (v3)\", \"mode\": \"out-proj+res+LN+MLP+res+LN, three launches\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g}\n", round, us3, gflop / us3 * 1e-3, e3);
+            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16\", \"mode\": \"out-proj+res+LN+MLP+res+LN, one launch\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g, \"max_abs_diff_vs_three_launches_all_rows\": %.3g}\n", round, usf, gflop / usf * 1e-3, ef, dmax);
+            fflush(stdout);
+        }
+        if (want("stamps")) {
+            setenv("LEANN_MI355X_ABLATE", "64", 1);
+            const int nwg = (T + 127) / 128;
+            for (int rep = 0; rep < 3; ++rep) runf();
+            CK(hipStreamSynchronize(st));
+            const float us = time_us(st, reps, runf);
+            auto ho = outf.host();
+            double sum[10] = {0};
+            for (int b = 0; b < nwg; ++b) {
+                unsigned long long t[10];
+                memcpy(t, (const char*)ho.data() + (size_t)b * 128 * H * 2, 80);
+                // stamp order in time: 0 start, 1 prologue done, 8 out-projection done, 9 LayerNorm 1 done, 2 first product, 3 iteration 0, 4 (s = 17), 5 steady done, 6 final, 7 end
+                const int ord[10] = {0, 1, 8, 9, 2, 3, 4, 5, 6, 7};
+                for (int i = 1; i < 10; ++i) sum[i] += (double)(t[ord[i]] - t[ord[i - 1]]);
+            }
+            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 stamps\", \"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"out-projection (12 slabs)\": %.0f, \"LayerNorm 1 in registers\": %.0f, "
+                   "\"first product of slab 0\": %.0f, \"iteration 0\": %.0f, \"per steady iteration s = 1..16\": %.0f, \"per steady iteration s = 17..46\": %.0f, "
+                   "\"last iteration + final second product\": %.0f, \"epilogue\": %.0f}}\n",
+                   us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg / 16, sum[7] / nwg / 30, sum[8] / nwg, sum[9] / nwg);
+            unsetenv("LEANN_MI355X_ABLATE");
+        }
+        unsetenv("LEANN_MI355X_MLP_VARIANT");
         fflush(stdout);
     }
     if (want("attn")) {

@@ -213,6 +213,60 @@ def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):
     assert (got.float() - dflt.float()).abs().max().item() <= 1.2e-2 * scale
 
 
+@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 128), (300, 160), (300, 2560)])
+def test_fused_attention_output_projection_and_mlp_h384(tokens, ffn, monkeypatch):
+    """lm_attn_out_mlp_fused_h384_f16 (the second half of a layer in one kernel; default, LEANN_MI355X_TAIL=0 for A/B) vs a plain
+    PyTorch fp32 reference of the same ops and vs the three-kernel path it replaces (weight-stationary GEMM, add + LayerNorm, fused MLP)."""
+    import torch
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import EncoderConfig, _Layer, fused_attn_out_mlp, fused_linear_h384, fused_mlp
+
+    torch.manual_seed(tokens + ffn)
+    cfg = EncoderConfig(hidden=384, layers=1, heads=12, ffn=ffn)
+    layer = _Layer(cfg).to("cuda", dtype=torch.float16)
+    with torch.no_grad():
+        for ln in (layer.ln1, layer.ln2):
+            ln.weight.copy_(1 + 0.1 * torch.randn(384))
+            ln.bias.copy_(0.1 * torch.randn(384))
+        layer.out.bias.copy_(0.2 * torch.randn(384))
+        layer.fc1.bias.copy_(0.2 * torch.randn(ffn))
+        layer.fc2.bias.copy_(0.2 * torch.randn(384))
+    a = torch.randn((tokens, 384), device="cuda").half()
+    res = torch.randn((tokens, 384), device="cuda").half()
+    with torch.no_grad():
+        got = fused_attn_out_mlp(a, res, layer)
+        assert got is not None and got.shape == a.shape and got.dtype == torch.float16
+        x1 = F.layer_norm(res.float() + a.float() @ layer.out.weight.float().t() + layer.out.bias.float(), (384,), layer.ln1.weight.float(),
+                          layer.ln1.bias.float(), layer.ln1.eps).half().float()  # the kernel keeps x as fp16 fragments, like the unfused path
+        hid = F.gelu(x1 @ layer.fc1.weight.float().t() + layer.fc1.bias.float())
+        ref = F.layer_norm(x1 + hid @ layer.fc2.weight.float().t() + layer.fc2.bias.float(), (384,), layer.ln2.weight.float(), layer.ln2.bias.float(),
+                           layer.ln2.eps)
+        monkeypatch.setenv("LEANN_MI355X_TAIL", "0")
+        assert fused_attn_out_mlp(a, res, layer) is None
+        three = fused_mlp(fused_linear_h384(a, layer.out, residual=res, ln=layer.ln1), layer)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any()
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got.float() - ref).abs().max().item() <= 1.2e-2 * scale  # 1-ulp flips of the fp16 x move single outputs
+    assert (got.float() - three.float()).abs().max().item() <= 1.5e-2 * scale
+
+
+def test_encoder_forward_with_and_without_the_fused_layer_tail(monkeypatch):
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=300, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    d = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_TAIL", "0")
+    t0 = enc.encode_tokens_packed(ti, tl)
+    assert (d - t0).abs().max() < 2e-3 and not torch.isnan(d).any()
+
+
 @pytest.mark.parametrize("gen", ["1", "2", "3"])
 @pytest.mark.parametrize("tokens", [1, 128, 129, 257, 5000])
 def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
