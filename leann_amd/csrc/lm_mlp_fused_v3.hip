@@ -46,6 +46,27 @@ constexpr int M3_B1_OFF = 2 * M3_STAGES * M3_SLAB;  // 147456: b1 as floats behi
 #define M3_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
 
+#ifdef LM_EMULATED_DEVICE
+#define M3_WAIT_LGKM0() ((void)0)
+#else
+#define M3_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
+// A wave's 32 token rows -- one contiguous 24 KB block of a [T][384] fp16 matrix -- into a 24 KB stage by LDS-DMA, as the image
+// of a W1 slab (row r, 16-byte chunk c at position (c & ~15) | ((c ^ r) & 15)): 24 fully coalesced 1 KB pieces per wave.  The
+// fragment loads they replace (lane = one row, 16 B per lane: 32 rows x 32 B per instruction) were the slowest part of the
+// kernel's prologue on the MI355X: 21,000 of a workgroup's 190,000 cycles for its two 98 KB row blocks
+// (profiles/r2_kbench_layer_tail_prologue_ablation_stamps.jsonl).  Rows >= rows_valid (past the end of the matrix) repeat the last valid row.
+__device__ __forceinline__ void m3_issue_rows(const unsigned char* rows, int rows_valid, unsigned char* stage, int lane) {
+    LM_KEEP_LOCAL(lane);  // the 24 source offsets are a few VALU operations each: recomputed per call, not kept alive between the two calls
+#pragma unroll
+    for (int p = 0; p < 24; ++p) {
+        const int L = 64 * p + lane, row = L / 48, pos = L - 48 * row;
+        const int rc = row < rows_valid ? row : rows_valid - 1;
+        lm_dma16_sv(rows, (unsigned)(rc * 768 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)), stage + 1024 * p);
+    }
+}
+
 // W1 slab [32 rows][48 chunks] -> stage: LDS chunk L = 256 i + tid = (row = L / 48, pos = L % 48) holds source chunk
 // (pos & ~15) | ((pos ^ row) & 15) of that row (rows are 768 B = 3 x 256 B apart: a 16-chunk XOR swizzle)
 __device__ __forceinline__ void m3_w1_offsets(int tid, int (&off)[6]) {  // per-thread source offsets of the 6 pieces, computed once
@@ -509,6 +530,7 @@ struct M3Pre {
     const __half* gamma1;
     const __half* beta1;
     float eps1;
+    int stagger;  // first-round workgroups (blockIdx < 256) start ((37 b) & 255) / 256 * stagger x 1024 cycles late: see the kernel
 };
 
 // w1:  [F][384] fp16 (nn.Linear weight; slab s = rows 32s .. 32s+31, contiguous)
@@ -536,6 +558,19 @@ __device__ __forceinline__ void m3_kernel_body(
     int F, float eps, const M3Pre& pre) {
     extern __shared__ __align__(16) unsigned char smem[];
     [[maybe_unused]] unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifndef LM_EMULATED_DEVICE
+    // Every workgroup of a launch does the same work in the same time, so the 256 resident workgroups stay in lock-step for the
+    // whole launch: all read their 2 x 98 KB of rows at the same moment (HBM at its limit: 11,000 cycles per block, 4 TB/s) and
+    // then leave HBM idle for the 150,000 cycles of their MFMA loops.  Starting the FIRST round's workgroups spread over
+    // `stagger` x 1024 cycles shifts the CUs' phases against each other for the rest of the launch (the dispatcher hands a CU its
+    // next workgroup when it finishes one), which turns the bursts into a steady trickle.
+    if constexpr (PRE) {
+        if (pre.stagger > 0 && blockIdx.x < 256) {
+            const int n = (int)(((blockIdx.x * 37u) & 255u) * (unsigned)pre.stagger) >> 8;
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+#endif
     M3_STAMP(0);
     constexpr int AF = ABL & 56;  // GELU form bits
     constexpr int GEL = (ABL & 4) ? 0 : (AF == 8 ? 2 : (AF == 16 ? 3 : (AF == 32 ? 4 : (AF == 48 ? 5 : 1))));  // GELU form (see gelu_uop)
@@ -569,28 +604,34 @@ __device__ __forceinline__ void m3_kernel_body(
         m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
     }
     [[maybe_unused]] const unsigned char* go = (const unsigned char*)pre.wo_p;
-    if constexpr (PRE) {  // the three W2 stages start with W_o slabs 0..2; W2 slab 0 follows W_o slab 11 through the same ring.
-        // (W1 slabs 0..2 and the residual rows are requested BEHIND the prologue barrier: the hardware counts at most 63 vector
-        // memory operations in flight per wave, and W_o + attention rows + the LDS fills are 56 already)
-        m3_issue_w2(go, smem + M3_W2_OFF, wv, tid);
-        m3_issue_w2(go + M3_SLAB, smem + M3_W2_OFF + M3_SLAB, wv, tid);
-        m3_issue_w2(go + 2 * M3_SLAB, smem + M3_W2_OFF + 2 * M3_SLAB, wv, tid);
+    // PRE: LDS = four 24 KB row tiles (stages 0..3 = W1 ring + W2 stage 0; wave w owns tile w: its attention rows, then its residual
+    // rows, at the end its output rows) + a two-stage ring for the W_o slabs (W2 stages 1, 2; slab s in stage 1 + (s & 1)).
+    [[maybe_unused]] unsigned char* mytile = smem + wv * M3_SLAB;
+    [[maybe_unused]] const int tok0c = (int)blockIdx.x * 128 + wv * 32 < T ? (int)blockIdx.x * 128 + wv * 32 : T - 1;  // wave uniform
+    [[maybe_unused]] const int rows_valid = T - tok0c < 32 ? T - tok0c : 32;
+    if constexpr (PRE) {
+        if constexpr (!(ABL & 512)) {  // ABL 512 / 256 / 1024 (stamp builds of this form only): no prologue DMA / no row tiles / no LDS fills
+            m3_issue_w2(go, smem + M3_W2_OFF + M3_SLAB, wv, tid);
+            m3_issue_w2(go + M3_SLAB, smem + M3_W2_OFF + 2 * M3_SLAB, wv, tid);
+        }
+        if constexpr (!(ABL & 256)) m3_issue_rows((const unsigned char*)pre.attn + (int64_t)tok0c * (ML_H * 2), rows_valid, mytile, lane);
     } else {
         m3_issue_w2(g2, smem + M3_W2_OFF, wv, tid);
     }
     half8 xf[ML_KS];  // PRE: the attention-output fragments first, the first LayerNorm's output (accumulator order) afterwards
-    {
-        const _Float16* xr = (const _Float16*)(PRE ? pre.attn : x) + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
+    if constexpr (!PRE) {
+        const _Float16* xr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
 #pragma unroll
         for (int ks = 0; ks < ML_KS; ++ks) {
-            half8 v = *(const half8*)(xr + 16 * ks);
             const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            half8 v = *(const half8*)(xr + 16 * ks);
             xf[ks] = valid ? v : z;
         }
     }
     [[maybe_unused]] half8 rf[PRE ? ML_KS : 1];  // PRE: the residual rows (the layer's input), natural fragment order
-    for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
-    for (int i = tid; i < ML_H; i += 256) {
+    if constexpr (!(ABL & 1024))
+        for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
+    for (int i = tid; i < ((ABL & 1024) ? 0 : ML_H); i += 256) {
         b2s[i] = b2[i];
         gam_s[i] = ((const _Float16*)gamma)[i];
         bet_s[i] = ((const _Float16*)beta)[i];
@@ -617,25 +658,21 @@ __device__ __forceinline__ void m3_kernel_body(
     __syncthreads();  // b1s written, every wave's DMA pieces landed (nothing is in flight: a plain barrier is fine here)
     M3_STAMP(1);
     if constexpr (PRE) {
-        // residual rows and the first three W1 slabs: needed after the projection, requested now (42 operations; the first counted
-        // wait below is at slab 3, two slabs of MFMAs later)
+        // attention rows: tile -> B fragments (the reads of a W1 fragment: conflict free); then the tile takes the residual rows
         {
-            const _Float16* rr = (const _Float16*)x + (int64_t)(valid ? token : 0) * ML_H + 8 * g;
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < ML_KS; ++ks) {
-                half8 v = *(const half8*)(rr + 16 * ks);
-                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                rf[ks] = valid ? v : z;
+                const half8 v = *(const half8*)(mytile + a1[ks & 7] + 256 * (ks >> 3));
+                xf[ks] = valid ? v : z;
             }
         }
-        m3_issue_w1(g1, smem + M3_W1_OFF, wv, w1off);
-        m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, wv, w1off);
-        m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
-        // ---- attention output projection: o = attn W_o^T + b_o, twelve 32-wide k slabs through the W2 ring (slab s in stage s % 3).
-        //      Top of slab s >= 1: every wave is done with slab s - 1 (barrier), whose stage takes slab s + 2 -- and "slab 12" is W2
-        //      slab 0, which the feed-forward loop expects in stage 0.  Slabs 0..2 landed in the prologue; from slab 3 on, slab s
-        //      has landed once only slab s + 1 may still be in flight (vmcnt(6): everything older -- the residual rows and W1
-        //      slabs 0..2 included -- is complete). ----
+        M3_WAIT_LGKM0();
+        LM_WAVE_SYNC();  // the tile is re-filled by this wave's own DMA: program order on the GPU
+        if constexpr (!(ABL & 256)) m3_issue_rows((const unsigned char*)x + (int64_t)tok0c * (ML_H * 2), rows_valid, mytile, lane);
+        // ---- attention output projection: o = attn W_o^T + b_o, twelve 32-wide k slabs through the two-stage ring.  Top of slab
+        //      s >= 1: slab s has landed (s >= 2: vmcnt(0) -- it is the youngest request; slabs 0, 1 came with the prologue), every
+        //      wave is done with slab s - 1 (barrier), whose stage takes slab s + 1. ----
 #pragma unroll
         for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
@@ -647,16 +684,33 @@ __device__ __forceinline__ void m3_kernel_body(
 #pragma unroll
         for (int s = 0; s < ML_H / 32; ++s) {
             if (s > 0) {
-                if (s > 2) M3_WAIT_VM(6);
+                if (s > 1) M3_WAIT_VM(0);
                 M3_BARRIER();
-                const unsigned char* src = s + 2 < ML_H / 32 ? go + (int64_t)(s + 2) * M3_SLAB : g2;
-                if (s + 2 <= ML_H / 32) m3_issue_w2(src, smem + M3_W2_OFF + ((s + 2) % M3_STAGES) * M3_SLAB, wv, tid);
+                if (s + 1 < ML_H / 32) m3_issue_w2(go + (int64_t)(s + 1) * M3_SLAB, smem + M3_W2_OFF + (1 + ((s + 1) & 1)) * M3_SLAB, wv, tid);
             }
             const half8 af[2] = {xf[2 * s], xf[2 * s + 1]};
-            m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (s % M3_STAGES) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, af, pfa, o);
+            m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (1 + (s & 1)) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, af, pfa, o);
         }
         M3_STAMP(8);
+        // residual rows: tile -> fragments (their DMA is older than every W_o slab waited for above).  Then all six stages are idle
+        // once every wave is here: the feed-forward block's first weights (W1 slabs 0..2, W2 slab 0) arrive under the LayerNorm
+        {
+            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < ML_KS; ++ks) {
+                const half8 v = *(const half8*)(mytile + a1[ks & 7] + 256 * (ks >> 3));
+                rf[ks] = valid ? v : z;
+            }
+        }
+        M3_WAIT_LGKM0();
+        M3_BARRIER();
+        m3_issue_w1(g1, smem + M3_W1_OFF, wv, w1off);
+        m3_issue_w1(g1 + M3_SLAB, smem + M3_W1_OFF + M3_SLAB, wv, w1off);
+        m3_issue_w1(g1 + 2 * M3_SLAB, smem + M3_W1_OFF + 2 * M3_SLAB, wv, w1off);
+        m3_issue_w2(g2, smem + M3_W2_OFF, wv, tid);
         m3_ln1(o, rf, xf, gam1_s, bet1_s, g, pre.eps1);
+        M3_WAIT_VM(0);
+        M3_BARRIER();
         M3_STAMP(9);
     }
 #pragma unroll
@@ -744,7 +798,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
     int F, float eps) {
-    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
+    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     m3_kernel_body<ABL, false>(x, w1, b1, w2p, b2, gamma, beta, out, T, F, eps, none);
 }
 
@@ -774,7 +828,8 @@ extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_
     const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 16;  // + b2, b_o (fp32), gamma, beta, gamma1, beta1 (fp16)
     if (ffn < 128 || shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "fused attention-output + MLP kernel: ffn must be in [128, 2560]");
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
-    const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1};
+    const char* sg = getenv("LEANN_MI355X_STAGGER");  // spread of the first round's start times, x 1024 cycles (default 40: measured 797 -> 779 us per 262k tokens; 0 = off)
+    const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1, sg ? atoi(sg) : 40};
     const char* ab = getenv("LEANN_MI355X_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
 #define M3P_GO(A)                                                                                                                     \
@@ -785,8 +840,8 @@ extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_
                            (__half*)d_out, (int)tokens, ffn, eps);                                                                      \
         break
     switch (abl) {
-        M3P_GO(0); M3P_GO(64);
-        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0 and 64 (stamps)");
+        M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856);
+        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps) and 64 + {256, 512, 1024}");
     }
 #undef M3P_GO
     LM_HIP(hipGetLastError());

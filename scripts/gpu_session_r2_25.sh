@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 2, GPU session 23: fused layer tail with DMA row tiles (coalesced 1 KB pieces) and the two-stage W_o ring: stamps + the kernel's tests.
+set -u
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/s25; rm -rf "$OUT"; mkdir -p "$OUT"
+KB=leann_amd/lib/bin/kbench
+timeout -k 5 60 $KB 4096 2 ln > $OUT/probe.log 2>&1 || { echo "BOX UNHEALTHY"; cat $OUT/probe.log; exit 0; }
+timeout -k 5 200 $KB 262107 20 wsgemm > $OUT/kbench_tail.jsonl 2> $OUT/kbench_tail.err; echo "== tail rc=$?"; cut -c1-1000 $OUT/kbench_tail.jsonl; tail -3 $OUT/kbench_tail.err
+
+
