@@ -427,8 +427,20 @@ def main():
     mlp, mlp_all = ktimes.get(kname), kall.get(kname)
     if mlp and mlp["ms"] > 0:
         mlp_tf = mlp["work"] / (mlp["ms"] * 1e-3) / 1e12
+        tpl = mlp["work"] / fpt / max(mlp["launches"], 1)  # tokens per launch
+        ktraffic = ktraffic_src = None
+        try:  # HBM-side bytes per launch: the separate PMC passes of this kernel (profiles/r2_pmc_layer_tail.json), per token x this run's launch size
+            pmc_t = json.loads((ROOT / "profiles" / "r2_pmc_layer_tail.json").read_text())
+            if kname == "attn_out_mlp_h384":
+                ktraffic = round(pmc_t["k_attn_out_mlp_h384"]["hbm_bytes_per_token"] * tpl)
+                ktraffic_src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over scripts/kbench.cpp (262107 tokens), FETCH_SIZE x2 as calibrated on a "
+                                "streaming read of known size in the same pass (profiles/r2_pmc_layer_tail.json): 2958 B/token = 1.28 x the algorithmic 2314 B/token "
+                                "(two row blocks in, one out, weights once), scaled by tokens/launch")
+        except Exception:  # noqa: BLE001
+            pass
         roofline = {"bound": "mfma", "kernel": kdesc,
-                    "achieved": round(mlp_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(mlp_tf / 2500.0, 5), "traffic": None,
+                    "achieved": round(mlp_tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(mlp_tf / 2500.0, 5), "traffic": ktraffic,
+                    "traffic_source": ktraffic_src,
                     "flops_per_token": fpt, "launches": mlp["launches"],
                     "avg_launch_us": round(1e3 * mlp["ms"] / max(mlp["launches"], 1), 1),
                     "tokens_per_launch": round(mlp["work"] / fpt / max(mlp["launches"], 1)),
