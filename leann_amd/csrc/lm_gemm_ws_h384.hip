@@ -36,6 +36,11 @@ constexpr int WS_LDS_TOTAL = WS_W_BYTES + WS_ROWS * 4;  // + the bias slice as f
 // grid: 256 workgroups (one per CU).  xcd = b % 8, slot = b / 8 (0..31); groups per XCD gpx = 32 / nblk; slots >= gpx * nblk idle.
 // feature block fb = slot % nblk, token group tg = xcd * gpx + slot / nblk of ntg = 8 gpx; the workgroup takes the 256-token
 // tiles tg, tg + ntg, ...; wave w of it the 32 tokens [32 w, 32 w + 32) of each.
+// STAMP (LEANN_MI355X_ABLATE=64 / 65, diagnosis only): s_memtime around the three phases of every tile -- row loads (waited for
+// in full, which the product kernel does not do), the 144 MFMAs, the stores (65: drained with vmcnt(0)) -- summed per wave and
+// written over the first bytes of `out` when the wave is done: {loads, mfma, stores, tiles} as four 64-bit words per wave
+// (scripts/kbench.cpp "wsgemm"; profiles/r2_kbench_gemm_ws_phase_stamps.jsonl).
+template <int STAMP>
 __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_gemm_ws_h384(
     const __half* __restrict__ x, const __half* __restrict__ w, const float* __restrict__ bias, __half* __restrict__ out, int T, int nblk) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -74,7 +79,15 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_gemm_ws_h384(
     const float* bl = bs + 4 * g;  // tile j, register 4q + i <-> feature 32 j + 8 q + 4 g + i of the block
 
     const int ntile = (T + 255) / 256;
+    [[maybe_unused]] unsigned long long tsum[4] = {0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0;
     for (int tile = tg; tile < ntile; tile += ntg) {
+#ifndef LM_EMULATED_DEVICE
+        if constexpr (STAMP != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            t0 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         const int token = tile * 256 + wv * 32 + r31;
         const bool valid = token < T;
         half8 xf[ML_KS];
@@ -83,6 +96,14 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_gemm_ws_h384(
 #pragma unroll
             for (int ks = 0; ks < ML_KS; ++ks) xf[ks] = *(const half8*)(xr + 16 * ks);
         }
+#ifndef LM_EMULATED_DEVICE
+        if constexpr (STAMP != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0);
+            t1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         float16v o[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
@@ -106,6 +127,13 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_gemm_ws_h384(
             }
             __builtin_amdgcn_sched_barrier(0);  // source order = issue order: the register budget (256 per wave) has no room for hoisted reads
         }
+#ifndef LM_EMULATED_DEVICE
+        if constexpr (STAMP != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            t2 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         // ---- store: lanes l / l ^ 32 trade halves (v_permlane32_swap) so that every lane owns 8 consecutive features ----
         _Float16* yr = (_Float16*)out + (int64_t)token * N + WS_ROWS * fb + 8 * g;
 #pragma unroll
@@ -125,7 +153,29 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_gemm_ws_h384(
                 if (valid) *(uint4*)(yr + 32 * j + 16 * qp) = y;
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef LM_EMULATED_DEVICE
+        if constexpr (STAMP != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STAMP == 2) __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            tsum[0] += t1 - t0;
+            tsum[1] += t2 - t1;
+            tsum[2] += t3 - t2;
+            tsum[3] += 1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
     }
+#ifndef LM_EMULATED_DEVICE
+    if constexpr (STAMP != 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (lane == 0) {
+            unsigned long long* dst = (unsigned long long*)out + (blockIdx.x * 8 + wv) * 4;
+            for (int i = 0; i < 4; ++i) dst[i] = tsum[i];
+        }
+    }
+#endif
 }
 
 }  // namespace lm
@@ -137,9 +187,18 @@ extern "C" int lm_gemm_ws_h384_f16(const void* d_x, const void* d_w, const float
     if (tokens == 0) return LM_OK;
     if (!d_x || !d_w || !d_bias || !d_out || tokens < 0 || tokens > 0x7fffffff) LM_FAIL(LM_EINVAL, "bad linear arguments");
     if (n_out <= 0 || n_out % WS_ROWS || n_out / WS_ROWS > 32) LM_FAIL(LM_EINVAL, "n_out must be a multiple of 192, at most 6144");
-    LM_HIP(hipFuncSetAttribute((const void*)k_gemm_ws_h384, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_TOTAL));
-    hipLaunchKernelGGL(k_gemm_ws_h384, dim3(256), dim3(512), WS_LDS_TOTAL, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w, d_bias,
-                       (__half*)d_out, (int)tokens, n_out / WS_ROWS);
+    const char* ab = getenv("LEANN_MI355X_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+#define WS_GO(S)                                                                                                                          \
+    do {                                                                                                                                  \
+        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_ws_h384<S>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_TOTAL));            \
+        hipLaunchKernelGGL(k_gemm_ws_h384<S>, dim3(256), dim3(512), WS_LDS_TOTAL, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w, \
+                           d_bias, (__half*)d_out, (int)tokens, n_out / WS_ROWS);                                                          \
+    } while (0)
+    if (abl == 64) WS_GO(1);
+    else if (abl == 65) WS_GO(2);
+    else WS_GO(0);
+#undef WS_GO
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -436,6 +436,38 @@ int main(int argc, char** argv) {
                gflop / (us1 + us2));
         fflush(stdout);
     }
+    if (want("wsgemm")) {  // weight-stationary GEMM alone: timing + where a wave's cycles go (LEANN_MI355X_ABLATE=64 / 65: phase stamps)
+        for (int N : {3 * H, H}) {
+            auto hw = rand_half((size_t)N * H, 0.05f, 50 + N);
+            Dev<__half> w(hw), out((size_t)T * N);
+            Dev<float> b(rand_float(N, 0.2f, 51));
+            auto run = [&] { LM(lm_gemm_ws_h384_f16(x.p, w.p, b.p, N, out.p, T, st)); };
+            const float us = time_us(st, reps, run);
+            printf("{\"kernel\": \"lm_gemm_ws_h384_f16\", \"mode\": \"N=%d\", \"us\": %.1f, \"TFLOPs\": %.3f}\n", N, us, 2.0 * T * N * H / us * 1e-6);
+            for (const char* ab : {"64", "65"}) {
+                setenv("LEANN_MI355X_ABLATE", ab, 1);
+                for (int rep = 0; rep < 2; ++rep) run();
+                CK(hipStreamSynchronize(st));
+                const float us2 = time_us(st, reps, run);
+                std::vector<unsigned long long> t(256 * 8 * 4);
+                CK(hipMemcpy(t.data(), out.p, t.size() * 8, hipMemcpyDeviceToHost));
+                double sum[3] = {0, 0, 0}, tiles = 0;
+                const int nblk = N / 192, used = (32 / nblk) * nblk;
+                for (int blk = 0; blk < 256; ++blk) {
+                    if ((blk >> 3) >= used) continue;
+                    for (int wv = 0; wv < 8; ++wv) {
+                        const unsigned long long* q = &t[(size_t)(blk * 8 + wv) * 4];
+                        sum[0] += (double)q[0]; sum[1] += (double)q[1]; sum[2] += (double)q[2]; tiles += (double)q[3];
+                    }
+                }
+                printf("{\"kernel\": \"lm_gemm_ws_h384_f16 stamps\", \"mode\": \"N=%d, ablate %s (64: loads waited in full; 65: + stores drained)\", \"us\": %.1f, "
+                       "\"mean_cycles_per_wave_tile\": {\"row loads (issue + wait)\": %.0f, \"144 MFMAs\": %.0f, \"stores\": %.0f}, \"wave_tiles\": %.0f}\n",
+                       N, ab, us2, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, tiles);
+                fflush(stdout);
+            }
+            unsetenv("LEANN_MI355X_ABLATE");
+        }
+    }
     if (want("tail")) {  // second half of a layer: out-projection + LN + feed-forward block + LN -- three kernels vs the fused one
         const int F = 1536;
         auto hwo = rand_half((size_t)H * H, 0.05f, 40), hw1 = rand_half((size_t)F * H, 0.05f, 41), hw2 = rand_half((size_t)H * F, 0.03f, 42);
@@ -492,8 +524,20 @@ int main(int argc, char** argv) {
             printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16\", \"mode\": \"out-proj+res+LN+MLP+res+LN, one launch\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g, \"max_abs_diff_vs_three_launches_all_rows\": %.3g}\n", round, usf, gflop / usf * 1e-3, ef, dmax);
             fflush(stdout);
         }
-        if (want("stamps")) {
-            setenv("LEANN_MI355X_ABLATE", "64", 1);
+        if (want("stagger")) {  // spread of the first round's start times, x 1024 cycles (0 = off; the library's default is 40)
+            for (int round = 0; round < 2; ++round)
+                for (const char* sg : {"0", "20", "40", "80", "120", "160"}) {
+                    setenv("LEANN_MI355X_STAGGER", sg, 1);
+                    const float us = time_us(st, reps, runf);
+                    printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16\", \"stagger_kcycles\": %s, \"round\": %d, \"us\": %.1f}\n", sg, round, us);
+                    fflush(stdout);
+                }
+            unsetenv("LEANN_MI355X_STAGGER");
+        }
+        for (const char* ab : {"64", "320", "576", "1088", "1856"}) {
+            if (!want("stamps")) break;
+            if (strcmp(ab, "64") && !want("prolog")) break;  // prologue ablations (results wrong by construction): "tailstampsprolog"
+            setenv("LEANN_MI355X_ABLATE", ab, 1);
             const int nwg = (T + 127) / 128;
             for (int rep = 0; rep < 3; ++rep) runf();
             CK(hipStreamSynchronize(st));
@@ -507,12 +551,13 @@ int main(int argc, char** argv) {
                 const int ord[10] = {0, 1, 8, 9, 2, 3, 4, 5, 6, 7};
                 for (int i = 1; i < 10; ++i) sum[i] += (double)(t[ord[i]] - t[ord[i - 1]]);
             }
-            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 stamps\", \"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"out-projection (12 slabs)\": %.0f, \"LayerNorm 1 in registers\": %.0f, "
+            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 stamps\", \"ablate\": \"%s (64 = product kernel; +256 no row tiles, +512 no prologue DMA, +1024 no LDS fills)\", \"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"out-projection (12 slabs)\": %.0f, \"LayerNorm 1 in registers\": %.0f, "
                    "\"first product of slab 0\": %.0f, \"iteration 0\": %.0f, \"per steady iteration s = 1..16\": %.0f, \"per steady iteration s = 17..46\": %.0f, "
                    "\"last iteration + final second product\": %.0f, \"epilogue\": %.0f}}\n",
-                   us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg / 16, sum[7] / nwg / 30, sum[8] / nwg, sum[9] / nwg);
-            unsetenv("LEANN_MI355X_ABLATE");
+                   ab, us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg / 16, sum[7] / nwg / 30, sum[8] / nwg, sum[9] / nwg);
+            fflush(stdout);
         }
+        unsetenv("LEANN_MI355X_ABLATE");
         unsetenv("LEANN_MI355X_MLP_VARIANT");
         fflush(stdout);
     }
