@@ -495,19 +495,34 @@ __device__ __forceinline__ void m3_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[M
     sq += __shfl_xor(sq, 32);
     const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
     const float2v rs = {rstd, rstd};
+    // gamma / beta of tile j + 1 are read while tile j is normalised (as in m3_epilogue: left to itself the compiler emits read,
+    // read, wait, use -- 48 exposed LDS round trips)
+    half4 gv[4], bv[4], gn[4], bn[4];
 #pragma unroll
-    for (int j = 0; j < ML_NJ; ++j)
+    for (int q = 0; q < 4; ++q) {
+        gv[q] = *(const half4*)(gam_s + 8 * q + 4 * g);
+        bv[q] = *(const half4*)(bet_s + 8 * q + 4 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < ML_NJ; ++j) {
+        if (j + 1 < ML_NJ) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gn[q] = *(const half4*)(gam_s + 32 * (j + 1) + 8 * q + 4 * g);
+                bn[q] = *(const half4*)(bet_s + 32 * (j + 1) + 8 * q + 4 * g);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             half8 h;
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int q = 2 * u + qq;
-                const half4 gv = *(const half4*)(gam_s + 32 * j + 8 * q + 4 * g), bv = *(const half4*)(bet_s + 32 * j + 8 * q + 4 * g);
                 float2v n0 = ((float2v){o[j][4 * q], o[j][4 * q + 1]} + nm) * rs;
                 float2v n1 = ((float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + nm) * rs;
-                float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[0], (float)gv[1]}, (float2v){(float)bv[0], (float)bv[1]});
-                float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[2], (float)gv[3]}, (float2v){(float)bv[2], (float)bv[3]});
+                float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[q][0], (float)gv[q][1]}, (float2v){(float)bv[q][0], (float)bv[q][1]});
+                float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[q][2], (float)gv[q][3]}, (float2v){(float)bv[q][2], (float)bv[q][3]});
                 const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
                 h[4 * qq] = h0[0];
                 h[4 * qq + 1] = h0[1];
@@ -516,6 +531,13 @@ __device__ __forceinline__ void m3_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[M
             }
             xf[2 * j + u] = h;
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            gv[q] = gn[q];
+            bv[q] = bn[q];
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
