@@ -109,3 +109,36 @@ def test_linear_h384_lane_level_data_flow_matches_a_plain_linear(passes):
     got = me.emulate_linear_wave(x, wp, b)
     ref = x.astype(np.float64) @ w.astype(np.float64).T + b
     assert np.abs(got.astype(np.float64) - ref).max() < 4e-3
+
+
+def test_accumulator_order_packing_of_w1_and_natural_slabs_of_wo():
+    """Host-side packing for the fused layer tail (csrc/lm_mlp_fused_v3.hip: k_attn_out_mlp_h384): W1's columns go into the order in
+    which a lane's accumulator registers hold the LayerNorm output (fragment 2j+u, lane group g, element e <- feature
+    32j + 16u + 8(e>>2) + 4g + (e&3)), W_o into natural-order 32-wide k slabs; both are pure permutations, so
+    x_acc_order @ W1_acc_order^T == x @ W1^T exactly."""
+    torch = pytest.importorskip("torch")
+    from leann_amd.encoder import fused_mlp_k_permutation, pack_w1_acc_order, pack_wo_slabs
+
+    rng = np.random.default_rng(5)
+    h, f = me.ML_H, 96
+    w1 = torch.from_numpy(rng.standard_normal((f, h)).astype(np.float32))
+    w1a = pack_w1_acc_order(w1)
+    assert w1a.shape == w1.shape
+    # the kernel's B fragment of k-step ks = 2j+u holds, in lane group g, element e, feature phi(ks, g, e); the A fragment of W1
+    # reads packed column 16 ks + 8 g + e -- so that column must be feature phi
+    for ks in range(h // 16):
+        j, u = divmod(ks, 2)
+        for g in range(2):
+            for e in range(8):
+                phi = 32 * j + 16 * u + 8 * (e >> 2) + 4 * g + (e & 3)
+                assert torch.equal(w1a[:, 16 * ks + 8 * g + e], w1[:, phi])
+    perm = fused_mlp_k_permutation().numpy()
+    cols = np.concatenate([32 * j + perm for j in range(h // 32)])
+    assert sorted(cols.tolist()) == list(range(h))
+    x = torch.from_numpy(rng.standard_normal((7, h)).astype(np.float32))
+    assert torch.allclose(x[:, cols] @ w1a.T, x @ w1.T, atol=1e-5)
+    wo = torch.from_numpy(rng.standard_normal((h, h)).astype(np.float32))
+    wos = pack_wo_slabs(wo)
+    assert wos.shape == (h // 32, h, 32)
+    for s in (0, 5, 11):
+        assert torch.equal(wos[s], wo[:, 32 * s : 32 * s + 32])
