@@ -21,6 +21,18 @@
 //         iteration s = { first product of slab s+1 | GELU of slab s | second product of slab s-1 };
 //   * fragment reads run four MFMAs ahead, across the boundary between the two products.
 // Role in the reference: the FFN inside compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
+//
+// TWO KERNELS share this body (m3_kernel_body<ABL, PRE>):
+//   k_mlp_fused_h384_v3   (PRE = false)  the feed-forward block alone, x read as B fragments straight from memory;
+//   k_attn_out_mlp_h384   (PRE = true)   the whole second half of a layer -- the DEFAULT path of leann_amd/encoder.py:
+//         x = LayerNorm(resid + attn W_o^T + b_o) * gamma1 + beta1,   y = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2) * gamma + beta.
+//     LDS = four 24 KB row tiles (one per wave: attention rows in, residual rows in, result rows out; all as coalesced 1 KB
+//     LDS-DMA / store pieces) + a two-stage ring for the twelve W_o slabs; the projection's accumulators are normalised in place
+//     (m3_ln1) and become the B fragments of the first product without leaving the registers -- W1's columns are packed in
+//     accumulator order on the host for that -- so x never touches memory and the second LayerNorm takes its residual from the
+//     same registers with no lane traffic.  Measured on the MI355X against k_gemm_ws_h384 + k_add_layernorm + the PRE = false
+//     kernel: 770-800 vs 925-1000 us per 262k tokens (profiles/r2_kbench_layer_tail_*.jsonl); cycle budget of a workgroup in
+//     DESIGN.md section 6.1.
 #include <cstdlib>
 #include <cstring>
 #include <utility>
