@@ -61,6 +61,7 @@ def main():
                          "ranks, all_gather + merge timed) run scripts/bench_c3.py / scripts/bench_c4.py with this command's --steps/--warmup")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
     ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows")
+    ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
     ap.add_argument("--autotune", action="store_true", help="A/B the switchable encoder kernels at start-up (leann_amd.autotune); default: the tested default set")
     args = ap.parse_args()
     if args.config in ("c3", "c4"):  # own entry points (different index type / sharded index); same JSON contract
@@ -129,7 +130,8 @@ def main():
     t_setup = time.time()
 
     # ---- corpus -> HBM token store ------------------------------------------------------------
-    spec = CorpusSpec(n_chunks=args.chunks, seed=1234)
+    spec = (CorpusSpec(n_chunks=args.chunks, seed=1234) if not args.fixed_len else
+            CorpusSpec(n_chunks=args.chunks, seed=1234, len_mean=float(args.fixed_len), len_std=0.0, len_min=args.fixed_len, len_max=args.fixed_len))
     corpus = SyntheticCorpus(spec)
     tok, off = corpus.chunks()
     tokens = TokenStore(tok, off, device=local_rank)
@@ -457,7 +459,7 @@ def main():
         "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * elapsed / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "encoder_dtype": "fp16 (fp32 accumulate)", "data": "synthetic",
-        "config": {"workload": f"{args.chunks} synthetic chunks (topic model, len~N(180,50)), HNSW M={args.M} GPU-built, "
+        "config": {"workload": f"{args.chunks} synthetic chunks (topic model, {'len~N(180,50)' if not args.fixed_len else 'every chunk ' + str(args.fixed_len) + ' tokens'}), HNSW M={args.M} GPU-built, "
                                f"{args.model} shape (random init), ef_search={ef}, beam={args.beam}, top-10, "
                                f"{B} queries/step/GPU, queries partitioned over {world} GPU(s), graph replicated",
                    "baseline_config": args.config, "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
