@@ -259,6 +259,18 @@ int lm_attn_out_mlp_fused_h384_f16(const void *d_attn, const void *d_resid, cons
                                    const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
                                    const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps, void *stream);
 
+/* The same with the NEXT layer's QKV projection of d_out behind it in the same launch:
+ *   d_qkv_out[tokens][1152] = d_out W_qkv^T + b_qkv   (fp16; d_out is written as well: it is the next layer's residual),
+ * d_wqkv_p = W_qkv [1152][384] packed as [36][384][32]: slab 12 p + s = rows 384 p .. 384 p + 383, input features of k slab s
+ * in the order of leann_amd/encoder.py: fused_mlp_k_permutation (pack_wqkv_slabs); ffn >= 1152.  Replaces lm_gemm_ws_h384_f16
+ * (n_out 1152) of the next layer.  Opt-in host switch: LEANN_MI355X_QKV_IN_TAIL=1 (validated in emulation and by the GPU tests;
+ * not the default until its speed has been measured on the MI355X). */
+int lm_layer_tail_qkv_fused_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_p, const float *d_bo,
+                                     const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1acc,
+                                     const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
+                                     const void *d_beta, void *d_out, const void *d_wqkv_p, const float *d_bqkv,
+                                     void *d_qkv_out, int64_t tokens, int32_t ffn, float eps, void *stream);
+
 /* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
  *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
  *   d_out[tokens][384]   = LayerNorm(residual + x W^T + b) gamma+beta (d_residual != NULL, n_out == 384)

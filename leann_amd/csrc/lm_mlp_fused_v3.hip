@@ -328,8 +328,32 @@ __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const uns
 //     fully coalesced 1 KB stores per wave (a wave's 32 token rows are one contiguous 24 KB block of the output).
 // ACCRES (the kernel with the attention output projection in front, below): the x fragments are already in ACCUMULATOR order
 // (fragment 2 j + u, element e = the value that belongs to register 8 u + e of tile j), so the residual needs no lane traffic.
-template <bool ACCRES>
-__device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
+// A wave's 24 KB tile (W1-slab image) back out in linear order: chunk L = 64 i + lane = (row L / 48, chunk L % 48) goes to
+// base + row * row_stride + 16 * chunk -- 24 coalesced 1 KB pieces when the rows are contiguous (row_stride 768), 768-byte row
+// segments otherwise (the QKV projection's output rows are 2304 bytes apart).  Eight reads in flight, then their eight stores.
+__device__ __forceinline__ void m3_store_tile(const unsigned char* tile, unsigned char* base, int row_stride, int rows_valid, int lane) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
+            v[i] = *(const u32x4*)(tile + row * 768 + ((c & ~15) | ((c ^ row) & 15)) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
+            if (L < 48 * rows_valid) *(u32x4*)(base + (int64_t)row * row_stride + 16 * c) = v[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// KEEP (the form with the next layer's QKV projection behind it): the normalised fp16 results also replace the x fragments, in
+// accumulator order -- they are the B operand of that projection.
+template <bool ACCRES, bool KEEP = false>
+__device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
                                             unsigned char* tile, __half* __restrict__ out, int64_t token0, int T, int r31, int g, int lane,
                                             float eps) {
     __builtin_amdgcn_sched_barrier(0);
@@ -425,6 +449,12 @@ __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&
             const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
             const half4 y = {h0[0], h0[1], h1[0], h1[1]};
             *(half4*)(trow + ((c & ~15) | ((c ^ r31) & 15)) * 16) = y;
+            if constexpr (KEEP) {  // fragment 2 j + u (u = q >> 1), elements 4 (q & 1) .. + 3
+                xf[2 * j + (q >> 1)][4 * (q & 1)] = y[0];
+                xf[2 * j + (q >> 1)][4 * (q & 1) + 1] = y[1];
+                xf[2 * j + (q >> 1)][4 * (q & 1) + 2] = y[2];
+                xf[2 * j + (q >> 1)][4 * (q & 1) + 3] = y[3];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -434,26 +464,9 @@ __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&
         }
     }
     LM_WAVE_SYNC();  // the rows were written by other lanes of this wave (lock-step on the GPU: program order is enough)
-    // the wave's tile back out in linear order: chunk L = 64 i + lane = (row L / 48, chunk L % 48) is bytes [16 L, 16 L + 16) of the
-    // wave's 24 KB of output
-    unsigned char* obase = (unsigned char*)out + token0 * (ML_H * 2);
+    // the wave's 32 rows are one contiguous 24 KB block of the output
     const int rows_valid = (int)((int64_t)T - token0 < 32 ? (int64_t)T - token0 : 32);
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {  // eight reads in flight, then their eight stores
-        u32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
-            v[i] = *(const u32x4*)(tile + row * 768 + ((c & ~15) | ((c ^ row) & 15)) * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int L = 64 * (8 * b + i) + lane;
-            if (L < 48 * rows_valid) *(u32x4*)(obase + 16 * L) = v[i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    m3_store_tile(tile, (unsigned char*)out + token0 * (ML_H * 2), ML_H * 2, rows_valid, lane);
 }
 
 // The kernel with the attention output projection in front (PRE, below) normalises INSIDE the registers:
@@ -564,6 +577,10 @@ struct M3Pre {
     const __half* gamma1;
     const __half* beta1;
     float eps1;
+    // QKV form only: the NEXT layer's QKV projection of this kernel's output, qkv = y W_qkv^T + b_qkv, [T][1152] fp16
+    const __half* wqkv_p;  // [36][384][32]: slab 12 p + s = output rows 384 p .. + 383, k slab s in accumulator order
+    const float* bqkv;     // [1152]
+    __half* qkv_out;
     int stagger;  // first-round workgroups (blockIdx < 256) start ((37 b) & 255) / 256 * stagger x 1024 cycles late: see the kernel
 };
 
@@ -585,7 +602,7 @@ struct M3Pre {
         __builtin_amdgcn_sched_barrier(0);                              \
     }
 #endif
-template <int ABL, bool PRE>
+template <int ABL, bool PRE, bool QKV = false>
 __device__ __forceinline__ void m3_kernel_body(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
@@ -812,7 +829,67 @@ __device__ __forceinline__ void m3_kernel_body(
                                      pfa, o);
     M3_STAMP(6);
     __syncthreads();  // every wave is done with the weight stages: they become the output staging tiles
-    m3_epilogue<PRE>(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
+    if constexpr (QKV) {
+        // The next layer's QKV projection follows in this kernel: its first two weight slabs and its bias (into the LDS space of b1,
+        // idle now) are requested before the LayerNorm so that they arrive under it.  Ring = W2 stages 1, 2 (slab t in stage
+        // 1 + (t & 1)); stages 0..3 (W1 ring + W2 stage 0) stay the waves' output tiles.
+        const unsigned char* gq = (const unsigned char*)pre.wqkv_p;
+        m3_issue_w2(gq, smem + M3_W2_OFF + M3_SLAB, wv, tid);
+        m3_issue_w2(gq + M3_SLAB, smem + M3_W2_OFF + 2 * M3_SLAB, wv, tid);
+        for (int i = tid; i < 3 * ML_H; i += 256) b1s[i] = pre.bqkv[i];
+    }
+    m3_epilogue<PRE, QKV>(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
+    if constexpr (QKV) {
+        // qkv = y W_qkv^T + b_qkv in three passes of 384 outputs (Q, K, V): y is in the x fragment registers (accumulator order, the
+        // k order W_qkv's slabs are packed in), each pass is twelve 24-MFMA slabs like the attention output projection in front, and
+        // its result leaves through the wave's tile as 768-byte row segments of the [T][1152] output.
+        const unsigned char* gq = (const unsigned char*)pre.wqkv_p;
+        unsigned char* mt = smem + wv * M3_SLAB;
+        const int64_t token0 = (int64_t)blockIdx.x * 128 + wv * 32;
+        const int rv = (int)((int64_t)T - token0 < 32 ? (int64_t)T - token0 : 32);
+        M3_WAIT_VM(0);
+        __syncthreads();  // slabs 0, 1 and the bias are in LDS (and this wave's y rows are on their way)
+#pragma unroll 1
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4v bv = *(const float4v*)(b1s + ML_H * p + 32 * j + 8 * q + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
+                }
+#pragma unroll
+            for (int s2 = 0; s2 < ML_H / 32; ++s2) {
+                const int t = 12 * p + s2;
+                if (t > 0) {
+                    if (t > 1) M3_WAIT_VM(0);
+                    M3_BARRIER();
+                    if (t + 1 < 36) m3_issue_w2(gq + (int64_t)(t + 1) * M3_SLAB, smem + M3_W2_OFF + (1 + ((t + 1) & 1)) * M3_SLAB, wv, tid);
+                }
+                const half8 yf[2] = {xf[2 * s2], xf[2 * s2 + 1]};
+                m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (1 + (t & 1)) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, yf, pfa, o);
+            }
+            // accumulators -> fp16 -> the wave's tile -> global (the tile's previous contents were read out before: program order)
+            {
+                unsigned char* trow = mt + r31 * 768 + 8 * g;
+#pragma unroll
+                for (int j = 0; j < ML_NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 4 * j + q;
+                        const float2v y0 = {o[j][4 * q], o[j][4 * q + 1]}, y1 = {o[j][4 * q + 2], o[j][4 * q + 3]};
+                        const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
+                        const half4 y = {h0[0], h0[1], h1[0], h1[1]};
+                        *(half4*)(trow + ((c & ~15) | ((c ^ r31) & 15)) * 16) = y;
+                    }
+            }
+            LM_WAVE_SYNC();
+            if (rv > 0) m3_store_tile(mt, (unsigned char*)pre.qkv_out + token0 * (3 * ML_H * 2) + p * (ML_H * 2), 3 * ML_H * 2, rv, lane);
+            M3_WAIT_LGKM0();
+            LM_WAVE_SYNC();  // the tile is rewritten by the next pass
+        }
+    }
 #ifndef LM_EMULATED_DEVICE
     if constexpr ((ABL & 64) != 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -832,7 +909,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
     int F, float eps) {
-    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, 0};
     m3_kernel_body<ABL, false>(x, w1, b1, w2p, b2, gamma, beta, out, T, F, eps, none);
 }
 
@@ -847,12 +924,23 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_attn_out_mlp_h384(
     m3_kernel_body<ABL, true>(resid, w1acc, b1, w2p, b2, gamma, beta, out, T, F, eps, pre);
 }
 
+// ... and with the NEXT layer's QKV projection behind it (M3Pre::wqkv_p): the LayerNorm output is already in registers in the k order
+// the projection needs, so the weight-stationary GEMM's six reads of x in 32-byte row segments and its strided stores
+// (profiles/r2_kbench_gemm_ws_phase_stamps.jsonl) disappear; opt-in until measured on hardware (LEANN_MI355X_QKV_IN_TAIL=1).
+template <int ABL>
+__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_attn_out_mlp_qkv_h384(
+    const __half* __restrict__ resid, M3Pre pre, const __half* __restrict__ w1acc, const float* __restrict__ b1,
+    const __half* __restrict__ w2p, const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta,
+    __half* __restrict__ out, int T, int F, float eps) {
+    m3_kernel_body<ABL, true, true>(resid, w1acc, b1, w2p, b2, gamma, beta, out, T, F, eps, pre);
+}
+
 }  // namespace lm
 
-extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
-                                              const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
-                                              const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
-                                              int64_t tokens, int32_t ffn, float eps, void* stream) {
+static int m3_launch_tail(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo, const void* d_gamma1, const void* d_beta1,
+                          float eps1, const void* d_w1acc, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
+                          const void* d_beta, void* d_out, const void* d_wqkv_p, const float* d_bqkv, void* d_qkv_out, int64_t tokens, int32_t ffn,
+                          float eps, void* stream) {
     using namespace lm;
     if (tokens == 0) return LM_OK;
     if (!d_attn || !d_resid || !d_wo_p || !d_bo || !d_gamma1 || !d_beta1 || !d_w1acc || !d_b1 || !d_w2p || !d_b2 || !d_gamma || !d_beta || !d_out ||
@@ -861,25 +949,59 @@ extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_
     if (ffn <= 0 || ffn % 32) LM_FAIL(LM_EINVAL, "ffn size must be a positive multiple of 32");
     const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 16;  // + b2, b_o (fp32), gamma, beta, gamma1, beta1 (fp16)
     if (ffn < 128 || shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "fused attention-output + MLP kernel: ffn must be in [128, 2560]");
+    const bool qkv = d_wqkv_p != nullptr;
+    if (qkv && (!d_bqkv || !d_qkv_out || ffn < 3 * ML_H))  // the projection's bias takes over b1's LDS space
+        LM_FAIL(LM_EINVAL, "fused layer tail + QKV projection: needs the bias, the output buffer and ffn >= 1152");
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
     const char* sg = getenv("LEANN_MI355X_STAGGER");  // spread of the first round's start times, x 1024 cycles (default 40: measured 797 -> 779 us per 262k tokens; 0 = off)
-    const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1, sg ? atoi(sg) : 40};
+    const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1,
+                       (const __half*)d_wqkv_p, d_bqkv, (__half*)d_qkv_out, sg ? atoi(sg) : 40};
     const char* ab = getenv("LEANN_MI355X_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
-#define M3P_GO(A)                                                                                                                     \
+#define M3P_GO_K(K, A)                                                                                                                \
     case A:                                                                                                                            \
-        LM_HIP(hipFuncSetAttribute((const void*)k_attn_out_mlp_h384<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
-        hipLaunchKernelGGL(k_attn_out_mlp_h384<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_resid, pre,               \
-                           (const __half*)d_w1acc, d_b1, (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta,    \
-                           (__half*)d_out, (int)tokens, ffn, eps);                                                                      \
+        LM_HIP(hipFuncSetAttribute((const void*)K<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                        \
+        hipLaunchKernelGGL(K<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_resid, pre, (const __half*)d_w1acc, d_b1,   \
+                           (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out, (int)tokens, ffn, \
+                           eps);                                                                                                        \
         break
-    switch (abl) {
-        M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856);
-        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps) and 64 + {256, 512, 1024}");
+#define M3P_GO(A) M3P_GO_K(k_attn_out_mlp_h384, A)
+    if (qkv) {
+        switch (abl) {
+            M3P_GO_K(k_attn_out_mlp_qkv_h384, 0);
+            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the layer tail with the QKV projection has no diagnosis builds");
+        }
+    } else {
+        switch (abl) {
+            M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856);
+            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps) and 64 + {256, 512, 1024}");
+        }
     }
 #undef M3P_GO
+#undef M3P_GO_K
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
+                                              const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
+                                              const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
+                                              int64_t tokens, int32_t ffn, float eps, void* stream) {
+    return m3_launch_tail(d_attn, d_resid, d_wo_p, d_bo, d_gamma1, d_beta1, eps1, d_w1acc, d_b1, d_w2p, d_b2, d_gamma, d_beta, d_out, nullptr,
+                          nullptr, nullptr, tokens, ffn, eps, stream);
+}
+
+extern "C" int lm_layer_tail_qkv_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
+                                                const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
+                                                const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
+                                                const void* d_wqkv_p, const float* d_bqkv, void* d_qkv_out, int64_t tokens, int32_t ffn,
+                                                float eps, void* stream) {
+    if (!d_wqkv_p) {
+        lm::set_error("lm_layer_tail_qkv_fused_h384_f16: missing QKV weights");
+        return LM_EINVAL;
+    }
+    return m3_launch_tail(d_attn, d_resid, d_wo_p, d_bo, d_gamma1, d_beta1, eps1, d_w1acc, d_b1, d_w2p, d_b2, d_gamma, d_beta, d_out, d_wqkv_p, d_bqkv,
+                          d_qkv_out, tokens, ffn, eps, stream);
 }
 
 int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,

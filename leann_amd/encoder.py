@@ -276,10 +276,19 @@ def pack_w1_acc_order(w1: torch.Tensor) -> torch.Tensor:
     return w1.reshape(f, h // 32, 32)[:, :, perm].reshape(f, h).contiguous()
 
 
-def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
+def pack_wqkv_slabs(wqkv: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [1152, 384] of a QKV projection -> [36, 384, 32]: slab 12 p + s = output rows 384 p .. 384 p + 383 (Q, K, V),
+    k slab s with its 32 input features in accumulator order (fused_mlp_k_permutation) -- the layout in which the fused layer tail
+    holds the previous layer's output when it runs this projection (csrc/lm_mlp_fused_v3.hip: k_attn_out_mlp_qkv_h384)."""
+    n, k = wqkv.shape
+    return torch.cat([pack_w2_fused_mlp(wqkv[384 * p : 384 * (p + 1)]) for p in range(n // 384)], 0).contiguous()
+
+
+def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer", next_layer: Optional["_Layer"] = None):
     """LayerNorm2(x + fc2(GELU(fc1(x)))) with x = LayerNorm1(resid + out(a)) in ONE kernel (csrc/lm_mlp_fused_v3.hip:
     k_attn_out_mlp_h384) for hidden 384, fp16 on the GPU.  LEANN_MI355X_TAIL=0 = the three-kernel path (A/B); None = the caller
-    takes that path."""
+    takes that path.  With ``next_layer`` and LEANN_MI355X_QKV_IN_TAIL=1 (opt-in) the same launch also computes the next layer's
+    QKV projection of its result: returns ``(y, qkv_next)`` then."""
     import os
 
     if os.environ.get("LEANN_MI355X_TAIL", "1") != "1" or os.environ.get("LEANN_MI355X_MLP", "1") != "1":
@@ -304,6 +313,23 @@ def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") ->
     out = torch.empty_like(resid)
     vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     tm = KernelTimers.active
+    if (next_layer is not None and os.environ.get("LEANN_MI355X_QKV_IN_TAIL", "0") == "1" and f >= 1152
+            and tuple(next_layer.qkv.weight.shape) == (1152, 384) and next_layer.qkv.bias is not None):
+        qp = getattr(next_layer, "_qkv_tail_pack", None)
+        if qp is None or qp[0].device != a.device:
+            qp = (pack_wqkv_slabs(next_layer.qkv.weight.detach()), next_layer.qkv.bias.detach().float().contiguous())
+            next_layer._qkv_tail_pack = qp
+        qkv = torch.empty((a.shape[0], 1152), dtype=torch.float16, device=a.device)
+        ev = tm.span("attn_out_mlp_qkv_h384", a.shape[0] * (4.0 * f * h + 2.0 * h * h + 2.0 * h * 1152)) if tm is not None else None
+        if ev:
+            ev[0].record()
+        _lib.check(_lib.load().lm_layer_tail_qkv_fused_h384_f16(
+            vp(a), vp(resid), vp(wo_p), vp(bo), vp(layer.ln1.weight), vp(layer.ln1.bias), float(layer.ln1.eps), vp(w1a), vp(b1), vp(w2p), vp(b2),
+            vp(layer.ln2.weight), vp(layer.ln2.bias), vp(out), vp(qp[0]), vp(qp[1]), vp(qkv), a.shape[0], f, float(layer.ln2.eps),
+            C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "lm_layer_tail_qkv_fused_h384_f16")
+        if ev:
+            ev[1].record()
+        return out, qkv
     ev = tm.span("attn_out_mlp_h384", a.shape[0] * (4.0 * f * h + 2.0 * h * h)) if tm is not None else None
     if ev:
         ev[0].record()
@@ -427,19 +453,22 @@ class _Layer(nn.Module):
         self.ln2 = nn.LayerNorm(c.hidden, eps=c.ln_eps)
         self.heads = c.heads
 
-    def forward_packed(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
-        """x: [total_tokens, H] (sequences packed back to back), cu: int32 cumulative lengths [n+1]."""
+    def forward_packed(self, x: torch.Tensor, cu: torch.Tensor, max_len: int, qkv_pre: Optional[torch.Tensor] = None,
+                       next_layer: Optional["_Layer"] = None):
+        """x: [total_tokens, H] (sequences packed back to back), cu: int32 cumulative lengths [n+1].  ``qkv_pre``: this layer's QKV
+        projection if the previous layer's tail kernel already computed it; with ``next_layer`` the result may be ``(y, qkv_next)``
+        (LEANN_MI355X_QKV_IN_TAIL=1), else it is ``y``."""
         from torch.nn.attention.varlen import varlen_attn
 
         tot, h = x.shape
-        qkv2 = fused_linear_h384(x, self.qkv)
+        qkv2 = qkv_pre if qkv_pre is not None else fused_linear_h384(x, self.qkv)
         if qkv2 is None:
             qkv2 = self.qkv(x)
         a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
         if a is None:
             qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
             a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
-        y = fused_attn_out_mlp(a, x, self)  # output projection + LayerNorm + feed-forward block + LayerNorm in one kernel
+        y = fused_attn_out_mlp(a, x, self, next_layer)  # output projection + LayerNorm + feed-forward block + LayerNorm in one kernel
         if y is not None:
             return y
         y = fused_linear_h384(a, self.out, residual=x, ln=self.ln1)
@@ -599,8 +628,10 @@ class BertEncoder(nn.Module):
         x = fused_embed_layernorm(tok, pos, self.word, self.pos, self.tok_type.weight[0], self.ln)
         if x is None:
             x = fused_add_layernorm(self.word(tok) + self.tok_type.weight[0][None], self.pos(pos), self.ln)
-        for L in self.layers:
-            x = L.forward_packed(x, cu, max_len)
+        qkv_pre = None
+        for li, L in enumerate(self.layers):
+            r = L.forward_packed(x, cu, max_len, qkv_pre, self.layers[li + 1] if li + 1 < len(self.layers) else None)
+            x, qkv_pre = r if isinstance(r, tuple) else (r, None)
         n = lengths.shape[0]
         if cfg.pooling != "cls":
             e = fused_meanpool(x, cu, cfg.normalize)

@@ -498,7 +498,33 @@ def case_mlp_v3_and_tail():
                                                   vp(pack_w1_acc_order(torch.from_numpy(w1)).numpy()), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(ot),
                                                   T, F, 1e-12, None), "tail")
     assert np.abs(ot.astype(f64) - mlp(x1, w1, b1, w2, b2, g2, be2)).max() < 1.2e-2
-    print("fused feed-forward kernels (variant 3 and the attention-output form): ok", flush=True)
+    # ... and with the next layer's QKV projection behind it (opt-in form): y and qkv = y W_qkv^T + b_qkv from one launch
+    from leann_amd.encoder import pack_wqkv_slabs
+
+    Tq, Fq = 97, 1152
+    atq, rsq = rng.standard_normal((Tq, H)).astype(np.float16), rng.standard_normal((Tq, H)).astype(np.float16)
+    w1q = (rng.standard_normal((Fq, H)) / np.sqrt(H)).astype(np.float16)
+    w2q = (rng.standard_normal((H, Fq)) / np.sqrt(Fq)).astype(np.float16)
+    b1q = (0.2 * rng.standard_normal(Fq)).astype(np.float32)
+    wqkv = (rng.standard_normal((3 * H, H)) / np.sqrt(H)).astype(np.float16)
+    bqkv = (0.2 * rng.standard_normal(3 * H)).astype(np.float32)
+    x1q = ln(rsq.astype(f64) + atq.astype(f64) @ wo.astype(f64).T + bo, g1, be1).astype(np.float16)
+    yref = mlp(x1q, w1q, b1q, w2q, b2, g2, be2)
+    yq, qkvq = np.zeros((Tq, H), np.float16), np.zeros((Tq, 3 * H), np.float16)
+    w2pq = pack_w2_fused_mlp(torch.from_numpy(w2q)).numpy()
+    args_tail = (vp(atq), vp(rsq), vp(pack_wo_slabs(torch.from_numpy(wo)).numpy()), vp(bo), vp(g1), vp(be1), 1e-12,
+                 vp(pack_w1_acc_order(torch.from_numpy(w1q)).numpy()), vp(b1q), vp(w2pq), vp(b2), vp(g2), vp(be2))
+    wqp = pack_wqkv_slabs(torch.from_numpy(wqkv)).numpy()
+    assert wqp.shape == (36, H, 32)
+    _lib.check(lib.lm_layer_tail_qkv_fused_h384_f16(*args_tail, vp(yq), vp(wqp), vp(bqkv), vp(qkvq), Tq, Fq, 1e-12, None), "tail+qkv")
+    assert np.abs(yq.astype(f64) - yref).max() < 1.2e-2
+    y2 = np.zeros((Tq, H), np.float16)
+    _lib.check(lib.lm_attn_out_mlp_fused_h384_f16(*args_tail, vp(y2), Tq, Fq, 1e-12, None), "tail")
+    assert np.array_equal(yq.view(np.uint16), y2.view(np.uint16))  # the layer output itself is the same kernel code
+    qref = yq.astype(f64) @ wqkv.astype(f64).T + bqkv  # from the fp16 y the kernel itself feeds to the projection
+    assert np.abs(qkvq.astype(f64) - qref).max() < 6e-3, np.abs(qkvq.astype(f64) - qref).max()
+    assert lib.lm_layer_tail_qkv_fused_h384_f16(*args_tail, vp(yq), vp(wqp), None, vp(qkvq), Tq, Fq, 1e-12, None) == -1  # bias missing
+    print("fused feed-forward kernels (variant 3, the attention-output form, the form with the next QKV projection): ok", flush=True)
 
 
 CASES = {
@@ -578,6 +604,28 @@ def case_encoder_python_wiring():
         with torch.no_grad():
             got2 = enc16.encode_tokens_packed(ti, tl, 4096)
     assert float((got2.float() - ref).abs().max()) < 6e-3
+    # the DEFAULT kernel set (weight-stationary QKV GEMM, attention revision 2, fused layer tail) and the opt-in form in which the
+    # tail kernel of layer l also runs the QKV projection of layer l + 1 (needs ffn >= 1152)
+    for ffn, extra, want in ((128, {}, {"lm_gemm_ws_h384_f16": 2, "lm_attn_out_mlp_fused_h384_f16": 2, "lm_layer_tail_qkv_fused_h384_f16": 0}),
+                             (1152, {"LEANN_MI355X_QKV_IN_TAIL": "1"},
+                              {"lm_gemm_ws_h384_f16": 1, "lm_attn_out_mlp_fused_h384_f16": 1, "lm_layer_tail_qkv_fused_h384_f16": 1})):
+        cfg3 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=ffn, max_pos=64, max_seq_length=48)
+        e32 = BertEncoder.random_init(cfg3, 5).eval()
+        with torch.no_grad():
+            ref3 = e32(ti, tl).float()
+        e16 = BertEncoder.random_init(cfg3, 5).eval().half()
+        used.clear()
+        env3 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+        env3.update(extra)
+        with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+                mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env3, clear=True), \
+                mock.patch.object(_lib, "check", new=recording_check):
+            with torch.no_grad():
+                got3 = e16.encode_tokens_packed(ti, tl, 4096)
+        counts3 = {k: used.count(k) for k in want}
+        assert counts3 == want and used.count("lm_attn_varlen_hd32_f16") == 2 and "lm_add_layernorm_f16" not in used, (ffn, counts3, sorted(set(used)))
+        err3 = float((got3.float() - ref3).abs().max())
+        assert err3 < 6e-3, (ffn, err3)
     err = float((got.float() - ref).abs().max())
     print(f"encoder.py packed forward, every switch on, through the emulated library: max|diff| vs fp32 torch = {err:.2e}", flush=True)
     assert err < 6e-3, err
