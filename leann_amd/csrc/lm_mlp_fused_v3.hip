@@ -847,6 +847,15 @@ __device__ __forceinline__ void m3_kernel_body(
         unsigned char* mt = smem + wv * M3_SLAB;
         const int64_t token0 = (int64_t)blockIdx.x * 128 + wv * 32;
         const int rv = (int)((int64_t)T - token0 < 32 ? (int64_t)T - token0 : 32);
+        // fragment addresses again, from opaque copies of the lane coordinates: kept alive across the LayerNorm instead, they are
+        // what pushes the allocation over 512 registers (81 dwords of scratch per lane)
+        int rq = r31, gq2 = g;
+        LM_KEEP_LOCAL(rq);
+        LM_KEEP_LOCAL(gq2);
+        int a1q[8];
+#pragma unroll
+        for (int k7 = 0; k7 < 8; ++k7) a1q[k7] = rq * 768 + ((((2 * k7 + gq2) ^ rq) & 15) << 4);
+        const int b20q = rq * 64 + ((gq2 ^ ((rq >> 2) & 3)) << 4), b21q = b20q ^ 32;
         M3_WAIT_VM(0);
         __syncthreads();  // slabs 0, 1 and the bias are in LDS (and this wave's y rows are on their way)
 #pragma unroll 1
@@ -855,7 +864,7 @@ __device__ __forceinline__ void m3_kernel_body(
             for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4v bv = *(const float4v*)(b1s + ML_H * p + 32 * j + 8 * q + 4 * g);
+                    const float4v bv = *(const float4v*)(b1s + ML_H * p + 32 * j + 8 * q + 4 * gq2);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
                 }
@@ -868,11 +877,11 @@ __device__ __forceinline__ void m3_kernel_body(
                     if (t + 1 < 36) m3_issue_w2(gq + (int64_t)(t + 1) * M3_SLAB, smem + M3_W2_OFF + (1 + ((t + 1) & 1)) * M3_SLAB, wv, tid);
                 }
                 const half8 yf[2] = {xf[2 * s2], xf[2 * s2 + 1]};
-                m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (1 + (t & 1)) * M3_SLAB, a1, b20, b21, nullptr, xf, accn, acc, yf, pfa, o);
+                m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (1 + (t & 1)) * M3_SLAB, a1q, b20q, b21q, nullptr, xf, accn, acc, yf, pfa, o);
             }
             // accumulators -> fp16 -> the wave's tile -> global (the tile's previous contents were read out before: program order)
             {
-                unsigned char* trow = mt + r31 * 768 + 8 * g;
+                unsigned char* trow = mt + rq * 768 + 8 * gq2;
 #pragma unroll
                 for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
@@ -881,7 +890,7 @@ __device__ __forceinline__ void m3_kernel_body(
                         const float2v y0 = {o[j][4 * q], o[j][4 * q + 1]}, y1 = {o[j][4 * q + 2], o[j][4 * q + 3]};
                         const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
                         const half4 y = {h0[0], h0[1], h1[0], h1[1]};
-                        *(half4*)(trow + ((c & ~15) | ((c ^ r31) & 15)) * 16) = y;
+                        *(half4*)(trow + ((c & ~15) | ((c ^ rq) & 15)) * 16) = y;
                     }
             }
             LM_WAVE_SYNC();
