@@ -1,37 +1,14 @@
 #!/bin/bash
-# First GPU call of the next session: validate the opt-in encoder kernels, time them, and (if they pass) run the bench
-# with them switched on.  Everything lands under gpurun_out/next/.  Usage (from the repo root, on the GPU box):
-#     bash scripts/next_gpu_session.sh            # ~6-8 GPU-minutes
-# Each step has its own timeout so that a hang costs one step, not the call.
+# First GPU session of the next round: the opt-in kernel that has only run in emulation so far.
+#   1. its GPU tests (marker gpu_next: NOT part of -m gpu)          2. its timing against the two launches it replaces
+#   3. the encoder-level A/B (one search round's worth of chunks)   -> make LEANN_MI355X_QKV_IN_TAIL=1 the default only if 2 and 3 win,
+#      then move tests/test_gpu_next.py's tests under -m gpu and re-run the reference session (scripts/gpu_session_r2_34.sh).
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/next
-mkdir -p $OUT
-export TMPDIR=/tmp
-
-echo "== 1. gpu_next tests (one pytest process per kernel family: a device fault in one does not hide the others)" | tee $OUT/summary.txt
-for k in attention layernorm meanpool embed pack_tokens "fused_mlp" linear "every_opt_in"; do
-    timeout 300 python -m pytest tests/test_gpu_next.py -m gpu_next -q -x -k "$k" > $OUT/test_$k.log 2>&1
-    echo "   $k: rc=$? $(tail -1 $OUT/test_$k.log)" | tee -a $OUT/summary.txt
-done
-
-echo "== 2. kernel A/B" | tee -a $OUT/summary.txt
-timeout 400 python -m leann_amd.autotune --device 0 > $OUT/autotune.jsonl 2> $OUT/autotune.err; echo "   autotune rc=$? $(tail -1 $OUT/autotune.jsonl | cut -c1-300)" | tee -a $OUT/summary.txt
-timeout 300 python scripts/attn_bench.py > $OUT/attn_bench.json 2> $OUT/attn_bench.err; echo "   attn_bench rc=$?" | tee -a $OUT/summary.txt
-timeout 600 python scripts/encoder_ops_bench.py > $OUT/encoder_ops_bench.json 2> $OUT/encoder_ops_bench.err; echo "   encoder_ops_bench rc=$?" | tee -a $OUT/summary.txt
-
-echo "== 3. per-kernel times with every switch on (rocprofv3 --kernel-trace --stats)" | tee -a $OUT/summary.txt
-( cd /tmp && LEANN_MI355X_ATTN=2 LEANN_MI355X_LN=2 LEANN_MI355X_POOL=1 LEANN_MI355X_EMBED=1 LEANN_MI355X_MLP=1 LEANN_MI355X_MLP_VARIANT=2 LEANN_MI355X_LINEAR=1 LEANN_MI355X_PACK=1 \
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_next -- python $OLDPWD/scripts/encoder_bench.py > $OLDPWD/$OUT/encoder_bench_all_on.json 2> $OLDPWD/$OUT/rocprof.err )
-find /tmp/prof_next -name "*kernel_stats.csv" -exec cp {} $OUT/encoder_all_on_kernel_stats.csv \; 2>/dev/null
-echo "   rocprof rc=$?" | tee -a $OUT/summary.txt
-
-echo "== 4. bench with the switches that passed (edit the list below after reading summary.txt if something failed)" | tee -a $OUT/summary.txt
-if ! grep -q "rc=[1-9]" $OUT/summary.txt; then
-    LEANN_MI355X_ATTN=2 LEANN_MI355X_LN=2 LEANN_MI355X_POOL=1 LEANN_MI355X_EMBED=1 LEANN_MI355X_MLP=1 LEANN_MI355X_MLP_VARIANT=2 LEANN_MI355X_LINEAR=1 LEANN_MI355X_PACK=1 \
-      timeout 1500 python bench.py --no-cpu-baseline > $OUT/bench_all_on.json 2> $OUT/bench_all_on.err
-    echo "   bench rc=$? $(python -c "import json;d=json.load(open('$OUT/bench_all_on.json'));print(d['value'],d['recall_at_10'],d['roofline_encoder'])" 2>/dev/null)" | tee -a $OUT/summary.txt
-else
-    echo "   skipped: a step above failed" | tee -a $OUT/summary.txt
-fi
-cat $OUT/summary.txt
+OUT=gpurun_out/next; rm -rf "$OUT"; mkdir -p "$OUT"
+KB=leann_amd/lib/bin/kbench
+timeout -k 5 60 $KB 4096 2 ln > $OUT/probe.log 2>&1 || { echo "BOX UNHEALTHY"; cat $OUT/probe.log; exit 0; }
+timeout -k 5 120 $KB 4000 5 tailqkv > $OUT/kbench_tailqkv_small.jsonl 2> $OUT/kbench.err; echo "== small rc=$?"; grep -E "tail_qkv|ws_h384" $OUT/kbench_tailqkv_small.jsonl | cut -c1-300
+timeout -k 5 200 $KB 262107 20 tailqkv > $OUT/kbench_tailqkv.jsonl 2>> $OUT/kbench.err; echo "== 262k rc=$?"; grep -E "tail_qkv|ws_h384" $OUT/kbench_tailqkv.jsonl | cut -c1-300; tail -3 $OUT/kbench.err
+timeout -k 10 300 python -m pytest tests/test_gpu_next.py -m gpu_next -q > $OUT/pytest_gpu_next.log 2>&1; echo "rc=$? $(tail -1 $OUT/pytest_gpu_next.log)"; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu_next.log | head
+for v in 0 1; do LEANN_MI355X_QKV_IN_TAIL=$v timeout -k 10 200 python scripts/subbatch_bench.py 2> /dev/null | grep '"fused_layer_tail": "1", "sub_batch_tokens": 524160' | sed "s/^/QKV_IN_TAIL=$v /"; done
