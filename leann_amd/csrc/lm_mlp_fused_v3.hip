@@ -964,7 +964,8 @@ static int m3_launch_tail(const void* d_attn, const void* d_resid, const void* d
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
     const char* sg = getenv("LEANN_MI355X_STAGGER");  // spread of the first round's start times, x 1024 cycles (default 40: measured 797 -> 779 us per 262k tokens; 0 = off)
     const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1,
-                       (const __half*)d_wqkv_p, d_bqkv, (__half*)d_qkv_out, sg ? atoi(sg) : 40};
+                       (const __half*)d_wqkv_p, d_bqkv, (__half*)d_qkv_out,
+                       grid.x >= 512 ? (sg ? atoi(sg) : 40) : 0};  // a launch of fewer than two rounds has no lock-step to break: no start delay (small-batch latency)
     const char* ab = getenv("LEANN_MI355X_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
 #define M3P_GO_K(K, A)                                                                                                                \
