@@ -234,30 +234,43 @@ struct M3Ctx {
     const unsigned char* w2s;
     int a1[8], b20, b21;
 };
-template <int SLOT>
+// What slot SLOT of an iteration does: -1 nothing, 0..23 = k-step of the first product, 100 + n = MFMA n of the second product
+// (n = 12 u + j).  Plain order: slots 0..23 first product, 24..47 second.  IL (LEANN_MI355X_ABLATE & 4096, opt-in until measured):
+// in iterations that compute a first product the two products ALTERNATE -- even slots first product, odd slots second -- so the
+// first product is ONE dependency chain whose links are an independent MFMA apart: no second partial sum, no 32 v_accvgpr_read +
+// 16 v_add to merge the two at the top of the next iteration, 16 accumulator registers fewer.
+template <bool FC1, bool FC2, bool IL, int SLOT>
+constexpr int m3_role() {
+    if (SLOT < 0 || SLOT >= 48) return -1;
+    if (IL && FC1) return (SLOT & 1) == 0 ? SLOT / 2 : (FC2 ? 100 + SLOT / 2 : -1);
+    if (SLOT < 24) return FC1 ? SLOT : -1;
+    return FC2 ? 100 + SLOT - 24 : -1;
+}
+template <int ROLE>
 __device__ __forceinline__ half8 m3_frag(const M3Ctx& c) {
-    if constexpr (SLOT < 24) return *(const half8*)(c.w1s + c.a1[SLOT & 7] + 256 * (SLOT >> 3));
+    if constexpr (ROLE < 100) return *(const half8*)(c.w1s + c.a1[ROLE & 7] + 256 * (ROLE >> 3));
     else {
-        constexpr int n = SLOT - 24, u = n / ML_NJ, j = n % ML_NJ;
+        constexpr int n = ROLE - 100, u = n / ML_NJ, j = n % ML_NJ;
         return *(const half8*)(c.w2s + (u ? c.b21 : c.b20) + 2048 * j);
     }
 }
-template <bool FC1, bool FC2, int SLOT>
-constexpr bool m3_live() { return SLOT < 24 ? FC1 : (SLOT < 48 ? FC2 : false); }
 
-template <bool FC1, bool FC2, int GEL, int RD, int I>
+template <bool FC1, bool FC2, int GEL, int RD, bool IL, int I>
 __device__ __forceinline__ void m3_slot(const M3Ctx& c, const half8 (&xf)[ML_KS], float16v (&accn)[2], const float (&acc)[16],
                                         const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[RD], GeluQuad& gq) {
-    if constexpr (m3_live<FC1, FC2, I>()) {
-        if constexpr (I < 24) {
-            // two accumulators in turn: an instruction issued between two MFMAs on the SAME accumulator costs ~43 cycles
-            // (MI355X_MICROARCH.md, per-instruction constants) -- and every gap here carries GELU micro-operations
-            accn[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], xf[I], accn[I & 1], 0, 0, 0);
+    constexpr int role = m3_role<FC1, FC2, IL, I>();
+    if constexpr (role >= 0) {
+        if constexpr (role < 100) {
+            // plain order: two accumulators in turn -- an instruction issued between two MFMAs on the SAME accumulator costs ~43
+            // cycles (MI355X_MICROARCH.md, per-instruction constants), and every gap here carries GELU micro-operations
+            constexpr int ai = IL ? 0 : (role & 1);
+            accn[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], xf[role], accn[ai], 0, 0, 0);
         } else {
-            constexpr int n = I - 24, u = n / ML_NJ, j = n % ML_NJ;
+            constexpr int n = role - 100, u = n / ML_NJ, j = n % ML_NJ;
             o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], pfprev[u], o[j], 0, 0, 0);
         }
-        if constexpr (m3_live<FC1, FC2, I + RD>()) ring[I & (RD - 1)] = m3_frag<I + RD>(c);
+        constexpr int nrole = m3_role<FC1, FC2, IL, I + RD>();
+        if constexpr (nrole >= 0) ring[I & (RD - 1)] = m3_frag<nrole>(c);
     }
     if constexpr (GEL != 0) {
         constexpr int n = 16 * gelu_rows<GEL>(), lo = (n * I) / 48, hi = (n * (I + 1)) / 48;
@@ -265,17 +278,24 @@ __device__ __forceinline__ void m3_slot(const M3Ctx& c, const half8 (&xf)[ML_KS]
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <bool FC1, bool FC2, int GEL, int RD, int... I>
+template <bool FC1, bool FC2, int GEL, int RD, bool IL, int... I>
 __device__ __forceinline__ void m3_slots(std::integer_sequence<int, I...>, const M3Ctx& c, const half8 (&xf)[ML_KS], float16v (&accn)[2],
                                          const float (&acc)[16], const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[RD],
                                          GeluQuad& gq) {
-    (m3_slot<FC1, FC2, GEL, RD, I>(c, xf, accn, acc, pfprev, pfcur, o, ring, gq), ...);
+    (m3_slot<FC1, FC2, GEL, RD, IL, I>(c, xf, accn, acc, pfprev, pfcur, o, ring, gq), ...);
+}
+template <bool FC1, bool FC2, bool IL, int RD, int FIRST, int... I>
+__device__ __forceinline__ void m3_ring_fill(std::integer_sequence<int, I...>, const M3Ctx& c, half8 (&ring)[RD]) {
+    ([&] {
+        constexpr int role = m3_role<FC1, FC2, IL, FIRST + I>();
+        if constexpr (role >= 0) ring[(FIRST + I) & (RD - 1)] = m3_frag<role>(c);
+    }(), ...);
 }
 
 // One iteration of the skewed pipeline.  FC1: first product of the slab in stage w1s (bias bs) -> accn;  GEL: GELU of acc[0..16)
 // -> pfcur;  FC2: second product of the slab in stage w2s with pfprev -> o.  48 slots, slot i = MFMA i (24 of FC1 then 24 of
 // FC2), the fragment read of slot i + 4 and GELU micro-operations [256 i / 48, 256 (i + 1) / 48).
-template <bool FC1, bool FC2, int GEL, int RD>
+template <bool FC1, bool FC2, int GEL, int RD, bool IL = false>
 __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const unsigned char* w2s, const int (&a1)[8], int b20, int b21,
                                              const float* bs, const half8 (&xf)[ML_KS], float16v (&accn)[2], const float (&acc)[16],
                                              const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ]) {
@@ -292,27 +312,16 @@ __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const uns
             float4v bv = *(const float4v*)(bs + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                accn[0][4 * q + i] = bv[i];  // bias in one of the two partial sums
-                accn[1][4 * q + i] = 0.0f;
+                accn[0][4 * q + i] = bv[i];  // bias in one of the two partial sums (IL: in the only one)
+                if constexpr (!IL) accn[1][4 * q + i] = 0.0f;
             }
         }
     }
     half8 ring[RD];  // fragment reads run RD MFMAs ahead
     constexpr int first = FC1 ? 0 : 24;
-    if constexpr (m3_live<FC1, FC2, first>()) {
-        ring[0] = m3_frag<first>(c);
-        ring[1] = m3_frag<first + 1>(c);
-        ring[2] = m3_frag<first + 2>(c);
-        ring[3] = m3_frag<first + 3>(c);
-        if constexpr (RD == 8) {
-            ring[4] = m3_frag<first + 4>(c);
-            ring[5] = m3_frag<first + 5>(c);
-            ring[6] = m3_frag<first + 6>(c);
-            ring[7] = m3_frag<first + 7>(c);
-        }
-    }
+    m3_ring_fill<FC1, FC2, IL, RD, first>(std::make_integer_sequence<int, RD>{}, c, ring);
     GeluQuad gq;
-    m3_slots<FC1, FC2, GEL, RD>(std::make_integer_sequence<int, 48>{}, c, xf, accn, acc, pfprev, pfcur, o, ring, gq);
+    m3_slots<FC1, FC2, GEL, RD, IL>(std::make_integer_sequence<int, 48>{}, c, xf, accn, acc, pfprev, pfcur, o, ring, gq);
 }
 
 // Epilogue of variant 3:  y = LayerNorm(o + residual) * gamma + beta  (b2 is already in the accumulators), written as fp16.
@@ -626,6 +635,7 @@ __device__ __forceinline__ void m3_kernel_body(
     constexpr int AF = ABL & 56;  // GELU form bits
     constexpr int GEL = (ABL & 4) ? 0 : (AF == 8 ? 2 : (AF == 16 ? 3 : (AF == 32 ? 4 : (AF == 48 ? 5 : 1))));  // GELU form (see gelu_uop)
     constexpr int RD = (ABL & 128) ? 8 : 4;  // fragment read-ahead distance
+    constexpr bool IL = (ABL & 4096) != 0;   // the two products of an iteration alternate slot by slot (see m3_role)
     float* b1s = (float*)(smem + M3_B1_OFF);
     float* b2s = b1s + F;                          // b2 (384 floats), gamma, beta (384 halfs each) behind b1
     _Float16* gam_s = (_Float16*)(b2s + ML_H);
@@ -774,14 +784,14 @@ __device__ __forceinline__ void m3_kernel_body(
         }
 
     // first product of slab 0, nothing to overlap it with
-    m3_iteration<true, false, 0, RD>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<true, false, 0, RD, IL>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
 
     // iteration s: FC1 of slab s+1 (stage (s+1) % 3), GELU of slab s, FC2 of slab s-1 (stage (s-1) % 3).
     // At its top: W1(s+1) and W2(s-1) must have landed; issued after them, one iteration ago: W1(s+2), W2(s).
     // Then W1(s+3) and W2(s+1) are issued into the stages W1(s) / W2(s-2) occupied -- idle once every wave passed the barrier.
     auto top = [&](int s) {  // everything an iteration does before its 48 slots
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = accn[0][r] + accn[1][r];
+        for (int r = 0; r < 16; ++r) acc[r] = IL ? accn[0][r] : accn[0][r] + accn[1][r];
 #ifndef LM_EMULATED_DEVICE
         if constexpr ((ABL & 4) != 0) {  // the "no GELU" ablation must keep the first product alive (round 2 timed it WITHOUT: the
 #pragma unroll                           // compiler had removed the 24 dead MFMAs and their fragment reads)
@@ -804,7 +814,7 @@ __device__ __forceinline__ void m3_kernel_body(
     M3_STAMP(2);
     M3_BARRIER();  // top(0) refills W1 stage 0: every wave must be done with slab 0 first
     top(0);
-    m3_iteration<true, false, GEL, RD>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<true, false, GEL, RD, IL>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
     pfb[0] = pfa[0];
     pfb[1] = pfa[1];
     // steady state: one basic block per iteration
@@ -812,7 +822,7 @@ __device__ __forceinline__ void m3_kernel_body(
     for (int s = 1; s + 1 < nslab; ++s) {
         if (s == 17) { M3_STAMP(4); }
         top(s);
-        m3_iteration<true, true, GEL, RD>(w1_stage(s), w2_stage(s), a1, b20, b21, b1s + 32 * (s + 1) + 4 * g, xf, accn, acc, pfb, pfa, o);
+        m3_iteration<true, true, GEL, RD, IL>(w1_stage(s), w2_stage(s), a1, b20, b21, b1s + 32 * (s + 1) + 4 * g, xf, accn, acc, pfb, pfa, o);
         pfb[0] = pfa[0];
         pfb[1] = pfa[1];
     }
@@ -983,8 +993,8 @@ static int m3_launch_tail(const void* d_attn, const void* d_resid, const void* d
         }
     } else {
         switch (abl) {
-            M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856);
-            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps) and 64 + {256, 512, 1024}");
+            M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856); M3P_GO(4096); M3P_GO(4160);
+            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps), 64 + {256, 512, 1024} and {0, 64} + 4096 (alternating products)");
         }
     }
 #undef M3P_GO
@@ -1030,7 +1040,7 @@ int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1,
                            (int)tokens, ffn, eps);                                                                                      \
         break
     switch (abl) {
-        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7); M3_GO(8); M3_GO(16); M3_GO(32); M3_GO(48); M3_GO(64); M3_GO(65); M3_GO(66); M3_GO(68); M3_GO(71); M3_GO(128); M3_GO(192); M3_GO(96); M3_GO(224);
+        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7); M3_GO(8); M3_GO(16); M3_GO(32); M3_GO(48); M3_GO(64); M3_GO(65); M3_GO(66); M3_GO(68); M3_GO(71); M3_GO(128); M3_GO(192); M3_GO(96); M3_GO(224); M3_GO(4096);
         default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: unknown combination");
     }
 #undef M3_GO

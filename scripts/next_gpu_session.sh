@@ -11,4 +11,9 @@ timeout -k 5 60 $KB 4096 2 ln > $OUT/probe.log 2>&1 || { echo "BOX UNHEALTHY"; c
 timeout -k 5 120 $KB 4000 5 tailqkv > $OUT/kbench_tailqkv_small.jsonl 2> $OUT/kbench.err; echo "== small rc=$?"; grep -E "tail_qkv|ws_h384" $OUT/kbench_tailqkv_small.jsonl | cut -c1-300
 timeout -k 5 200 $KB 262107 20 tailqkv > $OUT/kbench_tailqkv.jsonl 2>> $OUT/kbench.err; echo "== 262k rc=$?"; grep -E "tail_qkv|ws_h384" $OUT/kbench_tailqkv.jsonl | cut -c1-300; tail -3 $OUT/kbench.err
 timeout -k 10 300 python -m pytest tests/test_gpu_next.py -m gpu_next -q > $OUT/pytest_gpu_next.log 2>&1; echo "rc=$? $(tail -1 $OUT/pytest_gpu_next.log)"; grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu_next.log | head
+# 4. opt-in slot order of the feed-forward loop (the two products alternate, single first-product chain): interleaved A/B on one box
+for i in 1 2; do
+  timeout -k 5 200 $KB 262107 20 tail > $OUT/kbench_tail_plain_$i.jsonl 2>> $OUT/kbench.err; echo "== plain order"; grep one.launch $OUT/kbench_tail_plain_$i.jsonl | cut -c1-220
+  LEANN_MI355X_ABLATE=4096 timeout -k 5 200 $KB 262107 20 tail > $OUT/kbench_tail_alternating_$i.jsonl 2>> $OUT/kbench.err; echo "== alternating products"; grep one.launch $OUT/kbench_tail_alternating_$i.jsonl | cut -c1-220
+done
 for v in 0 1; do LEANN_MI355X_QKV_IN_TAIL=$v timeout -k 10 200 python scripts/subbatch_bench.py 2> /dev/null | grep '"fused_layer_tail": "1", "sub_batch_tokens": 524160' | sed "s/^/QKV_IN_TAIL=$v /"; done

@@ -498,6 +498,18 @@ def case_mlp_v3_and_tail():
                                                   vp(pack_w1_acc_order(torch.from_numpy(w1)).numpy()), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(ot),
                                                   T, F, 1e-12, None), "tail")
     assert np.abs(ot.astype(f64) - mlp(x1, w1, b1, w2, b2, g2, be2)).max() < 1.2e-2
+    # opt-in slot order (LEANN_MI355X_ABLATE=4096): the two products of an iteration alternate, the first one is a single chain
+    os.environ["LEANN_MI355X_ABLATE"] = "4096"
+    os.environ["LEANN_MI355X_MLP_VARIANT"] = "3"
+    o3i, oti = np.zeros((T, H), np.float16), np.zeros((T, H), np.float16)
+    _lib.check(lib.lm_mlp_fused_h384_f16(vp(rs), vp(w1), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(o3i), T, F, 1e-12, None), "mlp3 alternating")
+    _lib.check(lib.lm_attn_out_mlp_fused_h384_f16(vp(at), vp(rs), vp(pack_wo_slabs(torch.from_numpy(wo)).numpy()), vp(bo), vp(g1), vp(be1), 1e-12,
+                                                  vp(pack_w1_acc_order(torch.from_numpy(w1)).numpy()), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(oti),
+                                                  T, F, 1e-12, None), "tail alternating")
+    os.environ.pop("LEANN_MI355X_ABLATE")
+    os.environ.pop("LEANN_MI355X_MLP_VARIANT")
+    assert np.abs(o3i.astype(f64) - o3.astype(f64)).max() < 4e-3 and np.abs(oti.astype(f64) - ot.astype(f64)).max() < 4e-3  # summation order only
+    assert np.abs(oti.astype(f64) - mlp(x1, w1, b1, w2, b2, g2, be2)).max() < 1.2e-2
     # ... and with the next layer's QKV projection behind it (opt-in form): y and qkv = y W_qkv^T + b_qkv from one launch
     from leann_amd.encoder import pack_wqkv_slabs
 
