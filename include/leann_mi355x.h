@@ -294,6 +294,37 @@ int lm_gemm_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int
 int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, int32_t n_out, void *d_out, int64_t tokens,
                         void *stream);
 
+/* ---- the whole packed BERT forward (hidden 384, mean pooling) in one call ---------------------
+ * Replaces compute_embeddings' model.encode() (leann/embedding_compute.py:229-239) for sentence-transformers models of the
+ * all-MiniLM family: embedding front end, per layer {lm_gemm_ws_h384_f16 (QKV), lm_attn_varlen_hd32_f16,
+ * lm_attn_out_mlp_fused_h384_f16}, lm_meanpool_varlen_f16 -- one foreign-function call per recompute round instead of ~3 L + 2.
+ * All pointers are device pointers except `layers` (host array).  Weight layouts as documented at the entry points named above
+ * (leann_amd/encoder.py: pack_wo_slabs, pack_w1_acc_order, pack_w2_fused_mlp).  d_out: fp32 [n_seqs][384]. */
+typedef struct lm_bert_h384_layer {
+    const void *wqkv;  /* [1152][384] fp16, nn.Linear layout */
+    const float *bqkv; /* [1152] */
+    const void *wo_p;  /* [12][384][32] */
+    const float *bo;
+    const void *ln1_gamma, *ln1_beta; /* fp16 [384] */
+    const void *w1acc;                /* [ffn][384], columns in accumulator order */
+    const float *b1;
+    const void *w2p; /* [ffn/32][384][32] */
+    const float *b2;
+    const void *ln2_gamma, *ln2_beta;
+} lm_bert_h384_layer;
+
+typedef struct lm_bert_h384 {
+    int32_t n_layers, heads, ffn, normalize;
+    float ln_eps;
+    const void *word, *pos_table, *type0, *emb_gamma, *emb_beta; /* fp16 */
+    const lm_bert_h384_layer *layers;                           /* host array of n_layers entries */
+} lm_bert_h384;
+
+size_t lm_bert_h384_workspace_bytes(int64_t total_tokens);
+int lm_bert_h384_forward_packed(const lm_bert_h384 *m, const int32_t *d_tok, const int32_t *d_pos, const int32_t *d_cu_seqlens,
+                                int32_t n_seqs, int64_t total_tokens, int32_t max_len, void *d_workspace, size_t workspace_bytes,
+                                float *d_out, void *stream);
+
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
  * compute_embeddings (leann/embedding_compute.py:229-239) at query time: passages are tokenised

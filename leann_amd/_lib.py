@@ -62,6 +62,16 @@ class PqSearchParams(C.Structure):
     ]
 
 
+class BertH384Layer(C.Structure):  # include/leann_mi355x.h: lm_bert_h384_layer
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo_p", "bo", "ln1_gamma", "ln1_beta", "w1acc", "b1", "w2p", "b2", "ln2_gamma", "ln2_beta")]
+
+
+class BertH384(C.Structure):  # include/leann_mi355x.h: lm_bert_h384
+    _fields_ = [("n_layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("normalize", C.c_int32), ("ln_eps", C.c_float),
+                ("word", C.c_void_p), ("pos_table", C.c_void_p), ("type0", C.c_void_p), ("emb_gamma", C.c_void_p), ("emb_beta", C.c_void_p),
+                ("layers", C.POINTER(BertH384Layer))]
+
+
 PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p)
 
 # every symbol include/leann_mi355x.h declares (checked by tests/test_abi.py)
@@ -76,6 +86,7 @@ EXPORTED_SYMBOLS = [
     "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
     "lm_mlp_fused_h384_f16", "lm_attn_out_mlp_fused_h384_f16", "lm_layer_tail_qkv_fused_h384_f16", "lm_linear_h384_f16", "lm_gemm_h384_f16", "lm_gemm_ws_h384_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
+    "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
 ]
 
 _lib = None
@@ -137,6 +148,9 @@ def load() -> C.CDLL:
     lib.lm_tokens_gather.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.lm_tokens_count.argtypes = [vp]
     lib.lm_tokens_count.restype = i64
+    lib.lm_bert_h384_workspace_bytes.argtypes = [i64]
+    lib.lm_bert_h384_workspace_bytes.restype = C.c_size_t
+    lib.lm_bert_h384_forward_packed.argtypes = [C.POINTER(BertH384), vp, vp, vp, i32, i64, i32, vp, C.c_size_t, vp, vp]
     _lib = lib
     return lib
 

@@ -1,0 +1,48 @@
+// lm_encoder_forward.cpp -- the whole packed BERT forward for hidden 384 as ONE C-ABI call: embedding front end, per layer
+// {weight-stationary QKV GEMM, varlen attention, fused layer tail}, mean pooling.  Host code only: it strings together the
+// library's own entry points on one stream, so a search round costs one foreign-function call instead of ~3 L + 2 (at one query per
+// call a round recomputes ~5 chunks and the ~20 Python -> ctypes launches are most of its time).  What it replaces in the
+// reference: compute_embeddings' model.encode() call (leann/embedding_compute.py:229-239) for sentence-transformers models with
+// mean pooling (all-MiniLM-L6-v2 and relatives).  Opt-in from leann_amd/encoder.py with LEANN_MI355X_ONECALL=1 until its
+// latency has been measured on the MI355X; it runs in the thread-per-lane emulation (tests/emulated_search_cases.py).
+#include <cstdint>
+#include <cstdlib>
+
+#include "lm_internal.h"
+
+extern "C" size_t lm_bert_h384_workspace_bytes(int64_t total_tokens) {
+    return total_tokens <= 0 ? 0 : (size_t)total_tokens * (3 * 384 + 1152) * 2;  // x, attention output, y: [T][384]; qkv: [T][1152]; fp16
+}
+
+extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t* d_tok, const int32_t* d_pos, const int32_t* d_cu_seqlens,
+                                           int32_t n_seqs, int64_t total_tokens, int32_t max_len, void* d_workspace, size_t workspace_bytes,
+                                           float* d_out, void* stream) {
+    using namespace lm;
+    if (n_seqs == 0 || total_tokens == 0) return LM_OK;
+    if (!m || !m->layers || !d_tok || !d_pos || !d_cu_seqlens || !d_workspace || !d_out || n_seqs < 0 || total_tokens < 0)
+        LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: bad arguments");
+    if (m->n_layers <= 0 || m->heads * 32 != 384 || m->ffn < 128 || m->ffn > 2560 || m->ffn % 32)
+        LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: needs hidden 384 = heads x 32 and 128 <= ffn <= 2560, ffn % 32 == 0");
+    if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: sequence lengths 1..256");
+    if (workspace_bytes < lm_bert_h384_workspace_bytes(total_tokens)) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: workspace too small");
+    const size_t row = (size_t)total_tokens * 384 * 2;
+    unsigned char* ws = (unsigned char*)d_workspace;
+    void* x = ws;
+    void* a = ws + row;
+    void* y = ws + 2 * row;
+    void* qkv = ws + 3 * row;
+    int rc = lm_embed_layernorm_f16(d_tok, d_pos, m->word, m->pos_table, m->type0, m->emb_gamma, m->emb_beta, x, total_tokens, 384, m->ln_eps, stream);
+    if (rc) return rc;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const lm_bert_h384_layer& L = m->layers[l];
+        if ((rc = lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream))) return rc;
+        if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
+        if ((rc = lm_attn_out_mlp_fused_h384_f16(a, x, L.wo_p, L.bo, L.ln1_gamma, L.ln1_beta, m->ln_eps, L.w1acc, L.b1, L.w2p, L.b2, L.ln2_gamma,
+                                                 L.ln2_beta, y, total_tokens, m->ffn, m->ln_eps, stream)))
+            return rc;
+        void* t = x;
+        x = y;
+        y = t;
+    }
+    return lm_meanpool_varlen_f16(x, d_cu_seqlens, n_seqs, 384, m->normalize, d_out, stream);
+}

@@ -622,9 +622,62 @@ class BertEncoder(nn.Module):
     # ---- packed (padding-free) path: varlen flash attention, every other op on [total_tokens, H] ----
     _varlen_ok: Optional[bool] = None  # resolved on first use (per process)
 
+    def _forward_one_call(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
+        """The whole packed forward as ONE call into the library (csrc/lm_encoder_forward.cpp: lm_bert_h384_forward_packed) -- the same
+        kernels as the default path, strung together on the C++ side, so a recompute round costs one ctypes call instead of ~3 L + 2.
+        Opt-in (LEANN_MI355X_ONECALL=1) until its effect on small-batch latency has been measured; hidden 384 = heads x 32, fp16,
+        mean pooling, lengths <= 256, no A/B switch set, no per-kernel timers running.  None = not applicable."""
+        import os
+
+        cfg = self.cfg
+        if os.environ.get("LEANN_MI355X_ONECALL", "0") != "1" or KernelTimers.active is not None:
+            return None
+        if any(k.startswith("LEANN_MI355X_") and k not in ("LEANN_MI355X_ONECALL", "LEANN_MI355X_STAGGER") for k in os.environ):
+            return None  # an A/B run of a particular kernel generation goes through the per-kernel path
+        w = self.word.weight
+        if not (tok.is_cuda and w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling == "mean"
+                and 0 < max_len <= 256 and cfg.ffn % 32 == 0 and 128 <= cfg.ffn <= 2560 and tok.dtype == torch.int32 and pos.dtype == torch.int32
+                and cu.dtype == torch.int32):
+            return None
+        import ctypes as C
+
+        from . import _lib
+
+        pk = getattr(self, "_onecall_pack", None)
+        if pk is None or pk["device"] != tok.device:
+            keep, layers = [], (_lib.BertH384Layer * cfg.layers)()
+            ptr = lambda t: (keep.append(t), t.data_ptr())[1]  # noqa: E731 - tensors stay referenced for the life of the pack
+            for li, L in enumerate(self.layers):
+                vals = (L.qkv.weight.detach().contiguous(), L.qkv.bias.detach().float().contiguous(), pack_wo_slabs(L.out.weight.detach()),
+                        L.out.bias.detach().float().contiguous(), L.ln1.weight.detach().contiguous(), L.ln1.bias.detach().contiguous(),
+                        pack_w1_acc_order(L.fc1.weight.detach()), L.fc1.bias.detach().float().contiguous(), pack_w2_fused_mlp(L.fc2.weight.detach()),
+                        L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous())
+                for (name, _), v in zip(_lib.BertH384Layer._fields_, vals):
+                    setattr(layers[li], name, ptr(v))
+            m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, float(self.ln.eps), ptr(w.detach()),
+                              ptr(self.pos.weight.detach()), ptr(self.tok_type.weight[0].detach().contiguous()), ptr(self.ln.weight.detach()),
+                              ptr(self.ln.bias.detach()), layers)
+            pk = {"device": tok.device, "model": m, "layers": layers, "keep": keep}
+            self._onecall_pack = pk
+        lib = _lib.load()
+        tot, n = tok.shape[0], cu.shape[0] - 1
+        need = int(lib.lm_bert_h384_workspace_bytes(tot))
+        ws = getattr(self, "_onecall_ws", None)
+        if ws is None or ws.device != tok.device or ws.numel() < need:
+            ws = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=tok.device)
+            self._onecall_ws = ws
+        out = torch.empty((n, 384), dtype=torch.float32, device=tok.device)
+        _lib.check(lib.lm_bert_h384_forward_packed(C.byref(pk["model"]), C.c_void_p(tok.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(cu.data_ptr()),
+                                                   n, tot, int(max_len), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(tok.device).cuda_stream)), "lm_bert_h384_forward_packed")
+        return out
+
     def forward_packed(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, seq_of: torch.Tensor,
                        lengths: torch.Tensor, max_len: int) -> torch.Tensor:
         cfg = self.cfg
+        one = self._forward_one_call(tok, pos, cu, max_len)
+        if one is not None:
+            return one
         x = fused_embed_layernorm(tok, pos, self.word, self.pos, self.tok_type.weight[0], self.ln)
         if x is None:
             x = fused_add_layernorm(self.word(tok) + self.tok_type.weight[0][None], self.pos(pos), self.ln)

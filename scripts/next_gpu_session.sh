@@ -17,3 +17,5 @@ for i in 1 2; do
   LEANN_MI355X_ABLATE=4096 timeout -k 5 200 $KB 262107 20 tail > $OUT/kbench_tail_alternating_$i.jsonl 2>> $OUT/kbench.err; echo "== alternating products"; grep one.launch $OUT/kbench_tail_alternating_$i.jsonl | cut -c1-220
 done
 for v in 0 1; do LEANN_MI355X_QKV_IN_TAIL=$v timeout -k 10 200 python scripts/subbatch_bench.py 2> /dev/null | grep '"fused_layer_tail": "1", "sub_batch_tokens": 524160' | sed "s/^/QKV_IN_TAIL=$v /"; done
+# 5. one library call per forward (csrc/lm_encoder_forward.cpp) vs the per-kernel calls: small-batch latency on a 200k-chunk index
+for v in 0 1; do LEANN_MI355X_ONECALL=$v timeout -k 10 300 python scripts/latency_bench.py 2> /dev/null | tail -1 | cut -c1-400; done

@@ -638,6 +638,22 @@ def case_encoder_python_wiring():
         assert counts3 == want and used.count("lm_attn_varlen_hd32_f16") == 2 and "lm_add_layernorm_f16" not in used, (ffn, counts3, sorted(set(used)))
         err3 = float((got3.float() - ref3).abs().max())
         assert err3 < 6e-3, (ffn, err3)
+    # opt-in: the whole forward as ONE library call (csrc/lm_encoder_forward.cpp) -- same kernels, same result as the default path
+    cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=128, max_pos=64, max_seq_length=48)
+    e1 = BertEncoder.random_init(cfg1, 5).eval().half()
+    outs = {}
+    for onecall in ("0", "1"):
+        used.clear()
+        env1 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+        env1["LEANN_MI355X_ONECALL"] = onecall
+        with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+                mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env1, clear=True), \
+                mock.patch.object(_lib, "check", new=recording_check):
+            with torch.no_grad():
+                outs[onecall] = e1.encode_tokens_packed(ti, tl, 4096)
+        if onecall == "1":
+            assert used.count("lm_bert_h384_forward_packed") == 1 and "lm_gemm_ws_h384_f16" not in used, sorted(set(used))
+    assert torch.equal(outs["0"], outs["1"])
     err = float((got.float() - ref).abs().max())
     print(f"encoder.py packed forward, every switch on, through the emulated library: max|diff| vs fp32 torch = {err:.2e}", flush=True)
     assert err < 6e-3, err
