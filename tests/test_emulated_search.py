@@ -30,7 +30,9 @@ def test_product_library_on_the_cpu_matches_the_oracle(emul_dir):
     lib = build_emul_lib.build(emul_dir)
     r = subprocess.run([sys.executable, "-m", "tests.emulated_search_cases", str(lib)], cwd=str(ROOT), capture_output=True, text=True,
                        timeout=1800)
-    assert r.returncode == 0 and "ALL CASES OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    if r.returncode != 0 or "ALL CASES OK" not in r.stdout:  # keep the whole transcript: the tail alone does not always name the case
+        (emul_dir / "emulated_cases_failure.log").write_text(r.stdout + "\n==== stderr ====\n" + r.stderr)
+    assert r.returncode == 0 and "ALL CASES OK" in r.stdout, f"(full log: {emul_dir / 'emulated_cases_failure.log'})\n" + r.stdout[-3000:] + r.stderr[-5000:]
     assert "MISMATCH" not in r.stdout
 
 
