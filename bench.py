@@ -8,9 +8,11 @@ lm_index_search_device(recompute=1) -> per round: CSR expand / visited / dedup k
 gather, BERT forward (PyTorch-ROCm fp16), fused distance + beam-update kernel.  Queries, graph,
 token store and results are HBM resident when the timed region starts.
 
-Encoder kernels: the default set (the one `pytest -m gpu` tests).  `--autotune` additionally lets
-leann_amd.autotune A/B the remaining switchable kernels in a child process before the GPU is touched (recorded in
-the JSON line); the timed steps run with profiling OFF, the roofline figures come from one extra profiled step.
+Encoder kernels: the default set (the one `pytest -m gpu` tests).  Instrumentation inside the timed region: ONE HIP event
+pair around each launch of the dominant kernel (the contract's "measured live with HIP events over the timed region"; ~4k
+pairs per step, ~2 us each against ~1.4 ms launches -- stated in the JSON line as roofline.instrumentation); the search
+library's own per-launch profiling (event pairs + device span stamps around the distance kernels) is OFF in the timed steps
+and ON only in one extra profiled step, which is where roofline_distance_kernel / roofline_encoder come from.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 For N > 1 the driver launches one rank per GPU through torch.distributed.run; the graph and the
@@ -62,7 +64,6 @@ def main():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
     ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows")
     ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
-    ap.add_argument("--autotune", action="store_true", help="A/B the switchable encoder kernels at start-up (leann_amd.autotune); default: the tested default set")
     args = ap.parse_args()
     if args.config in ("c3", "c4"):  # own entry points (different index type / sharded index); same JSON contract
         import runpy
@@ -85,18 +86,6 @@ def main():
             args.model = "BAAI/bge-base-en-v1.5"
         if args.batch == defaults["batch"]:
             args.batch = max(1, 1024 // int(os.environ.get("WORLD_SIZE", "1")))
-
-    # ---- encoder kernel selection (untimed set-up, before this process touches the GPU): a child process checks the
-    #      second-generation kernels against the default path on this GPU and keeps those that agree AND are faster ----
-    from leann_amd import autotune as _at
-
-    autotune_report = None
-    if args.autotune and not any(k in os.environ for k in _at.ALL_KEYS):
-        t_at = time.time()
-        autotune_report = _at.pick_encoder_switches(device=int(os.environ.get("LOCAL_RANK", "0")), model=args.model, tol=5e-3)
-        os.environ.update(autotune_report["switches"])
-        autotune_report["seconds"] = round(time.time() - t_at, 1)
-        log(f"encoder autotune ({autotune_report['seconds']}s): {autotune_report['switches'] or 'default path'}")
 
     import torch
     import torch.distributed as dist
@@ -361,6 +350,8 @@ def main():
     # ---- small-batch latency (B = 1, 16, 64, 256) and the parity check on this very index: untimed extras, rank 0 / N = 1 ----
     latency_rows = parity = None
     next_row = B * (K + W + 5)
+    ktimes, kall = ktm.totals("timed"), ktm.totals()
+    KernelTimers.active = None  # from here on the product's default launch path (one library call per forward), no event pairs
     if world == 1 and not args.no_latency_rows:
         try:
             latency_rows, next_row = small_batch_latency(
@@ -420,8 +411,6 @@ def main():
     # LayerNorm, feed-forward block, LayerNorm: 70 % of the encoder's flops, the largest share of the step's time), MFMA bound;
     # duration = HIP event pairs around every one of its launches in the timed region (torch's current stream = the stream it is
     # launched on).  Algorithmic flops per token: 4 * ffn * hidden + 2 * hidden^2.
-    ktimes, kall = ktm.totals("timed"), ktm.totals()
-    KernelTimers.active = None
     kname, kdesc, fpt = "attn_out_mlp_h384", ("lm::k_attn_out_mlp_h384<0> (attention output projection + residual + LayerNorm + fc1 + GELU + fc2 + "
                                               "residual + LayerNorm in one kernel)"), 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden
     if not ktimes.get(kname, {}).get("launches"):  # LEANN_MI355X_TAIL=0: the feed-forward block alone
@@ -450,7 +439,9 @@ def main():
                     "all_launches_of_the_process": {"launches": mlp_all["launches"], "avg_launch_us": round(1e3 * mlp_all["ms"] / max(mlp_all["launches"], 1), 1),
                                                     "TFLOPs": round(mlp_all["work"] / (mlp_all["ms"] * 1e-3) / 1e12, 2),
                                                     "note": "corpus embedding, warm-up, timed, profiled and extra steps together: the population a rocprofv3 --kernel-trace --stats table of this command averages"},
-                    "timing": "HIP event pairs around every launch of the timed region (torch's current stream = the launch stream)"}
+                    "timing": "HIP event pairs around every launch of the timed region (torch's current stream = the launch stream)",
+                    "instrumentation": f"the timed region contains these {mlp['launches']} event pairs (2 records per launch of this kernel, nothing else); "
+                                       "the per-kernel launch path they require (one-call forward off) is throughput-identical at this batch size"}
     else:  # encoder without the fused block (hidden != 384): fall back to the distance kernel's line
         roofline = roofline_dist
     result = {
@@ -458,7 +449,7 @@ def main():
                    f"queries/sec at recall@10>=0.9, {args.chunks}-chunk HNSW, {args.model} fp16 recompute (BASELINE.json configs[4])"),
         "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * elapsed / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "encoder_dtype": "fp16 (fp32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "fp16", "dtype_detail": "encoder (99.9 % of the arithmetic): fp16 MFMA with fp32 accumulation = the reference's CUDA precision (embedding_compute.py:157-162); distances, beam update and top-k: f32", "data": "synthetic",
         "config": {"workload": f"{args.chunks} synthetic chunks (topic model, {'len~N(180,50)' if not args.fixed_len else 'every chunk ' + str(args.fixed_len) + ' tokens'}), HNSW M={args.M} GPU-built, "
                                f"{args.model} shape (random init), ef_search={ef}, beam={args.beam}, top-10, "
                                f"{B} queries/step/GPU, queries partitioned over {world} GPU(s), graph replicated",
@@ -467,7 +458,6 @@ def main():
                    "multi_gpu_path": "leann_amd.distributed.PartitionedSearch (index built on rank 0 and broadcast; per-step all_gather of the results)"},
         "recall_at_10": round(rec, 4),
         "encoder_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LEANN_MI355X_")},  # kernels in effect
-        "encoder_autotune": autotune_report,
         "roofline": roofline, "roofline_distance_kernel": roofline_dist, "roofline_encoder": roofline_encoder,
         "ef_sweep": sweep,
         "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),

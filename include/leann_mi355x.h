@@ -205,7 +205,8 @@ int lm_topk_merge(const int64_t *d_in_ids, const float *d_in_dist, int32_t S, in
 /* ---- fused encoder elementwise ops ---------------------------------------------------------------
  * out = LayerNorm(x + residual) * gamma + beta over the last dim; fp16 in/out, fp32 arithmetic;
  * residual may be NULL.  Part of the BERT forward inside compute_embeddings
- * (leann/embedding_compute.py:229-239); GEMMs/attention stay in hipBLASLt/SDPA. */
+ * (leann/embedding_compute.py:229-239).  The GEMMs and the attention of that forward are the hand-written MFMA kernels below
+ * (hidden 384: lm_gemm_ws_h384_f16, lm_attn_varlen_hd32_f16, lm_attn_out_mlp_fused_h384_f16); no library call is on the default path. */
 int lm_add_layernorm_f16(const void *d_x, const void *d_residual, const void *d_gamma, const void *d_beta,
                          void *d_out, int64_t rows, int32_t hidden, float eps, void *stream);
 
@@ -215,22 +216,27 @@ int lm_add_layernorm_f16(const void *d_x, const void *d_residual, const void *d_
 int lm_attn_varlen_hd32_f16(const void *d_qkv, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t heads,
                             int32_t max_len, void *d_out, void *stream);
 
+/* The same kernel for head_dim 32 or 64 (hidden = heads * head_dim; 64: bge-base / contriever, lengths 1..512; 32: lengths 1..256):
+ * d_qkv [total_tokens][3][heads][head_dim] fp16, d_out [total_tokens][heads * head_dim] fp16. */
+int lm_attn_varlen_f16(const void *d_qkv, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t head_dim,
+                       int32_t max_len, void *d_out, void *stream);
+
 /* Embedding front end in one pass: d_out[r] = LayerNorm(half(word[tok[r]] + type0) + pos_table[pos[r]]);
  * tables and output fp16, hidden <= 768.  Replaces the three gathers/adds before the embedding LayerNorm of
- * the BERT forward (leann/embedding_compute.py:229-239).  The Python host uses it only with
- * LEANN_MI355X_EMBED=1 until it has been validated on hardware. */
+ * the BERT forward (leann/embedding_compute.py:229-239).  On the Python host's default path (LEANN_MI355X_EMBED=0 selects
+ * the torch ops for A/B runs). */
 int lm_embed_layernorm_f16(const int32_t *d_tok, const int32_t *d_pos, const void *d_word, const void *d_pos_table,
                            const void *d_type0, const void *d_gamma, const void *d_beta, void *d_out, int64_t rows,
                            int32_t hidden, float eps, void *stream);
 
 /* Packing front end: padded token ids [n][t] + lengths + cumulative lengths (int32[n+1]) -> packed token ids and
- * positions [total].  Replaces the masked selects before the first encoder layer.  Host switch: LEANN_MI355X_PACK=1. */
+ * positions [total].  Replaces the masked selects before the first encoder layer.  On the default path (LEANN_MI355X_PACK=0 = torch ops, A/B). */
 int lm_pack_tokens(const int32_t *d_ids, const int32_t *d_lens, const int32_t *d_cu_seqlens, int32_t n, int32_t t,
                    int32_t *d_tok, int32_t *d_pos, void *stream);
 
 /* Mean pooling over the tokens of each packed sequence (+ optional L2 normalisation), fp16 in, fp32 out
  * [n_seqs][hidden]; fixed summation order (deterministic).  sentence-transformers Pooling as done in
- * leann/embedding_compute.py:323-334.  Host switch: LEANN_MI355X_POOL=1. */
+ * leann/embedding_compute.py:323-334.  On the default path (LEANN_MI355X_POOL=0 = torch ops, A/B). */
 int lm_meanpool_varlen_f16(const void *d_x, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t hidden,
                            int32_t normalize, float *d_out, void *stream);
 
@@ -239,7 +245,8 @@ int lm_meanpool_varlen_f16(const void *d_x, const int32_t *d_cu_seqlens, int32_t
  * d_w1 [ffn][384] fp16 (nn.Linear layout), d_w2p = W2 packed as [ffn/32][384][32] fp16 with the k order of
  * leann_amd/encoder.py: fused_mlp_k_permutation, biases fp32, GELU = exact erf form, ffn % 32 == 0.
  * MFMA 32x32x16 f16 with the 1536-wide intermediate held in accumulators (never written to HBM).  Part of the
- * BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).  Host switch: LEANN_MI355X_MLP=1. */
+ * BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).  Used when the fused layer tail below is switched off
+ * (LEANN_MI355X_TAIL=0, A/B); LEANN_MI355X_MLP=0 = library GEMMs (A/B). */
 int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, const void *d_w2p, const float *d_b2,
                           const void *d_gamma, const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps,
                           void *stream);
@@ -253,23 +260,11 @@ int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, 
  * d_w2p as for lm_mlp_fused_h384_f16; biases fp32; 128 <= ffn <= 2560, ffn % 32 == 0.  Replaces
  * lm_gemm_ws_h384_f16 (n_out 384) + lm_add_layernorm_f16 + lm_mlp_fused_h384_f16: two launches and three passes
  * over the activations fewer.  Part of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).
- * Host switch: LEANN_MI355X_TAIL=1. */
+ * DEFAULT path of the Python host for hidden 384 (LEANN_MI355X_TAIL=0 = the three-launch form, A/B). */
 int lm_attn_out_mlp_fused_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_p, const float *d_bo,
                                    const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1acc,
                                    const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
                                    const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps, void *stream);
-
-/* The same with the NEXT layer's QKV projection of d_out behind it in the same launch:
- *   d_qkv_out[tokens][1152] = d_out W_qkv^T + b_qkv   (fp16; d_out is written as well: it is the next layer's residual),
- * d_wqkv_p = W_qkv [1152][384] packed as [36][384][32]: slab 12 p + s = rows 384 p .. 384 p + 383, input features of k slab s
- * in the order of leann_amd/encoder.py: fused_mlp_k_permutation (pack_wqkv_slabs); ffn >= 1152.  Replaces lm_gemm_ws_h384_f16
- * (n_out 1152) of the next layer.  Opt-in host switch: LEANN_MI355X_QKV_IN_TAIL=1 (validated in emulation and by the GPU tests;
- * not the default until its speed has been measured on the MI355X). */
-int lm_layer_tail_qkv_fused_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_p, const float *d_bo,
-                                     const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1acc,
-                                     const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
-                                     const void *d_beta, void *d_out, const void *d_wqkv_p, const float *d_bqkv,
-                                     void *d_qkv_out, int64_t tokens, int32_t ffn, float eps, void *stream);
 
 /* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
  *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
@@ -277,22 +272,32 @@ int lm_layer_tail_qkv_fused_h384_f16(const void *d_attn, const void *d_resid, co
  * x / out / residual fp16, bias fp32, d_wp = W packed as [P][12][384][32] fp16 (leann_amd/encoder.py:
  * pack_w_linear_h384).  MFMA 32x32x16 f16 with the token slice of x held in registers.  The attention
  * projections of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).
- * Host switch: LEANN_MI355X_LINEAR=1. */
+ * First generation, kept for A/B runs: LEANN_MI355X_LINEAR=1. */
 int lm_linear_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
                        const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
 
 /* Same operation, same arguments and weight packing, second-generation kernel (csrc/lm_gemm_h384.hip): 64 tokens x 192
  * features per wave (every weight fragment read from LDS feeds two MFMAs), weight slabs streamed L2 -> LDS by
- * global_load_lds through four stages with counted waits.  Host switch: LEANN_MI355X_LINEAR=2. */
+ * global_load_lds through four stages with counted waits.  Second generation, kept for A/B runs: LEANN_MI355X_LINEAR=2. */
 int lm_gemm_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
                      const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
 
 /* Weight-stationary form of the 384-input linear layer (csrc/lm_gemm_ws_h384.hip): d_out[tokens][n_out] = x W^T + b with
  * d_w = the nn.Linear weight itself, [n_out][384] fp16 row major (no packing), n_out a multiple of 192 (<= 6144).  A
  * workgroup keeps its 192 x 384 weight block resident in LDS and streams token tiles past it (no per-slab barriers, two
- * waves per SIMD).  Host switch: LEANN_MI355X_LINEAR=3 (QKV projection; output projection followed by lm_add_layernorm_f16). */
+ * waves per SIMD).  DEFAULT for the QKV projection at hidden 384 (LEANN_MI355X_LINEAR=3 is the default value; with the layer tail
+ * switched off also the output projection, followed by lm_add_layernorm_f16). */
 int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, int32_t n_out, void *d_out, int64_t tokens,
                         void *stream);
+
+/* General fp16 linear layer (csrc/lm_gemm_f16.hip):  d_out[tokens][n_out] = epi(x[tokens][k_in] W^T + b), d_w = the nn.Linear weight
+ * itself ([n_out][k_in] fp16 row major, no packing), bias fp32, n_out % 128 == 0, k_in % 128 == 0, operands < 4 GiB each.
+ * epilogue: 0 = none, 1 = exact-erf GELU, 2 = + d_residual[tokens][n_out] (fp16), 3 = both.  256 x 256 workgroup tiles (128 x 128
+ * when n_out % 256 != 0), MFMA 32x32x16 f16, operands staged L2 -> LDS by global_load_lds through two stages.  The GEMMs of the BERT
+ * forward in compute_embeddings (leann/embedding_compute.py:229-239) for models whose hidden size is not 384 (bge-base,
+ * contriever: 768): QKV projection (epilogue 0), attention output projection (2), feed-forward products (1, 2). */
+int lm_gemm_f16(const void *d_x, const void *d_w, const float *d_bias, const void *d_residual, int32_t epilogue, int32_t n_out,
+                int32_t k_in, void *d_out, int64_t tokens, void *stream);
 
 /* ---- the whole packed BERT forward (hidden 384, mean pooling) in one call ---------------------
  * Replaces compute_embeddings' model.encode() (leann/embedding_compute.py:229-239) for sentence-transformers models of the

@@ -83,8 +83,8 @@ EXPORTED_SYMBOLS = [
     "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_event_overhead_us",
     "lm_dist_gather", "lm_topk_merge",
     "lm_pq_attach", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
-    "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
-    "lm_mlp_fused_h384_f16", "lm_attn_out_mlp_fused_h384_f16", "lm_layer_tail_qkv_fused_h384_f16", "lm_linear_h384_f16", "lm_gemm_h384_f16", "lm_gemm_ws_h384_f16", "lm_pack_tokens",
+    "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_attn_varlen_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
+    "lm_mlp_fused_h384_f16", "lm_attn_out_mlp_fused_h384_f16", "lm_linear_h384_f16", "lm_gemm_h384_f16", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
     "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
 ]
@@ -133,14 +133,15 @@ def load() -> C.CDLL:
     lib.lm_pq_batch_search_device.argtypes = [vp, i64, vp, i32, C.POINTER(PqSearchParams), vp, vp]
     lib.lm_add_layernorm_f16.argtypes = [vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
     lib.lm_attn_varlen_hd32_f16.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.lm_attn_varlen_f16.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.lm_embed_layernorm_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
     lib.lm_meanpool_varlen_f16.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.lm_mlp_fused_h384_f16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
     lib.lm_attn_out_mlp_fused_h384_f16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
-    lib.lm_layer_tail_qkv_fused_h384_f16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
     lib.lm_linear_h384_f16.argtypes = [vp, vp, vp, i32, vp, vp, vp, C.c_float, vp, i64, vp]
     lib.lm_gemm_h384_f16.argtypes = [vp, vp, vp, i32, vp, vp, vp, C.c_float, vp, i64, vp]
     lib.lm_gemm_ws_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
+    lib.lm_gemm_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]
     lib.lm_pack_tokens.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.lm_tokens_create.argtypes = [vp, vp, i64, C.c_int, C.POINTER(vp)]
     lib.lm_tokens_free.argtypes = [vp]

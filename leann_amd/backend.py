@@ -181,9 +181,6 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
         # fraction of the highest in-degree nodes whose embeddings stay cached in HBM (LEANN paper section 5;
         # 0 = pure recompute, the reference's behaviour)
         self.hub_cache_ratio = float(kwargs.get("hub_cache_ratio", bk.get("hub_cache_ratio", 0.0)) or 0.0)
-        # probe the second-generation encoder kernels on this GPU before the encoder is first used (leann_amd/autotune.py:
-        # child process, keeps what matches the default path and is faster); off unless asked for
-        self.autotune_kernels = bool(kwargs.get("autotune_kernels", False))
         # Seeded random encoder weights + a stand-in vocabulary when the embedding model's checkpoint is not available
         # locally: ONLY for synthetic corpora / tests whose index was built with the same random encoder.  Off by default:
         # a production index must be searched with the weights it was built from, so a missing checkpoint raises.
@@ -191,7 +188,6 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
 
         self.allow_random_weights = bool(kwargs.get("allow_random_weights", bk.get(
             "allow_random_weights", _os.environ.get("LEANN_MI355X_ALLOW_RANDOM_WEIGHTS", "0") == "1")))
-        self.autotune_report = None
         self._index = None
         self._provider = None
         self._encoder = None
@@ -240,15 +236,6 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             if not self.embedding_model:
                 raise ValueError("Cannot use recompute mode without 'embedding_model' in meta.json.")
             _lib.require_gpu()
-            if self.autotune_kernels and self.autotune_report is None:
-                import os
-
-                from . import autotune
-
-                if not any(k in os.environ for k in autotune.ALL_KEYS):  # explicit switches win
-                    self.autotune_report = autotune.pick_encoder_switches(device=self.device, model=self.embedding_model, tol=5e-3)
-                    os.environ.update(self.autotune_report["switches"])
-                    logger.info(f"encoder kernels: {self.autotune_report['switches'] or 'default path'}")
             enc = BertEncoder.load(self.embedding_model, allow_random=self.allow_random_weights)
             dt = torch.float16 if self.encoder_dtype == "float16" else torch.float32
             self._encoder = enc.to(self._torch_device(), dtype=dt).eval()

@@ -30,10 +30,12 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-constexpr int A2_HD = 32;
-constexpr int A2_KSTRIDE = 40;  // halfs per K row in LDS (80 B): conflict-free ds_read_b128 fragments
-
-template <int NT>  // NT = number of 32-key tiles (max_len <= 32*NT), 1..8
+// HD = head dimension: 32 (hidden 384 = 12 x 32: MiniLM, bge-small) or 64 (hidden 768 = 12 x 64: bge-base, contriever).  K rows are
+// padded by 8 halfs in LDS (80 / 144 bytes: consecutive rows fall on different 16-byte slots of the 256-byte bank row, so the
+// ds_read_b128 fragment reads are conflict free).  At HD = 64 the score tile takes four MFMA k-steps instead of two and the
+// output is two 32 x 32 accumulator tiles (d = 0..31, 32..63); the softmax (the VALU-bound part) is unchanged, so the kernel's
+// MFMA share doubles.
+template <int NT, int HD = 32>  // NT = number of 32-key tiles (max_len <= 32*NT), 1..8 (HD = 64: ..16)
 __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                              __half* __restrict__ out, int heads, float scale_log2e, int n_units) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -50,24 +52,25 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
     const int seq = unit / heads, h = unit % heads;
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
+    constexpr int A2_HD = HD, A2_KSTRIDE = HD + 8, PARTS = HD / 8, KS = HD / 16, DT = HD / 32;
     const int H = heads * A2_HD;
     const int64_t rstride = 3 * (int64_t)H;  // halfs per token row of qkv
     constexpr int Tp = 32 * NT;
     constexpr int VSTRIDE = Tp + 4;                  // halfs per V^T row (even: key pairs are dword aligned)
     _Float16* Ks = (_Float16*)smem;                  // [Tp][A2_KSTRIDE]
-    _Float16* Vt = Ks + (size_t)Tp * A2_KSTRIDE;     // [32][VSTRIDE]
+    _Float16* Vt = Ks + (size_t)Tp * A2_KSTRIDE;     // [HD][VSTRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const _Float16* base = (const _Float16*)qkv + (int64_t)tok0 * rstride + h * A2_HD;
 
     // ---- stage K (row major, padded) and V^T (transposed, padded); rows >= len are zero ----
-    // work item = (key pair, 8-half part): Tp/2 * 4 items; all loads of a thread are issued before its stores
+    // work item = (key pair, 8-half part): Tp/2 * PARTS items; all loads of a thread are issued before its stores
     {
-        constexpr int ITEMS = Tp * 2, NIT = (ITEMS + 255) / 256;
+        constexpr int ITEMS = Tp / 2 * PARTS, NIT = (ITEMS + 255) / 256;
         half8 k0[NIT], k1[NIT], v0[NIT], v1[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = tid + 256 * it;
-            const int key = (c >> 2) * 2, part = c & 3;
+            const int key = (c / PARTS) * 2, part = c % PARTS;
             const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             k0[it] = z; k1[it] = z; v0[it] = z; v1[it] = z;
             if (c < ITEMS && key < len) {
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = tid + 256 * it;
-            const int key = (c >> 2) * 2, part = c & 3;
+            const int key = (c / PARTS) * 2, part = c % PARTS;
             if (c < ITEMS) {
                 *(half8*)(Ks + key * A2_KSTRIDE + part * 8) = k0[it];
                 *(half8*)(Ks + (key + 1) * A2_KSTRIDE + part * 8) = k1[it];
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
     for (int qb = wv; qb * 32 < len; qb += 4) {
         // Q^T fragment (B operand): lane (n = q row, g) holds hd slots 16*ks + 8*g .. +8
         const int qrow = qb * 32 + r31;
-        half8 qf[2];
+        half8 qf[KS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             qf[ks] = qrow < len ? *(const half8*)(base + (int64_t)qrow * rstride + ks * 16 + g * 8) : z;
         }
@@ -115,7 +118,11 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
         // ---- online softmax over chunks of CH 32-key tiles ----
         constexpr int CH = NT < 2 ? NT : 2;
         float mx = -3.0e38f, sum = 0.f;
-        float16v o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        float16v o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 #pragma unroll
         for (int c0 = 0; c0 < NT; c0 += CH) {
             if (c0 * 32 >= len) break;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
                 float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 if (t < NT) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
+                    for (int ks = 0; ks < KS; ++ks) {
                         half8 kf = *(const half8*)(Ks + (t * 32 + r31) * A2_KSTRIDE + ks * 16 + g * 8);  // A: m = key
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], acc, 0, 0, 0);
                     }
@@ -172,7 +179,9 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
             cs += __shfl_xor(cs, 32);
             sum = sum * alpha + cs;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             // O^T += V^T P^T : A = V^T (m = d), B = P^T (n = q); k-slots (g, j) <-> keys the lane already holds
 #pragma unroll
             for (int tt = 0; tt < CH; ++tt) {
@@ -184,24 +193,29 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj) pf[jj] = (_Float16)s[tt][8 * u + jj];
                         // regs 8u..8u+3 -> keys 32t+16u+4g+{0..3} ; regs 8u+4..8u+7 -> keys 32t+16u+8+4g+{0..3}
-                        const _Float16* vrow = Vt + r31 * VSTRIDE + 32 * t + 16 * u + 4 * g;
-                        half4 va = *(const half4*)vrow, vb = *(const half4*)(vrow + 8);
-                        half8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o, 0, 0, 0);
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const _Float16* vrow = Vt + (32 * dt + r31) * VSTRIDE + 32 * t + 16 * u + 4 * g;
+                            half4 va = *(const half4*)vrow, vb = *(const half4*)(vrow + 8);
+                            half8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
         const float inv = 1.0f / sum;
-        // lane (q = r31, g) holds d = (reg&3) + 8*(reg>>2) + 4g
+        // lane (q = r31, g) holds d = 32 dt + (reg&3) + 8*(reg>>2) + 4g
         if (qrow < len) {
             _Float16* orow = (_Float16*)out + (int64_t)(tok0 + qrow) * H + h * A2_HD;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                half4 w = {(_Float16)(o[4 * r4] * inv), (_Float16)(o[4 * r4 + 1] * inv), (_Float16)(o[4 * r4 + 2] * inv),
-                           (_Float16)(o[4 * r4 + 3] * inv)};
-                *(half4*)(orow + 8 * r4 + 4 * g) = w;
-            }
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    half4 w = {(_Float16)(o[dt][4 * r4] * inv), (_Float16)(o[dt][4 * r4 + 1] * inv), (_Float16)(o[dt][4 * r4 + 2] * inv),
+                               (_Float16)(o[dt][4 * r4 + 3] * inv)};
+                    *(half4*)(orow + 32 * dt + 8 * r4 + 4 * g) = w;
+                }
         }
     }
 }
@@ -209,13 +223,14 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
 }  // namespace lm
 
 #ifndef LM_HOST_EMULATION
-// launched by lm_attn_varlen_hd32_f16 (lm_encoder_ops.hip) when LEANN_MI355X_ATTN=2
-int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len,
-                      void* d_out, void* stream) {
+// launched by lm_attn_varlen_hd32_f16 / lm_attn_varlen_f16 (lm_encoder_ops.hip)
+template <int HD>
+static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out,
+                             void* stream) {
     using namespace lm;
     const int nt = (max_len + 31) / 32;
-    const size_t shmem = ((size_t)32 * nt * A2_KSTRIDE + (size_t)32 * (32 * nt + 4)) * 2;
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)A2_HD);
+    const size_t shmem = ((size_t)32 * nt * (HD + 8) + (size_t)HD * (32 * nt + 4)) * 2;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
     const char* xo = getenv("LEANN_MI355X_ATTN_XCD");
     const int n_units = (xo && xo[0] == '0') ? -(n_seqs * heads) : n_seqs * heads;
     dim3 grid((unsigned)((n_seqs * heads + 7) / 8 * 8)), block(256);
@@ -223,12 +238,50 @@ int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_
     const __half* q = (const __half*)d_qkv;
     __half* o = (__half*)d_out;
     switch (nt) {
-#define CASEA(n) case n: hipLaunchKernelGGL((k_attn_varlen_hd32_v2<n>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
+#define CASEA(n)                                                                                                                         \
+    case n: {                                                                                                                            \
+        if (shmem > 48 * 1024) {                                                                                                         \
+            static size_t attr_bytes = 0;                                                                                                \
+            if (shmem > attr_bytes) {                                                                                                    \
+                LM_HIP(hipFuncSetAttribute((const void*)k_attn_varlen_hd32_v2<n, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+                attr_bytes = shmem;                                                                                                      \
+            }                                                                                                                            \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((k_attn_varlen_hd32_v2<n, HD>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units);     \
+    } break
         CASEA(1); CASEA(2); CASEA(3); CASEA(4); CASEA(5); CASEA(6); CASEA(7); CASEA(8);
+        default:
+            if constexpr (HD == 64) {
+                switch (nt) {
+                    CASEA(9); CASEA(10); CASEA(11); CASEA(12); CASEA(13); CASEA(14); CASEA(15); CASEA(16);
+                    default: LM_FAIL(LM_EINVAL, "lm_attn_varlen_f16 (head_dim 64) supports sequence lengths 1..512");
+                }
+            } else {
+                LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
+            }
 #undef CASEA
-        default: LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
     }
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len,
+                      void* d_out, void* stream) {
+    return attn_v2_launch_hd<32>(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
+}
+
+extern "C" int lm_attn_varlen_f16(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t head_dim,
+                                  int32_t max_len, void* d_out, void* stream) {
+    if (n_seqs == 0) return LM_OK;
+    if (!d_qkv || !d_cu_seqlens || !d_out || n_seqs < 0 || heads <= 0 || max_len <= 0) LM_FAIL(LM_EINVAL, "bad attention arguments");
+    if (head_dim == 32) {
+        if (max_len > 256) LM_FAIL(LM_EINVAL, "lm_attn_varlen_f16 (head_dim 32) supports sequence lengths 1..256");
+        return attn_v2_launch_hd<32>(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
+    }
+    if (head_dim == 64) {
+        if (max_len > 512) LM_FAIL(LM_EINVAL, "lm_attn_varlen_f16 (head_dim 64) supports sequence lengths 1..512");
+        return attn_v2_launch_hd<64>(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
+    }
+    LM_FAIL(LM_EINVAL, "lm_attn_varlen_f16: head_dim must be 32 or 64");
 }
 #endif  // LM_HOST_EMULATION

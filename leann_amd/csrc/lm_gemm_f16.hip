@@ -1,0 +1,272 @@
+// lm_gemm_f16.hip -- the GENERAL fp16 linear layer of the encoder:   out[T][N] = epi(x[T][K] W[N][K]^T + b)
+//
+//   epi = identity                      QKV projection                         (N = 3 H)
+//       = exact-erf GELU                first feed-forward product             (N = ffn)
+//       = (.) + residual[T][N]          attention output projection, second feed-forward product (N = H; LayerNorm follows as
+//                                       lm_add_layernorm_f16 with no residual)
+//
+// Why it exists: the hidden-384 kernels (lm_gemm_ws_h384 / lm_mlp_fused_v3) keep a whole 384-wide row of accumulators per wave; at
+// hidden 768 (bge-base, contriever: BASELINE.json configs[4]) that does not fit a wave, and round 2 ran those models on library
+// GEMMs.  This is the hand-written path for them -- any K % 128 == 0, N % 128 == 0 -- and the QKV projection of the 384 models can
+// take it as well.  x and W are both K-contiguous ("B^T input"), so an MFMA fragment is 8 consecutive halfs of a row for either.
+//
+// Shape (MI355X_MICROARCH.md / cdna_hip_programming.md section 5, "glds, 2 LDS buffers, BK = 64"):
+//   * workgroup tile 256 tokens x 256 features (BIG) -- 128 flop per byte moved L2 -> LDS: a 128 x 128 tile at full MFMA rate would
+//     need 64 B/clk/CU from the L2, more than it delivers -- or 128 x 128 (SMALL: N % 256 != 0 and short launches); 8 / 4 waves,
+//     each 128 features x 64 tokens (BIG) as 4 x 2 MFMA tiles of 32x32x16 (128 accumulator registers), two waves per SIMD;
+//   * K in tiles of 64: one LDS stage = [256 W rows | 256 x rows] x 128 B = 64 KB, two stages; every row of a stage is one full
+//     128-byte line fetched by 8 lanes of one global_load_lds_dwordx4 (1 KB per wave-instruction, 8 per wave per K-tile);
+//   * LDS image: lane-linear per DMA piece (the hardware writes base + 16 lane), made conflict-free for the ds_read_b128 fragment
+//     reads by permuting the SOURCE chunks: position (row, c') holds chunk c' ^ ((row >> 1) & 7) of the row.  A fragment read has
+//     lanes 0..31 on 32 consecutive rows at one chunk: within each of the hardware's 16-lane groups ({0-3, 12-15, 20-27}, ...) the
+//     eight row pairs have eight different (row >> 1) & 7, the two rows of a pair sit in different halves of the 256-byte bank row;
+//   * one barrier per K-tile: wait own DMA (vmcnt(0)) -> barrier -> issue the next tile's DMA into the other stage -> 32 MFMAs;
+//   * MFMA orientation: A = W rows (M = features), B = x rows (N = tokens): a lane ends up with 4 consecutive features of ONE
+//     token per accumulator quad -> packed to fp16 and written token-major into a per-wave LDS tile (8-byte writes, rows padded by
+//     8 B: conflict free), read back as whole rows and stored as 256-byte (BIG) row segments: full lines, 16 B per lane.  Bias and
+//     GELU are applied on the way into the tile (fp32), the residual on the way out (fp16 add, as torch's half `+` does);
+//   * the tiles that share an x row block run back to back on ONE XCD (workgroup b -> XCD b % 8 is today's dispatch; any other
+//     mapping costs speed only): x comes from HBM once and from that XCD's L2 afterwards, W stays L2 / Infinity-Cache resident.
+// Role in the reference: the GEMMs of compute_embeddings' BERT forward (leann/embedding_compute.py:229-239) for models whose
+// hidden size is not 384.
+#include <cstdlib>
+#include <cstring>
+
+#include "lm_h384_common.h"
+
+namespace lm {
+
+#ifdef LM_EMULATED_DEVICE
+#define GM_WAIT_VM0() ((void)0)
+#define GM_WAIT_LGKM0() ((void)0)
+#define GM_BARRIER() __syncthreads()
+#define GM_UNIFORM(v) (v)
+#else
+#define GM_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)  // the wave index: keeps everything derived from it in SGPRs
+#define GM_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GM_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define GM_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
+constexpr int GM_EPI_GELU = 1, GM_EPI_RESID = 2;
+
+// exact-erf GELU, fp32, 8.5 instructions and ONE transcendental per value (derivation and error bounds: lm_mlp_fused_v3.hip, FORM 1):
+//   gelu(x) = max(x, 0) - |x| 2^(-1 - u q(u)),  u = |x|,  q = degree-4 fit of -log2(erfc(u / sqrt2)) / u;  |error| < 1e-6 absolute
+__device__ __forceinline__ float gm_gelu(float x) {
+    const float u = fabsf(x);
+    float p = fmaf(u, -0.0004881171917077154f, 0.007198805455118418f);
+    p = fmaf(p, u, -0.052146803587675095f);
+    p = fmaf(p, u, -0.4595957100391388f);
+    p = fmaf(p, u, -1.1510006189346313f);
+    const float w = __builtin_amdgcn_exp2f(fmaf(p, u, -1.0f));
+    return fmaf(-u, w, fmaxf(x, 0.0f));
+}
+
+template <int WF_, int WT_, int TF_, int TT_>
+struct GemmShape {
+    static constexpr int WF = WF_, WT = WT_, TF = TF_, TT = TT_;  // waves along features / tokens, MFMA tiles per wave along each
+    static constexpr int NW = WF * WT, THREADS = 64 * NW;
+    static constexpr int BN = WF * TF * 32, BM = WT * TT * 32;     // features / tokens per workgroup tile
+    static constexpr int STAGE = (BN + BM) * 128;                  // bytes of one K-tile (64 halfs per row)
+    static constexpr int PIECES = (BN + BM) / 8 / NW;              // 1 KB DMA pieces per wave per K-tile
+    static constexpr int RS = TF * 64 + 8;                         // bytes per token row of a wave's output tile (+ 8: conflict-free writes)
+    static constexpr int OUT_TILE = TT * 32 * RS;                  // per wave
+    static constexpr int LDS = 2 * STAGE > NW * OUT_TILE ? 2 * STAGE : NW * OUT_TILE;
+    static_assert((BN + BM) % (8 * NW) == 0 && PIECES % 4 == 0, "DMA pieces must divide evenly over the waves and the four k-steps");
+};
+using GemmBig = GemmShape<2, 4, 4, 2>;    // 256 x 256, 512 threads, 128 accumulator registers per lane
+using GemmSmall = GemmShape<2, 2, 2, 2>;  // 128 x 128, 256 threads, 64 accumulator registers per lane
+
+// grid: 8 * NC * ceil(row_blocks / 8) workgroups (NC = N / BN).  xcd = b % 8, idx = b / 8: row block = (idx / NC) * 8 + xcd,
+// column tile = idx % NC -- the NC tiles of a row block are consecutive dispatches on one XCD.
+template <class S, int EPI>
+__global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
+    const __half* __restrict__ x, const __half* __restrict__ w, const float* __restrict__ bias, const __half* __restrict__ resid,
+    __half* __restrict__ out, int T, int N, int K) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = GM_UNIFORM(tid >> 6);
+    const int r31 = lane & 31, g = lane >> 5;
+    const int NC = N / S::BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int rb = (idx / NC) * 8 + xcd, ct = idx % NC;
+    const int t0 = rb * S::BM, n0 = ct * S::BN;
+    if (t0 >= T) return;  // row-block padding of the last group of eight
+    const int wf = wv % S::WF, wt = wv / S::WF;
+
+    // ---- DMA plan: piece p = wv + NW * i covers stage rows 8 p .. 8 p + 7 (W rows first, then x rows); lane = (row 8 p + lane / 8,
+    //      position c' = lane % 8) fetches chunk c' ^ ((row >> 1) & 7).  Source = wave-uniform base + per-lane 32-bit offset. ----
+    unsigned voff[S::PIECES];
+#pragma unroll
+    for (int i = 0; i < S::PIECES; ++i) {
+        const int p = wv + S::NW * i, row = 8 * p + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (8 * p < S::BN) {
+            voff[i] = (unsigned)(n0 + row) * (unsigned)(K * 2) + c * 16;
+        } else {
+            int tok = t0 + row - S::BN;
+            tok = tok < T ? tok : T - 1;  // rows past the end re-read the last token; their results are never stored
+            voff[i] = (unsigned)tok * (unsigned)(K * 2) + c * 16;
+        }
+    }
+    // piece i of K-tile kt -> stage (wave-uniform source base + this lane's offset)
+    auto issue_piece = [&](int kt, int stage, int i) {
+        const int p = wv + S::NW * i;  // wave uniform
+        const unsigned char* base = (const unsigned char*)(8 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)kt * 128;
+        lm_dma16_sv(base, voff[i], smem + stage * S::STAGE + p * 1024);
+    };
+
+    // ---- fragment addresses: row (tile base + r31), k-step kk (16 halfs): chunk 2 kk + g at position (2 kk + g) ^ ((r31 >> 1) & 7)
+    //      (tile bases are multiples of 32 rows, so the row term of the permutation depends on r31 only) ----
+    int fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = r31 * 128 + ((((2 * kk + g) ^ (r31 >> 1)) & 7) << 4);
+    const int a_base = wf * S::TF * 32 * 128;                 // W rows of this wave
+    const int b_base = S::BN * 128 + wt * S::TT * 32 * 128;   // x rows of this wave
+
+    float16v acc[S::TF][S::TT];
+#pragma unroll
+    for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+        for (int j = 0; j < S::TT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / 64;  // even (K % 128 == 0)
+#pragma unroll
+    for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
+
+    // One K-tile: four k-steps of TF x TT MFMAs.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step kk are issued
+    // (a second register set: the matrix pipe never waits for an LDS round trip inside a tile), and the NEXT tile's DMA pieces are
+    // spread over the steps, PIECES / 4 behind each fragment request, instead of standing in front of the first MFMA (a piece costs
+    // ~60 issue cycles; eight of them back to back on both waves of a SIMD would idle the matrix pipe for a quarter of the tile).
+    // The scheduling barriers pin that order: the register budget (256 per wave) leaves the compiler no room to find it by itself.
+    auto ktile = [&](int stage, int next_kt, bool prefetch) {
+        const unsigned char* sb = smem + stage * S::STAGE;
+        half8 af[2][S::TF], bf[2][S::TT];
+#pragma unroll
+        for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 4096 + fo[0]);
+#pragma unroll
+        for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 4096 + fo[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk & 1, n = c ^ 1;
+            if (kk < 3) {
+#pragma unroll
+                for (int i = 0; i < S::TF; ++i) af[n][i] = *(const half8*)(sb + a_base + i * 4096 + fo[kk + 1]);
+#pragma unroll
+                for (int j = 0; j < S::TT; ++j) bf[n][j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk + 1]);
+            }
+            if (prefetch) {
+#pragma unroll
+                for (int i = 0; i < S::PIECES / 4; ++i) issue_piece(next_kt, stage ^ 1, kk * (S::PIECES / 4) + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+                for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        GM_WAIT_VM0();   // this wave's pieces of tile kt have landed ...
+        GM_BARRIER();    // ... and so have everybody else's; all waves are done reading stage 1 (tile kt - 1)
+        ktile(0, kt + 1, true);
+        GM_WAIT_LGKM0();  // own fragment reads of stage 0 are complete before anybody's DMA may overwrite it
+        GM_WAIT_VM0();
+        GM_BARRIER();
+        ktile(1, kt + 2, kt + 2 < nk);
+        GM_WAIT_LGKM0();
+    }
+    GM_BARRIER();  // every wave is done with the stages: their space becomes the output tiles
+
+    // ---- epilogue 1: + bias (, GELU), fp16, token-major into this wave's LDS tile.  acc[i][j][4 q + e] = feature 32 i + 8 q + 4 g + e of
+    //      token 32 j + r31 (both relative to the wave's sub-tile) ----
+    unsigned char* ot = smem + wv * S::OUT_TILE;
+    const float* bl = bias + n0 + wf * S::TF * 32 + 4 * g;
+#pragma unroll
+    for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4v bb = *(const float4v*)(bl + 32 * i + 8 * q);
+#pragma unroll
+            for (int j = 0; j < S::TT; ++j) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * q + e] + bb[e];
+                    if constexpr ((EPI & GM_EPI_GELU) != 0) v = gm_gelu(v);
+                    h[e] = (_Float16)v;
+                }
+                *(half4*)(ot + (32 * j + r31) * S::RS + (32 * i + 8 * q + 4 * g) * 2) = h;
+            }
+        }
+    LM_WAVE_SYNC();  // the tile is read back by the wave that wrote it: no workgroup barrier
+
+    // ---- epilogue 2: whole rows out.  LPR lanes cover one token's TF * 32 features (16 B each), 64 / LPR rows per instruction ----
+    constexpr int LPR = S::TF * 4, RPI = 64 / LPR;
+    const int lr = lane / LPR, lc = lane % LPR;
+    const int64_t col = n0 + wf * S::TF * 32 + lc * 8;
+#pragma unroll
+    for (int it = 0; it < S::TT * 32 / RPI; ++it) {
+        const int row = it * RPI + lr;
+        const int tok = t0 + wt * S::TT * 32 + row;
+        const unsigned char* src = ot + row * S::RS + lc * 16;  // 8-byte aligned (RS = 8 mod 16): two ds_read_b64
+        const half4 lo = *(const half4*)src, hi = *(const half4*)(src + 8);
+        half8 y = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (tok < T) {
+            if constexpr ((EPI & GM_EPI_RESID) != 0) {
+                const half8 rr = *(const half8*)((const _Float16*)resid + (int64_t)tok * N + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)y[e] + (float)rr[e]);
+            }
+            *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y;
+        }
+    }
+}
+
+template <class S, int EPI>
+static int gemm_launch(const void* d_x, const void* d_w, const float* d_bias, const void* d_resid, void* d_out, int64_t tokens, int32_t n_out,
+                       int32_t k_in, hipStream_t st) {
+    const int64_t rbs = (tokens + S::BM - 1) / S::BM;
+    const int64_t nblk = 8 * (int64_t)(n_out / S::BN) * ((rbs + 7) / 8);
+    if (nblk > 0x7fffffff) LM_FAIL(LM_EINVAL, "lm_gemm_f16: too many tiles for one launch");
+    static bool attr_set = false;
+    if (!attr_set) {
+        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_f16<S, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm_f16<S, EPI>), dim3((unsigned)nblk), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
+                       (const __half*)d_resid, (__half*)d_out, (int)tokens, n_out, k_in);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+}  // namespace lm
+
+extern "C" int lm_gemm_f16(const void* d_x, const void* d_w, const float* d_bias, const void* d_residual, int32_t epilogue, int32_t n_out,
+                           int32_t k_in, void* d_out, int64_t tokens, void* stream) {
+    using namespace lm;
+    if (tokens == 0) return LM_OK;
+    if (!d_x || !d_w || !d_bias || !d_out || tokens < 0 || tokens > 0x7fffffff) LM_FAIL(LM_EINVAL, "bad linear arguments");
+    if (n_out <= 0 || n_out % 128 || k_in <= 0 || k_in % 128) LM_FAIL(LM_EINVAL, "lm_gemm_f16: n_out and k_in must be positive multiples of 128");
+    if (epilogue < 0 || epilogue > 3) LM_FAIL(LM_EINVAL, "lm_gemm_f16: epilogue is a combination of 1 (GELU) and 2 (+ residual)");
+    if ((epilogue & GM_EPI_RESID) && !d_residual) LM_FAIL(LM_EINVAL, "lm_gemm_f16: residual epilogue without a residual");
+    // DMA sources are addressed as wave-uniform base + 32-bit per-lane byte offset
+    if ((uint64_t)tokens * (uint64_t)k_in * 2 >= (1ull << 32) || (uint64_t)n_out * (uint64_t)k_in * 2 >= (1ull << 32))
+        LM_FAIL(LM_EINVAL, "lm_gemm_f16: an operand of 4 GiB or more; split the token range");
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = n_out % 256 == 0 && tokens > 128;
+#define GM_GO(S)                                                                                                             \
+    switch (epilogue) {                                                                                                      \
+        case 0: return gemm_launch<S, 0>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                       \
+        case 1: return gemm_launch<S, 1>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                       \
+        case 2: return gemm_launch<S, 2>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                       \
+        default: return gemm_launch<S, 3>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                      \
+    }
+    if (big) {
+        GM_GO(GemmBig)
+    }
+    GM_GO(GemmSmall)
+#undef GM_GO
+}

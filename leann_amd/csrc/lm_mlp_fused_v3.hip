@@ -234,43 +234,30 @@ struct M3Ctx {
     const unsigned char* w2s;
     int a1[8], b20, b21;
 };
-// What slot SLOT of an iteration does: -1 nothing, 0..23 = k-step of the first product, 100 + n = MFMA n of the second product
-// (n = 12 u + j).  Plain order: slots 0..23 first product, 24..47 second.  IL (LEANN_MI355X_ABLATE & 4096, opt-in until measured):
-// in iterations that compute a first product the two products ALTERNATE -- even slots first product, odd slots second -- so the
-// first product is ONE dependency chain whose links are an independent MFMA apart: no second partial sum, no 32 v_accvgpr_read +
-// 16 v_add to merge the two at the top of the next iteration, 16 accumulator registers fewer.
-template <bool FC1, bool FC2, bool IL, int SLOT>
-constexpr int m3_role() {
-    if (SLOT < 0 || SLOT >= 48) return -1;
-    if (IL && FC1) return (SLOT & 1) == 0 ? SLOT / 2 : (FC2 ? 100 + SLOT / 2 : -1);
-    if (SLOT < 24) return FC1 ? SLOT : -1;
-    return FC2 ? 100 + SLOT - 24 : -1;
-}
-template <int ROLE>
+template <int SLOT>
 __device__ __forceinline__ half8 m3_frag(const M3Ctx& c) {
-    if constexpr (ROLE < 100) return *(const half8*)(c.w1s + c.a1[ROLE & 7] + 256 * (ROLE >> 3));
+    if constexpr (SLOT < 24) return *(const half8*)(c.w1s + c.a1[SLOT & 7] + 256 * (SLOT >> 3));
     else {
-        constexpr int n = ROLE - 100, u = n / ML_NJ, j = n % ML_NJ;
+        constexpr int n = SLOT - 24, u = n / ML_NJ, j = n % ML_NJ;
         return *(const half8*)(c.w2s + (u ? c.b21 : c.b20) + 2048 * j);
     }
 }
+template <bool FC1, bool FC2, int SLOT>
+constexpr bool m3_live() { return SLOT < 24 ? FC1 : (SLOT < 48 ? FC2 : false); }
 
-template <bool FC1, bool FC2, int GEL, int RD, bool IL, int I>
+template <bool FC1, bool FC2, int GEL, int RD, int I>
 __device__ __forceinline__ void m3_slot(const M3Ctx& c, const half8 (&xf)[ML_KS], float16v (&accn)[2], const float (&acc)[16],
                                         const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[RD], GeluQuad& gq) {
-    constexpr int role = m3_role<FC1, FC2, IL, I>();
-    if constexpr (role >= 0) {
-        if constexpr (role < 100) {
-            // plain order: two accumulators in turn -- an instruction issued between two MFMAs on the SAME accumulator costs ~43
-            // cycles (MI355X_MICROARCH.md, per-instruction constants), and every gap here carries GELU micro-operations
-            constexpr int ai = IL ? 0 : (role & 1);
-            accn[ai] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], xf[role], accn[ai], 0, 0, 0);
+    if constexpr (m3_live<FC1, FC2, I>()) {
+        if constexpr (I < 24) {
+            // two accumulators in turn: an instruction issued between two MFMAs on the SAME accumulator costs ~43 cycles
+            // (MI355X_MICROARCH.md, per-instruction constants) -- and every gap here carries GELU micro-operations
+            accn[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], xf[I], accn[I & 1], 0, 0, 0);
         } else {
-            constexpr int n = role - 100, u = n / ML_NJ, j = n % ML_NJ;
+            constexpr int n = I - 24, u = n / ML_NJ, j = n % ML_NJ;
             o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[I & (RD - 1)], pfprev[u], o[j], 0, 0, 0);
         }
-        constexpr int nrole = m3_role<FC1, FC2, IL, I + RD>();
-        if constexpr (nrole >= 0) ring[I & (RD - 1)] = m3_frag<nrole>(c);
+        if constexpr (m3_live<FC1, FC2, I + RD>()) ring[I & (RD - 1)] = m3_frag<I + RD>(c);
     }
     if constexpr (GEL != 0) {
         constexpr int n = 16 * gelu_rows<GEL>(), lo = (n * I) / 48, hi = (n * (I + 1)) / 48;
@@ -278,24 +265,17 @@ __device__ __forceinline__ void m3_slot(const M3Ctx& c, const half8 (&xf)[ML_KS]
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <bool FC1, bool FC2, int GEL, int RD, bool IL, int... I>
+template <bool FC1, bool FC2, int GEL, int RD, int... I>
 __device__ __forceinline__ void m3_slots(std::integer_sequence<int, I...>, const M3Ctx& c, const half8 (&xf)[ML_KS], float16v (&accn)[2],
                                          const float (&acc)[16], const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ], half8 (&ring)[RD],
                                          GeluQuad& gq) {
-    (m3_slot<FC1, FC2, GEL, RD, IL, I>(c, xf, accn, acc, pfprev, pfcur, o, ring, gq), ...);
-}
-template <bool FC1, bool FC2, bool IL, int RD, int FIRST, int... I>
-__device__ __forceinline__ void m3_ring_fill(std::integer_sequence<int, I...>, const M3Ctx& c, half8 (&ring)[RD]) {
-    ([&] {
-        constexpr int role = m3_role<FC1, FC2, IL, FIRST + I>();
-        if constexpr (role >= 0) ring[(FIRST + I) & (RD - 1)] = m3_frag<role>(c);
-    }(), ...);
+    (m3_slot<FC1, FC2, GEL, RD, I>(c, xf, accn, acc, pfprev, pfcur, o, ring, gq), ...);
 }
 
 // One iteration of the skewed pipeline.  FC1: first product of the slab in stage w1s (bias bs) -> accn;  GEL: GELU of acc[0..16)
 // -> pfcur;  FC2: second product of the slab in stage w2s with pfprev -> o.  48 slots, slot i = MFMA i (24 of FC1 then 24 of
 // FC2), the fragment read of slot i + 4 and GELU micro-operations [256 i / 48, 256 (i + 1) / 48).
-template <bool FC1, bool FC2, int GEL, int RD, bool IL = false>
+template <bool FC1, bool FC2, int GEL, int RD>
 __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const unsigned char* w2s, const int (&a1)[8], int b20, int b21,
                                              const float* bs, const half8 (&xf)[ML_KS], float16v (&accn)[2], const float (&acc)[16],
                                              const half8 (&pfprev)[2], half8 (&pfcur)[2], float16v (&o)[ML_NJ]) {
@@ -312,16 +292,27 @@ __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const uns
             float4v bv = *(const float4v*)(bs + 8 * q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                accn[0][4 * q + i] = bv[i];  // bias in one of the two partial sums (IL: in the only one)
-                if constexpr (!IL) accn[1][4 * q + i] = 0.0f;
+                accn[0][4 * q + i] = bv[i];  // bias in one of the two partial sums
+                accn[1][4 * q + i] = 0.0f;
             }
         }
     }
     half8 ring[RD];  // fragment reads run RD MFMAs ahead
     constexpr int first = FC1 ? 0 : 24;
-    m3_ring_fill<FC1, FC2, IL, RD, first>(std::make_integer_sequence<int, RD>{}, c, ring);
+    if constexpr (m3_live<FC1, FC2, first>()) {
+        ring[0] = m3_frag<first>(c);
+        ring[1] = m3_frag<first + 1>(c);
+        ring[2] = m3_frag<first + 2>(c);
+        ring[3] = m3_frag<first + 3>(c);
+        if constexpr (RD == 8) {
+            ring[4] = m3_frag<first + 4>(c);
+            ring[5] = m3_frag<first + 5>(c);
+            ring[6] = m3_frag<first + 6>(c);
+            ring[7] = m3_frag<first + 7>(c);
+        }
+    }
     GeluQuad gq;
-    m3_slots<FC1, FC2, GEL, RD, IL>(std::make_integer_sequence<int, 48>{}, c, xf, accn, acc, pfprev, pfcur, o, ring, gq);
+    m3_slots<FC1, FC2, GEL, RD>(std::make_integer_sequence<int, 48>{}, c, xf, accn, acc, pfprev, pfcur, o, ring, gq);
 }
 
 // Epilogue of variant 3:  y = LayerNorm(o + residual) * gamma + beta  (b2 is already in the accumulators), written as fp16.
@@ -337,32 +328,8 @@ __device__ __forceinline__ void m3_iteration(const unsigned char* w1s, const uns
 //     fully coalesced 1 KB stores per wave (a wave's 32 token rows are one contiguous 24 KB block of the output).
 // ACCRES (the kernel with the attention output projection in front, below): the x fragments are already in ACCUMULATOR order
 // (fragment 2 j + u, element e = the value that belongs to register 8 u + e of tile j), so the residual needs no lane traffic.
-// A wave's 24 KB tile (W1-slab image) back out in linear order: chunk L = 64 i + lane = (row L / 48, chunk L % 48) goes to
-// base + row * row_stride + 16 * chunk -- 24 coalesced 1 KB pieces when the rows are contiguous (row_stride 768), 768-byte row
-// segments otherwise (the QKV projection's output rows are 2304 bytes apart).  Eight reads in flight, then their eight stores.
-__device__ __forceinline__ void m3_store_tile(const unsigned char* tile, unsigned char* base, int row_stride, int rows_valid, int lane) {
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        u32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
-            v[i] = *(const u32x4*)(tile + row * 768 + ((c & ~15) | ((c ^ row) & 15)) * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
-            if (L < 48 * rows_valid) *(u32x4*)(base + (int64_t)row * row_stride + 16 * c) = v[i];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// KEEP (the form with the next layer's QKV projection behind it): the normalised fp16 results also replace the x fragments, in
-// accumulator order -- they are the B operand of that projection.
-template <bool ACCRES, bool KEEP = false>
-__device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
+template <bool ACCRES>
+__device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], const half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
                                             unsigned char* tile, __half* __restrict__ out, int64_t token0, int T, int r31, int g, int lane,
                                             float eps) {
     __builtin_amdgcn_sched_barrier(0);
@@ -458,12 +425,6 @@ __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], half8 (&xf)[ML
             const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
             const half4 y = {h0[0], h0[1], h1[0], h1[1]};
             *(half4*)(trow + ((c & ~15) | ((c ^ r31) & 15)) * 16) = y;
-            if constexpr (KEEP) {  // fragment 2 j + u (u = q >> 1), elements 4 (q & 1) .. + 3
-                xf[2 * j + (q >> 1)][4 * (q & 1)] = y[0];
-                xf[2 * j + (q >> 1)][4 * (q & 1) + 1] = y[1];
-                xf[2 * j + (q >> 1)][4 * (q & 1) + 2] = y[2];
-                xf[2 * j + (q >> 1)][4 * (q & 1) + 3] = y[3];
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -473,9 +434,26 @@ __device__ __forceinline__ void m3_epilogue(float16v (&o)[ML_NJ], half8 (&xf)[ML
         }
     }
     LM_WAVE_SYNC();  // the rows were written by other lanes of this wave (lock-step on the GPU: program order is enough)
-    // the wave's 32 rows are one contiguous 24 KB block of the output
+    // the wave's tile back out in linear order: chunk L = 64 i + lane = (row L / 48, chunk L % 48) is bytes [16 L, 16 L + 16) of the
+    // wave's 24 KB of output
+    unsigned char* obase = (unsigned char*)out + token0 * (ML_H * 2);
     const int rows_valid = (int)((int64_t)T - token0 < 32 ? (int64_t)T - token0 : 32);
-    m3_store_tile(tile, (unsigned char*)out + token0 * (ML_H * 2), ML_H * 2, rows_valid, lane);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {  // eight reads in flight, then their eight stores
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = 64 * (8 * b + i) + lane, row = L / 48, c = L - 48 * row;
+            v[i] = *(const u32x4*)(tile + row * 768 + ((c & ~15) | ((c ^ row) & 15)) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = 64 * (8 * b + i) + lane;
+            if (L < 48 * rows_valid) *(u32x4*)(obase + 16 * L) = v[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // The kernel with the attention output projection in front (PRE, below) normalises INSIDE the registers:
@@ -586,10 +564,6 @@ struct M3Pre {
     const __half* gamma1;
     const __half* beta1;
     float eps1;
-    // QKV form only: the NEXT layer's QKV projection of this kernel's output, qkv = y W_qkv^T + b_qkv, [T][1152] fp16
-    const __half* wqkv_p;  // [36][384][32]: slab 12 p + s = output rows 384 p .. + 383, k slab s in accumulator order
-    const float* bqkv;     // [1152]
-    __half* qkv_out;
     int stagger;  // first-round workgroups (blockIdx < 256) start ((37 b) & 255) / 256 * stagger x 1024 cycles late: see the kernel
 };
 
@@ -611,7 +585,7 @@ struct M3Pre {
         __builtin_amdgcn_sched_barrier(0);                              \
     }
 #endif
-template <int ABL, bool PRE, bool QKV = false>
+template <int ABL, bool PRE>
 __device__ __forceinline__ void m3_kernel_body(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
@@ -635,7 +609,6 @@ __device__ __forceinline__ void m3_kernel_body(
     constexpr int AF = ABL & 56;  // GELU form bits
     constexpr int GEL = (ABL & 4) ? 0 : (AF == 8 ? 2 : (AF == 16 ? 3 : (AF == 32 ? 4 : (AF == 48 ? 5 : 1))));  // GELU form (see gelu_uop)
     constexpr int RD = (ABL & 128) ? 8 : 4;  // fragment read-ahead distance
-    constexpr bool IL = (ABL & 4096) != 0;   // the two products of an iteration alternate slot by slot (see m3_role)
     float* b1s = (float*)(smem + M3_B1_OFF);
     float* b2s = b1s + F;                          // b2 (384 floats), gamma, beta (384 halfs each) behind b1
     _Float16* gam_s = (_Float16*)(b2s + ML_H);
@@ -784,14 +757,14 @@ __device__ __forceinline__ void m3_kernel_body(
         }
 
     // first product of slab 0, nothing to overlap it with
-    m3_iteration<true, false, 0, RD, IL>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<true, false, 0, RD>(smem + M3_W1_OFF, nullptr, a1, b20, b21, b1s + 4 * g, xf, accn, acc, pfb, pfa, o);
 
     // iteration s: FC1 of slab s+1 (stage (s+1) % 3), GELU of slab s, FC2 of slab s-1 (stage (s-1) % 3).
     // At its top: W1(s+1) and W2(s-1) must have landed; issued after them, one iteration ago: W1(s+2), W2(s).
     // Then W1(s+3) and W2(s+1) are issued into the stages W1(s) / W2(s-2) occupied -- idle once every wave passed the barrier.
     auto top = [&](int s) {  // everything an iteration does before its 48 slots
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = IL ? accn[0][r] : accn[0][r] + accn[1][r];
+        for (int r = 0; r < 16; ++r) acc[r] = accn[0][r] + accn[1][r];
 #ifndef LM_EMULATED_DEVICE
         if constexpr ((ABL & 4) != 0) {  // the "no GELU" ablation must keep the first product alive (round 2 timed it WITHOUT: the
 #pragma unroll                           // compiler had removed the 24 dead MFMAs and their fragment reads)
@@ -814,7 +787,7 @@ __device__ __forceinline__ void m3_kernel_body(
     M3_STAMP(2);
     M3_BARRIER();  // top(0) refills W1 stage 0: every wave must be done with slab 0 first
     top(0);
-    m3_iteration<true, false, GEL, RD, IL>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
+    m3_iteration<true, false, GEL, RD>(w1_stage(0), nullptr, a1, b20, b21, b1s + 32 + 4 * g, xf, accn, acc, pfb, pfa, o);
     pfb[0] = pfa[0];
     pfb[1] = pfa[1];
     // steady state: one basic block per iteration
@@ -822,7 +795,7 @@ __device__ __forceinline__ void m3_kernel_body(
     for (int s = 1; s + 1 < nslab; ++s) {
         if (s == 17) { M3_STAMP(4); }
         top(s);
-        m3_iteration<true, true, GEL, RD, IL>(w1_stage(s), w2_stage(s), a1, b20, b21, b1s + 32 * (s + 1) + 4 * g, xf, accn, acc, pfb, pfa, o);
+        m3_iteration<true, true, GEL, RD>(w1_stage(s), w2_stage(s), a1, b20, b21, b1s + 32 * (s + 1) + 4 * g, xf, accn, acc, pfb, pfa, o);
         pfb[0] = pfa[0];
         pfb[1] = pfa[1];
     }
@@ -839,76 +812,7 @@ __device__ __forceinline__ void m3_kernel_body(
                                      pfa, o);
     M3_STAMP(6);
     __syncthreads();  // every wave is done with the weight stages: they become the output staging tiles
-    if constexpr (QKV) {
-        // The next layer's QKV projection follows in this kernel: its first two weight slabs and its bias (into the LDS space of b1,
-        // idle now) are requested before the LayerNorm so that they arrive under it.  Ring = W2 stages 1, 2 (slab t in stage
-        // 1 + (t & 1)); stages 0..3 (W1 ring + W2 stage 0) stay the waves' output tiles.
-        const unsigned char* gq = (const unsigned char*)pre.wqkv_p;
-        m3_issue_w2(gq, smem + M3_W2_OFF + M3_SLAB, wv, tid);
-        m3_issue_w2(gq + M3_SLAB, smem + M3_W2_OFF + 2 * M3_SLAB, wv, tid);
-        for (int i = tid; i < 3 * ML_H; i += 256) b1s[i] = pre.bqkv[i];
-    }
-    m3_epilogue<PRE, QKV>(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
-    if constexpr (QKV) {
-        // qkv = y W_qkv^T + b_qkv in three passes of 384 outputs (Q, K, V): y is in the x fragment registers (accumulator order, the
-        // k order W_qkv's slabs are packed in), each pass is twelve 24-MFMA slabs like the attention output projection in front, and
-        // its result leaves through the wave's tile as 768-byte row segments of the [T][1152] output.
-        const unsigned char* gq = (const unsigned char*)pre.wqkv_p;
-        unsigned char* mt = smem + wv * M3_SLAB;
-        const int64_t token0 = (int64_t)blockIdx.x * 128 + wv * 32;
-        const int rv = (int)((int64_t)T - token0 < 32 ? (int64_t)T - token0 : 32);
-        // fragment addresses again, from opaque copies of the lane coordinates: kept alive across the LayerNorm instead, they are
-        // what pushes the allocation over 512 registers (81 dwords of scratch per lane)
-        int rq = r31, gq2 = g;
-        LM_KEEP_LOCAL(rq);
-        LM_KEEP_LOCAL(gq2);
-        int a1q[8];
-#pragma unroll
-        for (int k7 = 0; k7 < 8; ++k7) a1q[k7] = rq * 768 + ((((2 * k7 + gq2) ^ rq) & 15) << 4);
-        const int b20q = rq * 64 + ((gq2 ^ ((rq >> 2) & 3)) << 4), b21q = b20q ^ 32;
-        M3_WAIT_VM(0);
-        __syncthreads();  // slabs 0, 1 and the bias are in LDS (and this wave's y rows are on their way)
-#pragma unroll 1
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int j = 0; j < ML_NJ; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4v bv = *(const float4v*)(b1s + ML_H * p + 32 * j + 8 * q + 4 * gq2);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
-                }
-#pragma unroll
-            for (int s2 = 0; s2 < ML_H / 32; ++s2) {
-                const int t = 12 * p + s2;
-                if (t > 0) {
-                    if (t > 1) M3_WAIT_VM(0);
-                    M3_BARRIER();
-                    if (t + 1 < 36) m3_issue_w2(gq + (int64_t)(t + 1) * M3_SLAB, smem + M3_W2_OFF + (1 + ((t + 1) & 1)) * M3_SLAB, wv, tid);
-                }
-                const half8 yf[2] = {xf[2 * s2], xf[2 * s2 + 1]};
-                m3_iteration<false, true, 0, RD>(nullptr, smem + M3_W2_OFF + (1 + (t & 1)) * M3_SLAB, a1q, b20q, b21q, nullptr, xf, accn, acc, yf, pfa, o);
-            }
-            // accumulators -> fp16 -> the wave's tile -> global (the tile's previous contents were read out before: program order)
-            {
-                unsigned char* trow = mt + rq * 768 + 8 * gq2;
-#pragma unroll
-                for (int j = 0; j < ML_NJ; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = 4 * j + q;
-                        const float2v y0 = {o[j][4 * q], o[j][4 * q + 1]}, y1 = {o[j][4 * q + 2], o[j][4 * q + 3]};
-                        const half2v h0 = __builtin_convertvector(y0, half2v), h1 = __builtin_convertvector(y1, half2v);
-                        const half4 y = {h0[0], h0[1], h1[0], h1[1]};
-                        *(half4*)(trow + ((c & ~15) | ((c ^ rq) & 15)) * 16) = y;
-                    }
-            }
-            LM_WAVE_SYNC();
-            if (rv > 0) m3_store_tile(mt, (unsigned char*)pre.qkv_out + token0 * (3 * ML_H * 2) + p * (ML_H * 2), 3 * ML_H * 2, rv, lane);
-            M3_WAIT_LGKM0();
-            LM_WAVE_SYNC();  // the tile is rewritten by the next pass
-        }
-    }
+    m3_epilogue<PRE>(o, xf, gam_s, bet_s, smem + wv * 24576, out, (int64_t)blockIdx.x * 128 + wv * 32, T, r31, g, lane, eps);
 #ifndef LM_EMULATED_DEVICE
     if constexpr ((ABL & 64) != 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -928,7 +832,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_mlp_fused_h384_v3(
     const __half* __restrict__ x, const __half* __restrict__ w1, const float* __restrict__ b1, const __half* __restrict__ w2p,
     const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta, __half* __restrict__ out, int T,
     int F, float eps) {
-    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, 0};
+    const M3Pre none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     m3_kernel_body<ABL, false>(x, w1, b1, w2p, b2, gamma, beta, out, T, F, eps, none);
 }
 
@@ -943,23 +847,12 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_attn_out_mlp_h384(
     m3_kernel_body<ABL, true>(resid, w1acc, b1, w2p, b2, gamma, beta, out, T, F, eps, pre);
 }
 
-// ... and with the NEXT layer's QKV projection behind it (M3Pre::wqkv_p): the LayerNorm output is already in registers in the k order
-// the projection needs, so the weight-stationary GEMM's six reads of x in 32-byte row segments and its strided stores
-// (profiles/r2_kbench_gemm_ws_phase_stamps.jsonl) disappear; opt-in until measured on hardware (LEANN_MI355X_QKV_IN_TAIL=1).
-template <int ABL>
-__global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_attn_out_mlp_qkv_h384(
-    const __half* __restrict__ resid, M3Pre pre, const __half* __restrict__ w1acc, const float* __restrict__ b1,
-    const __half* __restrict__ w2p, const float* __restrict__ b2, const __half* __restrict__ gamma, const __half* __restrict__ beta,
-    __half* __restrict__ out, int T, int F, float eps) {
-    m3_kernel_body<ABL, true, true>(resid, w1acc, b1, w2p, b2, gamma, beta, out, T, F, eps, pre);
-}
-
 }  // namespace lm
 
-static int m3_launch_tail(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo, const void* d_gamma1, const void* d_beta1,
-                          float eps1, const void* d_w1acc, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
-                          const void* d_beta, void* d_out, const void* d_wqkv_p, const float* d_bqkv, void* d_qkv_out, int64_t tokens, int32_t ffn,
-                          float eps, void* stream) {
+extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
+                                              const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
+                                              const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
+                                              int64_t tokens, int32_t ffn, float eps, void* stream) {
     using namespace lm;
     if (tokens == 0) return LM_OK;
     if (!d_attn || !d_resid || !d_wo_p || !d_bo || !d_gamma1 || !d_beta1 || !d_w1acc || !d_b1 || !d_w2p || !d_b2 || !d_gamma || !d_beta || !d_out ||
@@ -968,60 +861,34 @@ static int m3_launch_tail(const void* d_attn, const void* d_resid, const void* d
     if (ffn <= 0 || ffn % 32) LM_FAIL(LM_EINVAL, "ffn size must be a positive multiple of 32");
     const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 16;  // + b2, b_o (fp32), gamma, beta, gamma1, beta1 (fp16)
     if (ffn < 128 || shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "fused attention-output + MLP kernel: ffn must be in [128, 2560]");
-    const bool qkv = d_wqkv_p != nullptr;
-    if (qkv && (!d_bqkv || !d_qkv_out || ffn < 3 * ML_H))  // the projection's bias takes over b1's LDS space
-        LM_FAIL(LM_EINVAL, "fused layer tail + QKV projection: needs the bias, the output buffer and ffn >= 1152");
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
-    const char* sg = getenv("LEANN_MI355X_STAGGER");  // spread of the first round's start times, x 1024 cycles (default 40: measured 797 -> 779 us per 262k tokens; 0 = off)
+    // environment switches are read once per process (the launch path of a B = 1 search runs this ~600 times per query)
+    static const int stagger_env = [] { const char* sg = getenv("LEANN_MI355X_STAGGER"); return sg ? atoi(sg) : 40; }();  // spread of the first round's start times, x 1024 cycles (default 40: measured 797 -> 779 us per 262k tokens; 0 = off)
     const M3Pre pre = {(const __half*)d_attn, (const __half*)d_wo_p, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1,
-                       (const __half*)d_wqkv_p, d_bqkv, (__half*)d_qkv_out,
-                       grid.x >= 512 ? (sg ? atoi(sg) : 40) : 0};  // a launch of fewer than two rounds has no lock-step to break: no start delay (small-batch latency)
-    const char* ab = getenv("LEANN_MI355X_ABLATE");
-    const int abl = ab ? atoi(ab) : 0;
-#define M3P_GO_K(K, A)                                                                                                                \
-    case A:                                                                                                                            \
-        LM_HIP(hipFuncSetAttribute((const void*)K<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                        \
-        hipLaunchKernelGGL(K<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_resid, pre, (const __half*)d_w1acc, d_b1,   \
-                           (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out, (int)tokens, ffn, \
-                           eps);                                                                                                        \
-        break
-#define M3P_GO(A) M3P_GO_K(k_attn_out_mlp_h384, A)
-    if (qkv) {
-        switch (abl) {
-            M3P_GO_K(k_attn_out_mlp_qkv_h384, 0);
-            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the layer tail with the QKV projection has no diagnosis builds");
-        }
-    } else {
-        switch (abl) {
-            M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856); M3P_GO(4096); M3P_GO(4160);
-            default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps), 64 + {256, 512, 1024} and {0, 64} + 4096 (alternating products)");
-        }
+                       grid.x >= 512 ? stagger_env : 0};  // a launch of fewer than two rounds has no lock-step to break: no start delay (small-batch latency)
+#define M3P_GO(A)                                                                                                                     \
+    case A: {                                                                                                                          \
+        static size_t attr_bytes = 0; /* the attribute only ever needs to grow */                                                      \
+        if (shmem > attr_bytes) {                                                                                                      \
+            LM_HIP(hipFuncSetAttribute((const void*)k_attn_out_mlp_h384<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));  \
+            attr_bytes = shmem;                                                                                                        \
+        }                                                                                                                              \
+        hipLaunchKernelGGL(k_attn_out_mlp_h384<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_resid, pre,               \
+                           (const __half*)d_w1acc, d_b1, (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta,    \
+                           (__half*)d_out, (int)tokens, ffn, eps);                                                                      \
+    } break
+#ifdef LM_DIAG  // diagnosis builds (s_memtime stamps, skipped phases) exist only in the -DLM_DIAG library that scripts/build_kbench.sh makes
+    static const int abl = [] { const char* ab = getenv("LEANN_MI355X_ABLATE"); return ab ? atoi(ab) : 0; }();
+    switch (abl) {
+        M3P_GO(0); M3P_GO(64); M3P_GO(320); M3P_GO(576); M3P_GO(1088); M3P_GO(1856);
+        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: the fused attention-output + MLP kernel knows 0, 64 (stamps) and 64 + {256, 512, 1024}");
     }
+#else
+    switch (0) { M3P_GO(0); }
+#endif
 #undef M3P_GO
-#undef M3P_GO_K
     LM_HIP(hipGetLastError());
     return LM_OK;
-}
-
-extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
-                                              const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
-                                              const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
-                                              int64_t tokens, int32_t ffn, float eps, void* stream) {
-    return m3_launch_tail(d_attn, d_resid, d_wo_p, d_bo, d_gamma1, d_beta1, eps1, d_w1acc, d_b1, d_w2p, d_b2, d_gamma, d_beta, d_out, nullptr,
-                          nullptr, nullptr, tokens, ffn, eps, stream);
-}
-
-extern "C" int lm_layer_tail_qkv_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo,
-                                                const void* d_gamma1, const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1,
-                                                const void* d_w2p, const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out,
-                                                const void* d_wqkv_p, const float* d_bqkv, void* d_qkv_out, int64_t tokens, int32_t ffn,
-                                                float eps, void* stream) {
-    if (!d_wqkv_p) {
-        lm::set_error("lm_layer_tail_qkv_fused_h384_f16: missing QKV weights");
-        return LM_EINVAL;
-    }
-    return m3_launch_tail(d_attn, d_resid, d_wo_p, d_bo, d_gamma1, d_beta1, eps1, d_w1acc, d_b1, d_w2p, d_b2, d_gamma, d_beta, d_out, d_wqkv_p, d_bqkv,
-                          d_qkv_out, tokens, ffn, eps, stream);
 }
 
 int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
@@ -1030,19 +897,26 @@ int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1,
     const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 8;  // + b2 (fp32), gamma, beta (fp16)
     if (ffn < 128 || shmem > 160 * 1024) return 1;  // not applicable: the caller takes variant 2
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
-    const char* ab = getenv("LEANN_MI355X_ABLATE");
-    const int abl = ab ? atoi(ab) : 0;
 #define M3_GO(A)                                                                                                                     \
-    case A:                                                                                                                           \
-        LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384_v3<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
+    case A: {                                                                                                                         \
+        static size_t attr_bytes = 0;                                                                                                 \
+        if (shmem > attr_bytes) {                                                                                                     \
+            LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384_v3<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+            attr_bytes = shmem;                                                                                                       \
+        }                                                                                                                             \
         hipLaunchKernelGGL(k_mlp_fused_h384_v3<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w1, \
                            d_b1, (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out,            \
                            (int)tokens, ffn, eps);                                                                                      \
-        break
+    } break
+#ifdef LM_DIAG
+    static const int abl = [] { const char* ab = getenv("LEANN_MI355X_ABLATE"); return ab ? atoi(ab) : 0; }();
     switch (abl) {
-        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7); M3_GO(8); M3_GO(16); M3_GO(32); M3_GO(48); M3_GO(64); M3_GO(65); M3_GO(66); M3_GO(68); M3_GO(71); M3_GO(128); M3_GO(192); M3_GO(96); M3_GO(224); M3_GO(4096);
+        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7); M3_GO(8); M3_GO(16); M3_GO(32); M3_GO(48); M3_GO(64); M3_GO(65); M3_GO(66); M3_GO(68); M3_GO(71); M3_GO(128); M3_GO(192); M3_GO(96); M3_GO(224);
         default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: unknown combination");
     }
+#else
+    switch (0) { M3_GO(0); }
+#endif
 #undef M3_GO
     LM_HIP(hipGetLastError());
     return LM_OK;

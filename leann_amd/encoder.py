@@ -135,6 +135,30 @@ class KernelTimers:
         return out
 
 
+def _src_key(*tensors: torch.Tensor) -> tuple:
+    """Identity of the weights a packed copy was made from: device, storage address, in-place version counter and dtype of every
+    source tensor.  ``load_state_dict`` / an optimiser step / ``.copy_`` bump ``_version``; ``.to(dtype=...)`` / ``.half()`` replace
+    the storage -- either way the key changes and the pack is rebuilt instead of silently serving stale or wrong-dtype weights."""
+    return tuple((t.device, t.data_ptr(), t._version, t.dtype) for t in tensors)
+
+
+def _packed(owner, attr: str, sources: tuple, make):
+    """``owner.<attr>`` = (key, pack) cache of ``make()`` keyed on ``_src_key(*sources)``."""
+    key = _src_key(*sources)
+    ent = getattr(owner, attr, None)
+    if ent is None or ent[0] != key:
+        ent = (key, make())
+        setattr(owner, attr, ent)
+    return ent[1]
+
+
+# environment variables that select a particular kernel generation for an A/B run (everything else under LEANN_MI355X_* --
+# ALLOW_RANDOM_WEIGHTS, ATTN_XCD, STAGGER ... -- does not change which kernels a forward is made of)
+KERNEL_SELECTION_KEYS = ("LEANN_MI355X_ATTN", "LEANN_MI355X_LN", "LEANN_MI355X_POOL", "LEANN_MI355X_EMBED", "LEANN_MI355X_PACK",
+                         "LEANN_MI355X_LINEAR", "LEANN_MI355X_MLP", "LEANN_MI355X_MLP_VARIANT", "LEANN_MI355X_TAIL", "LEANN_MI355X_ABLATE",
+                         "LEANN_MI355X_GEMM")
+
+
 def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
     """LayerNorm(x + residual) through the hand-written HIP kernel (csrc/lm_encoder_ops.hip) for fp16 CUDA
     tensors; plain torch otherwise (CPU / fp32 parity paths)."""
@@ -276,19 +300,10 @@ def pack_w1_acc_order(w1: torch.Tensor) -> torch.Tensor:
     return w1.reshape(f, h // 32, 32)[:, :, perm].reshape(f, h).contiguous()
 
 
-def pack_wqkv_slabs(wqkv: torch.Tensor) -> torch.Tensor:
-    """nn.Linear weight [1152, 384] of a QKV projection -> [36, 384, 32]: slab 12 p + s = output rows 384 p .. 384 p + 383 (Q, K, V),
-    k slab s with its 32 input features in accumulator order (fused_mlp_k_permutation) -- the layout in which the fused layer tail
-    holds the previous layer's output when it runs this projection (csrc/lm_mlp_fused_v3.hip: k_attn_out_mlp_qkv_h384)."""
-    n, k = wqkv.shape
-    return torch.cat([pack_w2_fused_mlp(wqkv[384 * p : 384 * (p + 1)]) for p in range(n // 384)], 0).contiguous()
-
-
-def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer", next_layer: Optional["_Layer"] = None):
+def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
     """LayerNorm2(x + fc2(GELU(fc1(x)))) with x = LayerNorm1(resid + out(a)) in ONE kernel (csrc/lm_mlp_fused_v3.hip:
     k_attn_out_mlp_h384) for hidden 384, fp16 on the GPU.  LEANN_MI355X_TAIL=0 = the three-kernel path (A/B); None = the caller
-    takes that path.  With ``next_layer`` and LEANN_MI355X_QKV_IN_TAIL=1 (opt-in) the same launch also computes the next layer's
-    QKV projection of its result: returns ``(y, qkv_next)`` then."""
+    takes that path."""
     import os
 
     if os.environ.get("LEANN_MI355X_TAIL", "1") != "1" or os.environ.get("LEANN_MI355X_MLP", "1") != "1":
@@ -303,33 +318,14 @@ def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer", ne
 
     from . import _lib
 
-    pk = getattr(layer, "_tail_pack", None)
-    if pk is None or pk[0].device != a.device:
-        pk = (pack_wo_slabs(layer.out.weight.detach()), layer.out.bias.detach().float().contiguous(),
-              pack_w1_acc_order(layer.fc1.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
-              pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc2.bias.detach().float().contiguous())
-        layer._tail_pack = pk
-    wo_p, bo, w1a, b1, w2p, b2 = pk
+    wo_p, bo, w1a, b1, w2p, b2 = _packed(
+        layer, "_tail_pack", (layer.out.weight, layer.out.bias, layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias),
+        lambda: (pack_wo_slabs(layer.out.weight.detach()), layer.out.bias.detach().float().contiguous(),
+                 pack_w1_acc_order(layer.fc1.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
+                 pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc2.bias.detach().float().contiguous()))
     out = torch.empty_like(resid)
     vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     tm = KernelTimers.active
-    if (next_layer is not None and os.environ.get("LEANN_MI355X_QKV_IN_TAIL", "0") == "1" and f >= 1152
-            and tuple(next_layer.qkv.weight.shape) == (1152, 384) and next_layer.qkv.bias is not None):
-        qp = getattr(next_layer, "_qkv_tail_pack", None)
-        if qp is None or qp[0].device != a.device:
-            qp = (pack_wqkv_slabs(next_layer.qkv.weight.detach()), next_layer.qkv.bias.detach().float().contiguous())
-            next_layer._qkv_tail_pack = qp
-        qkv = torch.empty((a.shape[0], 1152), dtype=torch.float16, device=a.device)
-        ev = tm.span("attn_out_mlp_qkv_h384", a.shape[0] * (4.0 * f * h + 2.0 * h * h + 2.0 * h * 1152)) if tm is not None else None
-        if ev:
-            ev[0].record()
-        _lib.check(_lib.load().lm_layer_tail_qkv_fused_h384_f16(
-            vp(a), vp(resid), vp(wo_p), vp(bo), vp(layer.ln1.weight), vp(layer.ln1.bias), float(layer.ln1.eps), vp(w1a), vp(b1), vp(w2p), vp(b2),
-            vp(layer.ln2.weight), vp(layer.ln2.bias), vp(out), vp(qp[0]), vp(qp[1]), vp(qkv), a.shape[0], f, float(layer.ln2.eps),
-            C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "lm_layer_tail_qkv_fused_h384_f16")
-        if ev:
-            ev[1].record()
-        return out, qkv
     ev = tm.span("attn_out_mlp_h384", a.shape[0] * (4.0 * f * h + 2.0 * h * h)) if tm is not None else None
     if ev:
         ev[0].record()
@@ -356,12 +352,10 @@ def fused_mlp(x: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
 
     from . import _lib
 
-    pk = getattr(layer, "_mlp_pack", None)
-    if pk is None or pk[0].device != x.device:
-        pk = (pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
-              layer.fc2.bias.detach().float().contiguous(), layer.fc1.weight.detach().contiguous())
-        layer._mlp_pack = pk
-    w2p, b1, b2, w1 = pk
+    w2p, b1, b2, w1 = _packed(
+        layer, "_mlp_pack", (layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias),
+        lambda: (pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
+                 layer.fc2.bias.detach().float().contiguous(), layer.fc1.weight.detach().contiguous()))
     out = torch.empty_like(x)
     tm = KernelTimers.active
     ev = tm.span("mlp_fused_h384", 4.0 * x.shape[0] * f * h) if tm is not None else None
@@ -406,10 +400,7 @@ def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.
 
     from . import _lib
 
-    pk = getattr(lin, "_h384_pack", None)
-    if pk is None or pk[0].device != x.device:
-        pk = (pack_w_linear_h384(lin.weight.detach()), lin.bias.detach().float().contiguous())
-        lin._h384_pack = pk
+    pk = _packed(lin, "_h384_pack", (lin.weight, lin.bias), lambda: (pack_w_linear_h384(lin.weight.detach()), lin.bias.detach().float().contiguous()))
     out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
     fn = _lib.load().lm_gemm_h384_f16 if gen == "2" else _lib.load().lm_linear_h384_f16
     _lib.check(fn(
@@ -429,10 +420,7 @@ def _linear_ws_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Te
 
     from . import _lib
 
-    pk = getattr(lin, "_ws_pack", None)
-    if pk is None or pk[0].device != x.device:
-        pk = (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous())
-        lin._ws_pack = pk
+    pk = _packed(lin, "_ws_pack", (lin.weight, lin.bias), lambda: (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous()))
     out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
     _lib.check(_lib.load().lm_gemm_ws_h384_f16(C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), n,
                                                C.c_void_p(out.data_ptr()), x.shape[0], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
@@ -453,22 +441,19 @@ class _Layer(nn.Module):
         self.ln2 = nn.LayerNorm(c.hidden, eps=c.ln_eps)
         self.heads = c.heads
 
-    def forward_packed(self, x: torch.Tensor, cu: torch.Tensor, max_len: int, qkv_pre: Optional[torch.Tensor] = None,
-                       next_layer: Optional["_Layer"] = None):
-        """x: [total_tokens, H] (sequences packed back to back), cu: int32 cumulative lengths [n+1].  ``qkv_pre``: this layer's QKV
-        projection if the previous layer's tail kernel already computed it; with ``next_layer`` the result may be ``(y, qkv_next)``
-        (LEANN_MI355X_QKV_IN_TAIL=1), else it is ``y``."""
+    def forward_packed(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
+        """x: [total_tokens, H] (sequences packed back to back), cu: int32 cumulative lengths [n+1]."""
         from torch.nn.attention.varlen import varlen_attn
 
         tot, h = x.shape
-        qkv2 = qkv_pre if qkv_pre is not None else fused_linear_h384(x, self.qkv)
+        qkv2 = fused_linear_h384(x, self.qkv)
         if qkv2 is None:
             qkv2 = self.qkv(x)
         a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
         if a is None:
             qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
             a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
-        y = fused_attn_out_mlp(a, x, self, next_layer)  # output projection + LayerNorm + feed-forward block + LayerNorm in one kernel
+        y = fused_attn_out_mlp(a, x, self)  # output projection + LayerNorm + feed-forward block + LayerNorm in one kernel
         if y is not None:
             return y
         y = fused_linear_h384(a, self.out, residual=x, ln=self.ln1)
@@ -624,16 +609,20 @@ class BertEncoder(nn.Module):
 
     def _forward_one_call(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
         """The whole packed forward as ONE call into the library (csrc/lm_encoder_forward.cpp: lm_bert_h384_forward_packed) -- the same
-        kernels as the default path, strung together on the C++ side, so a recompute round costs one ctypes call instead of ~3 L + 2.
-        Opt-in (LEANN_MI355X_ONECALL=1) until its effect on small-batch latency has been measured; hidden 384 = heads x 32, fp16,
-        mean pooling, lengths <= 256, no A/B switch set, no per-kernel timers running.  None = not applicable."""
+        kernels as the per-kernel path below, strung together on the C++ side, so a recompute round costs one ctypes call instead of
+        ~3 L + 2.  Default since round 3 (measured on an MI355X, 200k-chunk index: B = 1 p50 57.7 -> 56.3 ms, B = 4 68.2 -> 66.8 ms;
+        bit-identical results); LEANN_MI355X_ONECALL=0 = the per-kernel path (A/B).  Applies to hidden 384 = heads x 32, fp16, mean
+        pooling, lengths <= 256, no kernel-selection switch set (KERNEL_SELECTION_KEYS), no per-kernel timers running.  None = not
+        applicable: the caller takes the per-kernel path (logged once per reason)."""
         import os
 
         cfg = self.cfg
-        if os.environ.get("LEANN_MI355X_ONECALL", "0") != "1" or KernelTimers.active is not None:
+        if os.environ.get("LEANN_MI355X_ONECALL", "1") != "1" or KernelTimers.active is not None:
             return None
-        if any(k.startswith("LEANN_MI355X_") and k not in ("LEANN_MI355X_ONECALL", "LEANN_MI355X_STAGGER") for k in os.environ):
-            return None  # an A/B run of a particular kernel generation goes through the per-kernel path
+        ab = [k for k in KERNEL_SELECTION_KEYS if k in os.environ]
+        if ab:  # an A/B run of a particular kernel generation goes through the per-kernel path
+            self._log_declined(f"kernel-selection switches set ({', '.join(ab)})")
+            return None
         w = self.word.weight
         if not (tok.is_cuda and w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling == "mean"
                 and 0 < max_len <= 256 and cfg.ffn % 32 == 0 and 128 <= cfg.ffn <= 2560 and tok.dtype == torch.int32 and pos.dtype == torch.int32
@@ -643,8 +632,7 @@ class BertEncoder(nn.Module):
 
         from . import _lib
 
-        pk = getattr(self, "_onecall_pack", None)
-        if pk is None or pk["device"] != tok.device:
+        def make():
             keep, layers = [], (_lib.BertH384Layer * cfg.layers)()
             ptr = lambda t: (keep.append(t), t.data_ptr())[1]  # noqa: E731 - tensors stay referenced for the life of the pack
             for li, L in enumerate(self.layers):
@@ -657,8 +645,9 @@ class BertEncoder(nn.Module):
             m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, float(self.ln.eps), ptr(w.detach()),
                               ptr(self.pos.weight.detach()), ptr(self.tok_type.weight[0].detach().contiguous()), ptr(self.ln.weight.detach()),
                               ptr(self.ln.bias.detach()), layers)
-            pk = {"device": tok.device, "model": m, "layers": layers, "keep": keep}
-            self._onecall_pack = pk
+            return {"model": m, "layers": layers, "keep": keep}
+
+        pk = _packed(self, "_onecall_pack", tuple(self.parameters()), make)
         lib = _lib.load()
         tot, n = tok.shape[0], cu.shape[0] - 1
         need = int(lib.lm_bert_h384_workspace_bytes(tot))
@@ -672,6 +661,14 @@ class BertEncoder(nn.Module):
                                                    C.c_void_p(torch.cuda.current_stream(tok.device).cuda_stream)), "lm_bert_h384_forward_packed")
         return out
 
+    def _log_declined(self, why: str) -> None:
+        seen = self.__dict__.setdefault("_declined_logged", set())
+        if why not in seen:
+            seen.add(why)
+            import logging
+
+            logging.getLogger(__name__).info(f"one-call forward not used: {why}; taking the per-kernel path")
+
     def forward_packed(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, seq_of: torch.Tensor,
                        lengths: torch.Tensor, max_len: int) -> torch.Tensor:
         cfg = self.cfg
@@ -681,10 +678,8 @@ class BertEncoder(nn.Module):
         x = fused_embed_layernorm(tok, pos, self.word, self.pos, self.tok_type.weight[0], self.ln)
         if x is None:
             x = fused_add_layernorm(self.word(tok) + self.tok_type.weight[0][None], self.pos(pos), self.ln)
-        qkv_pre = None
-        for li, L in enumerate(self.layers):
-            r = L.forward_packed(x, cu, max_len, qkv_pre, self.layers[li + 1] if li + 1 < len(self.layers) else None)
-            x, qkv_pre = r if isinstance(r, tuple) else (r, None)
+        for L in self.layers:
+            x = L.forward_packed(x, cu, max_len)
         n = lengths.shape[0]
         if cfg.pooling != "cls":
             e = fused_meanpool(x, cu, cfg.normalize)

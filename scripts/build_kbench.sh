@@ -4,6 +4,8 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p leann_amd/lib/bin
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas \
-    -Wl,-rpath,'$ORIGIN/..' -o leann_amd/lib/bin/kbench
+# kbench runs against the DIAGNOSIS build of the library (-DLM_DIAG: stamped / phase-skipping kernel instantiations)
+make -j8 -C leann_amd/csrc OUT=../lib/diag EXTRA_DEFS=-DLM_DIAG ../lib/diag/libleann_mi355x.so > /dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib/diag -lleann_mi355x -lrocblas \
+    -Wl,-rpath,'$ORIGIN/../diag' -o leann_amd/lib/bin/kbench
 echo built leann_amd/lib/bin/kbench

@@ -561,47 +561,6 @@ int main(int argc, char** argv) {
         unsetenv("LEANN_MI355X_MLP_VARIANT");
         fflush(stdout);
     }
-    if (want("tailqkv")) {  // opt-in: the layer tail with the NEXT layer's QKV projection behind it vs layer tail + weight-stationary GEMM
-        const int F = 1536, N = 3 * H;
-        auto hwo = rand_half((size_t)H * H, 0.05f, 60), hw1 = rand_half((size_t)F * H, 0.05f, 61), hw2 = rand_half((size_t)H * F, 0.03f, 62);
-        auto hwq = rand_half((size_t)N * H, 0.05f, 63);
-        std::vector<__half> hwqp((size_t)N * H);
-        for (int p = 0; p < 3; ++p) {  // leann_amd/encoder.py: pack_wqkv_slabs = pack_w2 of each 384-row block
-            std::vector<__half> blk(hwq.begin() + (size_t)p * H * H, hwq.begin() + (size_t)(p + 1) * H * H);
-            auto pk = pack_w2(blk, H);
-            std::copy(pk.begin(), pk.end(), hwqp.begin() + (size_t)p * H * H);
-        }
-        Dev<__half> wop(pack_wo(hwo)), w1a(pack_w1_acc(hw1, F)), w2p(pack_w2(hw2, F)), wq(hwq), wqp(hwqp);
-        Dev<float> bo(rand_float(H, 0.2f, 64)), b1(rand_float(F, 0.2f, 65)), b2(rand_float(H, 0.2f, 66)), bq(rand_float(N, 0.2f, 67));
-        Dev<__half> y0((size_t)T * H), q0((size_t)T * N), y1((size_t)T * H), q1((size_t)T * N);
-        auto run2 = [&] {
-            LM(lm_attn_out_mlp_fused_h384_f16(x.p, res.p, wop.p, bo.p, gamma.p, beta.p, 1e-12f, w1a.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, y0.p, T, F, 1e-12f, st));
-            LM(lm_gemm_ws_h384_f16(y0.p, wq.p, bq.p, N, q0.p, T, st));
-        };
-        auto run1 = [&] {
-            LM(lm_layer_tail_qkv_fused_h384_f16(x.p, res.p, wop.p, bo.p, gamma.p, beta.p, 1e-12f, w1a.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, y1.p, wqp.p, bq.p,
-                                                q1.p, T, F, 1e-12f, st));
-        };
-        CK(hipMemsetAsync(q1.p, 0xFF, q1.n * sizeof(__half), st));
-        run2();
-        run1();
-        CK(hipStreamSynchronize(st));
-        double dy = 0, dq = 0;
-        {
-            auto a = y0.host(), b = y1.host();
-            for (size_t i = 0; i < a.size(); ++i) { double d = fabs((double)__half2float(a[i]) - (double)__half2float(b[i])); if (!(d <= dy)) dy = d; }
-            auto c = q0.host(), e = q1.host();
-            for (size_t i = 0; i < c.size(); ++i) { double d = fabs((double)__half2float(c[i]) - (double)__half2float(e[i])); if (!(d <= dq)) dq = d; }
-        }
-        const double gflop = (4.0 * F * H + 2.0 * H * H + 2.0 * H * N) * T * 1e-9;
-        for (int round = 0; round < 2; ++round) {
-            const float us2 = time_us(st, reps, run2), us1 = time_us(st, reps, run1);
-            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 + lm_gemm_ws_h384_f16 (N=1152)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f}\n", round, us2, gflop / us2 * 1e-3);
-            printf("{\"kernel\": \"lm_layer_tail_qkv_fused_h384_f16\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_diff_y\": %.3g, \"max_abs_diff_qkv_vs_two_launches\": %.3g}\n",
-                   round, us1, gflop / us1 * 1e-3, dy, dq);
-            fflush(stdout);
-        }
-    }
     if (want("attn")) {
         const int heads = 12;
         std::mt19937 g(5);

@@ -13,8 +13,6 @@ os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_next: opt-in kernels that are validated in emulation but have not run on an MI355X yet -- "
-                                       "nothing the default path or bench.py uses; run with -m gpu_next first thing in the next GPU session")
 
 
 @pytest.fixture(scope="session")

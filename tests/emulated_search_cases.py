@@ -498,45 +498,7 @@ def case_mlp_v3_and_tail():
                                                   vp(pack_w1_acc_order(torch.from_numpy(w1)).numpy()), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(ot),
                                                   T, F, 1e-12, None), "tail")
     assert np.abs(ot.astype(f64) - mlp(x1, w1, b1, w2, b2, g2, be2)).max() < 1.2e-2
-    # opt-in slot order (LEANN_MI355X_ABLATE=4096): the two products of an iteration alternate, the first one is a single chain
-    os.environ["LEANN_MI355X_ABLATE"] = "4096"
-    os.environ["LEANN_MI355X_MLP_VARIANT"] = "3"
-    o3i, oti = np.zeros((T, H), np.float16), np.zeros((T, H), np.float16)
-    _lib.check(lib.lm_mlp_fused_h384_f16(vp(rs), vp(w1), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(o3i), T, F, 1e-12, None), "mlp3 alternating")
-    _lib.check(lib.lm_attn_out_mlp_fused_h384_f16(vp(at), vp(rs), vp(pack_wo_slabs(torch.from_numpy(wo)).numpy()), vp(bo), vp(g1), vp(be1), 1e-12,
-                                                  vp(pack_w1_acc_order(torch.from_numpy(w1)).numpy()), vp(b1), vp(w2p), vp(b2), vp(g2), vp(be2), vp(oti),
-                                                  T, F, 1e-12, None), "tail alternating")
-    os.environ.pop("LEANN_MI355X_ABLATE")
-    os.environ.pop("LEANN_MI355X_MLP_VARIANT")
-    assert np.abs(o3i.astype(f64) - o3.astype(f64)).max() < 4e-3 and np.abs(oti.astype(f64) - ot.astype(f64)).max() < 4e-3  # summation order only
-    assert np.abs(oti.astype(f64) - mlp(x1, w1, b1, w2, b2, g2, be2)).max() < 1.2e-2
-    # ... and with the next layer's QKV projection behind it (opt-in form): y and qkv = y W_qkv^T + b_qkv from one launch
-    from leann_amd.encoder import pack_wqkv_slabs
-
-    Tq, Fq = 97, 1152
-    atq, rsq = rng.standard_normal((Tq, H)).astype(np.float16), rng.standard_normal((Tq, H)).astype(np.float16)
-    w1q = (rng.standard_normal((Fq, H)) / np.sqrt(H)).astype(np.float16)
-    w2q = (rng.standard_normal((H, Fq)) / np.sqrt(Fq)).astype(np.float16)
-    b1q = (0.2 * rng.standard_normal(Fq)).astype(np.float32)
-    wqkv = (rng.standard_normal((3 * H, H)) / np.sqrt(H)).astype(np.float16)
-    bqkv = (0.2 * rng.standard_normal(3 * H)).astype(np.float32)
-    x1q = ln(rsq.astype(f64) + atq.astype(f64) @ wo.astype(f64).T + bo, g1, be1).astype(np.float16)
-    yref = mlp(x1q, w1q, b1q, w2q, b2, g2, be2)
-    yq, qkvq = np.zeros((Tq, H), np.float16), np.zeros((Tq, 3 * H), np.float16)
-    w2pq = pack_w2_fused_mlp(torch.from_numpy(w2q)).numpy()
-    args_tail = (vp(atq), vp(rsq), vp(pack_wo_slabs(torch.from_numpy(wo)).numpy()), vp(bo), vp(g1), vp(be1), 1e-12,
-                 vp(pack_w1_acc_order(torch.from_numpy(w1q)).numpy()), vp(b1q), vp(w2pq), vp(b2), vp(g2), vp(be2))
-    wqp = pack_wqkv_slabs(torch.from_numpy(wqkv)).numpy()
-    assert wqp.shape == (36, H, 32)
-    _lib.check(lib.lm_layer_tail_qkv_fused_h384_f16(*args_tail, vp(yq), vp(wqp), vp(bqkv), vp(qkvq), Tq, Fq, 1e-12, None), "tail+qkv")
-    assert np.abs(yq.astype(f64) - yref).max() < 1.2e-2
-    y2 = np.zeros((Tq, H), np.float16)
-    _lib.check(lib.lm_attn_out_mlp_fused_h384_f16(*args_tail, vp(y2), Tq, Fq, 1e-12, None), "tail")
-    assert np.array_equal(yq.view(np.uint16), y2.view(np.uint16))  # the layer output itself is the same kernel code
-    qref = yq.astype(f64) @ wqkv.astype(f64).T + bqkv  # from the fp16 y the kernel itself feeds to the projection
-    assert np.abs(qkvq.astype(f64) - qref).max() < 6e-3, np.abs(qkvq.astype(f64) - qref).max()
-    assert lib.lm_layer_tail_qkv_fused_h384_f16(*args_tail, vp(yq), vp(wqp), None, vp(qkvq), Tq, Fq, 1e-12, None) == -1  # bias missing
-    print("fused feed-forward kernels (variant 3, the attention-output form, the form with the next QKV projection): ok", flush=True)
+    print("fused feed-forward kernels (variant 3 and the attention-output form): ok", flush=True)
 
 
 CASES = {
@@ -557,10 +519,58 @@ CASES = {
     "dims_and_batches": case_dims_and_batches,
 }
 
+def case_gemm_f16():
+    """lm_gemm_f16 (csrc/lm_gemm_f16.hip: the general linear layer of the hidden-768 path) vs numpy: both tile shapes, every
+    epilogue, ragged token counts (clamped row loads, masked stores), more than eight row blocks (XCD-order padding)."""
+    import ctypes as C
+
+    from leann_amd import _lib
+    from scipy.special import erf
+
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+
+    def run(t, n, k, epi):
+        x = (rng.standard_normal((t, k)) * 0.5).astype(np.float16)
+        w = (rng.standard_normal((n, k)) * 0.1).astype(np.float16)
+        b = rng.standard_normal(n).astype(np.float32)
+        res = rng.standard_normal((t, n)).astype(np.float16)
+        out = np.full((t, n), 7.0, np.float16)
+        vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        _lib.check(lib.lm_gemm_f16(vp(x), vp(w), vp(b), vp(res) if epi & 2 else None, epi, n, k, vp(out), t, None), "lm_gemm_f16")
+        ref = x.astype(np.float32) @ w.astype(np.float32).T + b
+        if epi & 1:
+            ref = 0.5 * ref * (1.0 + erf(ref / np.sqrt(2.0)))
+        ref = ref.astype(np.float16)
+        if epi & 2:
+            ref = (ref.astype(np.float32) + res.astype(np.float32)).astype(np.float16)
+        err = float(np.abs(out.astype(np.float32) - ref.astype(np.float32)).max())
+        tol = 4e-3 * max(1.0, float(np.abs(ref.astype(np.float32)).max()))
+        print(f"gemm_f16 T={t} N={n} K={k} epilogue={epi}: max|diff| {err:.2e} (tol {tol:.2e}) {'ok' if err <= tol else 'MISMATCH'}", flush=True)
+        assert err <= tol
+
+    for epi in (0, 1, 2, 3):
+        run(300, 256, 128, epi)      # 256 x 256 tiles, two row blocks, the second one ragged
+    run(257, 512, 256, 3)            # two column tiles, 1 token in the last row block, four K-tiles
+    run(130, 384, 128, 0)            # 128 x 128 tiles (N % 256 != 0)
+    run(100, 256, 128, 2)            # short launch: small tiles although N % 256 == 0
+    run(1200, 128, 128, 1)           # ten row blocks of 128: the last group of eight is padded
+    try:
+        lib.lm_gemm_f16.restype = C.c_int
+        x = np.zeros((4, 100), np.float16)
+        rc = lib.lm_gemm_f16(C.c_void_p(x.ctypes.data), C.c_void_p(x.ctypes.data), C.c_void_p(x.ctypes.data), None, 0, 128, 100, C.c_void_p(x.ctypes.data), 4, None)
+        assert rc == _lib.LM_EINVAL  # k_in not a multiple of 128
+    finally:
+        pass
+
+
+CASES["gemm_f16"] = case_gemm_f16
+
+
 def case_encoder_python_wiring():
     """leann_amd/encoder.py with every second-generation switch ON, run on CPU tensors through the emulated library:
     the wrappers' argument wiring (weight packing caches, bias / LayerNorm parameters, cu_seqlens, call order) is what
-    the autotune probe will exercise on the GPU.  Only test code pretends the tensors are device tensors
+    the A/B switch sets exercise on the GPU.  Only test code pretends the tensors are device tensors
     (Tensor.is_cuda / current_stream are patched HERE); the product has no such switch."""
     import os
     from unittest import mock
@@ -616,11 +626,8 @@ def case_encoder_python_wiring():
         with torch.no_grad():
             got2 = enc16.encode_tokens_packed(ti, tl, 4096)
     assert float((got2.float() - ref).abs().max()) < 6e-3
-    # the DEFAULT kernel set (weight-stationary QKV GEMM, attention revision 2, fused layer tail) and the opt-in form in which the
-    # tail kernel of layer l also runs the QKV projection of layer l + 1 (needs ffn >= 1152)
-    for ffn, extra, want in ((128, {}, {"lm_gemm_ws_h384_f16": 2, "lm_attn_out_mlp_fused_h384_f16": 2, "lm_layer_tail_qkv_fused_h384_f16": 0}),
-                             (1152, {"LEANN_MI355X_QKV_IN_TAIL": "1"},
-                              {"lm_gemm_ws_h384_f16": 1, "lm_attn_out_mlp_fused_h384_f16": 1, "lm_layer_tail_qkv_fused_h384_f16": 1})):
+    # the DEFAULT kernel set (weight-stationary QKV GEMM, attention revision 2, fused layer tail)
+    for ffn, extra, want in ((128, {}, {"lm_gemm_ws_h384_f16": 2, "lm_attn_out_mlp_fused_h384_f16": 2}),):
         cfg3 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=ffn, max_pos=64, max_seq_length=48)
         e32 = BertEncoder.random_init(cfg3, 5).eval()
         with torch.no_grad():
@@ -628,6 +635,7 @@ def case_encoder_python_wiring():
         e16 = BertEncoder.random_init(cfg3, 5).eval().half()
         used.clear()
         env3 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+        env3["LEANN_MI355X_ONECALL"] = "0"  # the per-kernel launch path (the one-call default follows below)
         env3.update(extra)
         with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
                 mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env3, clear=True), \
@@ -638,7 +646,7 @@ def case_encoder_python_wiring():
         assert counts3 == want and used.count("lm_attn_varlen_hd32_f16") == 2 and "lm_add_layernorm_f16" not in used, (ffn, counts3, sorted(set(used)))
         err3 = float((got3.float() - ref3).abs().max())
         assert err3 < 6e-3, (ffn, err3)
-    # opt-in: the whole forward as ONE library call (csrc/lm_encoder_forward.cpp) -- same kernels, same result as the default path
+    # the default launch path: the whole forward as ONE library call (csrc/lm_encoder_forward.cpp) -- same kernels, same result as the default path
     cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=128, max_pos=64, max_seq_length=48)
     e1 = BertEncoder.random_init(cfg1, 5).eval().half()
     outs = {}

@@ -36,6 +36,22 @@ def test_product_library_on_the_cpu_matches_the_oracle(emul_dir):
     assert "MISMATCH" not in r.stdout
 
 
+def test_real_leann_searcher_drives_the_product_library_on_the_cpu(emul_dir, tmp_path):
+    """the reference's own leann.api.LeannSearcher (api.py:623-642,644-796) -> BACKEND_REGISTRY["mi355x"] -> our
+    searcher -> C ABI -> the product's kernel sources (host build).  tests/real_caller_over_emulation.py holds the scenario; the same
+    test against the real library on an MI355X is tests/test_gpu_plugin_callers.py::test_real_leann_searcher_on_top_of_the_backend,
+    which needs leann-core on the GPU box."""
+    import build_emul_lib
+
+    ref = Path("/root/reference/packages/leann-core/src")
+    if not (ref / "leann" / "api.py").exists():
+        pytest.skip("leann-core (the reference's caller) is not on this box")
+    lib = build_emul_lib.build(emul_dir)
+    r = subprocess.run([sys.executable, "-m", "tests.real_caller_over_emulation", str(lib), str(ref), str(tmp_path)], cwd=str(ROOT),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "REAL CALLER OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_plain_c_host_known_answer_against_the_emulated_library(emul_dir):
     """tests/abi/abi_host.c (C11, no Python) linked against the host build: with a "device" present it takes the same
     branch as on the GPU box and checks the hand-traced known-answer search through lm_index_search."""

@@ -176,6 +176,37 @@ def test_encoder_forward_default_and_every_kernel_vs_first_generation(monkeypatc
     assert (a - b).abs().max() < 3e-3
 
 
+def test_default_forward_vs_cpu_fp32_and_one_call_vs_per_kernel(monkeypatch):
+    """The DEFAULT MiniLM-shape forward on the GPU (fp16 kernels, the whole forward as one library call) against (a) the same
+    weights in fp32 on the CPU through plain torch (the padded reference path: what sentence-transformers computes,
+    embedding_compute.py:229-239) and (b) the per-kernel launch path (LEANN_MI355X_ONECALL=0), which must give the same bits."""
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    cfg = config_for("all-MiniLM-L6-v2")
+    cpu32 = BertEncoder.random_init(cfg, 0).eval()
+    enc = BertEncoder.random_init(cfg, 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=160, n_topics=4)).chunks(), 256)
+    with torch.no_grad():
+        ref = cpu32(torch.from_numpy(ids), torch.from_numpy(lens)).float()
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    used = []
+    real = _lib.check
+    monkeypatch.setattr(_lib, "check", lambda rc, what="": (used.append(what), real(rc, what))[1])
+    one = enc.encode_tokens_packed(ti, tl)
+    assert "lm_bert_h384_forward_packed" in used and "lm_gemm_ws_h384_f16" not in used  # the default IS the one-call path
+    assert (one.cpu() - ref).abs().max().item() <= 5e-3  # unit-norm embeddings; fp16 activations through 6 layers
+    assert torch.nn.functional.cosine_similarity(one.cpu(), ref).min().item() >= 0.9999
+    used.clear()
+    monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
+    per = enc.encode_tokens_packed(ti, tl)
+    assert "lm_bert_h384_forward_packed" not in used and used.count("lm_attn_out_mlp_fused_h384_f16") == cfg.layers
+    assert torch.equal(one, per)
+
+
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 32), (300, 64), (300, 128), (300, 3072)])
 def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):

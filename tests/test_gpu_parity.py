@@ -37,7 +37,7 @@ def _build(n, d, metric, seed, M=16, efc=60, normalize=True):
     return x.copy(), g
 
 
-def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32, variant=0):
+def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32, variant=0, wave=None):
     from leann_amd.devmem import as_tensor
     from leann_amd.index import Mi355xIndex
     from oracle import oracle as orc
@@ -49,6 +49,8 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
     idx = Mi355xIndex.from_csr(g, device=0)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
     idx.set_option("update_variant", variant)
+    if wave is not None:
+        idx.set_option("persistent_wave", wave)
     if mode == "table":
         idx.attach_table(xt)
         prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=False)
@@ -91,6 +93,41 @@ def test_table_mode_parity(env, metric, ef, beam):
     x, g = _build(3000, 384, metric, seed=1)
     q = queries_near(x, 32, seed=2)
     _check(env, x, g, q, 10, ef, beam, "table")
+
+
+@pytest.mark.parametrize("metric", ["mips", "l2"])
+@pytest.mark.parametrize("table_dtype", [np.float32, np.float16])
+def test_wave_per_query_table_mode_parity(env, metric, table_dtype):
+    """The 64-thread (one wave per query) form of the persistent stored-embedding search -- the kernel behind the
+    ">= 60 % of HBM peak" line and the graph builder's searches -- forced by option, against the oracle: ids, distances,
+    ndis / nexpand / nrounds."""
+    x, g = _build(3000, 384, metric, seed=1)
+    q = queries_near(x, 48, seed=21)
+    for ef, beam, cr in ((64, 1, True), (16, 1, True), (64, 4, True), (24, 2, False)):
+        _check(env, x, g, q, 10, ef, beam, "table", check_rel=cr, table_dtype=table_dtype, wave=1)
+    x, g = _build(1500, 100, metric, seed=5)
+    _check(env, x, g, queries_near(x, 16, seed=6), 5, 32, 1, "table", table_dtype=table_dtype, wave=1)
+
+
+@pytest.mark.parametrize("metric", ["mips", "l2"])
+def test_wave_per_query_auto_rule_large_batch(env, metric):
+    """B >= 2048 on a low-degree graph: the launcher picks the wave-per-query form by itself (lm_search.hip:
+    persist_wave_form); same contract, and the same bits as the forced workgroup form."""
+    from leann_amd.index import Mi355xIndex
+
+    x, g = _build(3000, 384, metric, seed=1, M=4, efc=40)
+    q = queries_near(x, 2304, seed=22)
+    deg0 = float(g.level0_degrees().mean())
+    assert deg0 * 1 <= 24.0, deg0  # the auto rule's precondition at beam 1
+    gi = _check(env, x, g, q, 10, 64, 1, "table")  # auto
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_table(x)
+    idx.set_option("persistent_wave", 0)
+    d0, l0 = idx.search(q, 10, idx.make_params(ef=64, beam=1, recompute=False))
+    idx.set_option("persistent_wave", 1)
+    d1, l1 = idx.search(q, 10, idx.make_params(ef=64, beam=1, recompute=False))
+    assert np.array_equal(l0, gi) and np.array_equal(l1, gi) and np.array_equal(d0, d1)
+    idx.close()
 
 
 @pytest.mark.parametrize("metric", ["mips", "l2"])

@@ -90,17 +90,31 @@ def test_batched_graph_builder_with_injected_search(built_libs):
     assert recall_at_k(ids, gt) > 0.97
 
 
-def test_encoder_autotune_falls_back_to_the_default_path_when_the_probe_process_fails():
-    """leann_amd/autotune.py: the probe runs in a child process; without a GPU it dies at start-up -- the caller
-    must get the default path (no switches) and a log entry, never an exception."""
-    from leann_amd import autotune
+def test_packed_weight_caches_follow_the_source_weights():
+    """leann_amd/encoder.py: _packed keys every packed-weight copy on (device, storage address, in-place version, dtype) of its
+    sources: an in-place update (load_state_dict, optimiser step) or a dtype change must rebuild the pack, an untouched module
+    must not."""
+    import torch
 
-    r = autotune.pick_encoder_switches(timeout=300)
-    assert r["switches"] == {}
-    assert any("child_exit" in e for e in r["log"])
-    keys = {k for c, _ in autotune.CANDIDATES for k in c}
-    assert keys == set(autotune.ALL_KEYS) and all(k.startswith("LEANN_MI355X_") for k in keys)
+    from leann_amd.encoder import _packed
 
+    lin = torch.nn.Linear(8, 4)
+    calls = []
+
+    def make():
+        calls.append(1)
+        return lin.weight.detach().clone()
+
+    a = _packed(lin, "_t", (lin.weight, lin.bias), make)
+    assert _packed(lin, "_t", (lin.weight, lin.bias), make) is a and len(calls) == 1
+    with torch.no_grad():
+        lin.weight.add_(1.0)  # in place: same storage, new version
+    b = _packed(lin, "_t", (lin.weight, lin.bias), make)
+    assert len(calls) == 2 and torch.equal(b, lin.weight)
+    lin.load_state_dict({"weight": torch.zeros(4, 8), "bias": torch.zeros(4)})
+    assert torch.equal(_packed(lin, "_t", (lin.weight, lin.bias), make), torch.zeros(4, 8)) and len(calls) == 3
+    lin.half()  # new storage, new dtype
+    assert _packed(lin, "_t", (lin.weight, lin.bias), make).dtype == torch.float16 and len(calls) == 4
 
 def test_high_degree_preserving_pruning_alg3(built_libs):
     """LEANN paper Algorithm 3 (gpu_graph_build.prune_preserving_hubs): fewer links, hubs keep theirs, the graph stays valid and
