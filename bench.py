@@ -415,10 +415,14 @@ def main():
                                               "residual + LayerNorm in one kernel)"), 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden
     if not ktimes.get(kname, {}).get("launches"):  # LEANN_MI355X_TAIL=0: the feed-forward block alone
         kname, kdesc, fpt = "mlp_fused_h384", "lm::k_mlp_fused_h384_v3<0> (fc1 + GELU + fc2 + residual + LayerNorm in one kernel)", 4 * cfg.ffn * cfg.hidden
+    if not ktimes.get(kname, {}).get("launches") and ktimes.get("gemm_f16", {}).get("launches"):  # hidden != 384: the general GEMM is the dominant kernel
+        kname, fpt = "gemm_f16", None
+        kdesc = ("lm::k_gemm_f16<GemmShape<2,4,4,2>, *> (general 256 x 256-tile MFMA GEMM with bias / GELU / residual epilogues: the QKV, "
+                 "attention-output and both feed-forward projections of every layer)")
     mlp, mlp_all = ktimes.get(kname), kall.get(kname)
     if mlp and mlp["ms"] > 0:
         mlp_tf = mlp["work"] / (mlp["ms"] * 1e-3) / 1e12
-        tpl = mlp["work"] / fpt / max(mlp["launches"], 1)  # tokens per launch
+        tpl = mlp["work"] / fpt / max(mlp["launches"], 1) if fpt else None  # tokens per launch
         ktraffic = ktraffic_src = None
         try:  # HBM-side bytes per launch: the separate PMC passes of this kernel (profiles/r2_pmc_layer_tail.json), per token x this run's launch size
             pmc_t = json.loads((ROOT / "profiles" / "r2_pmc_layer_tail.json").read_text())
@@ -434,7 +438,8 @@ def main():
                     "traffic_source": ktraffic_src,
                     "flops_per_token": fpt, "launches": mlp["launches"],
                     "avg_launch_us": round(1e3 * mlp["ms"] / max(mlp["launches"], 1), 1),
-                    "tokens_per_launch": round(mlp["work"] / fpt / max(mlp["launches"], 1)),
+                    "tokens_per_launch": round(tpl) if tpl else None,
+                    "gflop_per_launch": round(mlp["work"] / max(mlp["launches"], 1) / 1e9, 2),
                     "share_of_timed_region": round(mlp["ms"] / (elapsed * 1e3), 4),
                     "all_launches_of_the_process": {"launches": mlp_all["launches"], "avg_launch_us": round(1e3 * mlp_all["ms"] / max(mlp_all["launches"], 1), 1),
                                                     "TFLOPs": round(mlp_all["work"] / (mlp_all["ms"] * 1e-3) / 1e12, 2),

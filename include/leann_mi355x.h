@@ -173,6 +173,13 @@ int lm_index_set_option(lm_index *idx, const char *name, int64_t value);
  * re-ranked with exact distances of embeddings fetched ONCE through the provider (:444-449); without
  * it, stored embeddings are used when attached, else the PQ order is returned. */
 int lm_pq_attach(lm_index *idx, int32_t m, const float *codebooks, const uint8_t *codes, int64_t ntotal);
+/* The same with the sub-quantisers' dimension ranges given explicitly -- the chunking of a stock DiskANN bundle
+ * (<prefix>_pq_pivots.bin: 256 full-dimension pivots + centroid + chunk_offsets, diskann_backend.py:151-162): chunk j covers
+ * dimensions [chunk_offsets[j], chunk_offsets[j+1]), lengths may differ and may be 0, chunk_offsets[m] <= d (trailing dimensions
+ * carry no code: the augmentation coordinate of a MIPS bundle).  codebooks: chunk j's 256 centroids x len_j floats at float
+ * offset 256 * chunk_offsets[j].  m % 4 == 0 (pad the code rows with empty chunks).  leann_amd/diskann_files.py converts the files. */
+int lm_pq_attach_chunked(lm_index *idx, int32_t m, const int32_t *chunk_offsets, const float *codebooks, const uint8_t *codes,
+                         int64_t ntotal);
 typedef struct {
     int32_t complexity;          /* L: candidate list size                 :456 */
     int32_t beam_width;          /* W: nodes expanded per iteration (<=64) :457 */

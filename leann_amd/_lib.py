@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "lm_search_params_default", "lm_index_search", "lm_index_search_device",
     "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_event_overhead_us",
     "lm_dist_gather", "lm_topk_merge",
-    "lm_pq_attach", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
+    "lm_pq_attach", "lm_pq_attach_chunked", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
     "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_attn_varlen_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
     "lm_mlp_fused_h384_f16", "lm_attn_out_mlp_fused_h384_f16", "lm_linear_h384_f16", "lm_gemm_h384_f16", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     lib.lm_dist_gather.argtypes = [vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]
     lib.lm_topk_merge.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.lm_pq_attach.argtypes = [vp, i32, vp, vp, i64]
+    lib.lm_pq_attach_chunked.argtypes = [vp, i32, vp, vp, vp, i64]
     lib.lm_pq_search_params_default.argtypes = [C.POINTER(PqSearchParams)]
     lib.lm_pq_search_params_default.restype = None
     lib.lm_pq_batch_search.argtypes = [vp, i64, vp, i32, C.POINTER(PqSearchParams), vp, vp]

@@ -173,7 +173,7 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
         self.is_compact = self.meta.get("is_compact", bk.get("is_compact", True))
         self.is_pruned = self.meta.get("is_pruned", bool(self.is_compact and bk.get("is_recompute", True)))
         self.index_file = self.index_dir / f"{self.index_path.stem}.index"
-        if not self.index_file.exists():
+        if not self.index_file.exists() and not self._has_alternative_index_files():
             raise FileNotFoundError(f"HNSW index file not found at {self.index_file}")
         self.device = int(kwargs.get("device", 0))
         self.encoder_batch = int(kwargs.get("encoder_batch", 2048))
@@ -197,6 +197,10 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             self._ensure_index_loaded()
 
     # ---- loading ---------------------------------------------------------------------------
+    def _has_alternative_index_files(self) -> bool:
+        """Subclasses that can serve another backend's files (the DiskANN-style searcher: a stock DiskANN bundle) say so here."""
+        return False
+
     def _load_meta(self) -> dict:
         meta_path = self.index_dir / f"{self.index_path.name}.meta.json"
         if not meta_path.exists():
@@ -501,16 +505,44 @@ class Mi355xDiskannBuilder(LeannBackendBuilderInterface):
 
 
 class Mi355xDiskannSearcher(Mi355xSearcher):
-    """Mirror of DiskannSearcher (diskann_backend.py:300-471)."""
+    """Mirror of DiskannSearcher (diskann_backend.py:300-471).  Serves the bundle Mi355xDiskannBuilder writes (``<stem>.index`` +
+    ``<stem>_pq.npz``) and -- copy the meta.json with ``"backend_name": "mi355x_diskann"`` -- a bundle written by the STOCK DiskANN
+    backend in its default (non-recompute) mode: ``<stem>_pq_pivots.bin``, ``<stem>_pq_compressed.bin``, ``<stem>_disk.index``,
+    ``<stem>_disk.index_medoids.bin`` / ``_max_base_norm.bin`` in the public DiskANN layout (leann_amd/diskann_files.py).  A stock
+    recompute-mode bundle keeps its graph only in the fork's private ``_disk_graph.index`` / ``_partition.bin``: not readable."""
+
+    def _stock_prefix(self) -> str:
+        return str(self.index_dir / self.index_path.stem)
+
+    def _has_alternative_index_files(self) -> bool:
+        pre = self._stock_prefix()
+        return all(Path(pre + sfx).exists() for sfx in ("_pq_pivots.bin", "_pq_compressed.bin", "_disk.index"))
 
     def __init__(self, index_path: str, **kwargs):
         super().__init__(index_path, **kwargs)
         self.num_threads = kwargs.get("num_threads", 8)
         self.pq_file = self.index_dir / f"{self.index_path.stem}_pq.npz"
-        if not self.pq_file.exists():
+        self._stock = not self.index_file.exists()
+        if self._stock:
+            self.is_pruned = False  # the stock non-recompute bundle carries its vectors (_disk.index)
+        elif not self.pq_file.exists():
             raise FileNotFoundError(f"PQ file not found at {self.pq_file}")
+        if Path(self._stock_prefix() + "_disk_graph.index").exists() and self._stock and not self._has_alternative_index_files():
+            raise FileNotFoundError("this is a recompute-mode bundle of the stock DiskANN backend: its graph (_disk_graph.index / _partition.bin) is in "
+                                    "the fork's private format, which leann-backend-mi355x does not read")
 
     def _ensure_index_loaded(self):
+        if self._stock and self._index is None:
+            from .diskann_files import load_stock_bundle
+            from .index import Mi355xIndex
+
+            _lib.require_gpu()
+            b = load_stock_bundle(self._stock_prefix(), int(self.dimensions), self.distance_metric)
+            self._index = Mi355xIndex.from_csr(b.graph(), device=self.device)
+            self._index.attach_table(b.vectors)
+            self._index.attach_pq(b.codebooks, b.codes, b.chunk_offsets)
+            self._has_pq = True
+            return self._index
         idx = super()._ensure_index_loaded()  # attaches <stem>_pq.npz (checked to exist in __init__): one upload only
         if not self._has_pq:
             raise FileNotFoundError(f"PQ file not found at {self.pq_file}")

@@ -3,8 +3,9 @@
 // library's own entry points on one stream, so a search round costs one foreign-function call instead of ~3 L + 2 (at one query per
 // call a round recomputes ~5 chunks and the ~20 Python -> ctypes launches are most of its time).  What it replaces in the
 // reference: compute_embeddings' model.encode() call (leann/embedding_compute.py:229-239) for sentence-transformers models with
-// mean pooling (all-MiniLM-L6-v2 and relatives).  Opt-in from leann_amd/encoder.py with LEANN_MI355X_ONECALL=1 until its
-// latency has been measured on the MI355X; it runs in the thread-per-lane emulation (tests/emulated_search_cases.py).
+// mean pooling (all-MiniLM-L6-v2 and relatives).  The default launch path of leann_amd/encoder.py since round 3 (MI355X, 200k-chunk
+// index: B = 1 p50 57.7 -> 56.3 ms; LEANN_MI355X_ONECALL=0 = one call per kernel); also runs in the thread-per-lane emulation
+// (tests/emulated_search_cases.py) and under the real leann.api.LeannSearcher there (tests/real_caller_over_emulation.py).
 #include <cstdint>
 #include <cstdlib>
 

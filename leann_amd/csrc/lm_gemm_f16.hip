@@ -38,12 +38,14 @@ namespace lm {
 
 #ifdef LM_EMULATED_DEVICE
 #define GM_WAIT_VM0() ((void)0)
+#define GM_WAIT_VM(n) ((void)0)
 #define GM_WAIT_LGKM0() ((void)0)
 #define GM_BARRIER() __syncthreads()
 #define GM_UNIFORM(v) (v)
 #else
 #define GM_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)  // the wave index: keeps everything derived from it in SGPRs
 #define GM_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define GM_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define GM_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
@@ -77,9 +79,32 @@ struct GemmShape {
 using GemmBig = GemmShape<2, 4, 4, 2>;    // 256 x 256, 512 threads, 128 accumulator registers per lane
 using GemmSmall = GemmShape<2, 2, 2, 2>;  // 128 x 128, 256 threads, 64 accumulator registers per lane
 
+// VAR (diagnosis builds only, -DLM_DIAG + LEANN_MI355X_GEMM_VARIANT; the product library holds the default alone):
+//   0 = K-tiles of 64 through two stages, the next tile's eight DMA pieces spread two per k-step;  1 = all eight in front of the
+//   first MFMA;  2 = four behind each of the first two fragment requests;  3 = no DMA in the loop (stale operands: the bare
+//   MFMA + LDS + barrier rate);  4 = no MFMA (the load path alone);  6 = variant 0 without the global stores of the epilogue;
+//   5 = K half-tiles of 32 through a ring of FOUR slots, counted vmcnt: two half-tiles stay in flight across every barrier.
+//   7 = variant 2 with s_memtime stamps: wave 0 of every workgroup adds its cycle counts {prologue (until tile 0 has landed), main loop,
+//       bias + LDS tile write, row read-back + global store issue, store drain, workgroups} to the u64 words at `resid` (epilogue 0 only:
+//       the residual pointer is then a debug buffer; scripts/kbench.cpp "gemmstamp").
+constexpr int GM_VAR_DEFAULT = 2;
+
+#if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
+#define GM_STAMP(t)                                     \
+    do {                                                \
+        if constexpr (VAR == 7) {                       \
+            __builtin_amdgcn_sched_barrier(0);          \
+            t = __builtin_amdgcn_s_memtime();           \
+            __builtin_amdgcn_sched_barrier(0);          \
+        }                                               \
+    } while (0)
+#else
+#define GM_STAMP(t) ((void)0)
+#endif
+
 // grid: 8 * NC * ceil(row_blocks / 8) workgroups (NC = N / BN).  xcd = b % 8, idx = b / 8: row block = (idx / NC) * 8 + xcd,
 // column tile = idx % NC -- the NC tiles of a row block are consecutive dispatches on one XCD.
-template <class S, int EPI>
+template <class S, int EPI, int VAR>
 __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
     const __half* __restrict__ x, const __half* __restrict__ w, const float* __restrict__ bias, const __half* __restrict__ resid,
     __half* __restrict__ out, int T, int N, int K) {
@@ -92,36 +117,8 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
     const int t0 = rb * S::BM, n0 = ct * S::BN;
     if (t0 >= T) return;  // row-block padding of the last group of eight
     const int wf = wv % S::WF, wt = wv / S::WF;
-
-    // ---- DMA plan: piece p = wv + NW * i covers stage rows 8 p .. 8 p + 7 (W rows first, then x rows); lane = (row 8 p + lane / 8,
-    //      position c' = lane % 8) fetches chunk c' ^ ((row >> 1) & 7).  Source = wave-uniform base + per-lane 32-bit offset. ----
-    unsigned voff[S::PIECES];
-#pragma unroll
-    for (int i = 0; i < S::PIECES; ++i) {
-        const int p = wv + S::NW * i, row = 8 * p + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (8 * p < S::BN) {
-            voff[i] = (unsigned)(n0 + row) * (unsigned)(K * 2) + c * 16;
-        } else {
-            int tok = t0 + row - S::BN;
-            tok = tok < T ? tok : T - 1;  // rows past the end re-read the last token; their results are never stored
-            voff[i] = (unsigned)tok * (unsigned)(K * 2) + c * 16;
-        }
-    }
-    // piece i of K-tile kt -> stage (wave-uniform source base + this lane's offset)
-    auto issue_piece = [&](int kt, int stage, int i) {
-        const int p = wv + S::NW * i;  // wave uniform
-        const unsigned char* base = (const unsigned char*)(8 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)kt * 128;
-        lm_dma16_sv(base, voff[i], smem + stage * S::STAGE + p * 1024);
-    };
-
-    // ---- fragment addresses: row (tile base + r31), k-step kk (16 halfs): chunk 2 kk + g at position (2 kk + g) ^ ((r31 >> 1) & 7)
-    //      (tile bases are multiples of 32 rows, so the row term of the permutation depends on r31 only) ----
-    int fo[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = r31 * 128 + ((((2 * kk + g) ^ (r31 >> 1)) & 7) << 4);
-    const int a_base = wf * S::TF * 32 * 128;                 // W rows of this wave
-    const int b_base = S::BN * 128 + wt * S::TT * 32 * 128;   // x rows of this wave
+    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+    GM_STAMP(ts0);
 
     float16v acc[S::TF][S::TT];
 #pragma unroll
@@ -131,54 +128,162 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / 64;  // even (K % 128 == 0)
-#pragma unroll
-    for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
-
-    // One K-tile: four k-steps of TF x TT MFMAs.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step kk are issued
-    // (a second register set: the matrix pipe never waits for an LDS round trip inside a tile), and the NEXT tile's DMA pieces are
-    // spread over the steps, PIECES / 4 behind each fragment request, instead of standing in front of the first MFMA (a piece costs
-    // ~60 issue cycles; eight of them back to back on both waves of a SIMD would idle the matrix pipe for a quarter of the tile).
-    // The scheduling barriers pin that order: the register budget (256 per wave) leaves the compiler no room to find it by itself.
-    auto ktile = [&](int stage, int next_kt, bool prefetch) {
-        const unsigned char* sb = smem + stage * S::STAGE;
-        half8 af[2][S::TF], bf[2][S::TT];
-#pragma unroll
-        for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 4096 + fo[0]);
-#pragma unroll
-        for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 4096 + fo[0]);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int c = kk & 1, n = c ^ 1;
-            if (kk < 3) {
-#pragma unroll
-                for (int i = 0; i < S::TF; ++i) af[n][i] = *(const half8*)(sb + a_base + i * 4096 + fo[kk + 1]);
-#pragma unroll
-                for (int j = 0; j < S::TT; ++j) bf[n][j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk + 1]);
-            }
-            if (prefetch) {
-#pragma unroll
-                for (int i = 0; i < S::PIECES / 4; ++i) issue_piece(next_kt, stage ^ 1, kk * (S::PIECES / 4) + i);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < S::TF; ++i)
-#pragma unroll
-                for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    // global row of stage row `row` (W rows first, then x rows; rows past the end re-read the last token, their results are never stored)
+    auto src_row = [&](int row) -> unsigned {
+        if (row < S::BN) return (unsigned)(n0 + row);
+        const int tok = t0 + row - S::BN;
+        return (unsigned)(tok < T ? tok : T - 1);
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        GM_WAIT_VM0();   // this wave's pieces of tile kt have landed ...
-        GM_BARRIER();    // ... and so have everybody else's; all waves are done reading stage 1 (tile kt - 1)
-        ktile(0, kt + 1, true);
-        GM_WAIT_LGKM0();  // own fragment reads of stage 0 are complete before anybody's DMA may overwrite it
-        GM_WAIT_VM0();
-        GM_BARRIER();
-        ktile(1, kt + 2, kt + 2 < nk);
-        GM_WAIT_LGKM0();
+
+    if constexpr (VAR != 5) {
+        // ---- DMA plan: piece p = wv + NW * i covers stage rows 8 p .. 8 p + 7; lane = (row 8 p + lane / 8, position c' = lane % 8)
+        //      fetches chunk c' ^ ((row >> 1) & 7) of the row's 128-byte line.  Source = wave-uniform base + per-lane 32-bit offset. ----
+        unsigned voff[S::PIECES];
+#pragma unroll
+        for (int i = 0; i < S::PIECES; ++i) {
+            const int row = 8 * (wv + S::NW * i) + (lane >> 3);
+            voff[i] = src_row(row) * (unsigned)(K * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+        auto issue_piece = [&](int kt, int stage, int i) {
+            const int p = wv + S::NW * i;  // wave uniform
+            const unsigned char* base = (const unsigned char*)(8 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)kt * 128;
+            lm_dma16_sv(base, voff[i], smem + stage * S::STAGE + p * 1024);
+        };
+        // ---- fragment addresses: row (tile base + r31), k-step kk (16 halfs): chunk 2 kk + g at position (2 kk + g) ^ ((r31 >> 1) & 7)
+        //      (tile bases are multiples of 32 rows, so the row term of the permutation depends on r31 only) ----
+        int fo[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fo[kk] = r31 * 128 + ((((2 * kk + g) ^ (r31 >> 1)) & 7) << 4);
+        const int a_base = wf * S::TF * 32 * 128;                 // W rows of this wave
+        const int b_base = S::BN * 128 + wt * S::TT * 32 * 128;   // x rows of this wave
+
+        const int nk = K / 64;  // even (K % 128 == 0)
+#pragma unroll
+        for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
+
+        // One K-tile: four k-steps of TF x TT MFMAs.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step kk are
+        // issued (a second register set: the matrix pipe never waits for an LDS round trip inside a tile); the NEXT tile's DMA pieces
+        // go behind the fragment requests as VAR says.  The scheduling barriers pin that order: the register budget (256 per wave)
+        // leaves the compiler no room to find it by itself.
+        auto ktile = [&](int stage, int next_kt, bool prefetch) {
+            const unsigned char* sb = smem + stage * S::STAGE;
+            half8 af[2][S::TF], bf[2][S::TT];
+#pragma unroll
+            for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 4096 + fo[0]);
+#pragma unroll
+            for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 4096 + fo[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c = kk & 1, n = c ^ 1;
+                if (kk < 3) {
+#pragma unroll
+                    for (int i = 0; i < S::TF; ++i) af[n][i] = *(const half8*)(sb + a_base + i * 4096 + fo[kk + 1]);
+#pragma unroll
+                    for (int j = 0; j < S::TT; ++j) bf[n][j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk + 1]);
+                }
+                if (prefetch && VAR != 3) {
+                    constexpr int PER = (VAR == 1) ? S::PIECES : ((VAR == 2 || VAR == 7) ? S::PIECES / 2 : S::PIECES / 4);
+                    if (kk * PER < S::PIECES) {
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) issue_piece(next_kt, stage ^ 1, kk * PER + i);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR != 4) {
+#pragma unroll
+                    for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+                        for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < S::TF; ++i) asm volatile("" ::"v"(af[c][i]));
+#pragma unroll
+                    for (int j = 0; j < S::TT; ++j) asm volatile("" ::"v"(bf[c][j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            GM_WAIT_VM0();   // this wave's pieces of tile kt have landed ...
+            GM_BARRIER();    // ... and so have everybody else's; all waves are done reading stage 1 (tile kt - 1)
+            if (kt == 0) GM_STAMP(ts1);
+            ktile(0, kt + 1, true);
+            GM_WAIT_LGKM0();  // own fragment reads of stage 0 are complete before anybody's DMA may overwrite it
+            GM_WAIT_VM0();
+            GM_BARRIER();
+            ktile(1, kt + 2, kt + 2 < nk);
+            GM_WAIT_LGKM0();
+        }
+    } else {
+        // ---- VAR 5: half-tiles (32 halfs of K = 64 bytes per row) through a ring of four slots.  Piece p = wv + NW * i covers slot
+        //      rows 16 p .. 16 p + 15; lane = (row 16 p + lane / 4, position c' = lane % 4) fetches chunk c' ^ ((row >> 2) & 3) of the
+        //      row's 64-byte half line (conflict-free fragment reads: four rows share a 256-byte bank row, the rows of a 16-lane group
+        //      that share row % 4 differ in (row >> 2) % 4).  Half-tile h + 3 is requested while h is computed; the wait in front of
+        //      the barrier is COUNTED: it retires h and leaves h + 1 and h + 2 in flight. ----
+        constexpr int SLOT = (S::BN + S::BM) * 64, PH = (S::BN + S::BM) / 16 / S::NW;
+        static_assert(4 * SLOT <= S::LDS && PH % 2 == 0, "ring does not fit");
+        unsigned voff[PH];
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            const int row = 16 * (wv + S::NW * i) + (lane >> 2);
+            voff[i] = src_row(row) * (unsigned)(K * 2) + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+        }
+        auto issue_piece = [&](int h, int slot, int i) {
+            const int p = wv + S::NW * i;
+            const unsigned char* base = (const unsigned char*)(16 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)h * 64;
+            lm_dma16_sv(base, voff[i], smem + slot * SLOT + p * 1024);
+        };
+        int fo[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fo[kk] = r31 * 64 + ((((2 * kk + g) ^ (r31 >> 2)) & 3) << 4);
+        const int a_base = wf * S::TF * 32 * 64, b_base = S::BN * 64 + wt * S::TT * 32 * 64;
+        const int nh = K / 32;  // a multiple of 4
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+            for (int i = 0; i < PH; ++i) issue_piece(h, h, i);
+        auto htile = [&](int slot, int next_h, bool prefetch) {
+            const unsigned char* sb = smem + slot * SLOT;
+            half8 af[2][S::TF], bf[2][S::TT];
+#pragma unroll
+            for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 2048 + fo[0]);
+#pragma unroll
+            for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 2048 + fo[0]);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk == 0) {
+#pragma unroll
+                    for (int i = 0; i < S::TF; ++i) af[1][i] = *(const half8*)(sb + a_base + i * 2048 + fo[1]);
+#pragma unroll
+                    for (int j = 0; j < S::TT; ++j) bf[1][j] = *(const half8*)(sb + b_base + j * 2048 + fo[1]);
+                }
+                if (prefetch) {
+#pragma unroll
+                    for (int i = 0; i < PH / 2; ++i) issue_piece(next_h, (slot + 3) & 3, kk * (PH / 2) + i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+                    for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int h0 = 0; h0 < nh; h0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int h = h0 + u, rem = nh - 1 - h;  // half-tiles requested behind h
+                if (rem >= 2) GM_WAIT_VM(2 * PH);
+                else if (rem == 1) GM_WAIT_VM(PH);
+                else GM_WAIT_VM0();
+                GM_BARRIER();  // h has landed everywhere; everybody is done reading slot (u + 3) % 4 (half-tile h - 1)
+                htile(u, h + 3, h + 3 < nh);
+                GM_WAIT_LGKM0();
+            }
+        }
     }
     GM_BARRIER();  // every wave is done with the stages: their space becomes the output tiles
+    GM_STAMP(ts2);
 
     // ---- epilogue 1: + bias (, GELU), fp16, token-major into this wave's LDS tile.  acc[i][j][4 q + e] = feature 32 i + 8 q + 4 g + e of
     //      token 32 j + r31 (both relative to the wave's sub-tile) ----
@@ -202,6 +307,7 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
             }
         }
     LM_WAVE_SYNC();  // the tile is read back by the wave that wrote it: no workgroup barrier
+    GM_STAMP(ts3);
 
     // ---- epilogue 2: whole rows out.  LPR lanes cover one token's TF * 32 features (16 B each), 64 / LPR rows per instruction ----
     constexpr int LPR = S::TF * 4, RPI = 64 / LPR;
@@ -220,26 +326,59 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)y[e] + (float)rr[e]);
             }
-            *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y;
+            if constexpr (VAR != 6) *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y;
+            else asm volatile("" ::"v"(y));
         }
     }
+#if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
+    if constexpr (VAR == 7) {
+        GM_STAMP(ts4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GM_STAMP(ts5);
+        if (tid == 0) {
+            unsigned long long* dbg = (unsigned long long*)resid;
+            atomicAdd(dbg + 0, ts1 - ts0);
+            atomicAdd(dbg + 1, ts2 - ts1);
+            atomicAdd(dbg + 2, ts3 - ts2);
+            atomicAdd(dbg + 3, ts4 - ts3);
+            atomicAdd(dbg + 4, ts5 - ts4);
+            atomicAdd(dbg + 5, 1ull);
+        }
+    }
+#endif
 }
 
-template <class S, int EPI>
-static int gemm_launch(const void* d_x, const void* d_w, const float* d_bias, const void* d_resid, void* d_out, int64_t tokens, int32_t n_out,
-                       int32_t k_in, hipStream_t st) {
+template <class S, int EPI, int VAR>
+static int gemm_launch_var(const void* d_x, const void* d_w, const float* d_bias, const void* d_resid, void* d_out, int64_t tokens, int32_t n_out,
+                           int32_t k_in, hipStream_t st) {
     const int64_t rbs = (tokens + S::BM - 1) / S::BM;
     const int64_t nblk = 8 * (int64_t)(n_out / S::BN) * ((rbs + 7) / 8);
     if (nblk > 0x7fffffff) LM_FAIL(LM_EINVAL, "lm_gemm_f16: too many tiles for one launch");
     static bool attr_set = false;
     if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_f16<S, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS));
+        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_f16<S, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_f16<S, EPI>), dim3((unsigned)nblk), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
+    hipLaunchKernelGGL((k_gemm_f16<S, EPI, VAR>), dim3((unsigned)nblk), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
                        (const __half*)d_resid, (__half*)d_out, (int)tokens, n_out, k_in);
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+template <class S, int EPI>
+static int gemm_launch(const void* d_x, const void* d_w, const float* d_bias, const void* d_resid, void* d_out, int64_t tokens, int32_t n_out,
+                       int32_t k_in, hipStream_t st) {
+#ifdef LM_DIAG
+    static const int var = [] { const char* v = getenv("LEANN_MI355X_GEMM_VARIANT"); return v ? atoi(v) : GM_VAR_DEFAULT; }();
+    switch (var) {
+#define GM_V(V) case V: return gemm_launch_var<S, EPI, V>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st)
+        GM_V(0); GM_V(1); GM_V(2); GM_V(3); GM_V(4); GM_V(5); GM_V(6); GM_V(7);
+#undef GM_V
+        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_GEMM_VARIANT: 0..7");
+    }
+#else
+    return gemm_launch_var<S, EPI, GM_VAR_DEFAULT>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
+#endif
 }
 
 }  // namespace lm

@@ -11,7 +11,8 @@ struct PruneArgs {
     float* lut;          // B x m x 256
     const float* codebooks;
     const uint8_t* codes;
-    int32_t Dp, metric, m, dsub;
+    int32_t Dp, metric, m;
+    const int32_t* chunk_off;  // m + 1 (see PqDev)
     float keep;          // a = 1 - prune_ratio
     int32_t strategy;    // 0 global, 1 local, 2 proportional
     int32_t use_rbm;     // 1: mark the dedup bitmap, 2: only nodes without a memo row, 0: stored-embedding mode
@@ -23,17 +24,17 @@ __global__ __launch_bounds__(256) void k_pq_lut_all(PruneArgs a) {
     const float* qv = a.Q + (size_t)q * a.Dp;
     float* lut = a.lut + (size_t)q * a.m * 256;
     for (int e = threadIdx.x; e < a.m * 256; e += 256) {
-        const int j = e >> 8;
-        const float* cb = a.codebooks + (size_t)e * a.dsub;
-        const float* qs = qv + j * a.dsub;
+        const int j = e >> 8, lo = a.chunk_off[j], len = a.chunk_off[j + 1] - lo;
+        const float* cb = a.codebooks + (size_t)256 * lo + (size_t)(e & 255) * len;
+        const float* qs = qv + lo;
         float acc = 0.0f;
         if (a.metric == LM_METRIC_L2) {
-            for (int t = 0; t < a.dsub; ++t) {
+            for (int t = 0; t < len; ++t) {
                 float d = qs[t] - cb[t];
                 acc = __builtin_fmaf(d, d, acc);
             }
         } else {
-            for (int t = 0; t < a.dsub; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+            for (int t = 0; t < len; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
             acc = -acc;
         }
         lut[e] = acc;

@@ -16,9 +16,11 @@
 namespace lm {
 
 struct PqDev {
-    int32_t m, dsub;
-    const float* codebooks;  // m x 256 x dsub
-    const uint8_t* codes;    // N x m
+    int32_t m;
+    const int32_t* chunk_off;  // m + 1: sub-quantiser j covers dimensions [chunk_off[j], chunk_off[j + 1]) (uniform d / m for lm_pq_attach;
+                               // the public DiskANN pq_pivots chunking -- unequal, possibly empty chunks -- for lm_pq_attach_chunked)
+    const float* codebooks;    // chunk j: 256 centroids x len_j floats at 256 * chunk_off[j]   (uniform: m x 256 x dsub)
+    const uint8_t* codes;      // N x m
 };
 
 struct PqArgs {
@@ -45,17 +47,17 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
     const float* qv = a.Q + (size_t)q * a.Dp;
     // ---- lookup table (canonical: sequential fmaf over the sub-vector) ----
     for (int e = tid; e < pq.m * 256; e += 256) {
-        const int j = e >> 8;
-        const float* cb = pq.codebooks + (size_t)e * pq.dsub;
-        const float* qs = qv + j * pq.dsub;
+        const int j = e >> 8, lo = pq.chunk_off[j], len = pq.chunk_off[j + 1] - lo;
+        const float* cb = pq.codebooks + (size_t)256 * lo + (size_t)(e & 255) * len;
+        const float* qs = qv + lo;
         float acc = 0.0f;
         if (a.metric == LM_METRIC_L2) {
-            for (int t = 0; t < pq.dsub; ++t) {
+            for (int t = 0; t < len; ++t) {
                 float d = qs[t] - cb[t];
                 acc = __builtin_fmaf(d, d, acc);
             }
         } else {
-            for (int t = 0; t < pq.dsub; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+            for (int t = 0; t < len; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
             acc = -acc;
         }
         lut[e] = acc;
@@ -63,26 +65,41 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
     __syncthreads();
     uint32_t* vis = ws.visited + (size_t)q * ws.nw;
     const int mw = pq.m >> 2;  // u32 words per code
-    auto adc = [&](int32_t v, int r) -> float {  // partial sum of lane r (j = r, r+4, ...)
+    // ADC distance of node v by ONE lane: the canonical arithmetic of oracle/lm_oracle_pq.c:orc_pq_adc -- four partial sums over the
+    // sub-quantisers j = r, r + 4, ... (r = 0..3), each in increasing j, combined as (p0 + p1) + (p2 + p3) -- with the code row
+    // fetched as 16-byte pieces (m % 16 == 0) or dwords.  Round 2 spread one vector over 4 lanes (every lane re-loading all m / 4
+    // dwords): 64 vectors per workgroup pass and 100-byte gathers one dword at a time made the kernel latency bound (2 % of the HBM
+    // rate); one lane per vector puts 256 independent gathers in flight per pass and needs no cross-lane reduction.
+    auto adc1 = [&](int32_t v) -> float {
         const uint32_t* cw = (const uint32_t*)(pq.codes + (size_t)v * pq.m);
-        float p = 0.0f;
-        for (int i = 0; i < mw; ++i) {
-            uint32_t w = cw[i];
-            p = p + lut[((4 * i + r) << 8) + ((w >> (8 * r)) & 255u)];
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        auto word = [&](int i, uint32_t w) {
+            const float* l4 = lut + ((4 * i) << 8);
+            p0 = p0 + l4[w & 255u];
+            p1 = p1 + l4[256 + ((w >> 8) & 255u)];
+            p2 = p2 + l4[512 + ((w >> 16) & 255u)];
+            p3 = p3 + l4[768 + (w >> 24)];
+        };
+        if ((pq.m & 15) == 0) {
+            const uint4* c4 = (const uint4*)cw;
+            for (int i = 0; i < (mw >> 2); ++i) {
+                const uint4 w4 = c4[i];
+                word(4 * i, w4.x);
+                word(4 * i + 1, w4.y);
+                word(4 * i + 2, w4.z);
+                word(4 * i + 3, w4.w);
+            }
+        } else {
+            for (int i = 0; i < mw; ++i) word(i, cw[i]);
         }
-        return p;
+        return (p0 + p1) + (p2 + p3);
     };
     // ---- seed with the entry point (medoid) ----
     int npool = 0;
-    if (tid < 4) {
+    if (tid == 0) {
         const int32_t ep = g.entry_point;
-        float p = adc(ep, tid);
-        float s01 = p + __shfl_xor(p, 1, 4);
-        float tot = s01 + __shfl_xor(s01, 2, 4);
-        if (tid == 0) {
-            atomicOr(&vis[ep >> 5], 1u << (ep & 31));
-            lpool[0] = make_key(tot, ep);
-        }
+        atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+        lpool[0] = make_key(adc1(ep), ep);
     }
     npool = 1;
     unsigned long long n_adc = 1;
@@ -148,26 +165,36 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
         }
         const int n = total;
         n_adc += (unsigned long long)n;
-        int Pn = 1;
-        while (Pn < n) Pn <<= 1;
-        // ---- ADC distances: 4 lanes per vector ----
-        {
-            const int r = tid & 3, gi = tid >> 2;
-            for (int i0 = 0; i0 < n; i0 += 64) {
-                const int i = i0 + gi;
-                const int32_t v = i < n ? s_new[i] : s_new[0];
-                float p = adc(v, r);
-                float s01 = p + __shfl_xor(p, 1, 4);
-                float tot = s01 + __shfl_xor(s01, 2, 4);
-                if (r == 0 && i < n) newk[i] = make_key(tot, v);
+        // ---- ADC distances: one lane per fresh node, 256 gathers in flight per pass ----
+        // A key that is not below the worst entry of a FULL list can never enter it (keys are unique: (distance, id)): such keys are
+        // dropped before the sort -- in steady state most of a hop's candidates -- so the bitonic sort runs over the survivors only.
+        const uint64_t thr = npool >= a.L ? lpool[a.L - 1] : KEY_NONE;
+        int kept = 0;
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            const int i = i0 + tid;
+            uint64_t key = KEY_NONE;
+            if (i < n) {
+                const int32_t v = s_new[i];
+                key = make_key(adc1(v), v);
             }
-            for (int i = n + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+            const bool keep = key < thr;  // KEY_NONE (idle lanes) is never below thr
+            unsigned long long mk = __ballot(keep);
+            if (lane == 0) s_wcnt[wv] = __popcll(mk);
+            __syncthreads();
+            int woff = 0;
+            for (int w2 = 0; w2 < wv; ++w2) woff += s_wcnt[w2];
+            if (keep) newk[kept + woff + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+            kept += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            __syncthreads();
         }
+        int Pn = 1;
+        while (Pn < kept) Pn <<= 1;
+        for (int i = kept + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
         __syncthreads();
-        if (n > 0) {
+        if (kept > 0) {
             sort_keys<256>(newk, Pn, tid);
-            rank_merge<256>(lpool, npool, newk, n, outp, a.L, tid);
-            npool = min(a.L, npool + n);
+            rank_merge<256>(lpool, npool, newk, kept, outp, a.L, tid);
+            npool = min(a.L, npool + kept);
             for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
             __syncthreads();
         }
@@ -295,7 +322,7 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
         ix->pq_cap = B;
     }
     GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
-    PqDev pq{ix->pq_m, ix->D / ix->pq_m, ix->d_pq_codebooks, ix->d_pq_codes};
+    PqDev pq{ix->pq_m, ix->d_pq_chunk_off, ix->d_pq_codebooks, ix->d_pq_codes};
     PqArgs pa{};
     pa.Q = d_q; pa.Dp = ix->Dp; pa.metric = ix->metric; pa.L = L; pa.W = W; pa.maxnew = ws.maxnew;
     pa.Pmax = next_pow2(ws.maxnew);
@@ -361,22 +388,38 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
 
 extern "C" {
 
-int lm_pq_attach(lm_index* ix, int32_t m, const float* codebooks, const uint8_t* codes, int64_t ntotal) {
-    if (!ix || !codebooks || !codes) LM_FAIL(LM_EINVAL, "NULL argument");
+int lm_pq_attach_chunked(lm_index* ix, int32_t m, const int32_t* chunk_offsets, const float* codebooks, const uint8_t* codes, int64_t ntotal) {
+    if (!ix || !chunk_offsets || !codebooks || !codes) LM_FAIL(LM_EINVAL, "NULL argument");
     if (ntotal != ix->N) LM_FAIL(LM_EINVAL, "code count does not match the index");
-    if (m <= 0 || m % 4 || ix->D % m) LM_FAIL(LM_EINVAL, "m must be a multiple of 4 that divides d");
+    if (m <= 0 || m % 4 || m > 4096) LM_FAIL(LM_EINVAL, "m must be a positive multiple of 4 (pad the codes with empty chunks)");
+    if (chunk_offsets[0] != 0) LM_FAIL(LM_EINVAL, "chunk_offsets[0] must be 0");
+    for (int j = 0; j < m; ++j)
+        if (chunk_offsets[j + 1] < chunk_offsets[j]) LM_FAIL(LM_EINVAL, "chunk_offsets must not decrease");
+    if (chunk_offsets[m] > ix->D) LM_FAIL(LM_EINVAL, "chunk_offsets[m] exceeds the index dimension");
     LM_HIP(hipSetDevice(ix->device));
     if (ix->d_pq_codebooks) (void)hipFree(ix->d_pq_codebooks);
     if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
+    if (ix->d_pq_chunk_off) (void)hipFree(ix->d_pq_chunk_off);
     ix->d_pq_codebooks = nullptr;
     ix->d_pq_codes = nullptr;
-    const size_t cb_bytes = (size_t)256 * ix->D * 4, code_bytes = (size_t)ntotal * m;
-    LM_HIP(hipMalloc((void**)&ix->d_pq_codebooks, cb_bytes));
+    ix->d_pq_chunk_off = nullptr;
+    const size_t cb_bytes = (size_t)256 * chunk_offsets[m] * 4, code_bytes = (size_t)ntotal * m;
+    LM_HIP(hipMalloc((void**)&ix->d_pq_codebooks, std::max<size_t>(cb_bytes, 16)));
     LM_HIP(hipMalloc((void**)&ix->d_pq_codes, std::max<size_t>(code_bytes, 16)));
+    LM_HIP(hipMalloc((void**)&ix->d_pq_chunk_off, (size_t)(m + 1) * 4));
     LM_HIP(hipMemcpy(ix->d_pq_codebooks, codebooks, cb_bytes, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(ix->d_pq_codes, codes, code_bytes, hipMemcpyHostToDevice));
+    LM_HIP(hipMemcpy(ix->d_pq_chunk_off, chunk_offsets, (size_t)(m + 1) * 4, hipMemcpyHostToDevice));
     ix->pq_m = m;
     return LM_OK;
+}
+
+int lm_pq_attach(lm_index* ix, int32_t m, const float* codebooks, const uint8_t* codes, int64_t ntotal) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL argument");
+    if (m <= 0 || m % 4 || ix->D % m) LM_FAIL(LM_EINVAL, "m must be a multiple of 4 that divides d");
+    std::vector<int32_t> off((size_t)m + 1);
+    for (int j = 0; j <= m; ++j) off[j] = j * (ix->D / m);  // uniform chunks: the same code path, the same arithmetic
+    return lm_pq_attach_chunked(ix, m, off.data(), codebooks, codes, ntotal);
 }
 
 void lm_pq_search_params_default(lm_pq_search_params* p) {
@@ -447,29 +490,23 @@ int lm_pq_batch_search(lm_index* ix, int64_t n, const float* x, int32_t k, const
     if (n == 0) return LM_OK;
     if (!x || !labels || !distances) LM_FAIL(LM_EINVAL, "NULL buffer");
     LM_HIP(hipSetDevice(ix->device));
-    float* d_x = nullptr;
-    float* d_d = nullptr;
-    int64_t* d_l = nullptr;
+    const size_t need_x = (size_t)n * ix->D * 4, need_d = (size_t)n * k * 4, need_l = (size_t)n * k * 8;
+    if (int src = ensure_stage(ix, need_x, need_d, need_l)) return src;
+    float* d_x = ix->d_stage_x;
+    float* d_d = ix->d_stage_d;
+    int64_t* d_l = ix->d_stage_l;
     int rc = LM_OK;
-    if (hipMalloc((void**)&d_x, (size_t)n * ix->D * 4) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * k * 4) != hipSuccess ||
-        hipMalloc((void**)&d_l, (size_t)n * k * 8) != hipSuccess) {
-        set_error("out of device memory for the query / result staging buffers");
-        rc = LM_EHIP;
-    }
-    if (!rc && hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+    if (hipMemcpyAsync(d_x, x, need_x, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
         set_error("query upload failed");
         rc = LM_EHIP;
     }
     if (!rc) rc = pq_search_device(ix, n, d_x, k, params, d_l, d_d);
-    if (!rc && (hipMemcpyAsync(distances, d_d, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-                hipMemcpyAsync(labels, d_l, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+    if (!rc && (hipMemcpyAsync(distances, d_d, need_d, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                hipMemcpyAsync(labels, d_l, need_l, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
                 hipStreamSynchronize(ix->stream) != hipSuccess)) {
         set_error("result copy failed");
         rc = LM_EHIP;
     }
-    if (d_x) (void)hipFree(d_x);
-    if (d_d) (void)hipFree(d_d);
-    if (d_l) (void)hipFree(d_l);
     return rc;
 }
 

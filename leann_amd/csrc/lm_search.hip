@@ -57,6 +57,12 @@ struct lm_index {
     int32_t pq_m = 0;
     float* d_pq_codebooks = nullptr;
     uint8_t* d_pq_codes = nullptr;
+    int32_t* d_pq_chunk_off = nullptr;
+    // lm_index_search (host pointers): query / result staging, grown on demand, freed with the index
+    float* d_stage_x = nullptr;
+    float* d_stage_d = nullptr;
+    int64_t* d_stage_l = nullptr;
+    size_t stage_x_bytes = 0, stage_d_bytes = 0, stage_l_bytes = 0;
     unsigned long long* d_pq_nadc = nullptr;
     int32_t* d_pq_rounds = nullptr;
     int64_t pq_cap = 0;
@@ -335,7 +341,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             ix->lut_cap = need;
         }
         pa.Q = d_q; pa.lut = ix->d_lut; pa.codebooks = ix->d_pq_codebooks; pa.codes = ix->d_pq_codes;
-        pa.Dp = ix->Dp; pa.metric = ix->metric; pa.m = ix->pq_m; pa.dsub = ix->D / ix->pq_m;
+        pa.Dp = ix->Dp; pa.metric = ix->metric; pa.m = ix->pq_m; pa.chunk_off = ix->d_pq_chunk_off;
         pa.keep = 1.0f - prm.pq_pruning_ratio;
         pa.strategy = prm.local_prune ? 1 : (prm.send_neigh_times_ratio > 1e-6f ? 2 : 0);  // hnsw_backend.py:222-231
         pa.Pmax = next_pow2(ws.maxnew);
@@ -476,6 +482,24 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         ix->span_ms += (double)acc[0] / (double)khz;
         ix->span_launches += (int64_t)acc[1];
     }
+    return LM_OK;
+}
+
+// Query / result staging of the host-pointer entry points (lm_index_search, lm_pq_batch_search): the buffers live with the index and only
+// ever grow -- LEANN's real call is one query at a time (leann/api.py:644-796), three hipMalloc / hipFree pairs per call were a
+// measurable part of its latency.
+static int ensure_stage(lm_index* ix, size_t need_x, size_t need_d, size_t need_l) {
+    if (need_x <= ix->stage_x_bytes && need_d <= ix->stage_d_bytes && need_l <= ix->stage_l_bytes) return LM_OK;
+    if (ix->d_stage_x) (void)hipFree(ix->d_stage_x);
+    if (ix->d_stage_d) (void)hipFree(ix->d_stage_d);
+    if (ix->d_stage_l) (void)hipFree(ix->d_stage_l);
+    ix->d_stage_x = nullptr; ix->d_stage_d = nullptr; ix->d_stage_l = nullptr;
+    ix->stage_x_bytes = ix->stage_d_bytes = ix->stage_l_bytes = 0;
+    const size_t gx = std::max(need_x, (size_t)4096), gd = std::max(need_d, (size_t)4096), gl = std::max(need_l, (size_t)4096);
+    if (hipMalloc((void**)&ix->d_stage_x, gx) != hipSuccess || hipMalloc((void**)&ix->d_stage_d, gd) != hipSuccess ||
+        hipMalloc((void**)&ix->d_stage_l, gl) != hipSuccess)
+        LM_FAIL(LM_EHIP, "out of device memory for the query / result staging buffers");
+    ix->stage_x_bytes = gx; ix->stage_d_bytes = gd; ix->stage_l_bytes = gl;
     return LM_OK;
 }
 
@@ -679,6 +703,10 @@ void lm_index_free(lm_index* ix) {
     if (ix->d_hub_slot_init) (void)hipFree(ix->d_hub_slot_init);
     if (ix->d_pq_codebooks) (void)hipFree(ix->d_pq_codebooks);
     if (ix->d_pq_codes) (void)hipFree(ix->d_pq_codes);
+    if (ix->d_pq_chunk_off) (void)hipFree(ix->d_pq_chunk_off);
+    if (ix->d_stage_x) (void)hipFree(ix->d_stage_x);
+    if (ix->d_stage_d) (void)hipFree(ix->d_stage_d);
+    if (ix->d_stage_l) (void)hipFree(ix->d_stage_l);
     if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
     if (ix->d_pq_rounds) (void)hipFree(ix->d_pq_rounds);
     if (ix->d_lut) (void)hipFree(ix->d_lut);
@@ -869,29 +897,23 @@ int lm_index_search(lm_index* ix, int64_t n, const float* x, int32_t k, float* d
     if (n == 0) return LM_OK;
     if (!x || !distances || !labels) LM_FAIL(LM_EINVAL, "NULL buffer");
     LM_HIP(hipSetDevice(ix->device));
-    float* d_x = nullptr;
-    float* d_d = nullptr;
-    int64_t* d_l = nullptr;
+    const size_t need_x = (size_t)n * ix->D * 4, need_d = (size_t)n * k * 4, need_l = (size_t)n * k * 8;
+    if (int src = ensure_stage(ix, need_x, need_d, need_l)) return src;
+    float* d_x = ix->d_stage_x;
+    float* d_d = ix->d_stage_d;
+    int64_t* d_l = ix->d_stage_l;
     int rc = LM_OK;
-    if (hipMalloc((void**)&d_x, (size_t)n * ix->D * 4) != hipSuccess || hipMalloc((void**)&d_d, (size_t)n * k * 4) != hipSuccess ||
-        hipMalloc((void**)&d_l, (size_t)n * k * 8) != hipSuccess) {
-        set_error("out of device memory for the query / result staging buffers");
-        rc = LM_EHIP;
-    }
-    if (!rc && hipMemcpyAsync(d_x, x, (size_t)n * ix->D * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
+    if (hipMemcpyAsync(d_x, x, need_x, hipMemcpyHostToDevice, ix->stream) != hipSuccess) {
         set_error("query upload failed");
         rc = LM_EHIP;
     }
     if (!rc) rc = do_search_device(ix, n, d_x, k, d_d, d_l, params);
-    if (!rc && (hipMemcpyAsync(distances, d_d, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-                hipMemcpyAsync(labels, d_l, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+    if (!rc && (hipMemcpyAsync(distances, d_d, need_d, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+                hipMemcpyAsync(labels, d_l, need_l, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
                 hipStreamSynchronize(ix->stream) != hipSuccess)) {
         set_error("result copy failed");
         rc = LM_EHIP;
     }
-    if (d_x) (void)hipFree(d_x);
-    if (d_d) (void)hipFree(d_d);
-    if (d_l) (void)hipFree(d_l);
     return rc;
 }
 

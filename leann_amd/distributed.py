@@ -7,7 +7,7 @@ Two modes; the reference has no distributed code at all, so this i
   concatenates the slices on every rank with one all_gather.
 * **sharded graph** (60M-chunk config): each rank holds a disjoint shard (local node ids +
   ``id_base``), every rank searches ALL queries on its shard, the per-shard top-k lists
-  ``(B,k) x {f32 dist, i64 id}`` are exchanged with ONE all_gather (30 KB/rank at B=256, k=10 --
+  ``(B,k) x {f32 dist, i64 id}`` are packed into one buffer and exchanged with ONE all_gather (30 KB/rank at B=256, k=10 --
   latency bound, so a single one-shot collective, not a ring pipeline) and merged per query by
   ``lm_topk_merge`` (order: internal distance, then id).
 
@@ -49,6 +49,29 @@ def hip_merge_fn(ids: torch.Tensor, dist_: torch.Tensor, metric: int) -> Tuple[t
     return oi, od
 
 
+def pack_results(d: torch.Tensor, i: torch.Tensor) -> torch.Tensor:
+    """(m,k) f32 distances + (m,k) i64 ids -> ONE (m, 3k) int32 buffer (ids as two words each, then the distance bits): what a rank
+    contributes to the single all_gather of a step (12 bytes per result: 30 KB at B = 256, k = 10)."""
+    return torch.cat([i.contiguous().view(torch.int32), d.contiguous().view(torch.int32)], dim=1)
+
+
+def unpack_results(buf: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Inverse of pack_results on (..., 3k) int32 -> (dist (..., k) f32, ids (..., k) i64)."""
+    ids = buf[..., : 2 * k].contiguous().view(torch.int64)
+    d = buf[..., 2 * k :].contiguous().view(torch.float32)
+    return d, ids
+
+
+def all_gather_results(d: torch.Tensor, i: torch.Tensor, world: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE collective for a step's results: every rank's (m,k) distances and ids -> (world, m, k) of each on every rank."""
+    m, k = d.shape
+    buf = pack_results(d, i)
+    out = torch.empty((world * m, 3 * k), dtype=torch.int32, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    gd, gi = unpack_results(out, k)
+    return gd.view(world, m, k), gi.view(world, m, k)
+
+
 class PartitionedSearch:
     """Replicated index, queries partitioned across ranks."""
 
@@ -72,10 +95,7 @@ class PartitionedSearch:
         pd = torch.zeros((m, k), dtype=torch.float32, device=d.device)
         pi = torch.full((m, k), -1, dtype=torch.int64, device=i.device)
         pd[: hi - lo], pi[: hi - lo] = d, i
-        gd = [torch.empty_like(pd) for _ in range(self.world)]
-        gi = [torch.empty_like(pi) for _ in range(self.world)]
-        dist.all_gather(gd, pd, group=self.group)
-        dist.all_gather(gi, pi, group=self.group)
+        gd, gi = all_gather_results(pd, pi, self.world, self.group)  # one packed exchange (distances + ids together)
         od = torch.cat([gd[r][: partition(B, self.world, r)[1] - partition(B, self.world, r)[0]] for r in range(self.world)])
         oi = torch.cat([gi[r][: partition(B, self.world, r)[1] - partition(B, self.world, r)[0]] for r in range(self.world)])
         return od, oi
@@ -99,11 +119,8 @@ class ShardedSearch:
         i = torch.where(i >= 0, i + self.id_base, i)
         if self.world == 1:
             return self.merge_fn(i[None].contiguous(), d[None].contiguous(), self.metric)[::-1]
-        gd = [torch.empty_like(d) for _ in range(self.world)]
-        gi = [torch.empty_like(i) for _ in range(self.world)]
-        dist.all_gather(gd, d.contiguous(), group=self.group)
-        dist.all_gather(gi, i.contiguous(), group=self.group)
-        oi, od = self.merge_fn(torch.stack(gi), torch.stack(gd), self.metric)
+        gd, gi = all_gather_results(d, i, self.world, self.group)  # one packed exchange: (world, B, k) x {f32, i64}
+        oi, od = self.merge_fn(gi.contiguous(), gd.contiguous(), self.metric)
         return od, oi
 
 
@@ -114,7 +131,7 @@ def shard_bounds(n: int, world: int):
 
 def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, group: Optional[dist.ProcessGroup] = None):
     """Rank `src` built the compact-CSR graph; every other rank passes ``g=None`` and receives a copy (the index is
-    built ONCE per job and replicated, not rebuilt per rank).  Arrays travel as int64 tensors on `device` (RCCL
+    built ONCE per job and replicated, not rebuilt per rank).  Arrays travel in their own dtype as raw bytes on `device` (RCCL
     over xGMI when it is a GPU, gloo on the CPU tests); scalars in one header tensor."""
     from .csr_format import HnswCsr
 
@@ -136,12 +153,13 @@ def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, grou
     h = [int(v) for v in hdr.cpu().tolist()]
     out = []
     for i, n in enumerate(names):
+        nbytes = h[6 + i] * np.dtype(dtypes[n]).itemsize
         if rank == src:
-            t = torch.from_numpy(arrs[i].astype(np.int64)).to(dev)
+            t = torch.from_numpy(np.ascontiguousarray(arrs[i].astype(dtypes[n], copy=False)).view(np.uint8).copy()).to(dev)
         else:
-            t = torch.empty(h[6 + i], dtype=torch.int64, device=dev)
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         dist.broadcast(t, src, group=group)
-        out.append(t.cpu().numpy().astype(dtypes[n]))
+        out.append(t.cpu().numpy().view(dtypes[n]).copy())
     if rank == src:
         return g
     return HnswCsr(d=h[0], ntotal=h[1], metric_type=h[2], levels=out[0], level_ptr=out[1], node_offsets=out[2], neighbors=out[3],

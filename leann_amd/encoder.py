@@ -179,13 +179,15 @@ def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: n
 
 
 def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_len: int) -> Optional[torch.Tensor]:
-    """Hand-written MFMA varlen attention (csrc/lm_encoder_ops.hip) for head_dim 32, lengths <= 256, fp16 on the
-    GPU; returns None when the shape is outside that envelope (caller falls back to torch's varlen_attn)."""
+    """Hand-written MFMA varlen attention (csrc/lm_attn_v2.hip) for head_dim 32 (lengths <= 256) and head_dim 64 (lengths <= 512),
+    fp16 on the GPU; returns None when the shape is outside that envelope (caller falls back to torch's varlen_attn)."""
     import os
 
     tot, h3 = qkv.shape
     hidden = h3 // 3
-    if not (qkv.is_cuda and qkv.dtype == torch.float16 and qkv.is_contiguous() and hidden == heads * 32 and 0 < max_len <= 256):
+    hd = hidden // heads if heads else 0
+    if not (qkv.is_cuda and qkv.dtype == torch.float16 and qkv.is_contiguous() and hidden == heads * hd and (
+            (hd == 32 and 0 < max_len <= 256) or (hd == 64 and 0 < max_len <= 512))):
         return None
     if os.environ.get("LEANN_MI355X_ATTN", "1") == "0":
         return None
@@ -194,9 +196,51 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
     from . import _lib
 
     out = torch.empty((tot, hidden), dtype=torch.float16, device=qkv.device)
-    _lib.check(_lib.load().lm_attn_varlen_hd32_f16(
-        C.c_void_p(qkv.data_ptr()), C.c_void_p(cu.data_ptr()), cu.shape[0] - 1, heads, int(max_len), C.c_void_p(out.data_ptr()),
-        C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)), "lm_attn_varlen_hd32_f16")
+    st = C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+    if hd == 32:  # (also carries the revision-1 A/B switch)
+        _lib.check(_lib.load().lm_attn_varlen_hd32_f16(C.c_void_p(qkv.data_ptr()), C.c_void_p(cu.data_ptr()), cu.shape[0] - 1, heads, int(max_len),
+                                                       C.c_void_p(out.data_ptr()), st), "lm_attn_varlen_hd32_f16")
+    else:
+        _lib.check(_lib.load().lm_attn_varlen_f16(C.c_void_p(qkv.data_ptr()), C.c_void_p(cu.data_ptr()), cu.shape[0] - 1, heads, hd, int(max_len),
+                                                  C.c_void_p(out.data_ptr()), st), "lm_attn_varlen_f16")
+    return out
+
+
+GEMM_EPI_GELU, GEMM_EPI_RESIDUAL = 1, 2
+
+
+def fused_gemm(x: torch.Tensor, lin: nn.Linear, epilogue: int = 0, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """epi(x W^T + b) through the general hand-written MFMA GEMM (csrc/lm_gemm_f16.hip: 256 x 256 tiles, operands staged L2 -> LDS by
+    DMA, bias / exact-erf GELU / residual in the epilogue): the linear layers of every model whose hidden size is not 384 (bge-base,
+    contriever: 768).  ``epilogue`` = GEMM_EPI_GELU | GEMM_EPI_RESIDUAL.  LEANN_MI355X_GEMM=0 = library GEMMs (A/B); None = not
+    applicable, the caller takes the library path."""
+    import os
+
+    if os.environ.get("LEANN_MI355X_GEMM", "1") == "0":
+        return None
+    n, k = lin.weight.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and lin.weight.dtype == torch.float16 and n % 128 == 0 and k % 128 == 0
+            and lin.bias is not None and x.shape[-1] == k and x.numel() * 2 < (1 << 32)):
+        return None
+    if (epilogue & GEMM_EPI_RESIDUAL) and not (residual is not None and residual.is_contiguous() and residual.dtype == torch.float16
+                                               and tuple(residual.shape) == (x.shape[0], n)):
+        return None
+    import ctypes as C
+
+    from . import _lib
+
+    w, b = _packed(lin, "_gemm_pack", (lin.weight, lin.bias), lambda: (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous()))
+    out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
+    tm = KernelTimers.active
+    ev = tm.span("gemm_f16", 2.0 * x.shape[0] * n * k) if tm is not None else None
+    if ev:
+        ev[0].record()
+    _lib.check(_lib.load().lm_gemm_f16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()),
+                                       C.c_void_p(residual.data_ptr()) if residual is not None else None, int(epilogue), n, k,
+                                       C.c_void_p(out.data_ptr()), x.shape[0], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+               "lm_gemm_f16")
+    if ev:
+        ev[1].record()
     return out
 
 
@@ -443,10 +487,21 @@ class _Layer(nn.Module):
 
     def forward_packed(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
         """x: [total_tokens, H] (sequences packed back to back), cu: int32 cumulative lengths [n+1]."""
+        import os
+
         from torch.nn.attention.varlen import varlen_attn
 
         tot, h = x.shape
-        qkv2 = fused_linear_h384(x, self.qkv)
+        if h != 384 or os.environ.get("LEANN_MI355X_GEMM") == "2":
+            # general widths (768: bge-base, contriever): five launches of the general MFMA GEMM + attention + two LayerNorms, no
+            # library call -- QKV | attention | out-projection (+ residual) | LayerNorm | fc1 (+ GELU) | fc2 (+ residual) | LayerNorm.
+            # (LEANN_MI355X_GEMM=2 sends the hidden-384 models through the same path: A/B against their fused kernels.)
+            y = self._forward_packed_general(x, cu, max_len)
+            if y is not None:
+                return y
+        qkv2 = (fused_gemm(x, self.qkv) if os.environ.get("LEANN_MI355X_GEMM") == "1" else None) if h == 384 else None
+        if qkv2 is None:
+            qkv2 = fused_linear_h384(x, self.qkv)
         if qkv2 is None:
             qkv2 = self.qkv(x)
         a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
@@ -463,6 +518,25 @@ class _Layer(nn.Module):
             return y
         x = fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
         return x
+
+    def _forward_packed_general(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
+        """The layer on the general kernels (lm_gemm_f16 + lm_attn_varlen_f16 + lm_add_layernorm_f16); None = a shape outside their
+        envelope (the caller takes the library path)."""
+        qkv = fused_gemm(x, self.qkv)
+        if qkv is None:
+            return None
+        a = fused_attention_hd32(qkv, cu, self.heads, max_len)
+        if a is None:
+            return None
+        y = fused_gemm(a, self.out, GEMM_EPI_RESIDUAL, x)
+        if y is None:
+            return None
+        x1 = fused_add_layernorm(y, None, self.ln1)
+        hmid = fused_gemm(x1, self.fc1, GEMM_EPI_GELU)
+        y2 = fused_gemm(hmid, self.fc2, GEMM_EPI_RESIDUAL, x1) if hmid is not None else None
+        if y2 is None:
+            return None
+        return fused_add_layernorm(y2, None, self.ln2)
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
         n, t, h = x.shape

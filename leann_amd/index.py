@@ -178,10 +178,18 @@ class Mi355xIndex:
         return dist, labels
 
     # ---- DiskANN-style path -----------------------------------------------------------------
-    def attach_pq(self, codebooks: np.ndarray, codes: np.ndarray) -> None:
-        """codebooks: (m, 256, d/m) float32; codes: (N, m) uint8."""
+    def attach_pq(self, codebooks: np.ndarray, codes: np.ndarray, chunk_offsets: Optional[np.ndarray] = None) -> None:
+        """codebooks: (m, 256, d/m) float32; codes: (N, m) uint8.  With ``chunk_offsets`` (int32 [m + 1], the chunking of a stock
+        DiskANN bundle: leann_amd/diskann_files.py) the codebooks are the flat per-chunk tables of lm_pq_attach_chunked."""
         cb = np.ascontiguousarray(codebooks, dtype=np.float32)
         cd = np.ascontiguousarray(codes, dtype=np.uint8)
+        if chunk_offsets is not None:
+            co = np.ascontiguousarray(chunk_offsets, dtype=np.int32)
+            m = co.shape[0] - 1
+            if m <= 0 or cd.shape != (self.info.ntotal, m) or cb.size != 256 * int(co[-1]):
+                raise ValueError("chunk_offsets (m + 1), flat codebooks (256 * chunk_offsets[m]) and codes (N, m) do not fit together")
+            check(self._lib.lm_pq_attach_chunked(self._h, m, _np_ptr(co), _np_ptr(cb), _np_ptr(cd), cd.shape[0]), "lm_pq_attach_chunked")
+            return
         if cb.ndim != 3 or cb.shape[1] != 256 or cb.shape[0] * cb.shape[2] != self.info.d or cd.shape != (self.info.ntotal, cb.shape[0]):
             raise ValueError("codebooks must be (m, 256, d/m) and codes (N, m)")
         check(self._lib.lm_pq_attach(self._h, cb.shape[0], _np_ptr(cb), _np_ptr(cd), cd.shape[0]), "lm_pq_attach")

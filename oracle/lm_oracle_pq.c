@@ -46,9 +46,11 @@ float orc_dist(const float *e, const float *q, int32_t Dp, int32_t metric);
 
 typedef struct {
     int32_t m;    /* sub-quantisers */
-    int32_t dsub; /* D / m */
-    const float *codebooks; /* m x 256 x dsub */
+    int32_t dsub; /* D / m (uniform chunks; ignored when chunk_off is given) */
+    const float *codebooks; /* chunk j: 256 centroids x len_j floats at offset 256 * lo_j (uniform: m x 256 x dsub) */
     const uint8_t *codes;   /* N x m */
+    const int32_t *chunk_off; /* NULL = uniform; else m + 1 offsets: chunk j covers dimensions [chunk_off[j], chunk_off[j+1]) --
+                                 the public DiskANN pq_pivots layout (chunk_offsets), lengths may differ, zero-length chunks allowed */
 } orc_pq;
 
 typedef struct {
@@ -81,16 +83,18 @@ static inline int32_t pk_id(uint64_t key) { return (int32_t)((uint32_t)key >> 1)
 void orc_pq_lut(const orc_pq *pq, const float *q, int32_t metric, float *lut) {
     for (int j = 0; j < pq->m; ++j)
         for (int c = 0; c < 256; ++c) {
-            const float *cb = pq->codebooks + ((size_t)j * 256 + c) * pq->dsub;
-            const float *qs = q + (size_t)j * pq->dsub;
+            const int lo = pq->chunk_off ? pq->chunk_off[j] : j * pq->dsub;
+            const int len = pq->chunk_off ? pq->chunk_off[j + 1] - lo : pq->dsub;
+            const float *cb = pq->codebooks + (size_t)256 * lo + (size_t)c * len;
+            const float *qs = q + lo;
             float acc = 0.0f;
             if (metric == ORC_METRIC_L2) {
-                for (int t = 0; t < pq->dsub; ++t) {
+                for (int t = 0; t < len; ++t) {
                     float d = qs[t] - cb[t];
                     acc = fmaf(d, d, acc);
                 }
             } else {
-                for (int t = 0; t < pq->dsub; ++t) acc = fmaf(qs[t], cb[t], acc);
+                for (int t = 0; t < len; ++t) acc = fmaf(qs[t], cb[t], acc);
                 acc = -acc;
             }
             lut[j * 256 + c] = acc;

@@ -56,7 +56,7 @@ PRUNE_STRATEGY = {"global": 0, "local": 1, "proportional": 2}
 
 
 class _Pq(C.Structure):
-    _fields_ = [("m", C.c_int32), ("dsub", C.c_int32), ("codebooks", C.c_void_p), ("codes", C.c_void_p)]
+    _fields_ = [("m", C.c_int32), ("dsub", C.c_int32), ("codebooks", C.c_void_p), ("codes", C.c_void_p), ("chunk_off", C.c_void_p)]
 
 
 class _PqParams(C.Structure):
@@ -180,7 +180,7 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
     if pq is not None:  # (codebooks [m,256,dsub], codes [N,m]) for the two-level search
         cbk = np.ascontiguousarray(pq[0], dtype=np.float32)
         cds = np.ascontiguousarray(pq[1], dtype=np.uint8)
-        pqs = _Pq(cbk.shape[0], cbk.shape[2], _ptr(cbk), _ptr(cds))
+        pqs = _Pq(cbk.shape[0], cbk.shape[2], _ptr(cbk), _ptr(cds), None)
     tab = None
     err: list = []
     if table is not None:
@@ -227,20 +227,31 @@ def _make_provider(provider, Dp, err):
     return _PROVIDER(_cb)
 
 
-def pq_search(graph: OracleGraph, codebooks: np.ndarray, codes: np.ndarray, queries: np.ndarray, k: int, L: int = 64,
-              W: int = 1, table: Optional[np.ndarray] = None, provider=None, use_deferred_fetch: bool = False,
-              skip_search_reorder: bool = False):
-    """DiskANN-style oracle: PQ-ADC traversal (+ exact rerank from `table`, or from `provider` when
-    use_deferred_fetch).  Returns (ids, dist, stats)."""
+def _pq_struct(codebooks: np.ndarray, codes: np.ndarray, chunk_off=None):
+    """(_Pq, keep-alive tuple).  Uniform: codebooks [m, 256, dsub]; chunked (public DiskANN layout): flat codebooks of
+    256 * chunk_off[m] floats + chunk_off int32[m + 1]."""
     cb = np.ascontiguousarray(codebooks, dtype=np.float32)
     cd = np.ascontiguousarray(codes, dtype=np.uint8)
-    m, _, dsub = cb.shape
-    assert m * dsub == graph.D and cd.shape == (graph.N, m)
+    if chunk_off is None:
+        m, _, dsub = cb.shape
+        return _Pq(m, dsub, _ptr(cb), _ptr(cd), None), (cb, cd), m
+    co = np.ascontiguousarray(chunk_off, dtype=np.int32)
+    m = co.shape[0] - 1
+    assert cb.size == 256 * int(co[-1]) and cd.shape[1] == m and np.all(np.diff(co) >= 0) and co[0] == 0
+    return _Pq(m, 0, _ptr(cb), _ptr(cd), _ptr(co)), (cb, cd, co), m
+
+
+def pq_search(graph: OracleGraph, codebooks: np.ndarray, codes: np.ndarray, queries: np.ndarray, k: int, L: int = 64,
+              W: int = 1, table: Optional[np.ndarray] = None, provider=None, use_deferred_fetch: bool = False,
+              skip_search_reorder: bool = False, chunk_off=None):
+    """DiskANN-style oracle: PQ-ADC traversal (+ exact rerank from `table`, or from `provider` when
+    use_deferred_fetch).  Returns (ids, dist, stats)."""
+    pq, _keep, m = _pq_struct(codebooks, codes, chunk_off)
+    assert np.asarray(codes).shape == (graph.N, m)
     q = pad64(np.atleast_2d(queries))
     B = q.shape[0]
     ids = np.empty((B, k), dtype=np.int64)
     dd = np.empty((B, k), dtype=np.float32)
-    pq = _Pq(m, dsub, _ptr(cb), _ptr(cd))
     prm = _PqParams(L, W, k, 1 if use_deferred_fetch else 0, 1 if skip_search_reorder else 0)
     st = _PqStats()
     g = graph.cstruct()
@@ -256,12 +267,9 @@ def pq_search(graph: OracleGraph, codebooks: np.ndarray, codes: np.ndarray, quer
     return ids, dd, {f: int(getattr(st, f)) for f, _ in _PqStats._fields_}
 
 
-def pq_lut_adc(codebooks: np.ndarray, codes: np.ndarray, query: np.ndarray, metric: int, ids: np.ndarray):
+def pq_lut_adc(codebooks: np.ndarray, codes: np.ndarray, query: np.ndarray, metric: int, ids: np.ndarray, chunk_off=None):
     """Canonical LUT + ADC distances of `ids` (for kernel-level tests)."""
-    cb = np.ascontiguousarray(codebooks, dtype=np.float32)
-    cd = np.ascontiguousarray(codes, dtype=np.uint8)
-    m, _, dsub = cb.shape
-    pq = _Pq(m, dsub, _ptr(cb), _ptr(cd))
+    pq, _keep, m = _pq_struct(codebooks, codes, chunk_off)
     qv = np.ascontiguousarray(query, dtype=np.float32)
     lut = np.empty((m, 256), np.float32)
     lib().orc_pq_lut(C.byref(pq), _ptr(qv), metric, _ptr(lut))

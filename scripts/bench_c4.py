@@ -32,12 +32,14 @@ def main():
     ap.add_argument("--ef", type=int, default=64)
     ap.add_argument("--M", type=int, default=32)
     ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
     from leann_amd import _lib
-    from leann_amd.distributed import ShardedSearch, shard_bounds
-    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.distributed import ShardedSearch, all_gather_results, shard_bounds
+    from leann_amd.encoder import BertEncoder, KernelTimers, config_for
     from leann_amd.gpu_graph_build import build_graph_gpu
     from leann_amd.index import Mi355xIndex
     from leann_amd.recompute import RecomputeProvider
@@ -55,6 +57,7 @@ def main():
             print("[c4]", *a, file=sys.stderr, flush=True)
 
     B, K, W = args.batch, args.steps, args.warmup
+    ktm = KernelTimers.active = KernelTimers()  # HIP-event pairs around the dominant encoder kernel, labelled by phase (as bench.py)
     lo, hi = shard_bounds(args.chunks, world)[rank]
     ns = hi - lo
     t_all = time.time()
@@ -84,9 +87,13 @@ def main():
         Q = torch.empty((nq, D), dtype=torch.float32, device=dev)
     if world > 1:
         dist.broadcast(Q, 0)
-    # exact ground truth over ALL shards: local exact top-10, gathered and merged on the host
-    s = Q @ X.T
-    ld, li = torch.topk(s, 10, dim=1)
+    # exact ground truth over ALL shards: local exact top-10 (query blocks of 64: a (B, shard) score matrix at once would be
+    # 256 x 7.5M x 4 B = 7.7 GB, and more at larger batches), gathered and merged
+    ld = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    li = torch.empty((nq, 10), dtype=torch.int64, device=dev)
+    for b0 in range(0, nq, 64):
+        v, ix_ = torch.topk(Q[b0 : b0 + 64] @ X.T, 10, dim=1)
+        ld[b0 : b0 + 64], li[b0 : b0 + 64] = v, ix_
     li = li + lo
     if world > 1:
         gd = [torch.empty_like(ld) for _ in range(world)]
@@ -98,7 +105,7 @@ def main():
         gt = torch.gather(ai, 1, top).cpu().numpy()
     else:
         gt = li.cpu().numpy()
-    del X, s
+    del X
     torch.cuda.empty_cache()
     prm = idx.make_params(ef=args.ef, beam=1, recompute=True, max_batch=B)
     ss = ShardedSearch(lambda qq, k: idx.search_device(qq, k, prm), id_base=lo, metric=g.metric_type)
@@ -108,16 +115,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ktm.phase = "warmup"
     for w in range(W):
         ss.search(Q[w * B : (w + 1) * B].contiguous(), 10)
     labels = []
+    agg = {"ndis": 0, "nunique": 0, "nrounds": 0}
     barrier()
+    ktm.phase = "timed"
     t0 = time.perf_counter()
     for st in range(K):
         _, l = ss.search(Q[(W + st) * B : (W + st + 1) * B].contiguous(), 10)
         labels.append(l)
+        st_ = idx.stats()
+        for k_ in agg:
+            agg[k_] += st_[k_]
     barrier()
     elapsed = time.perf_counter() - t0
+    ktm.phase = "after"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -130,21 +144,48 @@ def main():
     t0 = time.perf_counter()
     for _ in range(20):
         if world > 1:
-            gd = [torch.empty_like(d0) for _ in range(world)]
-            gi = [torch.empty_like(i0) for _ in range(world)]
-            dist.all_gather(gd, d0)
-            dist.all_gather(gi, i0)
-            ss.merge_fn(torch.stack(gi), torch.stack(gd), g.metric_type)
+            gd, gi = all_gather_results(d0, i0, world)  # the packed exchange ShardedSearch.search does
+            ss.merge_fn(gi.contiguous(), gd.contiguous(), g.metric_type)
         else:
             ss.merge_fn(i0[None].contiguous(), d0[None].contiguous(), g.metric_type)
     barrier()
     coll_us = (time.perf_counter() - t0) / 20 * 1e6
+    # roofline of the dominant kernel of the timed region (the fused layer tail, MFMA bound), as in bench.py
+    kt = ktm.totals("timed").get("attn_out_mlp_h384")
+    KernelTimers.active = None
+    roofline = None
+    if kt and kt["ms"] > 0:
+        tf = kt["work"] / (kt["ms"] * 1e-3) / 1e12
+        fpt = 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden
+        roofline = {"bound": "mfma", "kernel": "lm::k_attn_out_mlp_h384<0> (attention output projection + LayerNorm + feed-forward block + LayerNorm)",
+                    "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5), "traffic": None,
+                    "flops_per_token": fpt, "launches": kt["launches"], "avg_launch_us": round(1e3 * kt["ms"] / kt["launches"], 1),
+                    "tokens_per_launch": round(kt["work"] / fpt / kt["launches"]), "share_of_timed_region": round(kt["ms"] / (elapsed * 1e3), 4),
+                    "timing": "HIP event pairs around every launch of the timed region, rank 0 (one pair per launch inside the timed region)"}
+    cpu_base = None
+    if rank == 0 and not args.no_cpu_baseline:  # the oracle traversal + fp32 CPU encoder on shard 0, a bounded sample of the same queries
+        try:
+            sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+            import bench as _b
+
+            class _A:
+                model, cpu_baseline_seconds = args.model, args.cpu_baseline_seconds
+
+            tok_np = tok.cpu().numpy() if isinstance(tok, torch.Tensor) else tok
+            off_np = off.cpu().numpy() if isinstance(off, torch.Tensor) else off
+            cpu_base = _b.cpu_baseline(_A, g, Q, tok_np, off_np, cfg, args.ef, 1)
+            cpu_base["sample"] += f"; ONE shard of {ns} chunks on this box's host cores (the {world}-shard job needs every shard searched: divide by {world} for one host)"
+        except Exception as ex:  # noqa: BLE001
+            cpu_base = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
     if rank == 0:
         print(json.dumps({
             "metric": f"queries/sec, {args.chunks}-chunk HNSW sharded {world}-way, query batch {B}, RCCL all_gather of per-shard top-k + merge",
             "value": round(K * B / elapsed, 3), "unit": "queries/s", "n_gpus": world, "rccl_ranks": world, "steps": K, "warmup": W,
-            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "encoder_dtype": "fp16 (fp32 accumulate)", "data": "synthetic",
+            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16",
+            "dtype_detail": "encoder fp16 MFMA with fp32 accumulation; distances / merge f32", "data": "synthetic",
+            "roofline": roofline, "cpu_baseline": cpu_base,
+            "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),
+                          "rounds_per_step": round(agg["nrounds"] / max(K, 1), 1)},
             "config": {"workload": f"{args.chunks} synthetic chunks in {world} shard(s) of {ns}, HNSW M={args.M} per shard (GPU-built), {args.model} shape, "
                                    f"ef_search={args.ef}, beam=1, top-10, {B} queries per step searched on EVERY shard, all_gather + lm_topk_merge in the timed region",
                        "baseline_config": "c4", "n_chunks": args.chunks, "shard_chunks": ns, "queries_per_step": B,

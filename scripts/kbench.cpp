@@ -80,6 +80,35 @@ __global__ void ref_linear(const __half* x, const __half* w, const float* b, con
     for (int k = 0; k < H; ++k) acc += __half2float(x[(size_t)r * H + k]) * __half2float(w[(size_t)c * H + k]);
     out[i] = acc;
 }
+// device-side operand fill: the host std::normal_distribution path costs a minute per GEMM shape at 262k tokens (GPU-box minutes)
+__global__ void fill_half_normal(__half* p, size_t n, float scale, uint32_t seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + ((uint64_t)seed << 32);
+    float acc = 0.f;
+    for (int k = 0; k < 4; ++k) {  // four uniforms -> roughly normal (Irwin-Hall), unit variance after scaling
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        acc += (float)(z & 0xFFFFFF) * (1.0f / 16777216.0f) - 0.5f;
+    }
+    p[i] = __float2half(acc * 1.7320508f * scale);
+}
+static void dev_fill(__half* p, size_t n, float scale, uint32_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(fill_half_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, scale, seed);
+}
+
+// general shape: out[i] = epi(x[rows[r]] . w[c] + b[c]) (+ res), the result rounded the way lm_gemm_f16 rounds it
+__global__ void ref_linear_k(const __half* x, const __half* w, const float* b, const __half* res, const int* rows, int nrows, int N, int K, int epi,
+                             float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * N) return;
+    int r = rows[i / N], c = i % N;
+    float acc = b[c];
+    for (int k = 0; k < K; ++k) acc += __half2float(x[(size_t)r * K + k]) * __half2float(w[(size_t)c * K + k]);
+    if (epi & 1) acc = 0.5f * acc * (1.0f + erff(acc * 0.70710678f));
+    acc = __half2float(__float2half(acc));
+    if (epi & 2) acc = __half2float(__float2half(acc + __half2float(res[(size_t)r * N + c])));
+    out[i] = acc;
+}
 __global__ void ref_gelu_fc1(const __half* x, const __half* w1, const float* b1, const int* rows, int nrows, int F, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * F) return;
@@ -606,6 +635,90 @@ int main(int argc, char** argv) {
             printf("{\"kernel\": \"lm_add_layernorm_f16\", \"mode\": \"revision %s\", \"us\": %.1f, \"GBps\": %.0f}\n", rev, us, (double)T * H * 6 / us * 1e-3);
         }
         unsetenv("LEANN_MI355X_LN");
+    }
+    if (want("gemmf16")) {
+        // lm_gemm_f16 (csrc/lm_gemm_f16.hip) on the encoder's GEMM shapes, against rocBLAS (no bias / epilogue) on the same operands
+        struct Shape { int N, K, epi; const char* what; };
+        const Shape shapes[] = {{1152, 384, 0, "MiniLM QKV"}, {2304, 768, 0, "bge-base QKV"}, {768, 768, 2, "bge-base out-proj + residual"},
+                                {3072, 768, 1, "bge-base fc1 + GELU"}, {768, 3072, 2, "bge-base fc2 + residual"}, {1536, 384, 1, "MiniLM fc1 + GELU"}};
+        for (const Shape& sh : shapes) {
+            const int N = sh.N, K = sh.K;
+            Dev<__half> xa((size_t)T * K), wa((size_t)N * K), ra((size_t)T * N);
+            dev_fill(xa.p, (size_t)T * K, 1.0f, 31, st);
+            dev_fill(wa.p, (size_t)N * K, 0.05f, 32, st);
+            dev_fill(ra.p, (size_t)T * N, 1.0f, 33, st);
+            Dev<float> ba(rand_float(N, 0.2f, 34));
+            Dev<__half> out((size_t)T * N), outl((size_t)T * N);
+            Dev<float> ref((size_t)nr * N);
+            hipLaunchKernelGGL(ref_linear_k, dim3((nr * N + 255) / 256), dim3(256), 0, st, xa.p, wa.p, ba.p, ra.p, d_rows.p, nr, N, K, sh.epi, ref.p);
+            LM(lm_gemm_f16(xa.p, wa.p, ba.p, ra.p, sh.epi, N, K, out.p, T, st));
+            CK(hipStreamSynchronize(st));
+            double err = 0;
+            {  // the sampled rows are the first and the last 192 of the output: copy those two slabs only
+                std::vector<__half> got((size_t)T * N);  // sparse use; rows outside the slabs stay zero
+                const size_t head = std::min<size_t>(192, T), tail0 = std::max<size_t>(192, T > 192 ? T - 192 : 0);
+                CK(hipMemcpy(got.data(), out.p, head * N * sizeof(__half), hipMemcpyDeviceToHost));
+                if (tail0 < (size_t)T) CK(hipMemcpy(got.data() + tail0 * N, out.p + tail0 * N, ((size_t)T - tail0) * N * sizeof(__half), hipMemcpyDeviceToHost));
+                err = max_err_rows(got, N, 0, N, rows, ref.host());
+            }
+            const double gflop = 2.0 * T * N * K * 1e-9;
+            for (int round = 0; round < 2; ++round) {
+                const float us = time_us(st, reps, [&] { LM(lm_gemm_f16(xa.p, wa.p, ba.p, ra.p, sh.epi, N, K, out.p, T, st)); });
+                const float usl = time_us(st, reps, [&] { lib_gemm(wa.p, N, K, xa.p, outl.p); });
+                printf("{\"kernel\": \"lm_gemm_f16\", \"mode\": \"%s (N=%d K=%d epilogue %d)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g, "
+                       "\"rocblas_us\": %.1f, \"rocblas_TFLOPs\": %.1f}\n", sh.what, N, K, sh.epi, round, us, gflop / us * 1e3, err, usl, gflop / usl * 1e3);
+                if (K == 384 && sh.epi == 0) {
+                    const float usw = time_us(st, reps, [&] { LM(lm_gemm_ws_h384_f16(xa.p, wa.p, ba.p, N, out.p, T, st)); });
+                    printf("{\"kernel\": \"lm_gemm_ws_h384_f16\", \"mode\": \"same operands\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, usw, gflop / usw * 1e3);
+                }
+                fflush(stdout);
+            }
+        }
+    }
+    if (want("gemmstamp")) {
+        // cycle stamps of lm_gemm_f16 (diagnosis variant 7, run with LEANN_MI355X_GEMM_VARIANT=7): per-workgroup means of wave 0's phases
+        struct Shape { int N, K; const char* what; };
+        for (const Shape& sh : {Shape{2304, 768, "bge-base QKV"}, Shape{3072, 768, "bge-base fc1 (no GELU here)"}, Shape{768, 3072, "bge-base fc2 (no residual here)"}, Shape{1152, 384, "MiniLM QKV"}}) {
+            Dev<__half> xa((size_t)T * sh.K), wa((size_t)sh.N * sh.K), out((size_t)T * sh.N);
+            dev_fill(xa.p, (size_t)T * sh.K, 1.0f, 31, st);
+            dev_fill(wa.p, (size_t)sh.N * sh.K, 0.05f, 32, st);
+            Dev<float> ba(rand_float(sh.N, 0.2f, 34));
+            Dev<unsigned long long> dbg(8);
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipMemsetAsync(dbg.p, 0, 64, st));
+                LM(lm_gemm_f16(xa.p, wa.p, ba.p, dbg.p, 0, sh.N, sh.K, out.p, T, st));
+                CK(hipStreamSynchronize(st));
+            }
+            auto h = dbg.host();
+            const double nb = (double)std::max<unsigned long long>(h[5], 1);
+            printf("{\"kernel\": \"lm_gemm_f16 stamps\", \"mode\": \"%s (N=%d K=%d)\", \"workgroups\": %llu, \"cycles_per_workgroup\": {\"prologue_until_tile0_landed\": %.0f, "
+                   "\"main_loop\": %.0f, \"bias_and_lds_tile_write\": %.0f, \"readback_and_store_issue\": %.0f, \"store_drain\": %.0f}, \"k_tiles\": %d}\n",
+                   sh.what, sh.N, sh.K, h[5], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, sh.K / 64);
+            fflush(stdout);
+        }
+    }
+    if (want("attn64")) {
+        // head_dim 64 attention (bge-base: 12 heads x 64) on sequences of the synthetic corpus' length distribution
+        const int heads = 12, Hh = heads * 64;
+        std::mt19937 g(7);
+        std::normal_distribution<float> nd(180.f, 50.f);
+        std::vector<int> cu{0};
+        while (cu.back() < T) {
+            int len = std::min(256, std::max(16, (int)lroundf(nd(g))));
+            cu.push_back(std::min(T, cu.back() + len));
+        }
+        const int ns = (int)cu.size() - 1;
+        Dev<int> dcu(cu);
+        Dev<__half> qkv((size_t)T * 3 * Hh), out((size_t)T * Hh);
+        dev_fill(qkv.p, (size_t)T * 3 * Hh, 1.0f, 41, st);
+        double flop = 0;
+        for (int i = 0; i < ns; ++i) flop += 4.0 * (cu[i + 1] - cu[i]) * (double)(cu[i + 1] - cu[i]) * Hh;
+        for (int round = 0; round < 2; ++round) {
+            const float us = time_us(st, reps, [&] { LM(lm_attn_varlen_f16(qkv.p, dcu.p, ns, heads, 64, 256, out.p, st)); });
+            printf("{\"kernel\": \"lm_attn_varlen_f16 head_dim 64\", \"mode\": \"%d sequences, %d tokens\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"GBps_qkv_plus_out\": %.0f}\n",
+                   ns, T, round, us, flop / us * 1e-6, (double)T * Hh * 8 / us * 1e-3);
+        }
+        fflush(stdout);
     }
     rocblas_destroy_handle(rb);
     return 0;

@@ -148,6 +148,37 @@ def case_pq(deferred=True):
     else:
         el, ed, _ = orc.pq_search(og, cb.numpy(), codes.numpy(), q, 5, L=12, W=2, table=x)
     _check(f"pq traversal deferred={deferred}", (d, l), (el, ed))
+    if not deferred:  # wide beam on a full list: > 256 fresh nodes per hop (several compaction passes) and the below-threshold filter in action
+        l2, d2 = idx.pq_search(q, 5, idx.make_pq_params(24, 40))
+        st2 = idx.stats()
+        el2, ed2, ost2 = orc.pq_search(og, cb.numpy(), codes.numpy(), q, 5, L=24, W=40, table=x)
+        _check("pq traversal, beam 40 on a 24-entry list", (d2, l2), (el2, ed2))
+        assert int(st2["ndis"]) == int(ost2["n_adc"]), (st2, ost2)
+    idx.close()
+
+
+def case_pq_stock_bundle():
+    """The DiskANN-style traversal over a STOCK bundle (tests/golden/stock_diskann: public DiskANN file layout, unequal PQ chunks, MIPS
+    augmentation undone by leann_amd/diskann_files.py) through lm_pq_attach_chunked, against the oracle with the same chunking."""
+    from leann_amd.diskann_files import load_stock_bundle
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    fx = Path(__file__).resolve().parent / "golden" / "stock_diskann"
+    b = load_stock_bundle(fx / "fx", 24, "mips")
+    g = b.graph()
+    x = b.vectors
+    q = x[[3, 77, 150]] + 0.05 * np.random.default_rng(2).standard_normal((3, 24)).astype(np.float32)
+    idx = Mi355xIndex.from_csr(g)
+    idx.attach_table(x)
+    idx.attach_pq(b.codebooks, b.codes, b.chunk_offsets)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 24)
+    for L, W in ((16, 2), (40, 4)):
+        l, d = idx.pq_search(q, 5, idx.make_pq_params(L, W))
+        el, ed, _ = orc.pq_search(og, b.codebooks, b.codes, q, 5, L=L, W=W, table=x, chunk_off=b.chunk_offsets)
+        _check(f"pq traversal over the stock DiskANN fixture L={L} W={W}", (d, l), (el, ed))
+    gt, _ = orc.bruteforce_topk(x, q, 5, 0)
+    assert np.mean([len(set(l[i].tolist()) & set(gt[i].tolist())) / 5 for i in range(3)]) >= 0.8  # L = 40: a working index
     idx.close()
 
 
@@ -513,6 +544,7 @@ CASES = {
     "pq_deferred": lambda: case_pq(True),
     "pq_table": lambda: case_pq(False),
     "two_level": case_two_level,
+    "pq_stock_bundle": case_pq_stock_bundle,
     "degenerate_graphs": case_degenerate_graphs,
     "hub_cache_and_helpers": case_hub_cache_and_helpers,
     "encoder_abi": case_encoder_abi,
@@ -565,6 +597,97 @@ def case_gemm_f16():
 
 
 CASES["gemm_f16"] = case_gemm_f16
+
+
+def case_hidden768():
+    """The hidden-768 path (bge-base / contriever shape: 12 heads x 64): lm_attn_varlen_f16 at head_dim 64 vs numpy, then
+    leann_amd/encoder.py's packed forward on the general kernels (lm_gemm_f16 x 4, attention, lm_add_layernorm_f16 x 2 per layer; no
+    library GEMM left) vs the fp32 torch forward of the same weights."""
+    import ctypes as C
+    import os
+    from unittest import mock
+
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+
+    lib = _lib.load()
+    rng = np.random.default_rng(23)
+    heads, hd = 3, 64
+    lens = np.array([70, 1, 33, 64], np.int32)  # three 32-key tiles with a ragged tail, a single token, exact tiles
+    cu = np.zeros(5, np.int32)
+    cu[1:] = np.cumsum(lens)
+    tot, Hh = int(cu[-1]), heads * hd
+    qkv = (rng.standard_normal((tot, 3 * Hh)) * 1.2).astype(np.float16)
+    q3 = qkv.astype(np.float64).reshape(tot, 3, heads, hd)
+    ref = np.zeros((tot, Hh))
+    for i in range(4):
+        a, b = cu[i], cu[i + 1]
+        for h in range(heads):
+            sc = q3[a:b, 0, h] @ q3[a:b, 1, h].T / np.sqrt(hd)
+            pr = np.exp(sc - sc.max(1, keepdims=True))
+            ref[a:b, h * hd:(h + 1) * hd] = (pr / pr.sum(1, keepdims=True)) @ q3[a:b, 2, h]
+    out = np.zeros((tot, Hh), np.float16)
+    vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    _lib.check(lib.lm_attn_varlen_f16(vp(qkv), vp(cu), 4, heads, hd, int(lens.max()), vp(out), None), "lm_attn_varlen_f16")
+    err = float(np.abs(out.astype(np.float64) - ref).max())
+    print(f"attention head_dim 64: max|diff| vs numpy {err:.2e}", flush=True)
+    assert err < 4e-3
+    out32 = np.zeros((tot, Hh), np.float16)  # the same entry point at head_dim 32 = the hd32 kernel (6 heads x 32 on the same buffer)
+    _lib.check(lib.lm_attn_varlen_f16(vp(qkv), vp(cu), 4, 6, 32, int(lens.max()), vp(out32), None), "lm_attn_varlen_f16")
+    ref32 = np.zeros((tot, Hh), np.float16)
+    _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv), vp(cu), 4, 6, int(lens.max()), vp(ref32), None), "lm_attn_varlen_hd32_f16")
+    assert np.array_equal(out32, ref32)
+
+    torch.manual_seed(0)
+    cfg = EncoderConfig(vocab_size=300, hidden=768, layers=2, heads=12, ffn=256, max_pos=64, max_seq_length=40, pooling="cls", normalize=True)
+    e32 = BertEncoder.random_init(cfg, 7).eval()
+    with torch.no_grad():
+        for L in e32.layers:  # biases and LayerNorm parameters that are not the identity
+            for lin in (L.qkv, L.out, L.fc1, L.fc2):
+                lin.bias.copy_(0.1 * torch.randn(lin.bias.shape))
+            for ln in (L.ln1, L.ln2):
+                ln.weight.copy_(1 + 0.1 * torch.randn(768))
+                ln.bias.copy_(0.1 * torch.randn(768))
+    e16 = BertEncoder.random_init(cfg, 7).eval()
+    e16.load_state_dict(e32.state_dict())
+    e16 = e16.half()
+    n, t = 7, 40
+    lens2 = rng.integers(1, t + 1, n).astype(np.int32)
+    lens2[0], lens2[1] = t, 1
+    ids = np.zeros((n, t), np.int32)
+    for i in range(n):
+        ids[i, : lens2[i]] = rng.integers(1, cfg.vocab_size, lens2[i])
+    ti, tl = torch.from_numpy(ids), torch.from_numpy(lens2)
+    with torch.no_grad():
+        ref_e = e32(ti, tl).float()
+
+    class _Stream:
+        cuda_stream = 0
+
+    used = []
+    real_check = _lib.check
+
+    def recording_check(rc, what=""):
+        used.append(what)
+        return real_check(rc, what)
+
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
+            mock.patch.object(_lib, "check", new=recording_check):
+        with torch.no_grad():
+            got = e16.encode_tokens_packed(ti, tl, 4096)
+    want = {"lm_gemm_f16": 4 * cfg.layers, "lm_attn_varlen_f16": cfg.layers, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_embed_layernorm_f16": 1}
+    counts = {k: used.count(k) for k in want}
+    assert counts == want, (counts, sorted(set(used)))
+    err = float((got.float() - ref_e).abs().max())
+    print(f"hidden 768 packed forward on the general kernels: max|diff| vs fp32 torch = {err:.2e}", flush=True)
+    assert err < 6e-3, err
+
+
+CASES["hidden768"] = case_hidden768
 
 
 def case_encoder_python_wiring():

@@ -98,3 +98,66 @@ def test_two_rank_gloo(mode, built_libs):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_pack_and_unpack_results_round_trip():
+    from leann_amd.distributed import pack_results, unpack_results
+
+    d = torch.tensor([[1.5, -2.25, float("inf")], [0.0, 3.0, -0.0]], dtype=torch.float32)
+    i = torch.tensor([[7, -1, 2**40 + 3], [0, 5, -1]], dtype=torch.int64)
+    buf = pack_results(d, i)
+    assert buf.dtype == torch.int32 and tuple(buf.shape) == (2, 9)
+    d2, i2 = unpack_results(buf, 3)
+    assert torch.equal(d2.view(torch.int32), d.view(torch.int32)) and torch.equal(i2, i)
+
+
+def _nccl_worker(rank, world, port, out):
+    """Both multi-GPU host classes on RCCL: one rank per GPU, HIP search + HIP merge, every rank must hold the single-GPU answer."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from leann_amd.distributed import broadcast_graph
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x = clustered(3000, 64, 5)
+    qn = queries_near(x, 33, 6)
+    q = torch.from_numpy(qn).to(dev)
+    g = broadcast_graph(build_hnsw(x, "mips", M=8, ef_construction=40, num_threads=1) if rank == 0 else None, 0, device=dev)
+    idx = Mi355xIndex.from_csr(g, device=rank)
+    idx.attach_table(x)
+    prm = idx.make_params(ef=32, recompute=False)
+    d, i = PartitionedSearch(lambda qq, k: idx.search_device(qq, k, prm)).search(q, 5)
+    ei, ed, _ = orc.search(oracle_graph(g, 64), qn, 5, ef=32, table=x)
+    ok = np.array_equal(i.cpu().numpy(), ei) and np.array_equal(d.cpu().numpy(), ed)
+    lo, hi = shard_bounds(3000, world)[rank]
+    gs = build_hnsw(x[lo:hi], "mips", M=8, ef_construction=40, num_threads=1)
+    ids = Mi355xIndex.from_csr(gs, device=rank)
+    ids.attach_table(x[lo:hi])
+    prs = ids.make_params(ef=64, recompute=False)
+    d2, i2 = ShardedSearch(lambda qq, k: ids.search_device(qq, k, prs), id_base=lo, metric=0).search(q, 5)
+    gt, _ = orc.bruteforce_topk(x, qn, 5, 0)
+    rec = np.mean([len(set(i2[r].tolist()) & set(gt[r].tolist())) / 5 for r in range(q.shape[0])])
+    ok = ok and rec > 0.95 and bool(torch.all(torch.diff(d2, dim=1) <= 0)) and int(i2.max()) < 3000
+    gi = [torch.empty_like(i2) for _ in range(world)]
+    dist.all_gather(gi, i2)
+    ok = ok and all(torch.equal(gi[0], t) for t in gi)
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_rccl(built_libs):
+    """The first RCCL execution of PartitionedSearch / ShardedSearch / broadcast_graph should not be the driver's 8-GPU run: runs
+    wherever two GPUs are visible (the 1-GPU test box skips it)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (one rank per GPU over RCCL)")
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}

@@ -356,3 +356,113 @@ def test_pack_tokens_front_end(monkeypatch):
     monkeypatch.setenv("LEANN_MI355X_PACK", "0")
     b = enc.encode_tokens_packed(ti, tl)
     assert torch.equal(a, b)
+
+
+# ---- the general kernels of the hidden-768 path (bge-base / contriever: BASELINE.json configs[4]) ----------------------------------
+@pytest.mark.parametrize("tokens,n,k,epi", [(300, 256, 128, 0), (1000, 2304, 768, 0), (777, 768, 768, 2), (2049, 3072, 768, 1), (513, 768, 3072, 2),
+                                            (130, 384, 128, 3), (5000, 1152, 384, 0), (100, 256, 256, 1), (1, 768, 768, 3), (4100, 1536, 384, 1)])
+def test_general_gemm_vs_fp32_torch(tokens, n, k, epi):
+    """lm_gemm_f16 (csrc/lm_gemm_f16.hip): epi(x W^T + b) with both tile shapes and every epilogue against fp32 torch."""
+    import torch
+
+    from leann_amd.encoder import GEMM_EPI_GELU, GEMM_EPI_RESIDUAL, fused_gemm
+
+    torch.manual_seed(tokens + n + k + epi)
+    lin = torch.nn.Linear(k, n).to("cuda", dtype=torch.float16)
+    with torch.no_grad():
+        lin.bias.copy_(0.3 * torch.randn(n))
+    x = (0.7 * torch.randn((tokens, k), device="cuda")).half()
+    res = torch.randn((tokens, n), device="cuda").half()
+    with torch.no_grad():
+        got = fused_gemm(x, lin, epi, res if epi & GEMM_EPI_RESIDUAL else None)
+        ref = x.float() @ lin.weight.float().t() + lin.bias.float()
+        if epi & GEMM_EPI_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        ref = ref.half().float()
+        if epi & GEMM_EPI_RESIDUAL:
+            ref = (ref.half() + res).float()
+    torch.cuda.synchronize()
+    assert got is not None and got.shape == (tokens, n) and not torch.isnan(got).any()
+    assert (got.float() - ref).abs().max().item() <= 2.5e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("heads,maxlen", [(12, 256), (12, 40), (3, 1), (2, 33), (12, 512), (4, 300)])
+def test_attention_head_dim_64_vs_fp32_torch(heads, maxlen):
+    """lm_attn_varlen_f16 at head_dim 64 (csrc/lm_attn_v2.hip, HD = 64) against fp32 torch softmax attention per sequence."""
+    import torch
+
+    from leann_amd.encoder import fused_attention_hd32
+
+    g = torch.Generator(device="cpu").manual_seed(heads * 1000 + maxlen)
+    nseq = 19
+    lens = torch.randint(1, maxlen + 1, (nseq,), generator=g)
+    lens[0], lens[-1] = maxlen, 1
+    lens[2] = max(1, (maxlen // 32) * 32)
+    cu = torch.zeros(nseq + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    tot, H = int(cu[-1]), heads * 64
+    qkv = (torch.randn((tot, 3 * H), generator=g) * 1.5).half().cuda()
+    q3 = qkv.float().view(tot, 3, heads, 64)
+    ref = torch.empty((tot, H), device="cuda")
+    for i in range(nseq):
+        a, b = int(cu[i]), int(cu[i + 1])
+        q, k, v = (q3[a:b, j].transpose(0, 1) for j in range(3))
+        p = torch.softmax(q @ k.transpose(1, 2) / 8.0, dim=-1)
+        ref[a:b] = (p @ v).transpose(0, 1).reshape(b - a, H)
+    got = fused_attention_hd32(qkv, cu.cuda(), heads, int(lens.max()))
+    torch.cuda.synchronize()
+    assert got is not None and not torch.isnan(got).any()
+    assert (got.float() - ref).abs().max().item() <= 4e-3
+
+
+@pytest.mark.parametrize("model", ["BAAI/bge-base-en-v1.5", "facebook/contriever"])
+def test_hidden_768_forward_runs_on_the_hand_written_kernels(model, monkeypatch):
+    """The whole packed forward of a 768-wide model: lm_gemm_f16 + lm_attn_varlen_f16 + lm_add_layernorm_f16 per layer, no library GEMM;
+    against the same weights in fp32 on the CPU (plain torch) and against the library path on the GPU (LEANN_MI355X_GEMM=0,
+    LEANN_MI355X_ATTN=0)."""
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    cfg = config_for(model)
+    assert cfg.hidden == 768
+    cpu32 = BertEncoder.random_init(cfg, 1).eval()
+    enc = BertEncoder.random_init(cfg, 1).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=96, n_topics=4)).chunks(), 256)
+    with torch.no_grad():
+        ref = cpu32(torch.from_numpy(ids[:24]), torch.from_numpy(lens[:24])).float()
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    used = []
+    real = _lib.check
+    monkeypatch.setattr(_lib, "check", lambda rc, what="": (used.append(what), real(rc, what))[1])
+    got = enc.encode_tokens_packed(ti, tl)
+    assert used.count("lm_gemm_f16") == 4 * cfg.layers and used.count("lm_attn_varlen_f16") == cfg.layers
+    tol = 5e-3 if cfg.normalize else 5e-3 * float(ref.abs().max())
+    assert (got[:24].cpu() - ref).abs().max().item() <= tol
+    assert torch.nn.functional.cosine_similarity(got[:24].cpu(), ref).min().item() >= 0.9999
+    monkeypatch.setenv("LEANN_MI355X_GEMM", "0")
+    monkeypatch.setenv("LEANN_MI355X_ATTN", "0")
+    used.clear()
+    lib = enc.encode_tokens_packed(ti, tl)
+    assert "lm_gemm_f16" not in used
+    assert (got - lib).abs().max().item() <= tol
+
+
+def test_minilm_forward_through_the_general_gemm_switches(monkeypatch):
+    """LEANN_MI355X_GEMM=1 (QKV projection through lm_gemm_f16) and =2 (the whole layer on the general kernels) for a hidden-384
+    model: the A/B paths of the default fused kernels give the same embeddings."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=200, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    d = enc.encode_tokens_packed(ti, tl)
+    for v in ("1", "2"):
+        monkeypatch.setenv("LEANN_MI355X_GEMM", v)
+        g = enc.encode_tokens_packed(ti, tl)
+        assert (g - d).abs().max().item() < 3e-3 and not torch.isnan(g).any()

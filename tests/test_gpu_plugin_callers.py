@@ -114,3 +114,38 @@ def test_real_leann_searcher_on_top_of_the_backend(tmp_path, built_libs):
     assert len(res) == 3 and res[0].id == "17" and res[0].text == texts[17]
     assert res[0].score >= res[1].score >= res[2].score
     searcher.cleanup()
+
+
+def test_diskann_searcher_serves_a_stock_diskann_bundle(tmp_path, built_libs):
+    """a bundle in the layout the STOCK DiskANN backend writes (tests/golden/stock_diskann, packed byte by byte by
+    tests/golden/make_golden_diskann.py: _pq_pivots.bin / _pq_compressed.bin / _disk.index / _medoids.bin / _max_base_norm.bin, MIPS
+    vectors in DiskANN's augmented L2 form, unequal PQ chunks) served through BACKEND_REGISTRY["mi355x_diskann"]: the meta.json is the
+    stock one with backend_name switched, nothing else converted; results must equal the oracle's on the same chunked quantiser."""
+    import json
+    import shutil
+
+    from leann_amd._compat import BACKEND_REGISTRY
+    from leann_amd.diskann_files import load_stock_bundle
+    from oracle import oracle as orc
+
+    fx = Path(__file__).resolve().parent / "golden" / "stock_diskann"
+    for f in fx.glob("fx_*"):
+        shutil.copy(f, tmp_path / f.name.replace("fx_", "docs_", 1))
+    exp = np.load(fx / "expected.npz")
+    meta = {"version": "1.0", "backend_name": "mi355x_diskann", "embedding_model": "facebook/contriever", "dimensions": 24,
+            "backend_kwargs": {"distance_metric": "mips", "graph_degree": 12, "complexity": 64, "is_recompute": False},
+            "embedding_mode": "sentence-transformers", "passage_sources": []}
+    (tmp_path / "docs.leann.meta.json").write_text(json.dumps(meta))
+    s = BACKEND_REGISTRY["mi355x_diskann"].searcher(str(tmp_path / "docs.leann"))
+    x = exp["x"]
+    q = x[[3, 77, 150, 9]] + 0.05 * np.random.default_rng(2).standard_normal((4, 24)).astype(np.float32)
+    r = s.search(q, 5, complexity=40, beam_width=4, recompute_embeddings=False)
+    b = load_stock_bundle(tmp_path / "docs", 24, "mips")
+    g = b.graph()
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 24)
+    el, ed, _ = orc.pq_search(og, b.codebooks, b.codes, q, 5, L=40, W=4, table=b.vectors, chunk_off=b.chunk_offsets)
+    assert [[int(v) for v in row] for row in r["labels"]] == el.tolist()
+    assert np.array_equal(r["distances"], ed)
+    gt, _ = orc.bruteforce_topk(x, q, 5, 0)
+    assert np.mean([len(set(el[i].tolist()) & set(gt[i].tolist())) / 5 for i in range(4)]) >= 0.8
+    s.cleanup()
