@@ -298,7 +298,7 @@ int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, i
                         void *stream);
 
 /* General fp16 linear layer (csrc/lm_gemm_f16.hip):  d_out[tokens][n_out] = epi(x[tokens][k_in] W^T + b), d_w = the nn.Linear weight
- * itself ([n_out][k_in] fp16 row major, no packing), bias fp32, n_out % 128 == 0, k_in % 128 == 0, operands < 4 GiB each.
+ * itself ([n_out][k_in] fp16 row major, no packing, < 4 GiB), bias fp32, n_out % 128 == 0, k_in % 128 == 0; any token count.
  * epilogue: 0 = none, 1 = exact-erf GELU, 2 = + d_residual[tokens][n_out] (fp16), 3 = both.  256 x 256 workgroup tiles (128 x 128
  * when n_out % 256 != 0), MFMA 32x32x16 f16, operands staged L2 -> LDS by global_load_lds through two stages.  The GEMMs of the BERT
  * forward in compute_embeddings (leann/embedding_compute.py:229-239) for models whose hidden size is not 384 (bge-base,
@@ -323,7 +323,14 @@ typedef struct lm_bert_h384_layer {
     const void *w2p; /* [ffn/32][384][32] */
     const float *b2;
     const void *ln2_gamma, *ln2_beta;
+    /* Optional (all three or none): the plain nn.Linear weights [384][384], [ffn][384], [384][ffn] fp16.  With them a forward of at
+     * most LM_BERT_SMALL_TOKENS tokens (a one-query search round recomputes ~5 chunks) runs every layer on the general kernels --
+     * lm_gemm_f16 x 4 + attention + lm_add_layernorm_f16 x 2: many small workgroups spread over the chip -- instead of the fused
+     * layer tail, whose 128-token workgroup is one ~77 us dependency chain however few tokens it holds (MI355X, 200k-chunk index,
+     * B = 1 search: p50 59.7 -> 47.2 ms).  Same arithmetic up to fp16 rounding of the intermediate activations. */
+    const void *wo, *w1, *w2;
 } lm_bert_h384_layer;
+#define LM_BERT_SMALL_TOKENS 6144
 
 typedef struct lm_bert_h384 {
     int32_t n_layers, heads, ffn, normalize;
@@ -332,7 +339,7 @@ typedef struct lm_bert_h384 {
     const lm_bert_h384_layer *layers;                           /* host array of n_layers entries */
 } lm_bert_h384;
 
-size_t lm_bert_h384_workspace_bytes(int64_t total_tokens);
+size_t lm_bert_h384_workspace_bytes(int64_t total_tokens); /* sized for either layer form (ffn <= 2560) */
 int lm_bert_h384_forward_packed(const lm_bert_h384 *m, const int32_t *d_tok, const int32_t *d_pos, const int32_t *d_cu_seqlens,
                                 int32_t n_seqs, int64_t total_tokens, int32_t max_len, void *d_workspace, size_t workspace_bytes,
                                 float *d_out, void *stream);

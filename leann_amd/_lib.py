@@ -63,7 +63,8 @@ class PqSearchParams(C.Structure):
 
 
 class BertH384Layer(C.Structure):  # include/leann_mi355x.h: lm_bert_h384_layer
-    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo_p", "bo", "ln1_gamma", "ln1_beta", "w1acc", "b1", "w2p", "b2", "ln2_gamma", "ln2_beta")]
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo_p", "bo", "ln1_gamma", "ln1_beta", "w1acc", "b1", "w2p", "b2", "ln2_gamma", "ln2_beta",
+                                          "wo", "w1", "w2")]
 
 
 class BertH384(C.Structure):  # include/leann_mi355x.h: lm_bert_h384

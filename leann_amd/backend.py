@@ -176,7 +176,7 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
         if not self.index_file.exists() and not self._has_alternative_index_files():
             raise FileNotFoundError(f"HNSW index file not found at {self.index_file}")
         self.device = int(kwargs.get("device", 0))
-        self.encoder_batch = int(kwargs.get("encoder_batch", 2048))
+        self.encoder_batch = int(kwargs.get("encoder_batch", 5461))  # chunks per encoder sub-batch (x 192 tokens = 1M tokens: measured 61.9 vs 64.4 ms per 11,264 chunks against 524k)
         self.encoder_dtype = kwargs.get("encoder_dtype", "float16")
         # fraction of the highest in-degree nodes whose embeddings stay cached in HBM (LEANN paper section 5;
         # 0 = pure recompute, the reference's behaviour)

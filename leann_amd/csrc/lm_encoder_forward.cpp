@@ -6,13 +6,23 @@
 // mean pooling (all-MiniLM-L6-v2 and relatives).  The default launch path of leann_amd/encoder.py since round 3 (MI355X, 200k-chunk
 // index: B = 1 p50 57.7 -> 56.3 ms; LEANN_MI355X_ONECALL=0 = one call per kernel); also runs in the thread-per-lane emulation
 // (tests/emulated_search_cases.py) and under the real leann.api.LeannSearcher there (tests/real_caller_over_emulation.py).
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
 #include "lm_internal.h"
 
+// tokens up to which the layers run on the general kernels (see lm_bert_h384_layer::wo); LEANN_MI355X_SMALL_TOKENS overrides (0 = never)
+static int64_t small_tokens_limit() {  // read per call (one getenv per forward): the Python host reads the same variable per call
+    const char* e = getenv("LEANN_MI355X_SMALL_TOKENS");
+    return e ? (int64_t)atoll(e) : (int64_t)LM_BERT_SMALL_TOKENS;
+}
+
 extern "C" size_t lm_bert_h384_workspace_bytes(int64_t total_tokens) {
-    return total_tokens <= 0 ? 0 : (size_t)total_tokens * (3 * 384 + 1152) * 2;  // x, attention output, y: [T][384]; qkv: [T][1152]; fp16
+    if (total_tokens <= 0) return 0;
+    // x, attention output, y: [T][384]; qkv: [T][1152]; small forwards additionally the feed-forward intermediate [T][ffn <= 2560]; fp16
+    const size_t small = total_tokens <= std::max<int64_t>(small_tokens_limit(), LM_BERT_SMALL_TOKENS) ? (size_t)total_tokens * 2560 * 2 : 0;
+    return (size_t)total_tokens * (3 * 384 + 1152) * 2 + small;
 }
 
 extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t* d_tok, const int32_t* d_pos, const int32_t* d_cu_seqlens,
@@ -34,8 +44,21 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     void* qkv = ws + 3 * row;
     int rc = lm_embed_layernorm_f16(d_tok, d_pos, m->word, m->pos_table, m->type0, m->emb_gamma, m->emb_beta, x, total_tokens, 384, m->ln_eps, stream);
     if (rc) return rc;
+    bool small = total_tokens <= small_tokens_limit() && m->ffn % 128 == 0;
+    for (int l = 0; small && l < m->n_layers; ++l) small = m->layers[l].wo && m->layers[l].w1 && m->layers[l].w2;
+    void* hid = ws + 3 * row + (size_t)total_tokens * 1152 * 2;  // [T][ffn], small forwards only (lm_bert_h384_workspace_bytes)
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
+        if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x
+            if ((rc = lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 1152, 384, qkv, total_tokens, stream))) return rc;
+            if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
+            if ((rc = lm_gemm_f16(a, L.wo, L.bo, x, 2, 384, 384, y, total_tokens, stream))) return rc;
+            if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln1_gamma, L.ln1_beta, x, total_tokens, 384, m->ln_eps, stream))) return rc;
+            if ((rc = lm_gemm_f16(x, L.w1, L.b1, nullptr, 1, m->ffn, 384, hid, total_tokens, stream))) return rc;
+            if ((rc = lm_gemm_f16(hid, L.w2, L.b2, x, 2, 384, m->ffn, y, total_tokens, stream))) return rc;
+            if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln2_gamma, L.ln2_beta, x, total_tokens, 384, m->ln_eps, stream))) return rc;
+            continue;
+        }
         if ((rc = lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream))) return rc;
         if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
         if ((rc = lm_attn_out_mlp_fused_h384_f16(a, x, L.wo_p, L.bo, L.ln1_gamma, L.ln1_beta, m->ln_eps, L.w1acc, L.b1, L.w2p, L.b2, L.ln2_gamma,

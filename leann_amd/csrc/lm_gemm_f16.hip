@@ -20,15 +20,22 @@
 //     reads by permuting the SOURCE chunks: position (row, c') holds chunk c' ^ ((row >> 1) & 7) of the row.  A fragment read has
 //     lanes 0..31 on 32 consecutive rows at one chunk: within each of the hardware's 16-lane groups ({0-3, 12-15, 20-27}, ...) the
 //     eight row pairs have eight different (row >> 1) & 7, the two rows of a pair sit in different halves of the 256-byte bank row;
-//   * one barrier per K-tile: wait own DMA (vmcnt(0)) -> barrier -> issue the next tile's DMA into the other stage -> 32 MFMAs;
+//   * one barrier per K-tile: wait own DMA (vmcnt(0)) -> barrier -> 32 MFMAs with the next K-tile's DMA pieces issued behind the first
+//     two fragment requests (measured best placement: profiles/r3_session3_gemm_loop_variants.txt);
+//   * PERSISTENT: one workgroup per CU walks a list of output tiles.  s_memtime stamps of the one-tile-per-workgroup form (QKV
+//     shape, 12 K-tiles): 3.4 k cycles until the first K-tile has landed + 34.0 k main loop + 5.6 k epilogue + 0.5 k store drain,
+//     and a workgroup swap on top.  Here the NEXT tile's first K-tile is requested before the epilogue starts (it lands under the
+//     epilogue's LDS round trip and stores), and no workgroup is ever re-dispatched;
 //   * MFMA orientation: A = W rows (M = features), B = x rows (N = tokens): a lane ends up with 4 consecutive features of ONE
-//     token per accumulator quad -> packed to fp16 and written token-major into a per-wave LDS tile (8-byte writes, rows padded by
-//     8 B: conflict free), read back as whole rows and stored as 256-byte (BIG) row segments: full lines, 16 B per lane.  Bias and
-//     GELU are applied on the way into the tile (fp32), the residual on the way out (fp16 add, as torch's half `+` does);
+//     token per accumulator quad -> packed to fp16 and written token-major into a per-wave LDS tile of 32 token rows (8-byte writes,
+//     rows padded by 8 B: conflict free; one tile per 32-token MFMA column block, behind the first stage so that the next tile's
+//     prefetch can use that stage), read back as whole rows and stored as 256-byte (BIG) row segments: full lines, 16 B per lane.
+//     Bias and GELU are applied on the way into the tile (fp32), the residual on the way out (fp16 add, as torch's half `+` does);
 //   * the tiles that share an x row block run back to back on ONE XCD (workgroup b -> XCD b % 8 is today's dispatch; any other
 //     mapping costs speed only): x comes from HBM once and from that XCD's L2 afterwards, W stays L2 / Infinity-Cache resident.
 // Role in the reference: the GEMMs of compute_embeddings' BERT forward (leann/embedding_compute.py:229-239) for models whose
 // hidden size is not 384.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -72,22 +79,23 @@ struct GemmShape {
     static constexpr int STAGE = (BN + BM) * 128;                  // bytes of one K-tile (64 halfs per row)
     static constexpr int PIECES = (BN + BM) / 8 / NW;              // 1 KB DMA pieces per wave per K-tile
     static constexpr int RS = TF * 64 + 8;                         // bytes per token row of a wave's output tile (+ 8: conflict-free writes)
-    static constexpr int OUT_TILE = TT * 32 * RS;                  // per wave
-    static constexpr int LDS = 2 * STAGE > NW * OUT_TILE ? 2 * STAGE : NW * OUT_TILE;
-    static_assert((BN + BM) % (8 * NW) == 0 && PIECES % 4 == 0, "DMA pieces must divide evenly over the waves and the four k-steps");
+    static constexpr int OUT_TILE = 32 * RS;                       // per wave: one 32-token column block at a time
+    static constexpr int OUT_OFF = STAGE;                          // the output tiles sit behind stage 0 (which the next tile's prefetch fills)
+    static constexpr int BIAS_OFF = 2 * STAGE > OUT_OFF + NW * OUT_TILE ? 2 * STAGE : OUT_OFF + NW * OUT_TILE;  // this tile's BN bias values (fp32)
+    static constexpr int LDS = BIAS_OFF + BN * 4;
+    static_assert((BN + BM) % (8 * NW) == 0 && PIECES % 2 == 0, "DMA pieces must divide evenly over the waves and two k-steps");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 using GemmBig = GemmShape<2, 4, 4, 2>;    // 256 x 256, 512 threads, 128 accumulator registers per lane
 using GemmSmall = GemmShape<2, 2, 2, 2>;  // 128 x 128, 256 threads, 64 accumulator registers per lane
 
-// VAR (diagnosis builds only, -DLM_DIAG + LEANN_MI355X_GEMM_VARIANT; the product library holds the default alone):
-//   0 = K-tiles of 64 through two stages, the next tile's eight DMA pieces spread two per k-step;  1 = all eight in front of the
-//   first MFMA;  2 = four behind each of the first two fragment requests;  3 = no DMA in the loop (stale operands: the bare
-//   MFMA + LDS + barrier rate);  4 = no MFMA (the load path alone);  6 = variant 0 without the global stores of the epilogue;
-//   5 = K half-tiles of 32 through a ring of FOUR slots, counted vmcnt: two half-tiles stay in flight across every barrier.
-//   7 = variant 2 with s_memtime stamps: wave 0 of every workgroup adds its cycle counts {prologue (until tile 0 has landed), main loop,
-//       bias + LDS tile write, row read-back + global store issue, store drain, workgroups} to the u64 words at `resid` (epilogue 0 only:
-//       the residual pointer is then a debug buffer; scripts/kbench.cpp "gemmstamp").
-constexpr int GM_VAR_DEFAULT = 2;
+// VAR (diagnosis builds only, -DLM_DIAG + LEANN_MI355X_GEMM_VARIANT; the product library holds variant 0 alone):
+//   7 = s_memtime stamps: wave 0 of every workgroup adds its cycle counts {until the first K-tile has landed, main loops, bias + LDS
+//       tile writes, row read-back + store issue, (unused), tiles} to the u64 words at `resid` (epilogue 0 only: the residual pointer
+//       is then a debug buffer; scripts/kbench.cpp "gemmstamp").
+// Launch shape (diagnosis: LEANN_MI355X_GEMM_GRID=tiles): the persistent grid is one workgroup per CU; a grid of one workgroup per
+// tile runs the same code with tile lists of length one (the round-3 session-2..4 form, for A/B).
+constexpr int GM_VAR_DEFAULT = 0;
 
 #if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
 #define GM_STAMP(t)                                     \
@@ -102,8 +110,10 @@ constexpr int GM_VAR_DEFAULT = 2;
 #define GM_STAMP(t) ((void)0)
 #endif
 
-// grid: 8 * NC * ceil(row_blocks / 8) workgroups (NC = N / BN).  xcd = b % 8, idx = b / 8: row block = (idx / NC) * 8 + xcd,
-// column tile = idx % NC -- the NC tiles of a row block are consecutive dispatches on one XCD.
+// Tile order: XCD x (workgroup b runs on XCD b % 8 today; any other mapping costs speed only) owns the row blocks rb = x (mod 8) and
+// walks its tiles i = 0, 1, ... as (rb = (i / NC) * 8 + x, column tile i % NC): the NC tiles of a row block are neighbours in time on
+// ONE XCD, so x is fetched from HBM once and re-read from that XCD's L2.  Workgroup b = (slot = b / 8, x = b % 8) takes the tiles
+// i = slot, slot + gridDim.x / 8, ... of its XCD.
 template <class S, int EPI, int VAR>
 __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
     const __half* __restrict__ x, const __half* __restrict__ w, const float* __restrict__ bias, const __half* __restrict__ resid,
@@ -111,238 +121,192 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = GM_UNIFORM(tid >> 6);
     const int r31 = lane & 31, g = lane >> 5;
-    const int NC = N / S::BN;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int rb = (idx / NC) * 8 + xcd, ct = idx % NC;
-    const int t0 = rb * S::BM, n0 = ct * S::BN;
-    if (t0 >= T) return;  // row-block padding of the last group of eight
+    const int NC = (N + S::BN - 1) / S::BN;  // the last column tile may be partial (N % 128 == 0): its surplus rows of W re-read row N - 1
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int nrb = (T + S::BM - 1) / S::BM;
+    const int tiles_x = ((nrb - xcd + 7) >> 3) * NC;  // tiles of this XCD (row blocks xcd, xcd + 8, ... < nrb)
+    if (slot >= tiles_x) return;
     const int wf = wv % S::WF, wt = wv / S::WF;
-    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+    [[maybe_unused]] unsigned long long ts0 = 0, ts1 = 0, tacc[4] = {0, 0, 0, 0}, ntile = 0;
     GM_STAMP(ts0);
 
-    float16v acc[S::TF][S::TT];
-#pragma unroll
-    for (int i = 0; i < S::TF; ++i)
-#pragma unroll
-        for (int j = 0; j < S::TT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // global row of stage row `row` (W rows first, then x rows; rows past the end re-read the last token, their results are never stored)
-    auto src_row = [&](int row) -> unsigned {
-        if (row < S::BN) return (unsigned)(n0 + row);
-        const int tok = t0 + row - S::BN;
-        return (unsigned)(tok < T ? tok : T - 1);
-    };
-
-    if constexpr (VAR != 5) {
-        // ---- DMA plan: piece p = wv + NW * i covers stage rows 8 p .. 8 p + 7; lane = (row 8 p + lane / 8, position c' = lane % 8)
-        //      fetches chunk c' ^ ((row >> 1) & 7) of the row's 128-byte line.  Source = wave-uniform base + per-lane 32-bit offset. ----
-        unsigned voff[S::PIECES];
+    // ---- DMA plan: piece p = wv + NW * i covers stage rows 8 p .. 8 p + 7 (W rows first, then x rows); lane = (row 8 p + lane / 8,
+    //      position c' = lane % 8) fetches chunk c' ^ ((row >> 1) & 7) of the row's 128-byte line.  Source = wave-uniform base +
+    //      per-lane 32-bit offset (recomputed per tile). ----
+    unsigned voff[S::PIECES];
+    auto plan = [&](int t0, int n0) {
 #pragma unroll
         for (int i = 0; i < S::PIECES; ++i) {
             const int row = 8 * (wv + S::NW * i) + (lane >> 3);
-            voff[i] = src_row(row) * (unsigned)(K * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-        }
-        auto issue_piece = [&](int kt, int stage, int i) {
-            const int p = wv + S::NW * i;  // wave uniform
-            const unsigned char* base = (const unsigned char*)(8 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)kt * 128;
-            lm_dma16_sv(base, voff[i], smem + stage * S::STAGE + p * 1024);
-        };
-        // ---- fragment addresses: row (tile base + r31), k-step kk (16 halfs): chunk 2 kk + g at position (2 kk + g) ^ ((r31 >> 1) & 7)
-        //      (tile bases are multiples of 32 rows, so the row term of the permutation depends on r31 only) ----
-        int fo[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fo[kk] = r31 * 128 + ((((2 * kk + g) ^ (r31 >> 1)) & 7) << 4);
-        const int a_base = wf * S::TF * 32 * 128;                 // W rows of this wave
-        const int b_base = S::BN * 128 + wt * S::TT * 32 * 128;   // x rows of this wave
-
-        const int nk = K / 64;  // even (K % 128 == 0)
-#pragma unroll
-        for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
-
-        // One K-tile: four k-steps of TF x TT MFMAs.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step kk are
-        // issued (a second register set: the matrix pipe never waits for an LDS round trip inside a tile); the NEXT tile's DMA pieces
-        // go behind the fragment requests as VAR says.  The scheduling barriers pin that order: the register budget (256 per wave)
-        // leaves the compiler no room to find it by itself.
-        auto ktile = [&](int stage, int next_kt, bool prefetch) {
-            const unsigned char* sb = smem + stage * S::STAGE;
-            half8 af[2][S::TF], bf[2][S::TT];
-#pragma unroll
-            for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 4096 + fo[0]);
-#pragma unroll
-            for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 4096 + fo[0]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int c = kk & 1, n = c ^ 1;
-                if (kk < 3) {
-#pragma unroll
-                    for (int i = 0; i < S::TF; ++i) af[n][i] = *(const half8*)(sb + a_base + i * 4096 + fo[kk + 1]);
-#pragma unroll
-                    for (int j = 0; j < S::TT; ++j) bf[n][j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk + 1]);
-                }
-                if (prefetch && VAR != 3) {
-                    constexpr int PER = (VAR == 1) ? S::PIECES : ((VAR == 2 || VAR == 7) ? S::PIECES / 2 : S::PIECES / 4);
-                    if (kk * PER < S::PIECES) {
-#pragma unroll
-                        for (int i = 0; i < PER; ++i) issue_piece(next_kt, stage ^ 1, kk * PER + i);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (VAR != 4) {
-#pragma unroll
-                    for (int i = 0; i < S::TF; ++i)
-#pragma unroll
-                        for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < S::TF; ++i) asm volatile("" ::"v"(af[c][i]));
-#pragma unroll
-                    for (int j = 0; j < S::TT; ++j) asm volatile("" ::"v"(bf[c][j]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            unsigned grow;
+            if (row < S::BN) {
+                grow = (unsigned)(n0 + row < N ? n0 + row : N - 1);  // features past N (partial last column tile): never stored
+            } else {
+                const int tok = t0 + row - S::BN;
+                grow = (unsigned)(tok < T ? tok : T - 1);  // rows past the end re-read the last token; their results are never stored
             }
-        };
+            voff[i] = grow * (unsigned)(K * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+    };
+    auto issue_piece = [&](int kt, int stage, int i) {
+        const int p = wv + S::NW * i;  // wave uniform
+        const unsigned char* base = (const unsigned char*)(8 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)kt * 128;
+        lm_dma16_sv(base, voff[i], smem + stage * S::STAGE + p * 1024);
+    };
+    // ---- fragment addresses: row (tile base + r31), k-step kk (16 halfs): chunk 2 kk + g at position (2 kk + g) ^ ((r31 >> 1) & 7)
+    //      (tile bases are multiples of 32 rows, so the row term of the permutation depends on r31 only) ----
+    int fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = r31 * 128 + ((((2 * kk + g) ^ (r31 >> 1)) & 7) << 4);
+    const int a_base = wf * S::TF * 32 * 128;                 // W rows of this wave
+    const int b_base = S::BN * 128 + wt * S::TT * 32 * 128;   // x rows of this wave
+    const int nk = K / 64;  // even (K % 128 == 0)
+
+    float16v acc[S::TF][S::TT];
+    // One K-tile: four k-steps of TF x TT MFMAs.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step kk are issued (a
+    // second register set: the matrix pipe never waits for an LDS round trip inside a tile); the NEXT K-tile's DMA pieces go behind the
+    // first two fragment requests.  The scheduling barriers pin that order: the register budget (256 per wave) leaves the compiler no
+    // room to find it by itself.
+    auto ktile = [&](int stage, int next_kt, bool prefetch) {
+        const unsigned char* sb = smem + stage * S::STAGE;
+        half8 af[2][S::TF], bf[2][S::TT];
+#pragma unroll
+        for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 4096 + fo[0]);
+#pragma unroll
+        for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 4096 + fo[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk & 1, n = c ^ 1;
+            if (kk < 3) {
+#pragma unroll
+                for (int i = 0; i < S::TF; ++i) af[n][i] = *(const half8*)(sb + a_base + i * 4096 + fo[kk + 1]);
+#pragma unroll
+                for (int j = 0; j < S::TT; ++j) bf[n][j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk + 1]);
+            }
+            if (prefetch && kk < 2) {
+#pragma unroll
+                for (int i = 0; i < S::PIECES / 2; ++i) issue_piece(next_kt, stage ^ 1, kk * (S::PIECES / 2) + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+                for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int ti = slot;
+    int t0 = ((ti / NC) * 8 + xcd) * S::BM, n0 = (ti % NC) * S::BN;
+    plan(t0, n0);
+#pragma unroll
+    for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+            for (int j = 0; j < S::TT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        [[maybe_unused]] unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
         for (int kt = 0; kt < nk; kt += 2) {
-            GM_WAIT_VM0();   // this wave's pieces of tile kt have landed ...
-            GM_BARRIER();    // ... and so have everybody else's; all waves are done reading stage 1 (tile kt - 1)
-            if (kt == 0) GM_STAMP(ts1);
+            GM_WAIT_VM0();   // this wave's pieces of K-tile kt have landed (and its stores of the previous tile's epilogue are out) ...
+            GM_BARRIER();    // ... and so have everybody else's; all waves are done with stage 1 (K-tile kt - 1 / the previous output tiles)
+            float bias_v = 0.f;
+            if (kt == 0) {
+                GM_STAMP(tm0);
+                if (ntile == 0) ts1 = tm0;
+                // this tile's bias slice -> LDS (read in the epilogue with ds_read: a vector-memory load there would have to wait for
+                // the NEXT tile's prefetched K-tile, which is older in the wave's in-order vmcnt queue -- stamps: 9.1 k cycles for the
+                // bias + tile-write phase instead of 3.0 k).  Requested here, written behind the wait that the K-tile needs anyway.
+                if (tid < S::BN) bias_v = bias[n0 + tid < N ? n0 + tid : N - 1];
+            }
             ktile(0, kt + 1, true);
             GM_WAIT_LGKM0();  // own fragment reads of stage 0 are complete before anybody's DMA may overwrite it
             GM_WAIT_VM0();
+            if (kt == 0 && tid < S::BN) ((float*)(smem + S::BIAS_OFF))[tid] = bias_v;
             GM_BARRIER();
             ktile(1, kt + 2, kt + 2 < nk);
             GM_WAIT_LGKM0();
         }
-    } else {
-        // ---- VAR 5: half-tiles (32 halfs of K = 64 bytes per row) through a ring of four slots.  Piece p = wv + NW * i covers slot
-        //      rows 16 p .. 16 p + 15; lane = (row 16 p + lane / 4, position c' = lane % 4) fetches chunk c' ^ ((row >> 2) & 3) of the
-        //      row's 64-byte half line (conflict-free fragment reads: four rows share a 256-byte bank row, the rows of a 16-lane group
-        //      that share row % 4 differ in (row >> 2) % 4).  Half-tile h + 3 is requested while h is computed; the wait in front of
-        //      the barrier is COUNTED: it retires h and leaves h + 1 and h + 2 in flight. ----
-        constexpr int SLOT = (S::BN + S::BM) * 64, PH = (S::BN + S::BM) / 16 / S::NW;
-        static_assert(4 * SLOT <= S::LDS && PH % 2 == 0, "ring does not fit");
-        unsigned voff[PH];
+        GM_BARRIER();  // every wave is done with both stages
+        GM_STAMP(tm1);
+        // ---- the NEXT tile's first K-tile goes into stage 0 now: it lands while this tile's epilogue runs ----
+        const int ti_next = ti + nslot;
+        const bool more = ti_next < tiles_x;
+        const int t0_cur = t0, n0_cur = n0;
+        if (more) {
+            t0 = ((ti_next / NC) * 8 + xcd) * S::BM;
+            n0 = (ti_next % NC) * S::BN;
+            plan(t0, n0);
 #pragma unroll
-        for (int i = 0; i < PH; ++i) {
-            const int row = 16 * (wv + S::NW * i) + (lane >> 2);
-            voff[i] = src_row(row) * (unsigned)(K * 2) + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+            for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
         }
-        auto issue_piece = [&](int h, int slot, int i) {
-            const int p = wv + S::NW * i;
-            const unsigned char* base = (const unsigned char*)(16 * p < S::BN ? (const void*)w : (const void*)x) + (size_t)h * 64;
-            lm_dma16_sv(base, voff[i], smem + slot * SLOT + p * 1024);
-        };
-        int fo[2];
+        // ---- epilogue, one 32-token column block (j) at a time.  (1) + bias (, GELU), fp16, token-major into this wave's LDS tile:
+        //      acc[i][j][4 q + e] = feature 32 i + 8 q + 4 g + e of token 32 j + r31 (relative to the wave's sub-tile).  (2) whole rows
+        //      out: LPR lanes cover one token's TF * 32 features (16 B each), 64 / LPR rows per instruction ----
+        unsigned char* ot = smem + S::OUT_OFF + wv * S::OUT_TILE;
+        const float* bl = (const float*)(smem + S::BIAS_OFF) + wf * S::TF * 32 + 4 * g;  // staged at the tile's first K-tile
+        constexpr int LPR = S::TF * 4, RPI = 64 / LPR;
+        const int lr = lane / LPR, lc = lane % LPR;
+        const int64_t col = n0_cur + wf * S::TF * 32 + lc * 8;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fo[kk] = r31 * 64 + ((((2 * kk + g) ^ (r31 >> 2)) & 3) << 4);
-        const int a_base = wf * S::TF * 32 * 64, b_base = S::BN * 64 + wt * S::TT * 32 * 64;
-        const int nh = K / 32;  // a multiple of 4
+        for (int j = 0; j < S::TT; ++j) {
+            GM_STAMP(tm2);
 #pragma unroll
-        for (int h = 0; h < 3; ++h)
+            for (int i = 0; i < S::TF; ++i)
 #pragma unroll
-            for (int i = 0; i < PH; ++i) issue_piece(h, h, i);
-        auto htile = [&](int slot, int next_h, bool prefetch) {
-            const unsigned char* sb = smem + slot * SLOT;
-            half8 af[2][S::TF], bf[2][S::TT];
+                for (int q = 0; q < 4; ++q) {
+                    const float4v bb = *(const float4v*)(bl + 32 * i + 8 * q);
+                    half4 h;
 #pragma unroll
-            for (int i = 0; i < S::TF; ++i) af[0][i] = *(const half8*)(sb + a_base + i * 2048 + fo[0]);
-#pragma unroll
-            for (int j = 0; j < S::TT; ++j) bf[0][j] = *(const half8*)(sb + b_base + j * 2048 + fo[0]);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if (kk == 0) {
-#pragma unroll
-                    for (int i = 0; i < S::TF; ++i) af[1][i] = *(const half8*)(sb + a_base + i * 2048 + fo[1]);
-#pragma unroll
-                    for (int j = 0; j < S::TT; ++j) bf[1][j] = *(const half8*)(sb + b_base + j * 2048 + fo[1]);
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * q + e] + bb[e];
+                        if constexpr ((EPI & GM_EPI_GELU) != 0) v = gm_gelu(v);
+                        h[e] = (_Float16)v;
+                    }
+                    *(half4*)(ot + r31 * S::RS + (32 * i + 8 * q + 4 * g) * 2) = h;
                 }
-                if (prefetch) {
+            LM_WAVE_SYNC();  // the tile is read back by the wave that wrote it: no workgroup barrier
+            GM_STAMP(tm3);
+            if constexpr (VAR == 7) tacc[2] += tm3 - tm2;
 #pragma unroll
-                    for (int i = 0; i < PH / 2; ++i) issue_piece(next_h, (slot + 3) & 3, kk * (PH / 2) + i);
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int row = it * RPI + lr;
+                const int tok = t0_cur + wt * S::TT * 32 + 32 * j + row;
+                const unsigned char* src = ot + row * S::RS + lc * 16;  // 8-byte aligned (RS = 8 mod 16): two ds_read_b64
+                const half4 lo = *(const half4*)src, hi = *(const half4*)(src + 8);
+                half8 y = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (tok < T && col < N) {
+                    if constexpr ((EPI & GM_EPI_RESID) != 0) {
+                        const half8 rr = *(const half8*)((const _Float16*)resid + (int64_t)tok * N + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)y[e] + (float)rr[e]);
+                    }
+                    *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < S::TF; ++i)
-#pragma unroll
-                    for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        for (int h0 = 0; h0 < nh; h0 += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int h = h0 + u, rem = nh - 1 - h;  // half-tiles requested behind h
-                if (rem >= 2) GM_WAIT_VM(2 * PH);
-                else if (rem == 1) GM_WAIT_VM(PH);
-                else GM_WAIT_VM0();
-                GM_BARRIER();  // h has landed everywhere; everybody is done reading slot (u + 3) % 4 (half-tile h - 1)
-                htile(u, h + 3, h + 3 < nh);
-                GM_WAIT_LGKM0();
-            }
+            LM_WAVE_SYNC();  // the read-back is done before the next column block overwrites the tile
+            GM_STAMP(tm2);
+            if constexpr (VAR == 7) tacc[3] += tm2 - tm3;
         }
-    }
-    GM_BARRIER();  // every wave is done with the stages: their space becomes the output tiles
-    GM_STAMP(ts2);
-
-    // ---- epilogue 1: + bias (, GELU), fp16, token-major into this wave's LDS tile.  acc[i][j][4 q + e] = feature 32 i + 8 q + 4 g + e of
-    //      token 32 j + r31 (both relative to the wave's sub-tile) ----
-    unsigned char* ot = smem + wv * S::OUT_TILE;
-    const float* bl = bias + n0 + wf * S::TF * 32 + 4 * g;
-#pragma unroll
-    for (int i = 0; i < S::TF; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4v bb = *(const float4v*)(bl + 32 * i + 8 * q);
-#pragma unroll
-            for (int j = 0; j < S::TT; ++j) {
-                half4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][4 * q + e] + bb[e];
-                    if constexpr ((EPI & GM_EPI_GELU) != 0) v = gm_gelu(v);
-                    h[e] = (_Float16)v;
-                }
-                *(half4*)(ot + (32 * j + r31) * S::RS + (32 * i + 8 * q + 4 * g) * 2) = h;
-            }
+        if constexpr (VAR == 7) {
+            tacc[1] += tm1 - tm0;
+            ntile += 1;
         }
-    LM_WAVE_SYNC();  // the tile is read back by the wave that wrote it: no workgroup barrier
-    GM_STAMP(ts3);
-
-    // ---- epilogue 2: whole rows out.  LPR lanes cover one token's TF * 32 features (16 B each), 64 / LPR rows per instruction ----
-    constexpr int LPR = S::TF * 4, RPI = 64 / LPR;
-    const int lr = lane / LPR, lc = lane % LPR;
-    const int64_t col = n0 + wf * S::TF * 32 + lc * 8;
-#pragma unroll
-    for (int it = 0; it < S::TT * 32 / RPI; ++it) {
-        const int row = it * RPI + lr;
-        const int tok = t0 + wt * S::TT * 32 + row;
-        const unsigned char* src = ot + row * S::RS + lc * 16;  // 8-byte aligned (RS = 8 mod 16): two ds_read_b64
-        const half4 lo = *(const half4*)src, hi = *(const half4*)(src + 8);
-        half8 y = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (tok < T) {
-            if constexpr ((EPI & GM_EPI_RESID) != 0) {
-                const half8 rr = *(const half8*)((const _Float16*)resid + (int64_t)tok * N + col);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)y[e] + (float)rr[e]);
-            }
-            if constexpr (VAR != 6) *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y;
-            else asm volatile("" ::"v"(y));
-        }
+        if (!more) break;
+        ti = ti_next;
     }
 #if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
     if constexpr (VAR == 7) {
-        GM_STAMP(ts4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GM_STAMP(ts5);
         if (tid == 0) {
             unsigned long long* dbg = (unsigned long long*)resid;
             atomicAdd(dbg + 0, ts1 - ts0);
-            atomicAdd(dbg + 1, ts2 - ts1);
-            atomicAdd(dbg + 2, ts3 - ts2);
-            atomicAdd(dbg + 3, ts4 - ts3);
-            atomicAdd(dbg + 4, ts5 - ts4);
-            atomicAdd(dbg + 5, 1ull);
+            atomicAdd(dbg + 1, tacc[1]);
+            atomicAdd(dbg + 2, tacc[2]);
+            atomicAdd(dbg + 3, tacc[3]);
+            atomicAdd(dbg + 5, ntile);
+            atomicAdd(dbg + 6, 1ull);
         }
     }
 #endif
@@ -352,14 +316,32 @@ template <class S, int EPI, int VAR>
 static int gemm_launch_var(const void* d_x, const void* d_w, const float* d_bias, const void* d_resid, void* d_out, int64_t tokens, int32_t n_out,
                            int32_t k_in, hipStream_t st) {
     const int64_t rbs = (tokens + S::BM - 1) / S::BM;
-    const int64_t nblk = 8 * (int64_t)(n_out / S::BN) * ((rbs + 7) / 8);
-    if (nblk > 0x7fffffff) LM_FAIL(LM_EINVAL, "lm_gemm_f16: too many tiles for one launch");
+    const int64_t per_xcd = (int64_t)((n_out + S::BN - 1) / S::BN) * ((rbs + 7) / 8);  // tiles of the fullest XCD
+    if (8 * per_xcd > 0x7fffffff) LM_FAIL(LM_EINVAL, "lm_gemm_f16: too many tiles for one launch");
+    // persistent grid: one workgroup per CU (32 per XCD on the MI355X), fewer when there are fewer tiles
+#ifdef LM_EMULATED_DEVICE
+    static const int cus_per_xcd = 1;  // host emulation: tiny grids, so that every test walks multi-tile lists
+#else
+    static const int cus_per_xcd = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount;
+        }
+        return cus / 8;
+    }();
+#endif
+    int64_t slots = std::min<int64_t>(per_xcd, cus_per_xcd * (S::LDS <= 80 * 1024 ? 2 : 1));
+#ifdef LM_DIAG
+    static const bool one_per_tile = [] { const char* v = getenv("LEANN_MI355X_GEMM_GRID"); return v && !strcmp(v, "tiles"); }();
+    if (one_per_tile) slots = per_xcd;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         LM_HIP(hipFuncSetAttribute((const void*)k_gemm_f16<S, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm_f16<S, EPI, VAR>), dim3((unsigned)nblk), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
+    hipLaunchKernelGGL((k_gemm_f16<S, EPI, VAR>), dim3((unsigned)(8 * slots)), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
                        (const __half*)d_resid, (__half*)d_out, (int)tokens, n_out, k_in);
     LM_HIP(hipGetLastError());
     return LM_OK;
@@ -370,15 +352,9 @@ static int gemm_launch(const void* d_x, const void* d_w, const float* d_bias, co
                        int32_t k_in, hipStream_t st) {
 #ifdef LM_DIAG
     static const int var = [] { const char* v = getenv("LEANN_MI355X_GEMM_VARIANT"); return v ? atoi(v) : GM_VAR_DEFAULT; }();
-    switch (var) {
-#define GM_V(V) case V: return gemm_launch_var<S, EPI, V>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st)
-        GM_V(0); GM_V(1); GM_V(2); GM_V(3); GM_V(4); GM_V(5); GM_V(6); GM_V(7);
-#undef GM_V
-        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_GEMM_VARIANT: 0..7");
-    }
-#else
-    return gemm_launch_var<S, EPI, GM_VAR_DEFAULT>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
+    if (var == 7) return gemm_launch_var<S, EPI, 7>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
 #endif
+    return gemm_launch_var<S, EPI, GM_VAR_DEFAULT>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
 }
 
 }  // namespace lm
@@ -391,11 +367,8 @@ extern "C" int lm_gemm_f16(const void* d_x, const void* d_w, const float* d_bias
     if (n_out <= 0 || n_out % 128 || k_in <= 0 || k_in % 128) LM_FAIL(LM_EINVAL, "lm_gemm_f16: n_out and k_in must be positive multiples of 128");
     if (epilogue < 0 || epilogue > 3) LM_FAIL(LM_EINVAL, "lm_gemm_f16: epilogue is a combination of 1 (GELU) and 2 (+ residual)");
     if ((epilogue & GM_EPI_RESID) && !d_residual) LM_FAIL(LM_EINVAL, "lm_gemm_f16: residual epilogue without a residual");
-    // DMA sources are addressed as wave-uniform base + 32-bit per-lane byte offset
-    if ((uint64_t)tokens * (uint64_t)k_in * 2 >= (1ull << 32) || (uint64_t)n_out * (uint64_t)k_in * 2 >= (1ull << 32))
-        LM_FAIL(LM_EINVAL, "lm_gemm_f16: an operand of 4 GiB or more; split the token range");
+    if ((uint64_t)n_out * (uint64_t)k_in * 2 >= (1ull << 32)) LM_FAIL(LM_EINVAL, "lm_gemm_f16: a weight matrix of 4 GiB or more");
     hipStream_t st = (hipStream_t)stream;
-    const bool big = n_out % 256 == 0 && tokens > 128;
 #define GM_GO(S)                                                                                                             \
     switch (epilogue) {                                                                                                      \
         case 0: return gemm_launch<S, 0>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                       \
@@ -403,6 +376,22 @@ extern "C" int lm_gemm_f16(const void* d_x, const void* d_w, const float* d_bias
         case 2: return gemm_launch<S, 2>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                       \
         default: return gemm_launch<S, 3>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                      \
     }
+    // DMA sources are addressed as wave-uniform base + 32-bit per-lane byte offset: an x operand of 4 GiB or more (1M tokens x 3072
+    // features is 6.4 GB) goes as several launches over token ranges of < 4 GiB each (multiples of 256 tokens)
+    const int64_t max_rows = (int64_t)(((1ull << 32) - 1) / ((uint64_t)k_in * 2)) / 256 * 256;
+    if (tokens > max_rows) {
+        for (int64_t r0 = 0; r0 < tokens; r0 += max_rows) {
+            const int64_t nr = std::min<int64_t>(max_rows, tokens - r0);
+            const int rc = lm_gemm_f16((const unsigned char*)d_x + (size_t)r0 * k_in * 2, d_w, d_bias,
+                                       d_residual ? (const unsigned char*)d_residual + (size_t)r0 * n_out * 2 : nullptr, epilogue, n_out, k_in,
+                                       (unsigned char*)d_out + (size_t)r0 * n_out * 2, nr, stream);
+            if (rc) return rc;
+        }
+        return LM_OK;
+    }
+    // 256-wide tiles also when the last column tile is half empty, as long as that wastes <= 1/8 of the matrix-pipe work (N >= 896):
+    // the 128 x 128 shape is L2-bandwidth bound at a third of the big shape's rate (QKV of the 384-wide models: N = 1152)
+    const bool big = tokens > 128 && (n_out % 256 == 0 || n_out >= 896);
     if (big) {
         GM_GO(GemmBig)
     }

@@ -31,12 +31,17 @@ struct PqArgs {
 };
 
 // dynamic LDS: lut[m*256] f32 | lpool[L] u64 | out[L] u64 | newk[Pmax] u64 | s_new[maxnew] i32
-__global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev ws, PqArgs a) {
+// NTH = threads per workgroup = per query.  The lookup table alone is m x 1 KB of LDS (96 KB at m = 96): one workgroup per CU, so the
+// workgroup's own width is all the latency hiding the CU gets.  Round 2 ran 256 threads (ONE wave per SIMD; 2 % of the HBM rate); with
+// 1024 threads (four waves per SIMD) a hop's visited tests, code-row gathers, compactions and the bitonic sort all run four times wider.
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev ws, PqArgs a) {
+    constexpr int NWV = NTH / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_off[65];
     __shared__ uint64_t s_b[64];
     __shared__ int32_t s_pop[64];
-    __shared__ int s_npop, s_wcnt[4];
+    __shared__ int s_npop, s_wcnt[NWV];
     float* lut = (float*)smem;
     uint64_t* lpool = (uint64_t*)(lut + pq.m * 256);
     uint64_t* outp = lpool + a.L;
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* qv = a.Q + (size_t)q * a.Dp;
     // ---- lookup table (canonical: sequential fmaf over the sub-vector) ----
-    for (int e = tid; e < pq.m * 256; e += 256) {
+    for (int e = tid; e < pq.m * 256; e += NTH) {
         const int j = e >> 8, lo = pq.chunk_off[j], len = pq.chunk_off[j + 1] - lo;
         const float* cb = pq.codebooks + (size_t)256 * lo + (size_t)(e & 255) * len;
         const float* qs = qv + lo;
@@ -136,9 +141,9 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
         rounds++;
         nexp += np;
         const uint32_t totalc = s_off[np];
-        // ---- flattened expansion over 256 threads, visited test-and-set, ordered compaction ----
+        // ---- flattened expansion over the workgroup, visited test-and-set, ordered compaction ----
         int total = 0;
-        for (uint32_t f0 = 0; f0 < totalc; f0 += 256) {
+        for (uint32_t f0 = 0; f0 < totalc; f0 += NTH) {
             const uint32_t f = f0 + tid;
             bool fresh = false;
             int32_t v = -1;
@@ -160,17 +165,18 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
             int woff = 0;
             for (int i = 0; i < wv; ++i) woff += s_wcnt[i];
             if (fresh) s_new[total + woff + __popcll(m & ((1ull << lane) - 1ull))] = v;
-            total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+#pragma unroll
+            for (int w2 = 0; w2 < NWV; ++w2) total += s_wcnt[w2];
             __syncthreads();
         }
         const int n = total;
         n_adc += (unsigned long long)n;
-        // ---- ADC distances: one lane per fresh node, 256 gathers in flight per pass ----
+        // ---- ADC distances: one lane per fresh node, NTH gathers in flight per pass ----
         // A key that is not below the worst entry of a FULL list can never enter it (keys are unique: (distance, id)): such keys are
         // dropped before the sort -- in steady state most of a hop's candidates -- so the bitonic sort runs over the survivors only.
         const uint64_t thr = npool >= a.L ? lpool[a.L - 1] : KEY_NONE;
         int kept = 0;
-        for (int i0 = 0; i0 < n; i0 += 256) {
+        for (int i0 = 0; i0 < n; i0 += NTH) {
             const int i = i0 + tid;
             uint64_t key = KEY_NONE;
             if (i < n) {
@@ -184,24 +190,25 @@ __global__ __launch_bounds__(256) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
             int woff = 0;
             for (int w2 = 0; w2 < wv; ++w2) woff += s_wcnt[w2];
             if (keep) newk[kept + woff + __popcll(mk & ((1ull << lane) - 1ull))] = key;
-            kept += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+#pragma unroll
+            for (int w2 = 0; w2 < NWV; ++w2) kept += s_wcnt[w2];
             __syncthreads();
         }
         int Pn = 1;
         while (Pn < kept) Pn <<= 1;
-        for (int i = kept + tid; i < Pn; i += 256) newk[i] = KEY_NONE;
+        for (int i = kept + tid; i < Pn; i += NTH) newk[i] = KEY_NONE;
         __syncthreads();
         if (kept > 0) {
-            sort_keys<256>(newk, Pn, tid);
-            rank_merge<256>(lpool, npool, newk, kept, outp, a.L, tid);
+            sort_keys<NTH>(newk, Pn, tid);
+            rank_merge<NTH>(lpool, npool, newk, kept, outp, a.L, tid);
             npool = min(a.L, npool + kept);
-            for (int i = tid; i < npool; i += 256) lpool[i] = outp[i];
+            for (int i = tid; i < npool; i += NTH) lpool[i] = outp[i];
             __syncthreads();
         }
     }
     // ---- final candidate list -> global pool ----
     uint64_t* pool = ws.pool + (size_t)q * ws.ef;
-    for (int i = tid; i < npool; i += 256) pool[i] = lpool[i];
+    for (int i = tid; i < npool; i += NTH) pool[i] = lpool[i];
     if (tid == 0) {
         ws.npool[q] = npool;
         ws.nsteps[q] = nexp;
@@ -330,12 +337,17 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     size_t shmem = (size_t)ix->pq_m * 256 * 4 + (size_t)2 * L * 8 + (size_t)pa.Pmax * 8 + (size_t)ws.maxnew * 4;
     if (shmem > 158 * 1024)  // 160 KiB per workgroup minus the kernel's ~1.1 KiB of static LDS
         LM_FAIL(LM_EINVAL, "PQ search state does not fit the 160 KB LDS (reduce m, complexity or beam_width)");
-    LM_HIP(hipFuncSetAttribute((const void*)k_pq_traverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (ix->pq_threads == 256) LM_HIP(hipFuncSetAttribute((const void*)k_pq_traverse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    else if (ix->pq_threads == 512) LM_HIP(hipFuncSetAttribute((const void*)k_pq_traverse<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    else LM_HIP(hipFuncSetAttribute((const void*)k_pq_traverse<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
     LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
     {
         EvScope es(ix, &ix->ev_update);
-        hipLaunchKernelGGL(k_pq_traverse, dim3(B), dim3(256), shmem, st, g, pq, ws, pa);
+        // option "pq_threads" (256 / 512 / 1024; default 1024): workgroup width of the traversal (A/B; identical results)
+        if (ix->pq_threads == 256) hipLaunchKernelGGL(k_pq_traverse<256>, dim3(B), dim3(256), shmem, st, g, pq, ws, pa);
+        else if (ix->pq_threads == 512) hipLaunchKernelGGL(k_pq_traverse<512>, dim3(B), dim3(512), shmem, st, g, pq, ws, pa);
+        else hipLaunchKernelGGL(k_pq_traverse<1024>, dim3(B), dim3(1024), shmem, st, g, pq, ws, pa);
     }
     LM_HIP(hipGetLastError());
     ix->stats.update_launches++;

@@ -98,6 +98,7 @@ struct lm_index {
     bool profiling = false;
     int update_variant = 0;  // 0: auto, 3: wave (64 lanes) per query, 4: workgroup (256 threads) per query   (1, 2: removed A/B forms)
     int persistent_table = 1;  // stored-embedding mode: one persistent launch per batch (0: lock-step rounds, for A/B)
+    int pq_threads = 1024;     // workgroup width of the PQ traversal kernel (option "pq_threads": 256 / 512 / 1024)
     int persistent_wave = -1;  // persistent search: 1 = one wave per query, 0 = one 256-thread workgroup per query, -1 = auto
     int wave_maxnew = 0;     // auto rule threshold on beam x mean level-0 degree; 0 = never: on the 1M-chunk HNSW graph
                              // (max degree 64, mean 9.3) the workgroup form is 1.5x faster (profiles/r1_bench_default_1M_b2048.json
@@ -827,6 +828,11 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     }
     if (!std::strcmp(name, "persistent_table")) {
         ix->persistent_table = value != 0;
+        return LM_OK;
+    }
+    if (!std::strcmp(name, "pq_threads")) {
+        if (value != 256 && value != 512 && value != 1024) LM_FAIL(LM_EINVAL, "pq_threads must be 256, 512 or 1024");
+        ix->pq_threads = (int)value;
         return LM_OK;
     }
     if (!std::strcmp(name, "persistent_wave")) {

@@ -207,6 +207,14 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
 
 
 GEMM_EPI_GELU, GEMM_EPI_RESIDUAL = 1, 2
+LM_BERT_SMALL_TOKENS = 6144  # include/leann_mi355x.h
+
+
+def small_tokens_limit() -> int:
+    """Forwards of at most this many tokens run the hidden-384 layers on the general kernels (LEANN_MI355X_SMALL_TOKENS overrides; 0 = never)."""
+    import os
+
+    return int(os.environ.get("LEANN_MI355X_SMALL_TOKENS", LM_BERT_SMALL_TOKENS))
 
 
 def fused_gemm(x: torch.Tensor, lin: nn.Linear, epilogue: int = 0, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -220,7 +228,7 @@ def fused_gemm(x: torch.Tensor, lin: nn.Linear, epilogue: int = 0, residual: Opt
         return None
     n, k = lin.weight.shape
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and lin.weight.dtype == torch.float16 and n % 128 == 0 and k % 128 == 0
-            and lin.bias is not None and x.shape[-1] == k and x.numel() * 2 < (1 << 32)):
+            and lin.bias is not None and x.shape[-1] == k):
         return None
     if (epilogue & GEMM_EPI_RESIDUAL) and not (residual is not None and residual.is_contiguous() and residual.dtype == torch.float16
                                                and tuple(residual.shape) == (x.shape[0], n)):
@@ -492,10 +500,12 @@ class _Layer(nn.Module):
         from torch.nn.attention.varlen import varlen_attn
 
         tot, h = x.shape
-        if h != 384 or os.environ.get("LEANN_MI355X_GEMM") == "2":
+        if h != 384 or os.environ.get("LEANN_MI355X_GEMM") == "2" or (tot <= small_tokens_limit() and "LEANN_MI355X_GEMM" not in os.environ):
             # general widths (768: bge-base, contriever): five launches of the general MFMA GEMM + attention + two LayerNorms, no
             # library call -- QKV | attention | out-projection (+ residual) | LayerNorm | fc1 (+ GELU) | fc2 (+ residual) | LayerNorm.
-            # (LEANN_MI355X_GEMM=2 sends the hidden-384 models through the same path: A/B against their fused kernels.)
+            # Hidden 384 takes this form for SMALL forwards (<= LM_BERT_SMALL_TOKENS tokens: a one-query search round recomputes ~5
+            # chunks): many small workgroups over the chip instead of the fused tail's one ~77 us workgroup chain (MI355X: B = 1
+            # search p50 59.7 -> 47.2 ms); LEANN_MI355X_GEMM=2 forces it at every size (A/B), =1 / =0 keep the fused kernels.
             y = self._forward_packed_general(x, cu, max_len)
             if y is not None:
                 return y
@@ -713,7 +723,8 @@ class BertEncoder(nn.Module):
                 vals = (L.qkv.weight.detach().contiguous(), L.qkv.bias.detach().float().contiguous(), pack_wo_slabs(L.out.weight.detach()),
                         L.out.bias.detach().float().contiguous(), L.ln1.weight.detach().contiguous(), L.ln1.bias.detach().contiguous(),
                         pack_w1_acc_order(L.fc1.weight.detach()), L.fc1.bias.detach().float().contiguous(), pack_w2_fused_mlp(L.fc2.weight.detach()),
-                        L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous())
+                        L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous(),
+                        L.out.weight.detach().contiguous(), L.fc1.weight.detach().contiguous(), L.fc2.weight.detach().contiguous())
                 for (name, _), v in zip(_lib.BertH384Layer._fields_, vals):
                     setattr(layers[li], name, ptr(v))
             m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, float(self.ln.eps), ptr(w.detach()),

@@ -18,7 +18,7 @@ class RecomputeProvider:
     """Callable ``(d_ids_ptr, n, stream_ptr) -> device pointer of fp32 [n][d_padded]``."""
 
     def __init__(self, encoder: BertEncoder, tokens: TokenStore, d_padded: int, device: torch.device,
-                 batch_size: int = 2730, bucket: int = 32, max_seq_length: int | None = None):
+                 batch_size: int = 5461, bucket: int = 32, max_seq_length: int | None = None):
         self.encoder = encoder
         self.tokens = tokens
         self.dp = d_padded

@@ -80,6 +80,8 @@ class _Conn:
                 size, hdr = struct.unpack(">Q", bytes(self.buf[1:9]))[0], 9
             else:
                 size, hdr = self.buf[1], 2
+            if size > MAX_FRAME_BYTES:  # a peer may not make the receive buffer grow without bound
+                raise ProtocolError(f"frame of {size} bytes exceeds the {MAX_FRAME_BYTES}-byte limit")
             if len(self.buf) < hdr + size:
                 return out
             body = bytes(self.buf[hdr : hdr + size])
@@ -99,6 +101,10 @@ class _Conn:
                 if b"" in msg:  # REQ envelope: everything up to and including the first empty frame is routing
                     msg = msg[msg.index(b"") + 1 :]
                 out.append(msg)
+
+
+MAX_FRAME_BYTES = 256 << 20  # largest request the reference's clients send is a list of node ids / a handful of texts
+CLIENT_IO_TIMEOUT_S = 30.0    # one stalled peer may not freeze the (single-threaded) server for longer than this
 
 
 class RepServer:
@@ -121,6 +127,7 @@ class RepServer:
                     if key.data is None:
                         c, _addr = self.lsock.accept()
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        c.settimeout(CLIENT_IO_TIMEOUT_S)
                         c.sendall(GREETING + _ready(b"REP"))
                         sel.register(c, selectors.EVENT_READ, _Conn(c))
                         continue
@@ -130,7 +137,13 @@ class RepServer:
                         if not data:
                             raise ConnectionResetError
                         for msg in conn.feed(data):
-                            reply = handler(msg[0] if msg else b"")
+                            try:
+                                reply = handler(msg[0] if msg else b"")
+                            except Exception:  # noqa: BLE001 - a failing request must not end the serve loop: empty reply = the reference servers' error answer
+                                import logging
+
+                                logging.getLogger(__name__).exception("request handler failed")
+                                reply = b""
                             conn.sock.sendall(_frame(b"", more=True) + _frame(reply))
                     except (OSError, ProtocolError):
                         sel.unregister(conn.sock)

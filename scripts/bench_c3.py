@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--M", type=int, default=16, help="graph degree / 2 of the Vamana-style flat graph (degree 32)")
     ap.add_argument("--efc", type=int, default=128)
     ap.add_argument("--cpu-baseline-queries", type=int, default=8)
+    ap.add_argument("--pq-threads", type=int, default=1024, choices=[256, 512, 1024], help="workgroup width of the traversal kernel (A/B)")
     ap.add_argument("--pooling", default="mean", choices=["mean", "cls"],
                     help="sentence pooling of the RANDOM-INIT stand-in encoder.  bge-small pools the [CLS] row, but with random weights the [CLS] rows of "
                          "different chunks are nearly parallel (mean pairwise cosine 0.997 on this corpus: attention is ~uniform, so [CLS] sees the same "
@@ -91,6 +92,7 @@ def main():
     idx = Mi355xIndex.from_csr(fg)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
     idx.attach_pq(cb.cpu().numpy(), codes.cpu().numpy())
+    idx.set_option("pq_threads", args.pq_threads)
     idx.set_provider(provider)
     nq = B * (K + W + 1)
     qt, qo, _ = corpus.queries(nq, seed=4321)
@@ -141,6 +143,15 @@ def main():
     torch.cuda.synchronize()
     pst = idx.stats()
     idx.set_profiling(False)
+    width_ab = {}
+    for th in (256, 512, 1024):  # the same batch through every workgroup width (traversal only: PQ order, no rerank)
+        idx.set_option("pq_threads", th)
+        idx.set_profiling(True)
+        idx.pq_search_device(Q[lo : lo + B], 10, idx.make_pq_params(args.complexity, args.beam, skip_search_reorder=True))
+        torch.cuda.synchronize()
+        width_ab[th] = round(1e3 * idx.stats()["update_ms"], 1)
+        idx.set_profiling(False)
+    idx.set_option("pq_threads", args.pq_threads)
     bytes_eval = args.pq_bytes + 4  # SURVEY 8(d) PQ unit: m code bytes + the id
     trav_ms = max(pst["update_ms"], 1e-9)
     ach = pst["ndis"] * bytes_eval / (trav_ms * 1e-3) / 1e9
@@ -155,7 +166,8 @@ def main():
         "recall_at_10": round(rec, 4), "complexity_sweep": sweep,
         "roofline": {"bound": "hbm", "kernel": "lm::k_pq_traverse (persistent PQ-ADC traversal, one launch per batch; codes gathered from HBM, LUT in LDS)",
                      "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
-                     "bytes_per_adc_eval": bytes_eval, "adc_evals_per_launch": pst["ndis"], "us_per_launch": round(1e3 * trav_ms, 1)},
+                     "bytes_per_adc_eval": bytes_eval, "adc_evals_per_launch": pst["ndis"], "us_per_launch": round(1e3 * trav_ms, 1),
+                     "threads_per_workgroup": args.pq_threads, "us_per_launch_by_workgroup_width": width_ab},
         "per_query": {"adc_evals": round(agg["ndis"] / (K * B), 1), "reranked_unique_chunks": round(agg["nunique"] / (K * B), 1)},
         "setup_s": {"total": round(setup_s), "embed_corpus": round(t_embed), "build_graph": round(t_graph), "pq": round(t_pq)},
     }

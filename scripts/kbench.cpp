@@ -690,10 +690,10 @@ int main(int argc, char** argv) {
                 CK(hipStreamSynchronize(st));
             }
             auto h = dbg.host();
-            const double nb = (double)std::max<unsigned long long>(h[5], 1);
-            printf("{\"kernel\": \"lm_gemm_f16 stamps\", \"mode\": \"%s (N=%d K=%d)\", \"workgroups\": %llu, \"cycles_per_workgroup\": {\"prologue_until_tile0_landed\": %.0f, "
-                   "\"main_loop\": %.0f, \"bias_and_lds_tile_write\": %.0f, \"readback_and_store_issue\": %.0f, \"store_drain\": %.0f}, \"k_tiles\": %d}\n",
-                   sh.what, sh.N, sh.K, h[5], h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, sh.K / 64);
+            const double nt = (double)std::max<unsigned long long>(h[5], 1), nwg = (double)std::max<unsigned long long>(h[6], 1);
+            printf("{\"kernel\": \"lm_gemm_f16 stamps\", \"mode\": \"%s (N=%d K=%d)\", \"workgroups\": %llu, \"tiles\": %llu, \"cycles\": {\"per_workgroup_until_first_k_tile_landed\": %.0f, "
+                   "\"per_tile_main_loop\": %.0f, \"per_tile_bias_and_lds_tile_writes\": %.0f, \"per_tile_readback_and_store_issue\": %.0f}, \"k_tiles\": %d}\n",
+                   sh.what, sh.N, sh.K, h[6], h[5], h[0] / nwg, h[1] / nt, h[2] / nt, h[3] / nt, sh.K / 64);
             fflush(stdout);
         }
     }

@@ -137,6 +137,9 @@ def case_pq(deferred=True):
     idx = Mi355xIndex.from_csr(g)
     idx.attach_pq(cb.numpy(), codes.numpy())
     if deferred:
+        # 256 threads per query here (the emulation pays for every barrier with as many OS threads; the stored-table case below runs
+        # the default 1024, `pytest -m gpu` all three widths on hardware)
+        idx.set_option("pq_threads", 256)
         idx.set_provider(NumpyProvider(x, idx.info.d_padded))
     else:
         idx.attach_table(x)
@@ -172,6 +175,7 @@ def case_pq_stock_bundle():
     idx = Mi355xIndex.from_csr(g)
     idx.attach_table(x)
     idx.attach_pq(b.codebooks, b.codes, b.chunk_offsets)
+    idx.set_option("pq_threads", 256)  # (emulation speed; see case_pq)
     og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 24)
     for L, W in ((16, 2), (40, 4)):
         l, d = idx.pq_search(q, 5, idx.make_pq_params(L, W))
@@ -587,6 +591,7 @@ def case_gemm_f16():
     run(130, 384, 128, 0)            # 128 x 128 tiles (N % 256 != 0)
     run(100, 256, 128, 2)            # short launch: small tiles although N % 256 == 0
     run(1200, 128, 128, 1)           # ten row blocks of 128: the last group of eight is padded
+    run(300, 1152, 128, 2)           # 256-wide tiles with a half-empty last column tile (the QKV width of the 384-wide models)
     try:
         lib.lm_gemm_f16.restype = C.c_int
         x = np.zeros((4, 100), np.float16)
@@ -721,7 +726,8 @@ def case_encoder_python_wiring():
         cuda_stream = 0
 
     switches = {"LEANN_MI355X_ATTN": "2", "LEANN_MI355X_LN": "2", "LEANN_MI355X_POOL": "1", "LEANN_MI355X_EMBED": "1",
-                "LEANN_MI355X_LINEAR": "1", "LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "2", "LEANN_MI355X_PACK": "1"}
+                "LEANN_MI355X_LINEAR": "1", "LEANN_MI355X_MLP": "1", "LEANN_MI355X_MLP_VARIANT": "2", "LEANN_MI355X_PACK": "1",
+                "LEANN_MI355X_SMALL_TOKENS": "0"}  # (0: the hidden-384 kernels also for this small forward)
     from leann_amd import _lib
 
     used = []
@@ -759,6 +765,7 @@ def case_encoder_python_wiring():
         used.clear()
         env3 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
         env3["LEANN_MI355X_ONECALL"] = "0"  # the per-kernel launch path (the one-call default follows below)
+        env3["LEANN_MI355X_SMALL_TOKENS"] = "0"  # ... of the LARGE-forward form (a forward this small takes the general kernels by default)
         env3.update(extra)
         with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
                 mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env3, clear=True), \
@@ -773,18 +780,28 @@ def case_encoder_python_wiring():
     cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=128, max_pos=64, max_seq_length=48)
     e1 = BertEncoder.random_init(cfg1, 5).eval().half()
     outs = {}
-    for onecall in ("0", "1"):
+    for onecall, small in (("0", "0"), ("1", "0"), ("0", None), ("1", None)):  # large-forward form, then the small-forward form (general kernels)
         used.clear()
         env1 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
         env1["LEANN_MI355X_ONECALL"] = onecall
+        if small is not None:
+            env1["LEANN_MI355X_SMALL_TOKENS"] = small
         with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
                 mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env1, clear=True), \
                 mock.patch.object(_lib, "check", new=recording_check):
             with torch.no_grad():
-                outs[onecall] = e1.encode_tokens_packed(ti, tl, 4096)
+                outs[(onecall, small)] = e1.encode_tokens_packed(ti, tl, 4096)
         if onecall == "1":
             assert used.count("lm_bert_h384_forward_packed") == 1 and "lm_gemm_ws_h384_f16" not in used, sorted(set(used))
-    assert torch.equal(outs["0"], outs["1"])
+        elif small is None:
+            assert used.count("lm_gemm_f16") == 4 * cfg1.layers and "lm_attn_out_mlp_fused_h384_f16" not in used, sorted(set(used))
+        else:
+            assert used.count("lm_attn_out_mlp_fused_h384_f16") == cfg1.layers and "lm_gemm_f16" not in used, sorted(set(used))
+    print("one-call vs per-kernel: large form max|diff|", float((outs[("0", "0")] - outs[("1", "0")]).abs().max()), "small form", float((outs[("0", None)] - outs[("1", None)]).abs().max()), flush=True)
+    assert torch.equal(outs[("0", "0")], outs[("1", "0")]) and torch.equal(outs[("0", None)], outs[("1", None)])
+    with torch.no_grad():
+        ref1 = BertEncoder.random_init(cfg1, 5).eval()(ti, tl).float()
+    assert float((outs[("1", None)].float() - ref1).abs().max()) < 6e-3 and float((outs[("1", "0")].float() - ref1).abs().max()) < 6e-3
     err = float((got.float() - ref).abs().max())
     print(f"encoder.py packed forward, every switch on, through the emulated library: max|diff| vs fp32 torch = {err:.2e}", flush=True)
     assert err < 6e-3, err

@@ -177,7 +177,7 @@ struct Pool {
                 else std::this_thread::sleep_for(std::chrono::microseconds(100));
             }
             seen = g;
-            if (stop.load(std::memory_order_relaxed)) return;
+            if (g < 0 || stop.load(std::memory_order_relaxed)) return;  // -1 in the mailbox: this worker is being retired
             tls.thread.x = (unsigned)i;
             tls.block.x = bx;
             tls.bdim.x = block.x;
@@ -189,6 +189,14 @@ struct Pool {
     void run_block(unsigned bx_, dim3 grid_, dim3 block_, const std::function<void()>& f) {
         const int n = (int)block_.x;
         if (n > MAXT) std::abort();
+        // A 1024-thread workgroup (the PQ traversal) leaves 1024 idle workers behind, each polling its mailbox every 100 us: on a small
+        // host that alone eats the machine and every later launch crawls.  Retire the surplus as soon as an ordinary launch follows.
+        if ((int)th.size() > 512 && n <= 256) {
+            for (int i = n; i < (int)th.size(); ++i) go[i].store(-1, std::memory_order_release);
+            for (int i = n; i < (int)th.size(); ++i) th[i].join();
+            th.resize(n);
+            for (int i = n; i < MAXT; ++i) go[i].store(0, std::memory_order_relaxed);
+        }
         while ((int)th.size() < n) {
             const int i = (int)th.size();
             th.emplace_back([this, i] { worker(i); });

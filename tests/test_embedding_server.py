@@ -238,3 +238,40 @@ def test_serve_loop_over_a_real_socket(tmp_path):
         finally:
             stop.set()
             th.join(10)
+
+
+def test_transport_survives_a_failing_handler_and_refuses_oversized_frames():
+    """leann_amd/zmtp.py: a handler exception answers with the empty (error) reply and the serve loop goes on; a frame header
+    announcing more than MAX_FRAME_BYTES drops that connection instead of growing the receive buffer."""
+    import socket
+    import struct
+    import threading
+
+    from leann_amd import zmtp
+
+    srv = zmtp.RepServer(0, host="127.0.0.1")
+    stop = threading.Event()
+
+    def handler(b):
+        if b == b"boom":
+            raise RuntimeError("handler failure")
+        return b"echo:" + b
+
+    th = threading.Thread(target=srv.serve, args=(handler, stop, 0.05), daemon=True)
+    th.start()
+    try:
+        c = zmtp.ReqClient(srv.port)
+        assert c.request(b"boom") == b"" and c.request(b"again") == b"echo:again"
+        raw = socket.create_connection(("127.0.0.1", srv.port), timeout=5)
+        raw.sendall(zmtp.GREETING + zmtp._ready(b"REQ") + bytes([zmtp.FLAG_LONG]) + struct.pack(">Q", zmtp.MAX_FRAME_BYTES + 1))
+        raw.settimeout(5)
+        data = b"x"
+        while data:  # the server closes the connection (after its own greeting / READY bytes)
+            data = raw.recv(4096)
+        raw.close()
+        assert c.request(b"still serving") == b"echo:still serving"
+        c.close()
+    finally:
+        stop.set()
+        th.join(timeout=5)
+        srv.close()

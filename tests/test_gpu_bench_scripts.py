@@ -22,13 +22,24 @@ def test_bench_c3_small():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in r
     assert r["config"]["baseline_config"] == "c3" and r["value"] > 0
-    assert r["recall_at_10"] >= 0.8
+    assert r["recall_at_10"] >= 0.9  # the timed steps run at the smallest complexity of the sweep that reaches the metric's bar
+    sw = r["complexity_sweep"]
+    assert sw and max(v["recall_at_10"] for v in sw.values()) >= 0.9 and set(r["roofline"]["us_per_launch_by_workgroup_width"]) == {"256", "512", "1024"}
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0
     assert r["cpu_baseline"]["value"] and r["cpu_baseline"]["value"] > 0
 
 
 def test_bench_c4_one_shard_small():
-    r = _run("bench_c4.py", "--chunks", "30000", "--batch", "64", "--steps", "2", "--warmup", "1")
+    r = _run("bench_c4.py", "--chunks", "30000", "--batch", "64", "--steps", "2", "--warmup", "1", "--cpu-baseline-seconds", "5")
     assert r["config"]["baseline_config"] == "c4" and r["rccl_ranks"] == 1 and r["value"] > 0
     assert r["recall_at_10"] >= 0.9
     assert r["allgather_plus_merge_us"] > 0
+    assert r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0 and "k_attn_out_mlp_h384" in r["roofline"]["kernel"]
+    assert r["cpu_baseline"]["value"] and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port"
+
+
+def test_bench_table_provider_variant_small():
+    """SURVEY 8(d)'s clustered-Gaussian table-provider variant (scripts/bench_table_provider.py) at a size that runs in seconds."""
+    r = _run("bench_table_provider.py", "--chunks", "40000", "--centres", "100", "--batch", "256", "--steps", "2", "--warmup", "1")
+    assert r["value"] > 0 and r["recall_at_10"] >= 0.9
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0 and r["per_query"]["provider_rows"] > 0

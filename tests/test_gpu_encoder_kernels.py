@@ -205,6 +205,16 @@ def test_default_forward_vs_cpu_fp32_and_one_call_vs_per_kernel(monkeypatch):
     per = enc.encode_tokens_packed(ti, tl)
     assert "lm_bert_h384_forward_packed" not in used and used.count("lm_attn_out_mlp_fused_h384_f16") == cfg.layers
     assert torch.equal(one, per)
+    # a SMALL forward (what a one-query search round is: a handful of chunks) takes the general kernels in both launch paths
+    used.clear()
+    per_s = enc.encode_tokens_packed(ti[:7], tl[:7])
+    assert used.count("lm_gemm_f16") == 4 * cfg.layers and "lm_attn_out_mlp_fused_h384_f16" not in used
+    monkeypatch.delenv("LEANN_MI355X_ONECALL")
+    used.clear()
+    one_s = enc.encode_tokens_packed(ti[:7], tl[:7])
+    assert "lm_bert_h384_forward_packed" in used and "lm_gemm_f16" not in used  # (inside the library now)
+    assert torch.equal(one_s, per_s)
+    assert (one_s.cpu() - ref[:7]).abs().max().item() <= 5e-3 and (one_s - one[:7]).abs().max().item() <= 3e-3
 
 
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
@@ -360,7 +370,7 @@ def test_pack_tokens_front_end(monkeypatch):
 
 # ---- the general kernels of the hidden-768 path (bge-base / contriever: BASELINE.json configs[4]) ----------------------------------
 @pytest.mark.parametrize("tokens,n,k,epi", [(300, 256, 128, 0), (1000, 2304, 768, 0), (777, 768, 768, 2), (2049, 3072, 768, 1), (513, 768, 3072, 2),
-                                            (130, 384, 128, 3), (5000, 1152, 384, 0), (100, 256, 256, 1), (1, 768, 768, 3), (4100, 1536, 384, 1)])
+                                            (130, 384, 128, 3), (5000, 1152, 384, 0), (700, 1152, 384, 3), (300, 896, 128, 1), (100, 256, 256, 1), (1, 768, 768, 3), (4100, 1536, 384, 1)])
 def test_general_gemm_vs_fp32_torch(tokens, n, k, epi):
     """lm_gemm_f16 (csrc/lm_gemm_f16.hip): epi(x W^T + b) with both tile shapes and every epilogue against fp32 torch."""
     import torch

@@ -43,10 +43,13 @@ def test_pq_search_parity(metric, L, W):
     idx.attach_pq(cb, codes)
     # (1) PQ order only
     oi, od, ost = orc.pq_search(og, cb, codes, q, 10, L=L, W=W, skip_search_reorder=True)
-    gi, gd = idx.pq_search(q, 10, idx.make_pq_params(L, W, skip_search_reorder=True))
-    st = idx.stats()
-    assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
-    assert st["ndis"] == ost["n_adc"] and st["nexpand"] == ost["n_expand"] and st["nrounds"] == ost["n_rounds"], (st, ost)
+    for threads in (1024, 512, 256):  # workgroup width of the traversal kernel (default 1024): a launch-shape choice, identical results
+        idx.set_option("pq_threads", threads)
+        gi, gd = idx.pq_search(q, 10, idx.make_pq_params(L, W, skip_search_reorder=True))
+        st = idx.stats()
+        assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), threads
+        assert st["ndis"] == ost["n_adc"] and st["nexpand"] == ost["n_expand"] and st["nrounds"] == ost["n_rounds"], (threads, st, ost)
+    idx.set_option("pq_threads", 1024)
     # (2) deferred fetch through the provider (one call, sorted unique ids)
     xdev = torch.zeros((x.shape[0], idx.info.d_padded), device="cuda")
     xdev[:, :96] = torch.from_numpy(x).cuda()
