@@ -90,7 +90,6 @@ using GemmBig = GemmShape<2, 4, 4, 2>;    // 256 x 256, 512 threads, 128 accumul
 using GemmSmall = GemmShape<2, 2, 2, 2>;  // 128 x 128, 256 threads, 64 accumulator registers per lane
 
 // VAR (diagnosis builds only, -DLM_DIAG + LEANN_MI355X_GEMM_VARIANT; the product library holds variant 0 alone):
-//   8 = the second half of the waves issues its DMA pieces BEHIND the k-step's MFMAs instead of in front of them (see ktile);
 //   7 = s_memtime stamps: wave 0 of every workgroup adds its cycle counts {until the first K-tile has landed, main loops, bias + LDS
 //       tile writes, row read-back + store issue, (unused), tiles} to the u64 words at `resid` (epilogue 0 only: the residual pointer
 //       is then a debug buffer; scripts/kbench.cpp "gemmstamp").
@@ -163,7 +162,6 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
     const int b_base = S::BN * 128 + wt * S::TT * 32 * 128;   // x rows of this wave
     const int nk = K / 64;  // even (K % 128 == 0)
 
-    constexpr bool LATE_HALF = (VAR == 8 || VAR == 9);  // diagnosis variants: 8 = the de-phased DMA issue (see ktile), 9 = 8 + stamps
     float16v acc[S::TF][S::TT];
     // One K-tile: four k-steps of TF x TT MFMAs.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step kk are issued (a
     // second register set: the matrix pipe never waits for an LDS round trip inside a tile); the NEXT K-tile's DMA pieces go behind the
@@ -185,12 +183,9 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
 #pragma unroll
                 for (int j = 0; j < S::TT; ++j) bf[n][j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk + 1]);
             }
-            // The two waves of a SIMD (w and w + NW / 2: a workgroup's waves go round the four SIMDs) leave the K-tile's barrier together.
-            // If both issued their DMA pieces first, the matrix pipe would idle for the ~250 cycles that takes, twice per K-tile; so the
-            // first half of the waves issues pieces THEN MFMAs, the second half MFMAs THEN pieces: one wave's issue slots sit under the
-            // other's MFMAs.
-            const bool dma_first = !LATE_HALF || wv < S::NW / 2;
-            if (prefetch && kk < 2 && dma_first) {
+            // (Measured and dropped, GPU session r3-10: letting the second half of the waves issue its pieces BEHIND the k-step's MFMAs so
+            // that one wave's DMA issue sits under its SIMD partner's MFMAs -- 1017 vs 962 us on the QKV shape.)
+            if (prefetch && kk < 2) {
 #pragma unroll
                 for (int i = 0; i < S::PIECES / 2; ++i) issue_piece(next_kt, stage ^ 1, kk * (S::PIECES / 2) + i);
             }
@@ -200,11 +195,6 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
 #pragma unroll
                 for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (prefetch && kk < 2 && !dma_first) {
-#pragma unroll
-                for (int i = 0; i < S::PIECES / 2; ++i) issue_piece(next_kt, stage ^ 1, kk * (S::PIECES / 2) + i);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
     };
 
@@ -365,7 +355,6 @@ static int gemm_launch(const void* d_x, const void* d_w, const float* d_bias, co
 #ifdef LM_DIAG
     static const int var = [] { const char* v = getenv("LEANN_MI355X_GEMM_VARIANT"); return v ? atoi(v) : GM_VAR_DEFAULT; }();
     if (var == 7) return gemm_launch_var<S, EPI, 7>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
-    if (var == 8) return gemm_launch_var<S, EPI, 8>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
 #endif
     return gemm_launch_var<S, EPI, GM_VAR_DEFAULT>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
 }

@@ -783,47 +783,48 @@ class BertEncoder(nn.Module):
 
     @torch.no_grad()
     def encode_tokens_packed(self, input_ids: torch.Tensor, lengths: torch.Tensor, max_tokens: int = 262144) -> torch.Tensor:
-        """No padding anywhere: sequences are concatenated; sub-batches are cut by token budget."""
+        """No padding anywhere: sequences are concatenated; sub-batches are cut by token budget.  Host-side cost matters here: a
+        one-query search calls this ~100 times with a handful of chunks, so the preamble is three small device ops (zeros, cumsum,
+        copy) and ONE device-to-host copy (the cumulative lengths: sub-batch bounds and allocation sizes come from that array)."""
         n, t = input_ids.shape
         out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=input_ids.device)
         if n == 0:
             return out
-        lens64 = lengths.long()
-        csum = torch.cumsum(lens64, 0)
-        # sub-batch boundaries by cumulative token count (host side: one small D2H copy)
-        cs = csum.cpu()
+        cu_all = torch.zeros(n + 1, dtype=torch.int32, device=input_ids.device)
+        cu_all[1:] = torch.cumsum(lengths, 0)
+        cs_np = cu_all.cpu().numpy().astype(np.int64)  # the one host sync of the forward
+        lens_np = np.diff(cs_np)
+        # sub-batch boundaries by cumulative token count
         bounds = [0]
-        base = 0
         while bounds[-1] < n:
-            j = int(torch.searchsorted(cs, torch.tensor(base + max_tokens), right=True))
-            j = max(j, bounds[-1] + 1)
-            j = min(j, n)
+            j = int(np.searchsorted(cs_np[1:], cs_np[bounds[-1]] + max_tokens, side="right"))
+            j = min(max(j, bounds[-1] + 1), n)
             bounds.append(j)
-            base = int(cs[j - 1])
-        ar = torch.arange(t, device=input_ids.device)
         import os
 
         pack_on = os.environ.get("LEANN_MI355X_PACK", "1") == "1"  # packed front end in one kernel (fused_pack_tokens)
-        cs_np = cs.numpy()
-        lens_np = cs_np - np.concatenate(([0], cs_np[:-1]))  # host copy of the lengths: no further syncs below
+        ar = None
         for b0, b1 in zip(bounds[:-1], bounds[1:]):
             ids = input_ids[b0:b1]
             ln = lengths[b0:b1]
+            cu = cu_all if (b0 == 0 and b1 == n) else (cu_all[b0 : b1 + 1] - cu_all[b0]).contiguous()
+            total = int(cs_np[b1] - cs_np[b0])
+            max_len = int(lens_np[b0:b1].max())
             if pack_on and ln.dtype == torch.int32:
-                cu = torch.zeros(b1 - b0 + 1, dtype=torch.int32, device=ids.device)
-                cu[1:] = torch.cumsum(ln, 0)
-                total = int(cs_np[b1 - 1]) - (int(cs_np[b0 - 1]) if b0 else 0)
                 packed = fused_pack_tokens(ids, ln, cu, total)
                 if packed is not None:
-                    out[b0:b1] = self.forward_packed(packed[0], packed[1], cu, None, ln, int(lens_np[b0:b1].max()))
+                    e = self.forward_packed(packed[0], packed[1], cu, None, ln, max_len)
+                    if b0 == 0 and b1 == n:
+                        return e
+                    out[b0:b1] = e
                     continue
+            if ar is None:
+                ar = torch.arange(t, device=input_ids.device)
             valid = ar[None, :] < ln[:, None]
             tok = ids[valid]
             pos = ar[None, :].expand(b1 - b0, t)[valid]
             seq_of = torch.arange(b1 - b0, device=ids.device)[:, None].expand(b1 - b0, t)[valid]
-            cu = torch.zeros(b1 - b0 + 1, dtype=torch.int32, device=ids.device)
-            cu[1:] = torch.cumsum(ln, 0)
-            out[b0:b1] = self.forward_packed(tok, pos, cu, seq_of, ln, int(ln.max()))
+            out[b0:b1] = self.forward_packed(tok, pos, cu, seq_of, ln, max_len)
         return out
 
     @torch.no_grad()

@@ -476,3 +476,25 @@ def test_minilm_forward_through_the_general_gemm_switches(monkeypatch):
         monkeypatch.setenv("LEANN_MI355X_GEMM", v)
         g = enc.encode_tokens_packed(ti, tl)
         assert (g - d).abs().max().item() < 3e-3 and not torch.isnan(g).any()
+
+
+def test_sub_batching_does_not_change_the_embeddings():
+    """encode_tokens_packed cuts the chunk list into sub-batches by token budget (one cumulative-length copy to the host decides the
+    bounds): one sub-batch, several, and one chunk per sub-batch give the same rows (same kernels per row; fp16 activations, fixed
+    summation orders), for a 384-wide and a 768-wide model."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=120, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    for name in ("all-MiniLM-L6-v2", "bge-base-en-v1.5"):
+        enc = BertEncoder.random_init(config_for(name), 2).to("cuda", dtype=torch.float16)
+        whole = enc.encode_tokens_packed(ti, tl, 1 << 20)
+        assert whole.shape == (120, enc.cfg.hidden) and whole.dtype == torch.float32
+        for budget in (7000, 2000, 1):
+            part = enc.encode_tokens_packed(ti, tl, budget)
+            # the 384-wide model switches layer form with the sub-batch size (<= 6144 tokens: general kernels): same arithmetic up to fp16
+            # rounding of intermediate activations
+            assert (part - whole).abs().max().item() <= 3e-3, (name, budget)
