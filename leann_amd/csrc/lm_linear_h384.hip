@@ -3,8 +3,8 @@
 //   MODE 0   out[T][N] = x W^T + b                          N = 384 P   (QKV projection: P = 3)
 //   MODE 1   out[T][384] = LayerNorm(res + x W^T + b)                   (attention output projection + LN1)
 //
-// STATUS: opt-in (LEANN_MI355X_LINEAR=1) until validated and timed on an MI355X (tests/test_gpu_next.py,
-// scripts/encoder_ops_bench.py).
+// STATUS: first generation of the 384-input linear kernels, validated on the MI355X (tests/test_gpu_encoder_kernels.py) and superseded by
+// the weight-stationary form (lm_gemm_ws_h384.hip, the default); LEANN_MI355X_LINEAR=1 selects it for A/B runs.
 //
 // Why: with K = 384 the library GEMMs of the layer run at ~240 TFLOP/s (12 k-iterations per 256x256 tile: the
 // prologue / epilogue of every tile is as long as its main loop) -- 1.3 ms of a 4.3 ms layer for 262k tokens

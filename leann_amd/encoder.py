@@ -8,8 +8,10 @@ Pooling(mean|cls) -> optional Normalize stack; weights are loaded from a Hugging
 checkpoint when one is available locally, otherwise seeded random weights of the identical
 architecture (throughput-identical; there is no network in the build/bench environment).
 
-MFMA is used only here (hipBLASLt GEMMs + fused attention through torch SDPA); the traversal,
-distance and beam-update kernels are the hand-written HIP in csrc/.
+MFMA is used only here, and only inside hand-written kernels (csrc/): hidden 384 -- weight-stationary QKV GEMM, varlen attention,
+fused attention-output + LayerNorm + feed-forward + LayerNorm; hidden 768 and small forwards -- the general GEMM lm_gemm_f16 with
+bias / GELU / residual epilogues, the same attention kernel at head_dim 64, LayerNorm.  Library GEMMs (hipBLASLt) and torch's varlen
+attention remain only as the A/B paths the LEANN_MI355X_* switches select and for shapes outside the kernels' envelopes (CPU, fp32).
 """
 
 from __future__ import annotations
@@ -160,7 +162,7 @@ KERNEL_SELECTION_KEYS = ("LEANN_MI355X_ATTN", "LEANN_MI355X_LN", "LEANN_MI355X_P
 
 
 def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
-    """LayerNorm(x + residual) through the hand-written HIP kernel (csrc/lm_encoder_ops.hip) for fp16 CUDA
+    """LayerNorm(x + residual) through the hand-written HIP kernel (csrc/lm_encoder_ops2.hip, 16 lanes per row) for fp16 CUDA
     tensors; plain torch otherwise (CPU / fp32 parity paths)."""
     if x.is_cuda and x.dtype == torch.float16 and x.shape[-1] % 8 == 0 and x.is_contiguous() and (
             residual is None or residual.is_contiguous()):
