@@ -119,9 +119,13 @@ typedef struct {
     int32_t zmq_port;                /* accepted, unused: the encoder is in-process   :205 */
     int32_t recompute;               /* 1: use the provider, 0: use the attached table */
     int32_t max_batch;               /* queries in flight per pass (0 = default 4096) */
-    int32_t recompute_memo;          /* 1: within ONE search call every node is recomputed at most once (fresh
-                                        embeddings are kept in HBM until the call returns); 0 (default): dedup
-                                        per round only.  Cf. DiskANN's dedup_node_dis (diskann_backend.py:463). */
+    int32_t recompute_memo;          /* 1 (default): within ONE pass of a search call (<= max_batch queries) every
+                                        node is recomputed at most once -- fresh embeddings stay in HBM until the
+                                        pass returns (N x d_padded x 4 bytes at most, grown on demand; results are
+                                        identical, only nunique drops); a one-query pass skips it (its visited
+                                        set already guarantees it).  0: dedup per lock-step round only, nothing
+                                        kept between rounds.  Cf. the reference's own dedup_node_dis ("cache and
+                                        reuse distance computations", diskann_backend.py:394,413,463). */
 } lm_search_params;
 void lm_search_params_default(lm_search_params *p);
 
@@ -154,10 +158,11 @@ int lm_index_get_stats(const lm_index *idx, lm_search_stats *out);
 int lm_index_set_profiling(lm_index *idx, int32_t enable); /* HIP events around kernels */
 /* Mean event-pair time around an empty kernel (us): the fixed part of every update_ms/launch. */
 int lm_index_event_overhead_us(lm_index *idx, double *out_us);
-/* Tuning knobs (A/B measurements): "update_variant" 0 = fused, sort-new + rank-merge (default), 1 = fused, full bitonic sort,
- * 2 = split (flat distance kernel over the pair list + one-wave-per-query merge kernel), 3/4 = fused with a
+/* Tuning knobs (A/B measurements): "update_variant" 0 = auto (default), 3 / 4 = the fused distance + beam-update kernel with a
  * wave / a workgroup per query.  "persistent_table" 1 (default) = stored-embedding searches run as ONE persistent
- * launch per batch, 0 = lock-step rounds. */
+ * launch per batch, 0 = lock-step rounds; "persistent_wave" -1 (auto) / 0 / 1 = its workgroup- or wave-per-query form.
+ * "pq_threads" 256 / 512 / 1024 (default) = workgroup width of the PQ traversal.  "memo_initial_rows" = first allocation of the
+ * per-call recompute memo in rows (0 = default: max(65536, 1024 per query of the pass)); it doubles on demand, never beyond N. */
 int lm_index_set_option(lm_index *idx, const char *name, int64_t value);
 
 /* ---- DiskANN-style path: PQ-ADC traversal + deferred exact rerank ---------------------------------

@@ -375,7 +375,10 @@ class Mi355xSearcher(LeannBackendSearcherInterface):
             ef=int(complexity), beam=int(beam_width), check_relative_distance=check_rel, recompute=bool(recompute_embeddings),
             prune_ratio=float(prune_ratio), local_prune=(pruning_strategy == "local"),
             send_neigh_times_ratio=(1.0 if pruning_strategy == "proportional" else 0.0),
-            batch_size=int(batch_size), zmq_port=int(zmq_port or 0), max_batch=int(kwargs.get("max_batch", 0)))
+            batch_size=int(batch_size), zmq_port=int(zmq_port or 0), max_batch=int(kwargs.get("max_batch", 0)),
+            # per-call memo (default on): in a multi-query call a node is recomputed at most once; `dedup_node_dis` is the reference's name
+            # for its own "cache and reuse" switch (diskann_backend.py:394,413), accepted here as a synonym
+            recompute_memo=bool(kwargs.get("recompute_memo", kwargs.get("dedup_node_dis", True))))
         if recompute_embeddings:
             import torch
 

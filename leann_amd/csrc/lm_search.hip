@@ -87,6 +87,7 @@ struct lm_index {
     int32_t* d_memo_slot = nullptr;
     float* d_memo = nullptr;
     int64_t memo_cap = 0;
+    int64_t memo_initial_rows = 0;  // option "memo_initial_rows": first allocation of the per-call memo (0 = max(65536, 1024 per query)); it doubles on demand up to N rows
     int32_t* d_hub_slot_init = nullptr;  // N: slot of every hub node, -1 elsewhere (hub-embedding cache)
     int64_t hub_n = 0;
     std::vector<void*> ws_allocs;
@@ -151,6 +152,29 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune 
 #undef A
     LM_HIP(hipMemsetAsync(w.rbm, 0, w.nw * 4, ix->stream));
     ix->ws_B = B; ix->ws_ef = ef; ix->ws_W = W; ix->ws_maxnew = maxnew;
+    return LM_OK;
+}
+
+// Rows of the embedding memo (hub cache rows first, then the rows a call appends).  Never more than N are needed: a node enters
+// the memo at most once.  Growth keeps the first `keep` rows (geometric: a call that touches u distinct nodes copies < 2u rows).
+static int ensure_memo_rows(lm_index* ix, int64_t need, int64_t keep) {
+    if (need <= ix->memo_cap) return LM_OK;
+    if (need > ix->N) LM_FAIL(LM_ESTATE, "internal: the embedding memo cannot need more rows than the index has nodes");
+    const int64_t cap = std::min<int64_t>(ix->N, std::max<int64_t>({need, 2 * ix->memo_cap, (int64_t)65536}));
+    float* grown = nullptr;
+    if (hipMalloc((void**)&grown, (size_t)cap * ix->Dp * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        LM_FAIL(LM_EHIP, "out of device memory for the per-call recompute memo (" + std::to_string((size_t)cap * ix->Dp * 4 >> 20) +
+                             " MiB); search with recompute_memo = 0 or a smaller max_batch");
+    }
+    if (ix->d_memo) {
+        if (keep > 0) LM_HIP(hipMemcpyAsync(grown, ix->d_memo, (size_t)keep * ix->Dp * 4, hipMemcpyDeviceToDevice, ix->stream));
+        LM_HIP(hipStreamSynchronize(ix->stream));  // kernels of earlier rounds still read the old rows
+        (void)hipFree(ix->d_memo);
+    }
+    ix->d_memo = grown;
+    ix->memo_cap = cap;
+    ix->ws.memo = grown;
     return LM_OK;
 }
 
@@ -350,20 +374,15 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         hipLaunchKernelGGL(k_pq_lut_all, dim3(B), dim3(256), 0, st, pa);
     }
     const bool hub = recompute && ix->hub_n > 0;
-    const bool memo_call = recompute && prm.recompute_memo != 0;  // keep rows until the call returns
+    // Per-call memo (the default): a node's embedding is recomputed at most once per pass and stays in HBM until the pass returns.
+    // A one-query pass never meets a node twice (visited set), so it skips the memo's bookkeeping.
+    const bool memo_call = recompute && prm.recompute_memo != 0 && B > 1;
     const bool memo = memo_call || hub;                                       // rows are addressed through memo_slot
     int64_t memo_used = 0;
     if (memo) {
         if (!ix->d_memo_slot) LM_HIP(hipMalloc((void**)&ix->d_memo_slot, (size_t)ix->N * 4));
-        const int64_t want = std::min<int64_t>(ix->N, 16ll << 20);
-        if (ix->memo_cap < want) {
-            if (hub) LM_FAIL(LM_ESTATE, "internal: memo buffer must be allocated when the hub cache is set");
-            if (ix->d_memo) (void)hipFree(ix->d_memo);
-            ix->d_memo = nullptr;
-            ix->memo_cap = 0;
-            LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
-            ix->memo_cap = want;
-        }
+        const int64_t first = ix->memo_initial_rows > 0 ? ix->memo_initial_rows : std::max<int64_t>(65536, (int64_t)B * 1024);
+        if ((rc = ensure_memo_rows(ix, std::min<int64_t>(ix->N, ix->hub_n + (memo_call ? first : 0)), hub ? ix->hub_n : 0)) != LM_OK) return rc;
         ws.memo_slot = ix->d_memo_slot;
         ws.memo = ix->d_memo;
         if (hub) {
@@ -440,7 +459,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             }
             if (memo) {
                 if (nu > 0) {
-                    if (memo_used + nu > ix->memo_cap) LM_FAIL(LM_ESTATE, "recompute memo is full (more than 16M distinct nodes in one call)");
+                    if ((rc = ensure_memo_rows(ix, memo_used + nu, memo_used)) != LM_OK) return rc;
                     hipLaunchKernelGGL(k_memo_append, dim3((unsigned)std::min<int64_t>(2048, ((int64_t)nu * (ix->Dp / 4) + 255) / 256)),
                                        dim3(256), 0, st, ws, (const float*)d_e, nu, memo_used, ix->Dp);
                     if (memo_call) memo_used += nu;
@@ -609,6 +628,7 @@ void lm_search_params_default(lm_search_params* p) {
     p->check_relative_distance = 1;
     p->recompute = 1;
     p->max_batch = 0;
+    p->recompute_memo = 1;
 }
 
 int lm_index_create_from_csr(int64_t ntotal, int32_t d, int32_t metric, const uint64_t* node_offsets,
@@ -783,15 +803,7 @@ int lm_index_set_hub_cache(lm_index* ix, const int32_t* ids, int32_t n, const fl
         if (ids[i] < 0 || ids[i] >= ix->N || slot[ids[i]] >= 0) LM_FAIL(LM_EINVAL, "hub ids must be unique and in range");
         slot[ids[i]] = i;
     }
-    const int64_t want = std::min<int64_t>(ix->N, 16ll << 20);
-    if (n > want / 2) LM_FAIL(LM_EINVAL, "hub cache too large (more than half of the memo capacity)");
-    if (ix->memo_cap < want) {
-        if (ix->d_memo) (void)hipFree(ix->d_memo);
-        ix->d_memo = nullptr;
-        ix->memo_cap = 0;
-        LM_HIP(hipMalloc((void**)&ix->d_memo, (size_t)want * ix->Dp * 4));
-        ix->memo_cap = want;
-    }
+    if (int mrc = ensure_memo_rows(ix, n, 0)) return mrc;
     if (!ix->d_hub_slot_init) LM_HIP(hipMalloc((void**)&ix->d_hub_slot_init, (size_t)ix->N * 4));
     LM_HIP(hipMemcpy(ix->d_hub_slot_init, slot.data(), (size_t)ix->N * 4, hipMemcpyHostToDevice));
     LM_HIP(hipMemcpy(ix->d_memo, d_embeddings, (size_t)n * ix->Dp * 4, hipMemcpyDeviceToDevice));
@@ -842,6 +854,11 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     }
     if (!std::strcmp(name, "wave_maxnew")) {
         ix->wave_maxnew = (int)value;
+        return LM_OK;
+    }
+    if (!std::strcmp(name, "memo_initial_rows")) {  // first allocation of the per-call recompute memo (it doubles on demand); 0 = default
+        if (value < 0) LM_FAIL(LM_EINVAL, "memo_initial_rows must not be negative");
+        ix->memo_initial_rows = value;
         return LM_OK;
     }
     LM_FAIL(LM_EINVAL, std::string("unknown option: ") + name);

@@ -140,7 +140,8 @@ class Mi355xIndex:
     @staticmethod
     def make_params(ef: int = 64, beam: int = 1, check_relative_distance: bool = True, recompute: bool = True,
                     prune_ratio: float = 0.0, local_prune: bool = False, send_neigh_times_ratio: float = 0.0,
-                    batch_size: int = 0, zmq_port: int = 0, max_batch: int = 0, recompute_memo: bool = False) -> SearchParams:
+                    batch_size: int = 0, zmq_port: int = 0, max_batch: int = 0, recompute_memo: bool = True) -> SearchParams:
+        """recompute_memo (default on, = lm_search_params_default): within one pass every node is recomputed at most once; identical results."""
         return SearchParams(ef, beam, 1 if check_relative_distance else 0, prune_ratio, 1 if local_prune else 0,
                             send_neigh_times_ratio, batch_size, zmq_port or 0, 1 if recompute else 0, max_batch,
                             1 if recompute_memo else 0)

@@ -163,9 +163,12 @@ class OracleGraph:
 def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: int = 1,
            check_relative_distance: bool = True, table: Optional[np.ndarray] = None,
            provider: Optional[Callable[[np.ndarray], np.ndarray]] = None, prune_ratio: float = 0.0,
-           pruning_strategy: str = "global", pq=None):
+           pruning_strategy: str = "global", pq=None, memo: bool = False):
     """Run the oracle search.  Exactly one of ``table`` (N x D, stored embeddings) or
     ``provider`` (callable: sorted unique int32 ids -> (n, D) float32) must be given.
+    ``memo`` restates the product's per-call recompute memo (lm_search_params.recompute_memo, the library default for a call of
+    more than one query): a node's embedding is requested from ``provider`` at most once per call and kept until the call returns;
+    ids, distances and ndis are unchanged by construction, ``stats["nunique"]`` becomes the number of rows actually requested.
     Returns (ids int64 (B,k), dist float32 (B,k), stats dict)."""
     assert (table is None) != (provider is None)
     q = pad64(np.atleast_2d(queries))
@@ -189,13 +192,31 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
         cb = _PROVIDER()
     else:
         Dp = graph.Dp
+        slot = np.full(graph.N, -1, dtype=np.int64) if memo else None  # memo: row of every node fetched so far in this call
+        rows: list = []
+        memo_rows = [0]
 
         def _cb(_user, ids_p, n, out_p):
             try:
                 idv = np.ctypeslib.as_array(ids_p, shape=(n,)).copy()
-                e = pad64(np.asarray(provider(idv), dtype=np.float32))
-                assert e.shape == (n, Dp), e.shape
-                np.ctypeslib.as_array(out_p, shape=(n, Dp))[:] = e
+                out = np.ctypeslib.as_array(out_p, shape=(n, Dp))
+                if slot is None:
+                    e = pad64(np.asarray(provider(idv), dtype=np.float32))
+                    assert e.shape == (n, Dp), e.shape
+                    out[:] = e
+                    return 0
+                fresh = idv[slot[idv] < 0]
+                if fresh.size:
+                    e = pad64(np.asarray(provider(fresh), dtype=np.float32))
+                    assert e.shape == (fresh.size, Dp), e.shape
+                    slot[fresh] = memo_rows[0] + np.arange(fresh.size)
+                    memo_rows[0] += fresh.size
+                    rows.append(e)
+                    if len(rows) > 64:  # keep the lookup below a handful of blocks
+                        rows[:] = [np.concatenate(rows)]
+                allrows = rows[0] if len(rows) == 1 else np.concatenate(rows)
+                rows[:] = [allrows]
+                out[:] = allrows[slot[idv]]
                 return 0
             except Exception as ex:  # noqa: BLE001 - surfaced after the C call returns
                 err.append(ex)
@@ -209,6 +230,8 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
     if rc:
         raise RuntimeError(f"orc_search failed rc={rc}")
     stats = {f: int(getattr(st, f)) for f, _ in _Stats._fields_}
+    if provider is not None and memo:
+        stats["nunique"] = int(memo_rows[0])
     return ids, dd, stats
 
 

@@ -74,22 +74,44 @@ def case_table(metric="mips", d=64, f16=False):
     idx.close()
 
 
-def case_recompute(variant=0, memo=False):
+def case_recompute(variant=0, memo=False, initial_rows=0, nq=3):
+    """Recompute mode.  memo=None: the library default (per-call memo ON for a pass of more than one query).  With the memo every node
+    reaches the provider at most once per call (asserted on the provider's own id log) and the results are those of the plain
+    lock-step recompute; initial_rows > 0 starts the memo that small, so that it has to grow (rows kept across the re-allocation)."""
     from leann_amd.hnsw_builder import build_hnsw
     from leann_amd.index import Mi355xIndex
     from oracle import oracle as orc
 
-    x, q = _data(240, 48, 11)  # d = 48 -> padded to 64
+    x, q = _data(240, 48, 11, nq=nq)  # d = 48 -> padded to 64
     g = build_hnsw(x, "mips", M=6, ef_construction=30)
     og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 48)
     idx = Mi355xIndex.from_csr(g)
     prov = NumpyProvider(x, idx.info.d_padded)
-    idx.set_provider(prov)
+    seen = []
+    inner = prov.__call__
+
+    def logging_provider(d_ids_ptr, n, stream_ptr):
+        seen.append(np.ctypeslib.as_array(C.cast(d_ids_ptr, C.POINTER(C.c_int32)), shape=(n,)).copy())
+        return inner(d_ids_ptr, n, stream_ptr)
+
+    idx.set_provider(logging_provider)
     idx.set_option("update_variant", variant)
-    got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True, recompute_memo=memo))
+    if initial_rows:
+        idx.set_option("memo_initial_rows", initial_rows)
+    kw = {} if memo is None else {"recompute_memo": memo}
+    got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True, **kw))
     exp = orc.search(og, q, 5, ef=14, beam=2, table=x)
-    _check(f"recompute variant={variant} memo={memo}", got, exp[:2], idx.stats(), exp[2])
+    _check(f"recompute variant={variant} memo={memo} initial_rows={initial_rows} nq={nq}", got, exp[:2], idx.stats(), exp[2])
     assert prov.calls > 0
+    allids = np.concatenate(seen)
+    st = idx.stats()
+    assert int(st["nunique"]) == allids.shape[0]
+    memo_on = (memo is None or memo) and nq > 1
+    if memo_on:
+        assert np.unique(allids).shape[0] == allids.shape[0], "a node reached the provider twice despite the memo"
+        assert allids.shape[0] < int(st["ndis"])
+    elif nq > 1:
+        assert np.unique(allids).shape[0] < allids.shape[0], "expected repeated nodes without the memo (else this case proves nothing)"
     idx.close()
 
 
@@ -541,8 +563,11 @@ CASES = {
     "table_mips": lambda: case_table("mips", 64),
     "table_l2_d100": lambda: case_table("l2", 100),
     "table_f16": lambda: case_table("mips", 64, f16=True),
-    "recompute": lambda: case_recompute(0),
+    "recompute": lambda: case_recompute(0, memo=False),
     "recompute_memo": lambda: case_recompute(0, memo=True),
+    "recompute_default_is_memo": lambda: case_recompute(0, memo=None, nq=6),
+    "recompute_memo_grows": lambda: case_recompute(0, memo=None, initial_rows=4, nq=6),
+    "recompute_one_query_skips_memo": lambda: case_recompute(0, memo=True, nq=1),
     "recompute_wave_variant": lambda: case_recompute(3),
     "stop_rules": case_stop_rules,
     "pq_deferred": lambda: case_pq(True),

@@ -76,8 +76,13 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
         # provider contract: sorted unique ids every round
         for s in seen:
             assert np.all(np.diff(s) > 0)
-        _, _, pst = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, provider=lambda idv: xt.astype(np.float32)[idv])
+        # the library default keeps a per-call memo for a call of more than one query: the oracle restates it (oracle.py: memo=)
+        _, _, pst = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, provider=lambda idv: xt.astype(np.float32)[idv],
+                               memo=q.shape[0] > 1)
         assert idx.stats()["nunique"] == pst["nunique"]
+        if q.shape[0] > 1:
+            allids = np.concatenate(seen)
+            assert np.unique(allids).shape[0] == allids.shape[0], "a node reached the provider twice in one call"
     st = idx.stats()
     assert np.array_equal(gi, oi), f"ids differ: {np.argwhere(gi != oi)[:5]}"
     assert np.array_equal(gd.view(np.uint32), od.view(np.uint32)), "distances not bit-exact"
@@ -193,6 +198,14 @@ def test_recompute_memo_same_results_fewer_recomputes(env):
     assert res[True][2] < res[False][2]
     assert len(np.unique(res[True][3])) == len(res[True][3])  # nothing recomputed twice within the call
     assert set(res[True][3].tolist()) == set(res[False][3].tolist())
+    # the memo starts small and doubles on demand (rows kept across the re-allocations): same results, same provider rows
+    idx.set_option("memo_initial_rows", 32)
+    seen.clear()
+    d, l = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))  # default: memo on
+    torch.cuda.synchronize()
+    assert np.array_equal(l.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od)
+    assert idx.stats()["nunique"] == res[True][2] and np.array_equal(np.concatenate(seen), res[True][3])
+    idx.set_option("memo_initial_rows", 0)
 
 
 def test_lockstep_table_mode_still_matches(env):
@@ -240,8 +253,11 @@ def test_hub_cache_same_results_fewer_recomputes(env):
 
     idx.set_provider(provider)
     oi, od, _ = orc.search(oracle_graph(g, 384), q, 10, ef=64, beam=2, table=x)
-    d0, l0 = idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))
-    base = idx.stats()["nunique"]
+    base = {}
+    for memo in (False, True):
+        idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True, recompute_memo=memo))
+        base[memo] = idx.stats()["nunique"]
+    assert base[True] < base[False]
     idx.set_hub_cache(hubs, xdev[torch.from_numpy(hubs).long().cuda()].contiguous())
     for memo in (False, True):
         seen.clear()
@@ -249,11 +265,11 @@ def test_hub_cache_same_results_fewer_recomputes(env):
         torch.cuda.synchronize()
         assert np.array_equal(l.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od)
         allids = np.concatenate(seen)
-        assert not np.isin(allids, hubs).any() and idx.stats()["nunique"] < base
+        assert not np.isin(allids, hubs).any() and idx.stats()["nunique"] < base[memo]
     idx.set_hub_cache(None)
     seen.clear()
-    idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))
-    assert idx.stats()["nunique"] == base and np.isin(np.concatenate(seen), hubs).any()
+    idx.search_device(torch.from_numpy(q).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))  # the default: memo on
+    assert idx.stats()["nunique"] == base[True] and np.isin(np.concatenate(seen), hubs).any()
 
 
 def test_fp16_table(env):

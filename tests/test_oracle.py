@@ -107,6 +107,19 @@ def test_provider_mode_equals_table_mode(built_libs):
     b = orc.search(og, q, 10, ef=48, beam=3, provider=provider)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert b[2]["nunique"] == sum(calls) <= b[2]["ndis"]
+    # per-call memo (the product's default for a call of more than one query): every node requested at most once, same results
+    per_round = sum(calls)
+    calls.clear()
+    fetched = []
+
+    def logging_provider(ids):
+        fetched.append(ids.copy())
+        return provider(ids)
+
+    c = orc.search(og, q, 10, ef=48, beam=3, provider=logging_provider, memo=True)
+    allids = np.concatenate(fetched)
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and c[2]["ndis"] == b[2]["ndis"]
+    assert np.unique(allids).shape[0] == allids.shape[0] == c[2]["nunique"] < per_round
 
 
 def test_ties_order_by_id(built_libs):
