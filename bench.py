@@ -121,7 +121,7 @@ def main():
     from leann_amd.encoder import KernelTimers
 
     ktm = KernelTimers.active = KernelTimers()
-    EXTRA_ROWS = 4096  # small-batch latency rows + parity-check queries (fresh, after every step's block)
+    EXTRA_ROWS = 8192  # small-batch latency rows (library-side provider, then the Python provider) + parity-check queries (fresh, after every step's block)
     n_q = B * (K + W + 5) + EXTRA_ROWS  # +5: the profiled step and the extra steps (smallest ef reaching recall 0.9; hub cache; two-level search; one spare)
     t_setup = time.time()
 
@@ -377,12 +377,39 @@ def main():
     next_row = B * (K + W + 5)
     ktimes, kall = ktm.totals("timed"), ktm.totals()
     KernelTimers.active = None  # from here on the product's default launch path (one library call per forward), no event pairs
+    # The timed steps above ran over the Python form of the provider (the event pairs around the dominant kernel need the per-kernel
+    # launch path); with the timers off, re-attaching the provider resolves to the product default: the LIBRARY-side provider
+    # (csrc/lm_recompute.hip -- no interpreter in the search loop, one host synchronisation per round).
+    latency_python_provider = provider_ab = None
+    idx.set_provider(provider)
     if world == 1 and not args.no_latency_rows:
         try:
             latency_rows, next_row = small_batch_latency(
                 idx, Q, lambda b: idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b), recall, next_row)
+            if idx.native_provider:  # A/B in the same run: the same batch sizes over the Python provider (round 3's path until now)
+                os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
+                try:
+                    idx.set_provider(provider)
+                    assert not idx.native_provider
+                    latency_python_provider, next_row = small_batch_latency(
+                        idx, Q, lambda b: idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b), recall, next_row, batches=(1, 16, 256))
+                finally:
+                    os.environ.pop("LEANN_MI355X_NATIVE_PROVIDER", None)
+                    idx.set_provider(provider)
         except Exception as ex:  # noqa: BLE001
             extras_errors["small_batch_latency"] = repr(ex)[:300]
+    if world == 1 and idx.native_provider and K:  # one full-size step over the library-side provider, on a timed step's own queries: same labels
+        try:
+            lo_ = W * B
+            torch.cuda.synchronize()
+            t1_ = time.perf_counter()
+            _, lx = idx.search_device(Q[lo_ : lo_ + B], 10, prm)
+            torch.cuda.synchronize()
+            provider_ab = {"queries_per_s_native_provider": round(B / (time.perf_counter() - t1_), 3), "steps": 1,
+                           "labels_identical_to_the_timed_step": bool(torch.equal(lx, out_labels[0])),
+                           "native_provider_stats": provider.native_stats()}
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["provider_ab"] = repr(ex)[:300]
     if world == 1 and not args.no_parity_check:
         try:
             t1 = time.time()
@@ -511,6 +538,12 @@ def main():
         result["with_two_level_search"] = two_level
     if latency_rows:
         result["small_batch_latency"] = latency_rows
+        result["small_batch_latency_provider"] = ("library-side provider (csrc/lm_recompute.hip): no interpreter in the search loop, one host "
+                                                  "synchronisation per round" if latency_python_provider is not None else "Python provider")
+    if latency_python_provider:
+        result["small_batch_latency_python_provider"] = latency_python_provider
+    if provider_ab:
+        result["full_step_over_the_library_side_provider"] = provider_ab
     if parity:
         result["parity_check"] = parity
     if table_roof:
@@ -594,6 +627,10 @@ def parity_check(idx, g, X, Q, provider, ef, beam, dim, n_table=256, n_recompute
     except (StopIteration, AssertionError) as ex:  # the oracle asked for more / different rounds than the GPU ran
         out["recompute"] = {"n": int(qr.shape[0]), "rounds": len(rounds), "same_ids_requested_every_round": False, "ids_exact": False,
                             "error": repr(ex)[:200]}
+    if getattr(idx, "native_provider", False):  # the same queries over the library-side provider (the product default): identical output
+        d2, l2 = idx.search_device(qr, 10, idx.make_params(ef=ef, beam=beam, recompute=True))
+        torch.cuda.synchronize()
+        out["recompute"]["library_side_provider_identical"] = bool(torch.equal(l2, l) and torch.equal(d2, d))
     return out
 
 

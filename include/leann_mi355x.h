@@ -362,6 +362,30 @@ int lm_tokens_gather(const lm_tokens *t, const int32_t *d_ids, int32_t n, int32_
                      int32_t *d_out_ids, int32_t *d_out_len, void *stream);
 int64_t lm_tokens_count(const lm_tokens *t);
 
+/* ---- the built-in recompute provider (csrc/lm_recompute.hip) ------------------------------------
+ * One recompute round trip of the reference -- ZMQ REQ of the node ids, PassageManager.get_passage per id, tokeniser,
+ * model.encode() (hnsw_embedding_server.py:148-284, leann/api.py:203-215, leann/embedding_compute.py:229-239) -- as library code:
+ * ids -> token store -> packed forward -> fp32 [n][384], no interpreter in the search loop.  `model` (the struct and its `layers`
+ * array are copied; the device weights they point to must outlive the handle) and `tokens` as above; chunks are truncated to
+ * max_seq_len (1..256) tokens; a call with more than max_tokens_per_forward tokens runs as several forwards (bounds by cumulative
+ * token count, as leann_amd/encoder.py: encode_tokens_packed cuts them).  Envelope: lm_bert_h384_forward_packed's.
+ *   lm_index_set_recompute(idx, rc)  attaches it as the index's embedding provider (NULL detaches) and lets the search loop
+ *                                    compute the round's chunk lengths before its own per-round device-to-host copy: ONE host
+ *                                    synchronisation per round (lm_index_set_provider with a foreign callback: the callback's own);
+ *   lm_recompute_provider            the same object as a plain lm_provider_fn (user = the handle), e.g. for lm_index_set_provider;
+ *   lm_recompute_embed               embeddings of n chunk ids into the caller's fp32 [n][384] buffer (index build time). */
+typedef struct lm_recompute lm_recompute;
+typedef struct lm_recompute_stats {
+    int64_t calls, chunks, tokens, forwards, host_syncs;
+} lm_recompute_stats;
+int lm_recompute_create(const lm_bert_h384 *model, const lm_tokens *tokens, int32_t max_seq_len, int64_t max_tokens_per_forward,
+                        lm_recompute **out);
+void lm_recompute_free(lm_recompute *rc);
+int lm_recompute_provider(void *user, const int32_t *d_ids, int32_t n, void **d_out, void *stream);
+int lm_recompute_embed(lm_recompute *rc, const int32_t *d_ids, int32_t n, float *d_out, void *stream);
+int lm_recompute_get_stats(const lm_recompute *rc, lm_recompute_stats *out);
+int lm_index_set_recompute(lm_index *idx, lm_recompute *rc);
+
 #ifdef __cplusplus
 }
 #endif

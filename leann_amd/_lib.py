@@ -73,6 +73,10 @@ class BertH384(C.Structure):  # include/leann_mi355x.h: lm_bert_h384
                 ("layers", C.POINTER(BertH384Layer))]
 
 
+class RecomputeStats(C.Structure):  # include/leann_mi355x.h: lm_recompute_stats
+    _fields_ = [(n, C.c_int64) for n in ("calls", "chunks", "tokens", "forwards", "host_syncs")]
+
+
 PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p)
 
 # every symbol include/leann_mi355x.h declares (checked by tests/test_abi.py)
@@ -88,6 +92,7 @@ EXPORTED_SYMBOLS = [
     "lm_mlp_fused_h384_f16", "lm_attn_out_mlp_fused_h384_f16", "lm_linear_h384_f16", "lm_gemm_h384_f16", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
     "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
+    "lm_recompute_create", "lm_recompute_free", "lm_recompute_provider", "lm_recompute_embed", "lm_recompute_get_stats", "lm_index_set_recompute",
 ]
 
 _lib = None
@@ -154,6 +159,13 @@ def load() -> C.CDLL:
     lib.lm_bert_h384_workspace_bytes.argtypes = [i64]
     lib.lm_bert_h384_workspace_bytes.restype = C.c_size_t
     lib.lm_bert_h384_forward_packed.argtypes = [C.POINTER(BertH384), vp, vp, vp, i32, i64, i32, vp, C.c_size_t, vp, vp]
+    lib.lm_recompute_create.argtypes = [C.POINTER(BertH384), vp, i32, i64, C.POINTER(vp)]
+    lib.lm_recompute_free.argtypes = [vp]
+    lib.lm_recompute_free.restype = None
+    lib.lm_recompute_provider.argtypes = [vp, vp, i32, C.POINTER(vp), vp]
+    lib.lm_recompute_embed.argtypes = [vp, vp, i32, vp, vp]
+    lib.lm_recompute_get_stats.argtypes = [vp, C.POINTER(RecomputeStats)]
+    lib.lm_index_set_recompute.argtypes = [vp, vp]
     _lib = lib
     return lib
 

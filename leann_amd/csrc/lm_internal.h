@@ -90,6 +90,23 @@ int read_csr_file(const char* path, HostCsr& out);  // returns LM_* code
 
 }  // namespace lm
 
+// HBM-resident pre-tokenised passage store (lm_tokens.hip; read by the built-in recompute provider, lm_recompute.hip)
+struct lm_tokens {
+    int device = 0;
+    int64_t n = 0;
+    uint64_t total = 0;
+    uint16_t* d_tok = nullptr;  // packed token ids of every chunk
+    uint64_t* d_off = nullptr;  // n + 1 offsets into d_tok
+};
+
+// lm_recompute.hip: the search loop's half of the built-in provider's one-synchronisation round
+struct lm_recompute;
+namespace lm {
+int rc_prepare(lm_recompute* rc, const int32_t* d_ids, const unsigned long long* d_n, int64_t cap, unsigned long long* d_total,
+               unsigned long long* d_maxlen, hipStream_t st);
+void rc_prepared(lm_recompute* rc, const int32_t* d_ids, int32_t n, int64_t total, int32_t max_len);
+}  // namespace lm
+
 // lm_attn_v2.hip: revision 2 of the hd=32 attention kernel (opt-in, LEANN_MI355X_ATTN=2); arguments as lm_attn_varlen_hd32_f16
 int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out,
                       void* stream);

@@ -79,6 +79,7 @@ struct lm_index {
     // provider
     lm_provider_fn provider = nullptr;
     void* provider_user = nullptr;
+    lm_recompute* native_rc = nullptr;  // lm_index_set_recompute: the built-in provider (provider == lm_recompute_provider, user == this)
     hipStream_t stream = nullptr;
     // workspace
     WsDev ws{};
@@ -442,6 +443,12 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             }
         }
         rounds++;
+        // built-in provider: lengths of the round's chunks (count still on the device) before the copy below, so that this round
+        // needs no second synchronisation inside the provider
+        const bool native = recompute && ix->native_rc && ix->provider == lm_recompute_provider && ix->provider_user == (void*)ix->native_rc;
+        if (native && (rc = rc_prepare(ix->native_rc, ws.uniq, ws.counters + C_NUNIQ, ix->ws_ucap, ws.counters + C_RC_TOKENS,
+                                       ws.counters + C_RC_MAXLEN, st)) != LM_OK)
+            return rc;
         bool do_sync = (rounds % sync_every) == 0;
         if (do_sync) {
             LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -452,6 +459,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             int32_t nu = (int32_t)hc[C_NUNIQ];
             void* d_e = nullptr;
             ix->stats.nunique += nu;
+            if (native) rc_prepared(ix->native_rc, ws.uniq, nu, (int64_t)hc[C_RC_TOKENS], (int32_t)hc[C_RC_MAXLEN]);
             if (nu > 0) {
                 EvScope es(ix, &ix->ev_provider);
                 int prc = ix->provider(ix->provider_user, ws.uniq, nu, &d_e, (void*)st);
@@ -815,6 +823,15 @@ int lm_index_set_provider(lm_index* ix, lm_provider_fn fn, void* user) {
     if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
     ix->provider = fn;
     ix->provider_user = user;
+    return LM_OK;
+}
+
+int lm_index_set_recompute(lm_index* ix, lm_recompute* rc) {
+    if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
+    if (rc && ix->Dp != 384) LM_FAIL(LM_EINVAL, "lm_index_set_recompute: the built-in provider produces 384-d embeddings; this index has d = " + std::to_string(ix->D));
+    ix->native_rc = rc;
+    ix->provider = rc ? lm_recompute_provider : nullptr;
+    ix->provider_user = rc;
     return LM_OK;
 }
 

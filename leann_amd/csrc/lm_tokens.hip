@@ -8,14 +8,6 @@
 
 using namespace lm;
 
-struct lm_tokens {
-    int device = 0;
-    int64_t n = 0;
-    uint64_t total = 0;
-    uint16_t* d_tok = nullptr;
-    uint64_t* d_off = nullptr;
-};
-
 namespace lm {
 // one wave per chunk: coalesced u16 reads, int32 writes (pad beyond the length)
 __global__ __launch_bounds__(256) void k_tokens_gather(const uint16_t* tok, const uint64_t* off, const int32_t* ids,

@@ -693,29 +693,15 @@ class BertEncoder(nn.Module):
     # ---- packed (padding-free) path: varlen flash attention, every other op on [total_tokens, H] ----
     _varlen_ok: Optional[bool] = None  # resolved on first use (per process)
 
-    def _forward_one_call(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
-        """The whole packed forward as ONE call into the library (csrc/lm_encoder_forward.cpp: lm_bert_h384_forward_packed) -- the same
-        kernels as the per-kernel path below, strung together on the C++ side, so a recompute round costs one ctypes call instead of
-        ~3 L + 2.  Default since round 3 (measured on an MI355X, 200k-chunk index: B = 1 p50 57.7 -> 56.3 ms, B = 4 68.2 -> 66.8 ms;
-        bit-identical results); LEANN_MI355X_ONECALL=0 = the per-kernel path (A/B).  Applies to hidden 384 = heads x 32, fp16, mean
-        pooling, lengths <= 256, no kernel-selection switch set (KERNEL_SELECTION_KEYS), no per-kernel timers running.  None = not
-        applicable: the caller takes the per-kernel path (logged once per reason)."""
-        import os
-
+    def onecall_model(self) -> Optional[dict]:
+        """``{"model": lm_bert_h384 struct, ...}`` over this encoder's weights (packed copies cached, rebuilt when a weight changes: _packed)
+        -- the argument of lm_bert_h384_forward_packed and of the built-in recompute provider (lm_recompute_create) -- or None when the
+        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights, mean pooling, 128 <= ffn <= 2560, ffn % 32 == 0."""
         cfg = self.cfg
-        if os.environ.get("LEANN_MI355X_ONECALL", "1") != "1" or KernelTimers.active is not None:
-            return None
-        ab = [k for k in KERNEL_SELECTION_KEYS if k in os.environ]
-        if ab:  # an A/B run of a particular kernel generation goes through the per-kernel path
-            self._log_declined(f"kernel-selection switches set ({', '.join(ab)})")
-            return None
         w = self.word.weight
-        if not (tok.is_cuda and w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling == "mean"
-                and 0 < max_len <= 256 and cfg.ffn % 32 == 0 and 128 <= cfg.ffn <= 2560 and tok.dtype == torch.int32 and pos.dtype == torch.int32
-                and cu.dtype == torch.int32):
+        if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling == "mean" and cfg.ffn % 32 == 0
+                and 128 <= cfg.ffn <= 2560):
             return None
-        import ctypes as C
-
         from . import _lib
 
         def make():
@@ -734,7 +720,32 @@ class BertEncoder(nn.Module):
                               ptr(self.ln.bias.detach()), layers)
             return {"model": m, "layers": layers, "keep": keep}
 
-        pk = _packed(self, "_onecall_pack", tuple(self.parameters()), make)
+        return _packed(self, "_onecall_pack", tuple(self.parameters()), make)
+
+    def _forward_one_call(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
+        """The whole packed forward as ONE call into the library (csrc/lm_encoder_forward.cpp: lm_bert_h384_forward_packed) -- the same
+        kernels as the per-kernel path below, strung together on the C++ side, so a recompute round costs one ctypes call instead of
+        ~3 L + 2.  Default since round 3 (measured on an MI355X, 200k-chunk index: B = 1 p50 57.7 -> 56.3 ms, B = 4 68.2 -> 66.8 ms;
+        bit-identical results); LEANN_MI355X_ONECALL=0 = the per-kernel path (A/B).  Applies to hidden 384 = heads x 32, fp16, mean
+        pooling, lengths <= 256, no kernel-selection switch set (KERNEL_SELECTION_KEYS), no per-kernel timers running.  None = not
+        applicable: the caller takes the per-kernel path (logged once per reason)."""
+        import os
+
+        if os.environ.get("LEANN_MI355X_ONECALL", "1") != "1" or KernelTimers.active is not None:
+            return None
+        ab = [k for k in KERNEL_SELECTION_KEYS if k in os.environ]
+        if ab:  # an A/B run of a particular kernel generation goes through the per-kernel path
+            self._log_declined(f"kernel-selection switches set ({', '.join(ab)})")
+            return None
+        if not (tok.is_cuda and 0 < max_len <= 256 and tok.dtype == torch.int32 and pos.dtype == torch.int32 and cu.dtype == torch.int32):
+            return None
+        pk = self.onecall_model()
+        if pk is None:
+            return None
+        import ctypes as C
+
+        from . import _lib
+
         lib = _lib.load()
         tot, n = tok.shape[0], cu.shape[0] - 1
         need = int(lib.lm_bert_h384_workspace_bytes(tot))

@@ -91,13 +91,25 @@ class Mi355xIndex:
         self._refresh()
 
     def set_provider(self, fn: Optional[Callable[[int, int, int], int]]) -> None:
-        """``fn(d_ids_ptr, n, stream_ptr) -> device pointer (int) of fp32 [n][d_padded]`` (or raises)."""
+        """``fn(d_ids_ptr, n, stream_ptr) -> device pointer (int) of fp32 [n][d_padded]`` (or raises).  A provider that offers a
+        library-side form (``fn.native()`` -> ``lm_recompute`` handle: recompute.py) is attached as that -- the search loop then calls
+        library code directly, no interpreter per round (lm_index_set_recompute); ``fn`` itself is what runs otherwise."""
+        self.native_provider = False
         if fn is None:
             self._provider_keepalive = None
+            check(self._lib.lm_index_set_recompute(self._h, None), "lm_index_set_recompute")
             check(self._lib.lm_index_set_provider(self._h, _lib.PROVIDER_FN(), None))
             self._refresh()
             return
         self._provider_error = None
+        h = fn.native() if hasattr(fn, "native") else None
+        if h is not None and self.info.d_padded == 384:
+            self._provider_keepalive = fn
+            check(self._lib.lm_index_set_recompute(self._h, h), "lm_index_set_recompute")
+            self.native_provider = True
+            self._refresh()
+            return
+        check(self._lib.lm_index_set_recompute(self._h, None), "lm_index_set_recompute")
 
         def _cb(_user, d_ids, n, out_pp, stream):
             try:

@@ -835,6 +835,105 @@ def case_encoder_python_wiring():
 CASES["encoder_python_wiring"] = case_encoder_python_wiring
 
 
+def case_native_recompute():
+    """The built-in recompute provider (csrc/lm_recompute.hip) against the Python one (leann_amd/recompute.py: RecomputeProvider.__call__)
+    on the same encoder, token store and graph: (1) embeddings of a ragged id list, one forward and -- with a 192-token budget -- several
+    sub-batched forwards, bit-identical between the two forms (same token batches into the same kernels); (2) a recompute-mode search
+    whose provider is the library's (lm_index_set_recompute: lengths computed by the search loop's own round, ONE synchronisation per
+    round) equals the search over the Python provider AND the oracle over the table of those embeddings: labels, distances, evaluation
+    counts; one query (no memo) and several (default memo).  Device tensors are pretended as in case_encoder_python_wiring."""
+    import os
+    from unittest import mock
+
+    import torch
+
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.token_store import TokenStore
+    from oracle import oracle as orc
+
+    class _Stream:
+        cuda_stream = 0
+
+    torch.manual_seed(1)
+    cfg = EncoderConfig(vocab_size=300, hidden=384, layers=1, heads=12, ffn=128, max_pos=32, max_seq_length=24)
+    enc = BertEncoder.random_init(cfg, 7).eval().half()
+    rng = np.random.default_rng(5)
+    n = 72
+    lens = rng.integers(1, 20, n)
+    lens[3], lens[10] = 24, 1
+    seqs = [rng.integers(1, cfg.vocab_size, int(l)).tolist() for l in lens]
+    store = TokenStore.from_lists(seqs)
+    dev = torch.device("cpu")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True):
+        py = RecomputeProvider(enc, store, 384, dev)
+        with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
+            assert py.native() is None
+            ids_all = torch.arange(n, dtype=torch.int32)
+            X = py.embed_ids(ids_all).clone()  # Python form: gather + encode_tokens (one-call forward)
+        nat = RecomputeProvider(enc, store, 384, dev)
+        assert nat.native() is not None
+        Xn = nat.embed_ids(ids_all)
+        print("native vs Python provider, all chunks in one forward: max|diff|", float((X - Xn).abs().max()), flush=True)
+        assert torch.equal(X, Xn)
+        pick = torch.from_numpy(np.sort(rng.choice(n, 23, replace=False)).astype(np.int32))
+        small_py = RecomputeProvider(enc, store, 384, dev, batch_size=1)   # 192 tokens per forward: several forwards
+        small_nat = RecomputeProvider(enc, store, 384, dev, batch_size=1)
+        with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
+            a = small_py.embed_ids(pick).clone()
+        b = small_nat.embed_ids(pick)
+        st = small_nat.native_stats()
+        assert st["forwards"] > 1 and st["chunks"] == 23, st
+        assert torch.equal(a, b) and torch.equal(a, X[pick.long()]), float((a - b).abs().max())
+        # ---- search: library provider vs Python provider vs oracle over the table of the same embeddings
+        x = X.numpy().astype(np.float32)
+        g = build_hnsw(x, "mips", M=4, ef_construction=24)
+        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 384)
+        q = (x[[5, 40, 61]] + 0.05 * rng.standard_normal((3, 384))).astype(np.float32)
+        for nq in (1, 3):
+            exp = orc.search(og, q[:nq], 4, ef=8, beam=2, table=x)
+            idx = Mi355xIndex.from_csr(g)
+            idx.set_provider(nat)
+            assert idx.native_provider
+            s0 = nat.native_stats()
+            got = idx.search(q[:nq], 4, idx.make_params(ef=8, beam=2, recompute=True))
+            st_n, s1 = idx.stats(), nat.native_stats()
+            _check(f"native provider nq={nq} vs oracle", got, exp[:2], st_n, exp[2])
+            # one synchronisation per round: the provider itself never synchronised during the search (buffers were already grown)
+            assert s1["host_syncs"] == s0["host_syncs"], (s0, s1)
+            assert s1["chunks"] - s0["chunks"] == int(st_n["nunique"])
+            idx.close()
+            idx2 = Mi355xIndex.from_csr(g)
+            with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
+                idx2.set_provider(py)
+                assert not idx2.native_provider
+                got2 = idx2.search(q[:nq], 4, idx2.make_params(ef=8, beam=2, recompute=True))
+            _check(f"python provider nq={nq} vs oracle", got2, exp[:2], idx2.stats(), exp[2])
+            assert int(idx2.stats()["nunique"]) == int(st_n["nunique"])
+            idx2.close()
+        # as a plain lm_provider_fn (lm_index_set_provider with the exported function): same result, the provider synchronises itself
+        from leann_amd import _lib
+
+        lib = _lib.load()
+        idx3 = Mi355xIndex.from_csr(g)
+        fn = C.cast(lib.lm_recompute_provider, _lib.PROVIDER_FN)
+        _lib.check(lib.lm_index_set_provider(idx3._h, fn, nat.native()), "lm_index_set_provider")
+        got3 = idx3.search(q, 4, idx3.make_params(ef=8, beam=2, recompute=True))
+        exp = orc.search(og, q, 4, ef=8, beam=2, table=x)
+        _check("native provider as a plain lm_provider_fn", got3, exp[:2], idx3.stats(), exp[2])
+        idx3.close()
+        for p_ in (nat, small_nat, py, small_py):
+            p_.close()
+    store.close()
+
+
+CASES["native_recompute"] = case_native_recompute
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     _load(sys.argv[1])

@@ -1,0 +1,194 @@
+"""GPU tests of the built-in recompute provider (csrc/lm_recompute.hip: ids -> token store -> packed forward, library code called by the
+search loop directly) against the Python provider (leann_amd/recompute.py: RecomputeProvider.__call__) and the oracle.  What the
+reference does at this point: one ZMQ round trip to the embedding server per hop (hnsw_embedding_server.py:148-284).  Everything goes
+through the C ABI; the same scenarios run on the CPU box in thread-per-lane emulation (tests/emulated_search_cases.py: native_recompute)."""
+import os
+from unittest import mock
+
+import numpy as np
+import pytest
+
+from tests.util import oracle_graph, recall_at_k
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus
+    from leann_amd.token_store import TokenStore
+
+    _lib.require_gpu()
+    n = 6000
+    c = SyntheticCorpus(CorpusSpec(n_chunks=n, n_topics=8))
+    tok, off = c.chunks()
+    ts = TokenStore(tok, off)
+    cfg = EncoderConfig(vocab_size=30522, hidden=384, layers=2, heads=12, ffn=1536, max_pos=512, max_seq_length=256)
+    enc = BertEncoder.random_init(cfg, seed=11).to("cuda", dtype=torch.float16).eval()
+    return {"torch": torch, "corpus": c, "tokens": ts, "enc": enc, "n": n, "off": off}
+
+
+def _providers(w, **kw):
+    from leann_amd.recompute import RecomputeProvider
+
+    dev = w["torch"].device("cuda")
+    return RecomputeProvider(w["enc"], w["tokens"], 384, dev, **kw), RecomputeProvider(w["enc"], w["tokens"], 384, dev, **kw)
+
+
+def _python_form():
+    return mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"})
+
+
+@pytest.mark.parametrize("batch_size", [5461, 8])
+def test_native_embeddings_bit_identical_to_the_python_provider(world, batch_size):
+    """Same token batches into the same kernels: one forward (batch_size 5461 = 1M tokens) and many sub-batched forwards
+    (batch_size 8 = 1536 tokens per forward), ragged id list with repeats, the longest and the shortest chunk."""
+    torch = world["torch"]
+    nat, py = _providers(world, batch_size=batch_size)
+    assert nat.native() is not None
+    lens = np.diff(world["off"].astype(np.int64))
+    rng = np.random.default_rng(0)
+    ids = np.concatenate([rng.choice(world["n"], 700, replace=False), [int(lens.argmax()), int(lens.argmin()), 0, 0, world["n"] - 1]]).astype(np.int32)
+    d_ids = torch.from_numpy(ids).cuda()
+    a = nat.embed_ids(d_ids)
+    with _python_form():
+        assert py.native() is None
+        b = py.embed_ids(d_ids)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (ids.shape[0], 384)
+    assert torch.equal(a, b), float((a - b).abs().max())
+    st = nat.native_stats()
+    assert st["chunks"] == ids.shape[0] and st["tokens"] == int(np.minimum(lens[ids], 256).sum())
+    assert (st["forwards"] == 1) == (batch_size == 5461)
+    # a one-chunk call and an empty call
+    one = nat.embed_ids(d_ids[:1])
+    assert torch.equal(one, a[:1])
+    assert nat.embed_ids(d_ids[:0]).shape == (0, 384)
+    nat.close()
+
+
+@pytest.mark.parametrize("nq,memo", [(1, True), (24, True), (24, False)])
+def test_search_over_the_native_provider_equals_python_provider_and_oracle(world, nq, memo):
+    """Recompute-mode search with the library-side provider attached (lm_index_set_recompute): labels, distances, evaluation and
+    recompute counts equal the search over the Python provider and the oracle over the table of the same embeddings; the provider adds
+    no host synchronisation of its own (the search loop's per-round copy carries the token counts)."""
+    torch = world["torch"]
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.token_store import TokenStore
+    from oracle import oracle as orc
+
+    nat, py = _providers(world)
+    n = world["n"]
+    X = nat.embed_ids(torch.arange(n, dtype=torch.int32, device="cuda"))
+    g = build_graph_gpu(X, "mips", M=12, ef_construction=60)
+    qt, qo, _ = world["corpus"].queries(nq)
+    qs = TokenStore(qt, qo)
+    Q = RecomputeProvider(world["enc"], qs, 384, torch.device("cuda")).embed_ids(torch.arange(nq, dtype=torch.int32, device="cuda"))
+    x_np, q_np = X.cpu().numpy(), Q.cpu().numpy()
+    oi, od, ost = orc.search(oracle_graph(g, 384), q_np, 10, ef=40, beam=2, table=x_np)
+
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_provider(nat)
+    assert idx.native_provider
+    prm = idx.make_params(ef=40, beam=2, recompute=True, recompute_memo=memo)
+    idx.search_device(Q, 10, prm)  # first call grows the provider's buffers
+    s0 = nat.native_stats()
+    gd, gi = idx.search_device(Q, 10, prm)
+    torch.cuda.synchronize()
+    st, s1 = idx.stats(), nat.native_stats()
+    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od)
+    assert int(st["ndis"]) == int(ost["ndis"])
+    assert s1["host_syncs"] == s0["host_syncs"], (s0, s1)
+    assert s1["chunks"] - s0["chunks"] == int(st["nunique"])
+
+    with _python_form():
+        idx.set_provider(py)
+        assert not idx.native_provider
+        pd_, pi = idx.search_device(Q, 10, prm)
+        torch.cuda.synchronize()
+    assert torch.equal(pi, gi) and torch.equal(pd_, gd)
+    assert int(idx.stats()["nunique"]) == int(st["nunique"]) and py.chunks == int(st["nunique"])
+    gt, _ = orc.bruteforce_topk(x_np, q_np, 10, 0)
+    assert recall_at_k(oi, gt) > 0.9
+    idx.close()
+    nat.close()
+
+
+def test_native_provider_behind_the_pq_traversal_and_as_plain_provider_fn(world):
+    """The provider interface has other callers: the DiskANN-style traversal's deferred rerank (lm_pq_batch_search) and any host that
+    passes lm_recompute_provider to lm_index_set_provider itself.  Both equal the Python provider's results."""
+    import ctypes as C
+
+    torch = world["torch"]
+    from leann_amd import _lib
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.pq import encode_pq, train_pq
+
+    nat, py = _providers(world)
+    n = world["n"]
+    X = nat.embed_ids(torch.arange(n, dtype=torch.int32, device="cuda"))
+    g = build_graph_gpu(X, "mips", M=12, ef_construction=60)
+    cb = train_pq(X, 48, iters=4, seed=0)
+    codes = encode_pq(X, cb)
+    Q = X[:16] + 0.02 * torch.randn((16, 384), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    Q = Q.contiguous()
+
+    def pq_run(provider):
+        idx = Mi355xIndex.from_csr(g)
+        idx.set_stream(torch.cuda.current_stream().cuda_stream)
+        idx.attach_pq(cb.cpu().numpy(), codes.cpu().numpy())
+        idx.set_provider(provider)
+        out = idx.pq_search_device(Q, 10, idx.make_pq_params(complexity=48, beam_width=4, use_deferred_fetch=True))
+        torch.cuda.synchronize()
+        res = (out[0].clone(), out[1].clone(), idx.native_provider)
+        idx.close()
+        return res
+
+    d1, l1, was_native = pq_run(nat)
+    assert was_native
+    with _python_form():
+        d2, l2, was_native2 = pq_run(py)
+    assert not was_native2
+    assert torch.equal(l1, l2) and torch.equal(d1, d2)
+
+    lib = _lib.load()
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    fn = C.cast(lib.lm_recompute_provider, _lib.PROVIDER_FN)
+    _lib.check(lib.lm_index_set_provider(idx._h, fn, nat.native()), "lm_index_set_provider")
+    prm = idx.make_params(ef=32, beam=1, recompute=True)
+    a = idx.search_device(Q, 10, prm)
+    idx.set_provider(nat)
+    b = idx.search_device(Q, 10, prm)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    idx.close()
+    nat.close()
+
+
+def test_native_provider_declines_outside_its_envelope(world):
+    """Hidden 768 / CLS pooling / per-kernel timers: native() is None and the Python provider over the general kernels runs."""
+    torch = world["torch"]
+    from leann_amd.encoder import BertEncoder, EncoderConfig, KernelTimers
+    from leann_amd.recompute import RecomputeProvider
+
+    dev = torch.device("cuda")
+    cfg = EncoderConfig(vocab_size=30522, hidden=768, layers=1, heads=12, ffn=3072, max_pos=512, max_seq_length=256, pooling="cls")
+    enc768 = BertEncoder.random_init(cfg, seed=2).to("cuda", dtype=torch.float16).eval()
+    assert RecomputeProvider(enc768, world["tokens"], 768, dev).native() is None
+    p = RecomputeProvider(world["enc"], world["tokens"], 384, dev)
+    KernelTimers.active = KernelTimers()
+    try:
+        assert p.native() is None
+    finally:
+        KernelTimers.active = None
+    assert p.native() is not None
+    p.close()
