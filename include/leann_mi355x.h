@@ -311,10 +311,11 @@ int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, i
 int lm_gemm_f16(const void *d_x, const void *d_w, const float *d_bias, const void *d_residual, int32_t epilogue, int32_t n_out,
                 int32_t k_in, void *d_out, int64_t tokens, void *stream);
 
-/* ---- the whole packed BERT forward (hidden 384, mean pooling) in one call ---------------------
+/* ---- the whole packed BERT forward (hidden 384, mean or CLS pooling) in one call ---------------------
  * Replaces compute_embeddings' model.encode() (leann/embedding_compute.py:229-239) for sentence-transformers models of the
  * all-MiniLM family: embedding front end, per layer {lm_gemm_ws_h384_f16 (QKV), lm_attn_varlen_hd32_f16,
- * lm_attn_out_mlp_fused_h384_f16}, lm_meanpool_varlen_f16 -- one foreign-function call per recompute round instead of ~3 L + 2.
+ * lm_attn_out_mlp_fused_h384_f16}, lm_meanpool_varlen_f16 / lm_clspool_varlen_f16 -- one foreign-function call per recompute round
+ * instead of ~3 L + 2.
  * All pointers are device pointers except `layers` (host array).  Weight layouts as documented at the entry points named above
  * (leann_amd/encoder.py: pack_wo_slabs, pack_w1_acc_order, pack_w2_fused_mlp).  d_out: fp32 [n_seqs][384]. */
 typedef struct lm_bert_h384_layer {
@@ -339,6 +340,7 @@ typedef struct lm_bert_h384_layer {
 
 typedef struct lm_bert_h384 {
     int32_t n_layers, heads, ffn, normalize;
+    int32_t pooling; /* 0 = mean over the tokens (all-MiniLM), 1 = CLS (bge-small) */
     float ln_eps;
     const void *word, *pos_table, *type0, *emb_gamma, *emb_beta; /* fp16 */
     const lm_bert_h384_layer *layers;                           /* host array of n_layers entries */
@@ -348,6 +350,43 @@ size_t lm_bert_h384_workspace_bytes(int64_t total_tokens); /* sized for either l
 int lm_bert_h384_forward_packed(const lm_bert_h384 *m, const int32_t *d_tok, const int32_t *d_pos, const int32_t *d_cu_seqlens,
                                 int32_t n_seqs, int64_t total_tokens, int32_t max_len, void *d_workspace, size_t workspace_bytes,
                                 float *d_out, void *stream);
+
+/* ---- the whole packed BERT forward, general widths, in one call (csrc/lm_encoder_forward.cpp) -------
+ * The same replacement of compute_embeddings' model.encode() (leann/embedding_compute.py:229-239) for BERT-architecture models the
+ * hidden-384 kernels do not cover (bge-base-en-v1.5, contriever: hidden 768, head_dim 64, CLS or mean pooling): embedding front end,
+ * per layer {lm_gemm_f16 (QKV) | lm_attn_varlen_f16 | lm_gemm_f16 (+ residual) | lm_add_layernorm_f16 | lm_gemm_f16 (+ GELU) |
+ * lm_gemm_f16 (+ residual) | lm_add_layernorm_f16}, lm_meanpool_varlen_f16 / lm_clspool_varlen_f16 -- the launch sequence of
+ * leann_amd/encoder.py: EncoderLayer._forward_packed_general, as one foreign-function call.  Weights are the nn.Linear tensors
+ * themselves (fp16 [n_out][k_in], biases fp32, LayerNorm parameters fp16).  Envelope: hidden % 128 == 0 and <= 768, ffn % 128 == 0,
+ * head_dim = hidden / heads = 32 (chunk lengths <= 256) or 64 (<= 512).  d_out: fp32 [n_seqs][hidden]. */
+typedef struct lm_bert_layer {
+    const void *wqkv;  /* [3 hidden][hidden] */
+    const float *bqkv;
+    const void *wo;    /* [hidden][hidden] */
+    const float *bo;
+    const void *ln1_gamma, *ln1_beta;
+    const void *w1;    /* [ffn][hidden] */
+    const float *b1;
+    const void *w2;    /* [hidden][ffn] */
+    const float *b2;
+    const void *ln2_gamma, *ln2_beta;
+} lm_bert_layer;
+
+typedef struct lm_bert {
+    int32_t hidden, n_layers, heads, ffn;
+    int32_t pooling;   /* 0 = mean over the tokens, 1 = CLS (first token) */
+    int32_t normalize; /* L2-normalise the pooled vector */
+    float ln_eps;
+    const void *word, *pos_table, *type0, *emb_gamma, *emb_beta; /* fp16 */
+    const lm_bert_layer *layers;                                  /* host array of n_layers entries */
+} lm_bert;
+
+size_t lm_bert_workspace_bytes(const lm_bert *m, int64_t total_tokens);
+int lm_bert_forward_packed(const lm_bert *m, const int32_t *d_tok, const int32_t *d_pos, const int32_t *d_cu_seqlens, int32_t n_seqs,
+                           int64_t total_tokens, int32_t max_len, void *d_workspace, size_t workspace_bytes, float *d_out, void *stream);
+/* CLS pooling of packed sequences (+ optional L2 normalisation): d_out[s] = float(x[first token of s]); fp16 in, fp32 out. */
+int lm_clspool_varlen_f16(const void *d_x, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t hidden, int32_t normalize,
+                          float *d_out, void *stream);
 
 /* ---- token store ---------------------------------------------------------------------------
  * Replaces PassageManager.get_passage (leann/api.py:203-215) + tokenisation inside
@@ -365,21 +404,25 @@ int64_t lm_tokens_count(const lm_tokens *t);
 /* ---- the built-in recompute provider (csrc/lm_recompute.hip) ------------------------------------
  * One recompute round trip of the reference -- ZMQ REQ of the node ids, PassageManager.get_passage per id, tokeniser,
  * model.encode() (hnsw_embedding_server.py:148-284, leann/api.py:203-215, leann/embedding_compute.py:229-239) -- as library code:
- * ids -> token store -> packed forward -> fp32 [n][384], no interpreter in the search loop.  `model` (the struct and its `layers`
+ * ids -> token store -> packed forward -> fp32 [n][hidden], no interpreter in the search loop.  `model` (the struct and its `layers`
  * array are copied; the device weights they point to must outlive the handle) and `tokens` as above; chunks are truncated to
  * max_seq_len (1..256) tokens; a call with more than max_tokens_per_forward tokens runs as several forwards (bounds by cumulative
- * token count, as leann_amd/encoder.py: encode_tokens_packed cuts them).  Envelope: lm_bert_h384_forward_packed's.
+ * token count, as leann_amd/encoder.py: encode_tokens_packed cuts them).  Envelope: lm_bert_h384_forward_packed's
+ * (lm_recompute_create: hidden 384, the fused kernels) or lm_bert_forward_packed's (lm_recompute_create_general: e.g. bge-base,
+ * 768-d; max_seq_len up to 512 at head_dim 64); the embeddings are fp32 [n][hidden].
  *   lm_index_set_recompute(idx, rc)  attaches it as the index's embedding provider (NULL detaches) and lets the search loop
  *                                    compute the round's chunk lengths before its own per-round device-to-host copy: ONE host
  *                                    synchronisation per round (lm_index_set_provider with a foreign callback: the callback's own);
  *   lm_recompute_provider            the same object as a plain lm_provider_fn (user = the handle), e.g. for lm_index_set_provider;
- *   lm_recompute_embed               embeddings of n chunk ids into the caller's fp32 [n][384] buffer (index build time). */
+ *   lm_recompute_embed               embeddings of n chunk ids into the caller's fp32 [n][hidden] buffer (index build time). */
 typedef struct lm_recompute lm_recompute;
 typedef struct lm_recompute_stats {
     int64_t calls, chunks, tokens, forwards, host_syncs;
 } lm_recompute_stats;
 int lm_recompute_create(const lm_bert_h384 *model, const lm_tokens *tokens, int32_t max_seq_len, int64_t max_tokens_per_forward,
                         lm_recompute **out);
+int lm_recompute_create_general(const lm_bert *model, const lm_tokens *tokens, int32_t max_seq_len, int64_t max_tokens_per_forward,
+                                lm_recompute **out);
 void lm_recompute_free(lm_recompute *rc);
 int lm_recompute_provider(void *user, const int32_t *d_ids, int32_t n, void **d_out, void *stream);
 int lm_recompute_embed(lm_recompute *rc, const int32_t *d_ids, int32_t n, float *d_out, void *stream);

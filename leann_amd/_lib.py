@@ -68,9 +68,20 @@ class BertH384Layer(C.Structure):  # include/leann_mi355x.h: lm_bert_h384_layer
 
 
 class BertH384(C.Structure):  # include/leann_mi355x.h: lm_bert_h384
-    _fields_ = [("n_layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("normalize", C.c_int32), ("ln_eps", C.c_float),
+    _fields_ = [("n_layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("normalize", C.c_int32), ("pooling", C.c_int32), ("ln_eps", C.c_float),
                 ("word", C.c_void_p), ("pos_table", C.c_void_p), ("type0", C.c_void_p), ("emb_gamma", C.c_void_p), ("emb_beta", C.c_void_p),
                 ("layers", C.POINTER(BertH384Layer))]
+
+
+class BertLayer(C.Structure):  # include/leann_mi355x.h: lm_bert_layer (plain nn.Linear weights)
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_gamma", "ln1_beta", "w1", "b1", "w2", "b2", "ln2_gamma", "ln2_beta")]
+
+
+class Bert(C.Structure):  # include/leann_mi355x.h: lm_bert
+    _fields_ = [("hidden", C.c_int32), ("n_layers", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32), ("pooling", C.c_int32),
+                ("normalize", C.c_int32), ("ln_eps", C.c_float),
+                ("word", C.c_void_p), ("pos_table", C.c_void_p), ("type0", C.c_void_p), ("emb_gamma", C.c_void_p), ("emb_beta", C.c_void_p),
+                ("layers", C.POINTER(BertLayer))]
 
 
 class RecomputeStats(C.Structure):  # include/leann_mi355x.h: lm_recompute_stats
@@ -92,7 +103,8 @@ EXPORTED_SYMBOLS = [
     "lm_mlp_fused_h384_f16", "lm_attn_out_mlp_fused_h384_f16", "lm_linear_h384_f16", "lm_gemm_h384_f16", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
     "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
-    "lm_recompute_create", "lm_recompute_free", "lm_recompute_provider", "lm_recompute_embed", "lm_recompute_get_stats", "lm_index_set_recompute",
+    "lm_bert_workspace_bytes", "lm_bert_forward_packed", "lm_clspool_varlen_f16",
+    "lm_recompute_create", "lm_recompute_create_general", "lm_recompute_free", "lm_recompute_provider", "lm_recompute_embed", "lm_recompute_get_stats", "lm_index_set_recompute",
 ]
 
 _lib = None
@@ -159,7 +171,12 @@ def load() -> C.CDLL:
     lib.lm_bert_h384_workspace_bytes.argtypes = [i64]
     lib.lm_bert_h384_workspace_bytes.restype = C.c_size_t
     lib.lm_bert_h384_forward_packed.argtypes = [C.POINTER(BertH384), vp, vp, vp, i32, i64, i32, vp, C.c_size_t, vp, vp]
+    lib.lm_bert_workspace_bytes.argtypes = [C.POINTER(Bert), i64]
+    lib.lm_bert_workspace_bytes.restype = C.c_size_t
+    lib.lm_bert_forward_packed.argtypes = [C.POINTER(Bert), vp, vp, vp, i32, i64, i32, vp, C.c_size_t, vp, vp]
+    lib.lm_clspool_varlen_f16.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.lm_recompute_create.argtypes = [C.POINTER(BertH384), vp, i32, i64, C.POINTER(vp)]
+    lib.lm_recompute_create_general.argtypes = [C.POINTER(Bert), vp, i32, i64, C.POINTER(vp)]
     lib.lm_recompute_free.argtypes = [vp]
     lib.lm_recompute_free.restype = None
     lib.lm_recompute_provider.argtypes = [vp, vp, i32, C.POINTER(vp), vp]

@@ -1,5 +1,5 @@
 // lm_encoder_forward.cpp -- the whole packed BERT forward for hidden 384 as ONE C-ABI call: embedding front end, per layer
-// {weight-stationary QKV GEMM, varlen attention, fused layer tail}, mean pooling.  Host code only: it strings together the
+// {weight-stationary QKV GEMM, varlen attention, fused layer tail}, mean / CLS pooling.  Host code only: it strings together the
 // library's own entry points on one stream, so a search round costs one foreign-function call instead of ~3 L + 2 (at one query per
 // call a round recomputes ~5 chunks and the ~20 Python -> ctypes launches are most of its time).  What it replaces in the
 // reference: compute_embeddings' model.encode() call (leann/embedding_compute.py:229-239) for sentence-transformers models with
@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <string>
 
 #include "lm_internal.h"
 
@@ -35,6 +36,7 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     if (m->n_layers <= 0 || m->heads * 32 != 384 || m->ffn < 128 || m->ffn > 2560 || m->ffn % 32)
         LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: needs hidden 384 = heads x 32 and 128 <= ffn <= 2560, ffn % 32 == 0");
     if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: sequence lengths 1..256");
+    if (m->pooling != 0 && m->pooling != 1) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: pooling 0 (mean) or 1 (CLS)");
     if (workspace_bytes < lm_bert_h384_workspace_bytes(total_tokens)) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: workspace too small");
     const size_t row = (size_t)total_tokens * 384 * 2;
     unsigned char* ws = (unsigned char*)d_workspace;
@@ -68,5 +70,57 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
         x = y;
         y = t;
     }
-    return lm_meanpool_varlen_f16(x, d_cu_seqlens, n_seqs, 384, m->normalize, d_out, stream);
+    return m->pooling == 1 ? lm_clspool_varlen_f16(x, d_cu_seqlens, n_seqs, 384, m->normalize, d_out, stream)
+                           : lm_meanpool_varlen_f16(x, d_cu_seqlens, n_seqs, 384, m->normalize, d_out, stream);
+}
+
+// ---- general widths (hidden 768: bge-base, contriever) ---------------------------------------------------------------------------
+// The launch sequence of leann_amd/encoder.py: EncoderLayer._forward_packed_general + the pooling kernels, on the C++ side: one call per
+// forward for the Python host (B = 1 search on bge-base: ~9 launches per layer x 12 layers through ctypes otherwise) and the forward of
+// the built-in recompute provider (lm_recompute_create_general).
+static const char* bert_envelope(const lm_bert* m) {
+    if (!m || !m->layers || m->n_layers <= 0) return "NULL model / no layers";
+    if (m->hidden <= 0 || m->hidden % 128 || m->hidden > 768) return "hidden must be a multiple of 128, <= 768";
+    if (m->ffn <= 0 || m->ffn % 128) return "ffn must be a multiple of 128";
+    if (m->heads <= 0 || (m->heads * 32 != m->hidden && m->heads * 64 != m->hidden)) return "head_dim = hidden / heads must be 32 or 64";
+    if (m->pooling != 0 && m->pooling != 1) return "pooling: 0 = mean, 1 = CLS";
+    return nullptr;
+}
+
+extern "C" size_t lm_bert_workspace_bytes(const lm_bert* m, int64_t total_tokens) {
+    if (!m || total_tokens <= 0) return 0;
+    // x, attention output, y: [T][H]; qkv: [T][3H]; feed-forward intermediate: [T][ffn]; fp16
+    return (size_t)total_tokens * ((size_t)6 * m->hidden + m->ffn) * 2;
+}
+
+extern "C" int lm_bert_forward_packed(const lm_bert* m, const int32_t* d_tok, const int32_t* d_pos, const int32_t* d_cu_seqlens, int32_t n_seqs,
+                                      int64_t total_tokens, int32_t max_len, void* d_workspace, size_t workspace_bytes, float* d_out,
+                                      void* stream) {
+    using namespace lm;
+    if (n_seqs == 0 || total_tokens == 0) return LM_OK;
+    if (const char* why = bert_envelope(m)) LM_FAIL(LM_EINVAL, std::string("lm_bert_forward_packed: ") + why);
+    if (!d_tok || !d_pos || !d_cu_seqlens || !d_workspace || !d_out || n_seqs < 0 || total_tokens < 0)
+        LM_FAIL(LM_EINVAL, "lm_bert_forward_packed: bad arguments");
+    const int32_t H = m->hidden, hd = H / m->heads;
+    if (max_len <= 0 || max_len > (hd == 32 ? 256 : 512)) LM_FAIL(LM_EINVAL, "lm_bert_forward_packed: sequence lengths 1..256 (head_dim 32) / 1..512 (head_dim 64)");
+    if (workspace_bytes < lm_bert_workspace_bytes(m, total_tokens)) LM_FAIL(LM_EINVAL, "lm_bert_forward_packed: workspace too small");
+    const size_t row = (size_t)total_tokens * H * 2;
+    unsigned char* ws = (unsigned char*)d_workspace;
+    void *x = ws, *a = ws + row, *y = ws + 2 * row, *qkv = ws + 3 * row, *hid = ws + 6 * row;
+    int rc = lm_embed_layernorm_f16(d_tok, d_pos, m->word, m->pos_table, m->type0, m->emb_gamma, m->emb_beta, x, total_tokens, H, m->ln_eps, stream);
+    if (rc) return rc;
+    for (int l = 0; l < m->n_layers; ++l) {  // x -> y (scratch) -> x
+        const lm_bert_layer& L = m->layers[l];
+        if ((rc = lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 3 * H, H, qkv, total_tokens, stream))) return rc;
+        if ((rc = hd == 32 ? lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream)
+                           : lm_attn_varlen_f16(qkv, d_cu_seqlens, n_seqs, m->heads, hd, max_len, a, stream)))
+            return rc;
+        if ((rc = lm_gemm_f16(a, L.wo, L.bo, x, 2, H, H, y, total_tokens, stream))) return rc;
+        if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln1_gamma, L.ln1_beta, x, total_tokens, H, m->ln_eps, stream))) return rc;
+        if ((rc = lm_gemm_f16(x, L.w1, L.b1, nullptr, 1, m->ffn, H, hid, total_tokens, stream))) return rc;
+        if ((rc = lm_gemm_f16(hid, L.w2, L.b2, x, 2, H, m->ffn, y, total_tokens, stream))) return rc;
+        if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln2_gamma, L.ln2_beta, x, total_tokens, H, m->ln_eps, stream))) return rc;
+    }
+    return m->pooling == 1 ? lm_clspool_varlen_f16(x, d_cu_seqlens, n_seqs, H, m->normalize, d_out, stream)
+                           : lm_meanpool_varlen_f16(x, d_cu_seqlens, n_seqs, H, m->normalize, d_out, stream);
 }

@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256) void k_embed_layernorm_f16(const int32_t* __re
 // thread = (row group r0, 16-byte column c): sums rows r0, r0+RG, ... in fp32 in a fixed order (deterministic,
 // unlike atomics), row groups are combined through LDS.
 __global__ __launch_bounds__(256) void k_meanpool_varlen_f16(const __half* __restrict__ x, const int32_t* __restrict__ cu,
-                                                             float* __restrict__ out, int H, int normalize) {
+                                                             float* __restrict__ out, int H, int normalize, int first_only = 0) {
     __shared__ float red[256 * 8];
     __shared__ float wsum[4];
     const int seq = blockIdx.x, tid = threadIdx.x;
     const int tok0 = cu[seq];
-    const int len = cu[seq + 1] - tok0;
+    // first_only: CLS pooling = the "mean" over the sequence's first token alone (x * 1.0f is exact)
+    const int len = first_only ? min(cu[seq + 1] - tok0, 1) : cu[seq + 1] - tok0;
     const int nvec = H >> 3;      // <= 256
     const int rg = 256 / nvec;    // row groups
     const int c = tid % nvec, r0 = tid / nvec;
@@ -295,7 +296,20 @@ extern "C" int lm_meanpool_varlen_f16(const void* d_x, const int32_t* d_cu_seqle
     if (!d_x || !d_cu_seqlens || !d_out || n_seqs < 0) LM_FAIL(LM_EINVAL, "bad meanpool arguments");
     if (hidden <= 0 || hidden % 8 || hidden > 2048) LM_FAIL(LM_EINVAL, "hidden must be a multiple of 8, <= 2048");
     hipLaunchKernelGGL(k_meanpool_varlen_f16, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, (const __half*)d_x,
-                       d_cu_seqlens, d_out, hidden, normalize);
+                       d_cu_seqlens, d_out, hidden, normalize, 0);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// CLS pooling (+ optional L2 normalisation): d_out[s] = float(x[first token of sequence s]), the same kernel restricted to one row
+extern "C" int lm_clspool_varlen_f16(const void* d_x, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t hidden, int32_t normalize,
+                                     float* d_out, void* stream) {
+    using namespace lm;
+    if (n_seqs == 0) return LM_OK;
+    if (!d_x || !d_cu_seqlens || !d_out || n_seqs < 0) LM_FAIL(LM_EINVAL, "bad clspool arguments");
+    if (hidden <= 0 || hidden % 8 || hidden > 2048) LM_FAIL(LM_EINVAL, "hidden must be a multiple of 8, <= 2048");
+    hipLaunchKernelGGL(k_meanpool_varlen_f16, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, (const __half*)d_x,
+                       d_cu_seqlens, d_out, hidden, normalize, 1);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

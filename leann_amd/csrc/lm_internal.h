@@ -105,6 +105,7 @@ namespace lm {
 int rc_prepare(lm_recompute* rc, const int32_t* d_ids, const unsigned long long* d_n, int64_t cap, unsigned long long* d_total,
                unsigned long long* d_maxlen, hipStream_t st);
 void rc_prepared(lm_recompute* rc, const int32_t* d_ids, int32_t n, int64_t total, int32_t max_len);
+int32_t rc_width(const lm_recompute* rc);  // floats per embedding row
 }  // namespace lm
 
 // lm_attn_v2.hip: revision 2 of the hd=32 attention kernel (opt-in, LEANN_MI355X_ATTN=2); arguments as lm_attn_varlen_hd32_f16

@@ -17,8 +17,9 @@
 // are those of leann_amd/encoder.py: encode_tokens_packed, so both providers hand the same token batches to the same kernels and
 // return bit-identical embeddings (tests/test_gpu_native_provider.py, emulated case native_recompute).
 //
-// Envelope = that of the one-call forward: hidden 384 = heads x 32, mean pooling, fp16 weights, chunk lengths <= 256 tokens.  Other
-// models (hidden 768: bge-base, contriever) keep the Python provider over the general kernels -- a GPU path as well, not a fallback.
+// Envelope = that of the one-call forwards (csrc/lm_encoder_forward.cpp): hidden 384 = heads x 32 with mean pooling on the fused kernels
+// (lm_recompute_create), or any width the general kernels take -- hidden 768: bge-base, contriever, CLS or mean pooling
+// (lm_recompute_create_general).  fp16 weights.  A model outside both keeps the Python provider (a GPU path as well, not a fallback).
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -28,8 +29,12 @@
 
 struct lm_recompute {
     int device = 0;
-    lm_bert_h384 model{};
+    lm_bert_h384 model{};                    // hidden 384: the fused kernels (lm_recompute_create)
     std::vector<lm_bert_h384_layer> layers;  // model.layers points here
+    bool general = false;                    // any supported width on the general kernels (lm_recompute_create_general)
+    lm_bert gmodel{};
+    std::vector<lm_bert_layer> glayers;
+    int32_t hidden = 384;  // width of an output row
     const lm_tokens* tokens = nullptr;
     int32_t T = 0;           // chunks are truncated to T tokens (min(max_seq_length, position table, longest chunk))
     int64_t max_tokens = 0;  // tokens per forward (sub-batch budget)
@@ -41,7 +46,7 @@ struct lm_recompute {
     int64_t tok_cap = 0;
     void* d_ws = nullptr;  // activations of one forward (lm_bert_h384_workspace_bytes)
     size_t ws_bytes = 0;
-    float* d_out = nullptr;  // [n][384] fp32: valid until the next call on the same stream
+    float* d_out = nullptr;  // [n][hidden] fp32: valid until the next call on the same stream
     int64_t out_cap = 0;
     unsigned long long* d_meta = nullptr;  // {total tokens, longest chunk}
     unsigned long long* h_meta = nullptr;  // pinned
@@ -188,7 +193,7 @@ static int rc_forward(lm_recompute* rc, const int32_t* d_ids, int32_t b0, int32_
     int r;
     if ((r = rc_grow(rc, &rc->d_tok, &rc->tok_cap, 2 * total, 4, st, (int64_t)1 << 18))) return r;  // ids in the first half, positions in the second
     int32_t* d_pos = rc->d_tok + rc->tok_cap / 2;
-    const size_t need = lm_bert_h384_workspace_bytes(total);
+    const size_t need = rc->general ? lm_bert_workspace_bytes(&rc->gmodel, total) : lm_bert_h384_workspace_bytes(total);
     if (need > rc->ws_bytes) {
         if (rc->d_ws) {
             LM_HIP(hipStreamSynchronize(st));
@@ -205,11 +210,13 @@ static int rc_forward(lm_recompute* rc, const int32_t* d_ids, int32_t b0, int32_
                        n_sub, rc->d_tok, d_pos, rc->d_cu_sub);
     LM_HIP(hipGetLastError());
     rc->forwards++;
+    if (rc->general)
+        return lm_bert_forward_packed(&rc->gmodel, rc->d_tok, d_pos, rc->d_cu_sub, n_sub, total, max_len, rc->d_ws, rc->ws_bytes, d_out, (void*)st);
     return lm_bert_h384_forward_packed(&rc->model, rc->d_tok, d_pos, rc->d_cu_sub, n_sub, total, max_len, rc->d_ws, rc->ws_bytes, d_out,
                                        (void*)st);
 }
 
-// embeddings of n chunks into d_out [n][384]
+// embeddings of n chunks into d_out [n][hidden]
 static int rc_embed(lm_recompute* rc, const int32_t* d_ids, int32_t n, float* d_out, hipStream_t st) {
     int r;
     rc->calls++;
@@ -236,7 +243,7 @@ static int rc_embed(lm_recompute* rc, const int32_t* d_ids, int32_t n, float* d_
     rc->chunks += n;
     rc->tokens_seen += total;
     if (total == 0) {  // every chunk empty: mean pooling of nothing is the zero vector
-        LM_HIP(hipMemsetAsync(d_out, 0, (size_t)n * 384 * 4, st));
+        LM_HIP(hipMemsetAsync(d_out, 0, (size_t)n * rc->hidden * 4, st));
         return LM_OK;
     }
     if (total <= rc->max_tokens) return rc_forward(rc, d_ids, 0, n, total, max_len, d_out, st);
@@ -257,12 +264,29 @@ static int rc_embed(lm_recompute* rc, const int32_t* d_ids, int32_t n, float* d_
         for (int32_t i = b0; i < j; ++i) ml = std::max(ml, cs[i + 1] - cs[i]);
         const int64_t sub_total = (int64_t)cs[j] - cs[b0];
         if (sub_total > 0) {
-            if ((r = rc_forward(rc, d_ids, b0, j - b0, sub_total, ml, d_out + (size_t)b0 * 384, st))) return r;
+            if ((r = rc_forward(rc, d_ids, b0, j - b0, sub_total, ml, d_out + (size_t)b0 * rc->hidden, st))) return r;
         } else {
-            LM_HIP(hipMemsetAsync(d_out + (size_t)b0 * 384, 0, (size_t)(j - b0) * 384 * 4, st));
+            LM_HIP(hipMemsetAsync(d_out + (size_t)b0 * rc->hidden, 0, (size_t)(j - b0) * rc->hidden * 4, st));
         }
         b0 = j;
     }
+    return LM_OK;
+}
+
+int32_t rc_width(const lm_recompute* rc) { return rc->hidden; }
+
+static int rc_finish_create(lm_recompute* rc, const lm_tokens* tokens, int32_t max_seq_len, int64_t max_tokens, lm_recompute** out) {
+    rc->device = tokens->device;
+    rc->tokens = tokens;
+    rc->T = max_seq_len;
+    rc->max_tokens = max_tokens;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&rc->d_meta, 16)) != hipSuccess || (e = hipHostMalloc((void**)&rc->h_meta, 16)) != hipSuccess) {
+        set_error(std::string("lm_recompute_create: ") + hipGetErrorString(e));
+        lm_recompute_free(rc);
+        return LM_EHIP;
+    }
+    *out = rc;
     return LM_OK;
 }
 
@@ -282,21 +306,33 @@ int lm_recompute_create(const lm_bert_h384* model, const lm_tokens* tokens, int3
     if (max_tokens_per_forward <= 0) LM_FAIL(LM_EINVAL, "lm_recompute_create: max_tokens_per_forward must be positive");
     LM_HIP(hipSetDevice(tokens->device));
     lm_recompute* rc = new lm_recompute();
-    rc->device = tokens->device;
     rc->model = *model;
     rc->layers.assign(model->layers, model->layers + model->n_layers);
     rc->model.layers = rc->layers.data();
-    rc->tokens = tokens;
-    rc->T = max_seq_len;
-    rc->max_tokens = max_tokens_per_forward;
-    hipError_t e;
-    if ((e = hipMalloc((void**)&rc->d_meta, 16)) != hipSuccess || (e = hipHostMalloc((void**)&rc->h_meta, 16)) != hipSuccess) {
-        set_error(std::string("lm_recompute_create: ") + hipGetErrorString(e));
-        lm_recompute_free(rc);
-        return LM_EHIP;
-    }
-    *out = rc;
-    return LM_OK;
+    return rc_finish_create(rc, tokens, max_seq_len, max_tokens_per_forward, out);
+}
+
+int lm_recompute_create_general(const lm_bert* model, const lm_tokens* tokens, int32_t max_seq_len, int64_t max_tokens_per_forward,
+                                lm_recompute** out) {
+    using namespace lm;
+    if (!out) LM_FAIL(LM_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!model || !model->layers || !tokens) LM_FAIL(LM_EINVAL, "lm_recompute_create_general: NULL model / token store");
+    if (model->n_layers <= 0 || model->hidden <= 0 || model->hidden % 128 || model->hidden > 768 || model->ffn <= 0 || model->ffn % 128 ||
+        model->heads <= 0 || (model->heads * 32 != model->hidden && model->heads * 64 != model->hidden) || (model->pooling != 0 && model->pooling != 1))
+        LM_FAIL(LM_EINVAL, "lm_recompute_create_general: outside lm_bert_forward_packed's envelope (hidden % 128 == 0 and <= 768, ffn % 128 == 0, "
+                           "head_dim 32 or 64, mean or CLS pooling)");
+    if (max_seq_len <= 0 || max_seq_len > (model->heads * 32 == model->hidden ? 256 : 512))
+        LM_FAIL(LM_EINVAL, "lm_recompute_create_general: chunk length limit must be 1..256 tokens (head_dim 32) / 1..512 (head_dim 64)");
+    if (max_tokens_per_forward <= 0) LM_FAIL(LM_EINVAL, "lm_recompute_create_general: max_tokens_per_forward must be positive");
+    LM_HIP(hipSetDevice(tokens->device));
+    lm_recompute* rc = new lm_recompute();
+    rc->general = true;
+    rc->gmodel = *model;
+    rc->glayers.assign(model->layers, model->layers + model->n_layers);
+    rc->gmodel.layers = rc->glayers.data();
+    rc->hidden = model->hidden;
+    return rc_finish_create(rc, tokens, max_seq_len, max_tokens_per_forward, out);
 }
 
 void lm_recompute_free(lm_recompute* rc) {
@@ -316,7 +352,7 @@ int lm_recompute_provider(void* user, const int32_t* d_ids, int32_t n, void** d_
     hipStream_t st = (hipStream_t)stream;
     // first allocation: 4096 rows (6 MB) -- the rounds of a small-batch search grow from one chunk to a few hundred, and every
     // re-allocation costs a synchronisation
-    int r = rc_grow(rc, &rc->d_out, &rc->out_cap, (int64_t)std::max(n, 1) * 384, 4, st, (int64_t)4096 * 384);
+    int r = rc_grow(rc, &rc->d_out, &rc->out_cap, (int64_t)std::max(n, 1) * rc->hidden, 4, st, (int64_t)4096 * rc->hidden);
     if (r) return r;
     *d_out = rc->d_out;
     return rc_embed(rc, d_ids, n, rc->d_out, st);

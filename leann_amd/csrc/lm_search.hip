@@ -828,7 +828,9 @@ int lm_index_set_provider(lm_index* ix, lm_provider_fn fn, void* user) {
 
 int lm_index_set_recompute(lm_index* ix, lm_recompute* rc) {
     if (!ix) LM_FAIL(LM_EINVAL, "NULL index");
-    if (rc && ix->Dp != 384) LM_FAIL(LM_EINVAL, "lm_index_set_recompute: the built-in provider produces 384-d embeddings; this index has d = " + std::to_string(ix->D));
+    if (rc && ix->Dp != lm::rc_width(rc))
+        LM_FAIL(LM_EINVAL, "lm_index_set_recompute: the provider's embeddings are " + std::to_string(lm::rc_width(rc)) + " wide; this index has padded d = " +
+                               std::to_string(ix->Dp));
     ix->native_rc = rc;
     ix->provider = rc ? lm_recompute_provider : nullptr;
     ix->provider_user = rc;

@@ -300,9 +300,9 @@ def fused_pack_tokens(ids: torch.Tensor, lens: torch.Tensor, cu: torch.Tensor, t
     return tok, pos
 
 
-def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool) -> Optional[torch.Tensor]:
-    """Segmented mean (+ L2 normalise) over packed sequences (csrc/lm_encoder_ops2.hip), fp32 [n, H].  Default on
-    (LEANN_MI355X_POOL=0 = torch path, A/B); None = the caller takes the torch path."""
+def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool, cls: bool = False) -> Optional[torch.Tensor]:
+    """Segmented mean -- or, with ``cls``, the first token -- (+ L2 normalise) over packed sequences (csrc/lm_encoder_ops2.hip), fp32 [n, H].
+    Default on (LEANN_MI355X_POOL=0 = torch path, A/B); None = the caller takes the torch path."""
     import os
 
     if os.environ.get("LEANN_MI355X_POOL", "1") != "1":
@@ -316,9 +316,9 @@ def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool) -> Option
 
     n = cu.shape[0] - 1
     out = torch.empty((n, h), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().lm_meanpool_varlen_f16(
-        C.c_void_p(x.data_ptr()), C.c_void_p(cu.data_ptr()), n, h, 1 if normalize else 0, C.c_void_p(out.data_ptr()),
-        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_meanpool_varlen_f16")
+    fn = _lib.load().lm_clspool_varlen_f16 if cls else _lib.load().lm_meanpool_varlen_f16
+    _lib.check(fn(C.c_void_p(x.data_ptr()), C.c_void_p(cu.data_ptr()), n, h, 1 if normalize else 0, C.c_void_p(out.data_ptr()),
+                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_clspool_varlen_f16" if cls else "lm_meanpool_varlen_f16")
     return out
 
 
@@ -696,10 +696,10 @@ class BertEncoder(nn.Module):
     def onecall_model(self) -> Optional[dict]:
         """``{"model": lm_bert_h384 struct, ...}`` over this encoder's weights (packed copies cached, rebuilt when a weight changes: _packed)
         -- the argument of lm_bert_h384_forward_packed and of the built-in recompute provider (lm_recompute_create) -- or None when the
-        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights, mean pooling, 128 <= ffn <= 2560, ffn % 32 == 0."""
+        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights, mean or CLS pooling, 128 <= ffn <= 2560, ffn % 32 == 0."""
         cfg = self.cfg
         w = self.word.weight
-        if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling == "mean" and cfg.ffn % 32 == 0
+        if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling in ("mean", "cls") and cfg.ffn % 32 == 0
                 and 128 <= cfg.ffn <= 2560):
             return None
         from . import _lib
@@ -715,12 +715,41 @@ class BertEncoder(nn.Module):
                         L.out.weight.detach().contiguous(), L.fc1.weight.detach().contiguous(), L.fc2.weight.detach().contiguous())
                 for (name, _), v in zip(_lib.BertH384Layer._fields_, vals):
                     setattr(layers[li], name, ptr(v))
-            m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, float(self.ln.eps), ptr(w.detach()),
+            m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, 1 if cfg.pooling == "cls" else 0, float(self.ln.eps), ptr(w.detach()),
                               ptr(self.pos.weight.detach()), ptr(self.tok_type.weight[0].detach().contiguous()), ptr(self.ln.weight.detach()),
                               ptr(self.ln.bias.detach()), layers)
             return {"model": m, "layers": layers, "keep": keep}
 
         return _packed(self, "_onecall_pack", tuple(self.parameters()), make)
+
+    def general_model(self) -> Optional[dict]:
+        """``{"model": lm_bert struct, ...}`` over this encoder's own (unpacked) weights: the argument of lm_bert_forward_packed and
+        lm_recompute_create_general -- every width the general kernels take (hidden % 128 == 0 and <= 768, ffn % 128 == 0, head_dim 32
+        or 64, mean or CLS pooling, fp16): bge-base, contriever.  None outside that envelope."""
+        cfg = self.cfg
+        w = self.word.weight
+        hd = cfg.hidden // cfg.heads if cfg.heads else 0
+        if not (w.dtype == torch.float16 and cfg.hidden % 128 == 0 and cfg.hidden <= 768 and cfg.ffn % 128 == 0 and hd * cfg.heads == cfg.hidden
+                and hd in (32, 64) and cfg.pooling in ("mean", "cls")):
+            return None
+        from . import _lib
+
+        def make():
+            keep, layers = [], (_lib.BertLayer * cfg.layers)()
+            ptr = lambda t: (keep.append(t), t.data_ptr())[1]  # noqa: E731 - tensors stay referenced for the life of the pack
+            for li, L in enumerate(self.layers):
+                vals = (L.qkv.weight.detach().contiguous(), L.qkv.bias.detach().float().contiguous(), L.out.weight.detach().contiguous(),
+                        L.out.bias.detach().float().contiguous(), L.ln1.weight.detach().contiguous(), L.ln1.bias.detach().contiguous(),
+                        L.fc1.weight.detach().contiguous(), L.fc1.bias.detach().float().contiguous(), L.fc2.weight.detach().contiguous(),
+                        L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous())
+                for (name, _), v in zip(_lib.BertLayer._fields_, vals):
+                    setattr(layers[li], name, ptr(v))
+            m = _lib.Bert(cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.pooling == "cls" else 0, 1 if cfg.normalize else 0, float(self.ln.eps),
+                          ptr(w.detach()), ptr(self.pos.weight.detach()), ptr(self.tok_type.weight[0].detach().contiguous()),
+                          ptr(self.ln.weight.detach()), ptr(self.ln.bias.detach()), layers)
+            return {"model": m, "layers": layers, "keep": keep}
+
+        return _packed(self, "_general_pack", tuple(self.parameters()), make)
 
     def _forward_one_call(self, tok: torch.Tensor, pos: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
         """The whole packed forward as ONE call into the library (csrc/lm_encoder_forward.cpp: lm_bert_h384_forward_packed) -- the same
@@ -737,10 +766,7 @@ class BertEncoder(nn.Module):
         if ab:  # an A/B run of a particular kernel generation goes through the per-kernel path
             self._log_declined(f"kernel-selection switches set ({', '.join(ab)})")
             return None
-        if not (tok.is_cuda and 0 < max_len <= 256 and tok.dtype == torch.int32 and pos.dtype == torch.int32 and cu.dtype == torch.int32):
-            return None
-        pk = self.onecall_model()
-        if pk is None:
+        if not (tok.is_cuda and 0 < max_len <= 512 and tok.dtype == torch.int32 and pos.dtype == torch.int32 and cu.dtype == torch.int32):
             return None
         import ctypes as C
 
@@ -748,6 +774,21 @@ class BertEncoder(nn.Module):
 
         lib = _lib.load()
         tot, n = tok.shape[0], cu.shape[0] - 1
+        pk = self.onecall_model() if max_len <= 256 else None
+        if pk is None:  # other widths (768: bge-base, contriever): the general kernels, also strung together on the C++ side
+            gk = self.general_model() if self.cfg.hidden != 384 and max_len <= (256 if self.cfg.hidden == self.cfg.heads * 32 else 512) else None
+            if gk is None:
+                return None
+            need = int(lib.lm_bert_workspace_bytes(C.byref(gk["model"]), tot))
+            ws = getattr(self, "_onecall_ws", None)
+            if ws is None or ws.device != tok.device or ws.numel() < need:
+                ws = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=tok.device)
+                self._onecall_ws = ws
+            out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=tok.device)
+            _lib.check(lib.lm_bert_forward_packed(C.byref(gk["model"]), C.c_void_p(tok.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(cu.data_ptr()),
+                                                  n, tot, int(max_len), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream(tok.device).cuda_stream)), "lm_bert_forward_packed")
+            return out
         need = int(lib.lm_bert_h384_workspace_bytes(tot))
         ws = getattr(self, "_onecall_ws", None)
         if ws is None or ws.device != tok.device or ws.numel() < need:
@@ -779,10 +820,9 @@ class BertEncoder(nn.Module):
         for L in self.layers:
             x = L.forward_packed(x, cu, max_len)
         n = lengths.shape[0]
-        if cfg.pooling != "cls":
-            e = fused_meanpool(x, cu, cfg.normalize)
-            if e is not None:
-                return e
+        e = fused_meanpool(x, cu, cfg.normalize, cls=cfg.pooling == "cls")  # mean or CLS (+ normalisation) in one kernel
+        if e is not None:
+            return e
         if cfg.pooling == "cls":
             e = x[cu[:-1].long()].float()
         else:

@@ -103,7 +103,7 @@ class Mi355xIndex:
             return
         self._provider_error = None
         h = fn.native() if hasattr(fn, "native") else None
-        if h is not None and self.info.d_padded == 384:
+        if h is not None and self.info.d_padded == getattr(fn, "dp", -1):
             self._provider_keepalive = fn
             check(self._lib.lm_index_set_recompute(self._h, h), "lm_index_set_recompute")
             self.native_provider = True

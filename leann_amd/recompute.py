@@ -54,18 +54,25 @@ class RecomputeProvider:
         if (os.environ.get("LEANN_MI355X_NATIVE_PROVIDER", "1") != "1" or os.environ.get("LEANN_MI355X_ONECALL", "1") != "1"
                 or KernelTimers.active is not None or any(k in os.environ for k in KERNEL_SELECTION_KEYS)):
             return None
-        pk = self.encoder.onecall_model()  # cached; a NEW pack means the weights changed: the handle holds the old pointers
+        cfg = self.encoder.cfg
+        fused = cfg.hidden == 384 and self.T <= 256
+        # cached packs; a NEW pack object means the weights changed: the handle holds the old pointers
+        pk = self.encoder.onecall_model() if fused else None
+        if pk is None:
+            fused, pk = False, (self.encoder.general_model() if cfg.hidden != 384 else None)
         if self._native_tried and pk is getattr(self, "_native_pack", None):
             return self._native
         self.close()
         self._native_tried, self._native_pack = True, pk
-        if pk is None or not (0 < self.T <= 256) or self.dp != 384:
+        t_max = 256 if cfg.heads and cfg.hidden == cfg.heads * 32 else 512
+        if pk is None or not (0 < self.T <= t_max) or self.dp != cfg.hidden or not self.encoder.word.weight.is_cuda:
             return None
         from . import _lib
 
         h = C.c_void_p()
-        _lib.check(_lib.load().lm_recompute_create(C.byref(pk["model"]), self.tokens._h, int(self.T), int(self.batch_size) * 192, C.byref(h)),
-                   "lm_recompute_create")
+        create = _lib.load().lm_recompute_create if fused else _lib.load().lm_recompute_create_general
+        _lib.check(create(C.byref(pk["model"]), self.tokens._h, int(self.T), int(self.batch_size) * 192, C.byref(h)),
+                   "lm_recompute_create" if fused else "lm_recompute_create_general")
         self._native = h  # self._native_pack (the device weights) outlives it
         return h
 
@@ -136,7 +143,7 @@ class RecomputeProvider:
         if h is not None and ids.dtype == torch.int32 and ids.is_contiguous():
             from . import _lib
 
-            out = torch.empty((n, 384), dtype=torch.float32, device=ids.device)
+            out = torch.empty((n, self.encoder.cfg.hidden), dtype=torch.float32, device=ids.device)
             _lib.check(_lib.load().lm_recompute_embed(h, C.c_void_p(ids.data_ptr()), n, C.c_void_p(out.data_ptr()), C.c_void_p(stream)),
                        "lm_recompute_embed")
             return out

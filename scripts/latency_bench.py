@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Small-batch latency of the recompute search (LEANN's real call is one query at a time, leann/api.py:644-796) on a 200k-chunk
 index (set-up ~20 s), for A/B runs of host-side switches:   LEANN_MI355X_ONECALL=1 python scripts/latency_bench.py
-Prints one JSON line: p50 / mean latency at B = 1, 4, 16."""
+Prints one JSON line: p50 / mean latency at B = 1, 4, 16, 64, 256, for the library-side provider and the Python provider (same queries)."""
 import json, os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -30,21 +30,49 @@ g = build_graph_gpu(X, "mips", M=32, ef_construction=200)
 idx = Mi355xIndex.from_csr(g, device=0)
 idx.set_stream(torch.cuda.current_stream().cuda_stream)
 idx.set_provider(provider)
-qt, qo, _ = corpus.queries(1024, seed=4321)
-Q = RecomputeProvider(enc, TokenStore(qt, qo, device=0), 384, dev).embed_ids(torch.arange(1024, dtype=torch.int32, device=dev)).contiguous()
-rows, lo = [], 0
-for b in (1, 4, 16):
+qt, qo, _ = corpus.queries(2048, seed=4321)
+Q = RecomputeProvider(enc, TokenStore(qt, qo, device=0), 384, dev).embed_ids(torch.arange(2048, dtype=torch.int32, device=dev)).contiguous()
+# A/B in one process on the SAME queries: the library-side provider (csrc/lm_recompute.hip, the default) against the Python provider
+# (LEANN_MI355X_NATIVE_PROVIDER=0), interleaved per batch size; results must be identical
+def attach(native: bool):
+    if native:
+        os.environ.pop("LEANN_MI355X_NATIVE_PROVIDER", None)
+    else:
+        os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
+    idx.set_provider(provider)
+    os.environ.pop("LEANN_MI355X_NATIVE_PROVIDER", None)
+    return idx.native_provider
+
+
+forms = [("library_side_provider", True), ("python_provider", False)] if attach(True) else [("python_provider", False)]
+rows, lo, same = [], 0, True
+for b in (1, 4, 16, 64, 256):
     prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b)
-    idx.search_device(Q[lo : lo + b].contiguous(), 10, prm)
-    lo += b
-    lat = []
-    for _ in range(24 if b == 1 else 12):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    reps = 24 if b == 1 else (12 if b <= 16 else 4)
+    if lo + b * (reps + 1) > Q.shape[0]:
+        lo = 0
+    row, ref = {"batch": b}, None
+    for name, native in forms:
+        assert attach(native) == native
         idx.search_device(Q[lo : lo + b].contiguous(), 10, prm)
-        torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t0) * 1e3)
-        lo += b
-    st = idx.stats()
-    rows.append({"batch": b, "p50_ms": round(float(np.median(lat)), 2), "mean_ms": round(float(np.mean(lat)), 2), "rounds_last_call": st["nrounds"]})
-print(json.dumps({"chunks": n, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows}))
+        lat, outs, p = [], [], lo + b
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d, l = idx.search_device(Q[p : p + b].contiguous(), 10, prm)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+            outs.append((d, l))
+            p += b
+        st = idx.stats()
+        row[name] = {"p50_ms": round(float(np.median(lat)), 2), "mean_ms": round(float(np.mean(lat)), 2), "queries_per_s": round(b / float(np.mean(lat)) * 1e3, 1),
+                     "rounds_last_call": st["nrounds"]}
+        if ref is None:
+            ref = outs
+        else:
+            same &= all(torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) for a, c in zip(ref, outs))
+    lo += b * (reps + 1)
+    rows.append(row)
+attach(True)
+print(json.dumps({"chunks": n, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
+                  "identical_results_between_the_providers": same, "library_side_provider_stats": provider.native_stats()}))

@@ -835,13 +835,15 @@ def case_encoder_python_wiring():
 CASES["encoder_python_wiring"] = case_encoder_python_wiring
 
 
-def case_native_recompute():
+def case_native_recompute(hidden=384, heads=12, pooling="mean", searches=True):
     """The built-in recompute provider (csrc/lm_recompute.hip) against the Python one (leann_amd/recompute.py: RecomputeProvider.__call__)
     on the same encoder, token store and graph: (1) embeddings of a ragged id list, one forward and -- with a 192-token budget -- several
     sub-batched forwards, bit-identical between the two forms (same token batches into the same kernels); (2) a recompute-mode search
     whose provider is the library's (lm_index_set_recompute: lengths computed by the search loop's own round, ONE synchronisation per
     round) equals the search over the Python provider AND the oracle over the table of those embeddings: labels, distances, evaluation
-    counts; one query (no memo) and several (default memo).  Device tensors are pretended as in case_encoder_python_wiring."""
+    counts; one query (no memo) and several (default memo).  Model shapes: hidden 384 / mean pooling (all-MiniLM: fused kernels,
+    lm_recompute_create), hidden 384 / CLS (bge-small), and a general width with head_dim 64 and CLS pooling (the bge-base form:
+    lm_bert_forward_packed, lm_recompute_create_general).  Device tensors are pretended as in case_encoder_python_wiring."""
     import os
     from unittest import mock
 
@@ -858,7 +860,7 @@ def case_native_recompute():
         cuda_stream = 0
 
     torch.manual_seed(1)
-    cfg = EncoderConfig(vocab_size=300, hidden=384, layers=1, heads=12, ffn=128, max_pos=32, max_seq_length=24)
+    cfg = EncoderConfig(vocab_size=300, hidden=hidden, layers=1, heads=heads, ffn=128, max_pos=32, max_seq_length=24, pooling=pooling)
     enc = BertEncoder.random_init(cfg, 7).eval().half()
     rng = np.random.default_rng(5)
     n = 72
@@ -867,22 +869,43 @@ def case_native_recompute():
     seqs = [rng.integers(1, cfg.vocab_size, int(l)).tolist() for l in lens]
     store = TokenStore.from_lists(seqs)
     dev = torch.device("cpu")
+    tag = f"native provider h={hidden} {pooling}"
     env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+    from leann_amd import _lib
+
+    used = []
+    real_check = _lib.check
+
+    def recording_check(rc, what=""):
+        used.append(what)
+        return real_check(rc, what)
+
     with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
-            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True):
-        py = RecomputeProvider(enc, store, 384, dev)
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
+            mock.patch.object(_lib, "check", new=recording_check):
+        py = RecomputeProvider(enc, store, hidden, dev)
         with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
             assert py.native() is None
             ids_all = torch.arange(n, dtype=torch.int32)
             X = py.embed_ids(ids_all).clone()  # Python form: gather + encode_tokens (one-call forward)
-        nat = RecomputeProvider(enc, store, 384, dev)
+            assert ("lm_bert_h384_forward_packed" if hidden == 384 else "lm_bert_forward_packed") in used, sorted(set(used))
+            with mock.patch.dict(os.environ, {"LEANN_MI355X_ONECALL": "0"}):  # ... and the per-kernel launch path: same kernels, same bits
+                Xk = py.embed_ids(ids_all).clone()
+            assert torch.equal(X, Xk), float((X - Xk).abs().max())
+        nat = RecomputeProvider(enc, store, hidden, dev)
         assert nat.native() is not None
+        assert ("lm_recompute_create" if hidden == 384 else "lm_recompute_create_general") in used
         Xn = nat.embed_ids(ids_all)
-        print("native vs Python provider, all chunks in one forward: max|diff|", float((X - Xn).abs().max()), flush=True)
+        print(f"{tag}: vs Python provider, all chunks in one forward: max|diff|", float((X - Xn).abs().max()), flush=True)
         assert torch.equal(X, Xn)
+        if pooling == "cls":  # the pooling kernel against torch: first token's row, normalised
+            with torch.no_grad():
+                ref = BertEncoder.random_init(cfg, 7).eval()(torch.tensor([s + [0] * (24 - len(s)) for s in seqs], dtype=torch.int32),
+                                                            torch.tensor([len(s) for s in seqs], dtype=torch.int32)).float()
+            assert float((X - ref).abs().max()) < 6e-3, float((X - ref).abs().max())
         pick = torch.from_numpy(np.sort(rng.choice(n, 23, replace=False)).astype(np.int32))
-        small_py = RecomputeProvider(enc, store, 384, dev, batch_size=1)   # 192 tokens per forward: several forwards
-        small_nat = RecomputeProvider(enc, store, 384, dev, batch_size=1)
+        small_py = RecomputeProvider(enc, store, hidden, dev, batch_size=1)   # 192 tokens per forward: several forwards
+        small_nat = RecomputeProvider(enc, store, hidden, dev, batch_size=1)
         with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
             a = small_py.embed_ids(pick).clone()
         b = small_nat.embed_ids(pick)
@@ -892,9 +915,9 @@ def case_native_recompute():
         # ---- search: library provider vs Python provider vs oracle over the table of the same embeddings
         x = X.numpy().astype(np.float32)
         g = build_hnsw(x, "mips", M=4, ef_construction=24)
-        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 384)
-        q = (x[[5, 40, 61]] + 0.05 * rng.standard_normal((3, 384))).astype(np.float32)
-        for nq in (1, 3):
+        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, hidden)
+        q = (x[[5, 40, 61]] + 0.05 * rng.standard_normal((3, hidden))).astype(np.float32)
+        for nq in ((1, 3) if searches else (3,)):
             exp = orc.search(og, q[:nq], 4, ef=8, beam=2, table=x)
             idx = Mi355xIndex.from_csr(g)
             idx.set_provider(nat)
@@ -902,11 +925,13 @@ def case_native_recompute():
             s0 = nat.native_stats()
             got = idx.search(q[:nq], 4, idx.make_params(ef=8, beam=2, recompute=True))
             st_n, s1 = idx.stats(), nat.native_stats()
-            _check(f"native provider nq={nq} vs oracle", got, exp[:2], st_n, exp[2])
+            _check(f"{tag} nq={nq} vs oracle", got, exp[:2], st_n, exp[2])
             # one synchronisation per round: the provider itself never synchronised during the search (buffers were already grown)
             assert s1["host_syncs"] == s0["host_syncs"], (s0, s1)
             assert s1["chunks"] - s0["chunks"] == int(st_n["nunique"])
             idx.close()
+            if not searches:
+                continue
             idx2 = Mi355xIndex.from_csr(g)
             with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
                 idx2.set_provider(py)
@@ -915,23 +940,33 @@ def case_native_recompute():
             _check(f"python provider nq={nq} vs oracle", got2, exp[:2], idx2.stats(), exp[2])
             assert int(idx2.stats()["nunique"]) == int(st_n["nunique"])
             idx2.close()
-        # as a plain lm_provider_fn (lm_index_set_provider with the exported function): same result, the provider synchronises itself
-        from leann_amd import _lib
-
-        lib = _lib.load()
-        idx3 = Mi355xIndex.from_csr(g)
-        fn = C.cast(lib.lm_recompute_provider, _lib.PROVIDER_FN)
-        _lib.check(lib.lm_index_set_provider(idx3._h, fn, nat.native()), "lm_index_set_provider")
-        got3 = idx3.search(q, 4, idx3.make_params(ef=8, beam=2, recompute=True))
-        exp = orc.search(og, q, 4, ef=8, beam=2, table=x)
-        _check("native provider as a plain lm_provider_fn", got3, exp[:2], idx3.stats(), exp[2])
-        idx3.close()
+        if searches:
+            # as a plain lm_provider_fn (lm_index_set_provider with the exported function): same result, the provider synchronises itself
+            lib = _lib.load()
+            idx3 = Mi355xIndex.from_csr(g)
+            fn = C.cast(lib.lm_recompute_provider, _lib.PROVIDER_FN)
+            _lib.check(lib.lm_index_set_provider(idx3._h, fn, nat.native()), "lm_index_set_provider")
+            got3 = idx3.search(q, 4, idx3.make_params(ef=8, beam=2, recompute=True))
+            exp = orc.search(og, q, 4, ef=8, beam=2, table=x)
+            _check(f"{tag} as a plain lm_provider_fn", got3, exp[:2], idx3.stats(), exp[2])
+            idx3.close()
+            # a provider of another width is refused by the index
+            other = Mi355xIndex.from_csr(build_hnsw(x[:, :64].copy(), "mips", M=4, ef_construction=24))
+            try:
+                _lib.check(lib.lm_index_set_recompute(other._h, nat.native()), "lm_index_set_recompute")
+                raise AssertionError("a 64-d index accepted a provider of another width")
+            except ValueError:
+                pass
+            other.close()
         for p_ in (nat, small_nat, py, small_py):
             p_.close()
     store.close()
 
 
 CASES["native_recompute"] = case_native_recompute
+CASES["native_recompute_h384_cls"] = lambda: case_native_recompute(384, 12, "cls", searches=False)
+CASES["native_recompute_general_hd64_cls"] = lambda: case_native_recompute(128, 2, "cls", searches=False)
+CASES["native_recompute_general_hd32_mean"] = lambda: case_native_recompute(256, 8, "mean", searches=False)
 
 
 if __name__ == "__main__":
