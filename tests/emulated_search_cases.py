@@ -708,10 +708,15 @@ def case_hidden768():
             mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
             mock.patch.object(_lib, "check", new=recording_check):
         with torch.no_grad():
-            got = e16.encode_tokens_packed(ti, tl, 4096)
+            one = e16.encode_tokens_packed(ti, tl, 4096)  # the default: the whole forward as ONE library call (lm_bert_forward_packed)
+        assert "lm_bert_forward_packed" in used and "lm_gemm_f16" not in used, sorted(set(used))
+        used.clear()
+        with mock.patch.dict(os.environ, {"LEANN_MI355X_ONECALL": "0"}), torch.no_grad():
+            got = e16.encode_tokens_packed(ti, tl, 4096)  # ... and kernel by kernel: the same launches from the Python side
     want = {"lm_gemm_f16": 4 * cfg.layers, "lm_attn_varlen_f16": cfg.layers, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_embed_layernorm_f16": 1}
     counts = {k: used.count(k) for k in want}
-    assert counts == want, (counts, sorted(set(used)))
+    assert counts == want and "lm_bert_forward_packed" not in used, (counts, sorted(set(used)))
+    assert torch.equal(one, got), float((one - got).abs().max())
     err = float((got.float() - ref_e).abs().max())
     print(f"hidden 768 packed forward on the general kernels: max|diff| vs fp32 torch = {err:.2e}", flush=True)
     assert err < 6e-3, err

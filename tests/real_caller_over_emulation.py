@@ -112,9 +112,10 @@ def main(lib_path: str, leann_src: str, tmp: str) -> None:
     exact = emb @ emb[q]
     assert abs(res[0].score - float(exact[q])) < 5e-3 * max(1.0, abs(float(exact[q])))
     assert st["nrounds"] > 3 and st["nunique"] > 10, st           # a real recompute traversal, not a one-hop lookup
-    # the whole stack went through the C ABI: graph reader, token store + gather kernel, the fp16 forward (default launch path: the
-    # QKV GEMM, attention and fused layer-tail kernels strung together by lm_bert_h384_forward_packed), the search itself
-    for name in ("lm_index_read", "lm_tokens_create", "lm_tokens_gather", "lm_bert_h384_forward_packed", "lm_index_search"):
+    # the whole stack went through the C ABI: graph reader, token store, the built-in recompute provider (csrc/lm_recompute.hip: the search
+    # rounds' token packing and fp16 forwards -- QKV GEMM, attention, fused layer tail / general kernels -- run INSIDE lm_index_search,
+    # no Python per round), the search itself
+    for name in ("lm_index_read", "lm_tokens_create", "lm_recompute_create", "lm_index_set_recompute", "lm_index_search"):
         assert any(u.startswith(name) for u in used), (name, sorted(set(used)))
     print(json.dumps({"ids": [r.id for r in res], "scores": [round(float(r.score), 5) for r in res], "stats": {k: st[k] for k in ("nrounds", "nunique", "ndis")},
                       "abi_calls": len(used)}))

@@ -111,7 +111,7 @@ def test_layernorm_16_lanes_per_row(hidden, monkeypatch):
 
 @pytest.mark.parametrize("hidden,normalize", [(384, True), (384, False), (768, True), (64, True), (1024, False)])
 def test_meanpool_varlen(hidden, normalize, monkeypatch):
-    """lm_meanpool_varlen_f16 vs a plain PyTorch fp32 reference (per-sequence mean, optional L2 normalise)."""
+    """lm_meanpool_varlen_f16 / lm_clspool_varlen_f16 vs a plain PyTorch fp32 reference (per-sequence mean or first token, optional L2 normalise)."""
     import torch
     import torch.nn.functional as F
 
@@ -130,6 +130,14 @@ def test_meanpool_varlen(hidden, normalize, monkeypatch):
     if normalize:
         ref = F.normalize(ref, p=2, dim=1)
     assert (got - ref).abs().max().item() < 1e-5
+    # CLS pooling (lm_clspool_varlen_f16: the same kernel over the first token alone): exact row, torch's normalisation
+    cls = fused_meanpool(x, cu.cuda(), normalize, cls=True)
+    ref_cls = x[cu[:-1].long().cuda()].float()
+    if normalize:
+        ref_cls = F.normalize(ref_cls, p=2, dim=1)
+        assert (cls - ref_cls).abs().max().item() < 1e-6
+    else:
+        assert torch.equal(cls, ref_cls)
     monkeypatch.setenv("LEANN_MI355X_POOL", "0")
     assert fused_meanpool(x, cu.cuda(), normalize) is None
 
@@ -427,7 +435,8 @@ def test_attention_head_dim_64_vs_fp32_torch(heads, maxlen):
 
 @pytest.mark.parametrize("model", ["BAAI/bge-base-en-v1.5", "facebook/contriever"])
 def test_hidden_768_forward_runs_on_the_hand_written_kernels(model, monkeypatch):
-    """The whole packed forward of a 768-wide model: lm_gemm_f16 + lm_attn_varlen_f16 + lm_add_layernorm_f16 per layer, no library GEMM;
+    """The whole packed forward of a 768-wide model: lm_gemm_f16 + lm_attn_varlen_f16 + lm_add_layernorm_f16 per layer + the pooling kernel,
+    no library GEMM, as one library call (lm_bert_forward_packed: the default) and kernel by kernel;
     against the same weights in fp32 on the CPU (plain torch) and against the library path on the GPU (LEANN_MI355X_GEMM=0,
     LEANN_MI355X_ATTN=0)."""
     import torch
@@ -448,7 +457,14 @@ def test_hidden_768_forward_runs_on_the_hand_written_kernels(model, monkeypatch)
     real = _lib.check
     monkeypatch.setattr(_lib, "check", lambda rc, what="": (used.append(what), real(rc, what))[1])
     got = enc.encode_tokens_packed(ti, tl)
-    assert used.count("lm_gemm_f16") == 4 * cfg.layers and used.count("lm_attn_varlen_f16") == cfg.layers
+    assert "lm_bert_forward_packed" in used and "lm_gemm_f16" not in used  # the default: the whole forward as ONE library call
+    monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
+    used.clear()
+    per = enc.encode_tokens_packed(ti, tl)  # ... and the per-kernel launch path: the same kernels, the same bits
+    assert used.count("lm_gemm_f16") == 4 * cfg.layers and used.count("lm_attn_varlen_f16") == cfg.layers and "lm_bert_forward_packed" not in used
+    assert used.count("lm_clspool_varlen_f16" if cfg.pooling == "cls" else "lm_meanpool_varlen_f16") == 1
+    assert torch.equal(got, per)
+    monkeypatch.delenv("LEANN_MI355X_ONECALL")
     tol = 5e-3 if cfg.normalize else 5e-3 * float(ref.abs().max())
     assert (got[:24].cpu() - ref).abs().max().item() <= tol
     assert torch.nn.functional.cosine_similarity(got[:24].cpu(), ref).min().item() >= 0.9999

@@ -174,16 +174,69 @@ def test_native_provider_behind_the_pq_traversal_and_as_plain_provider_fn(world)
     nat.close()
 
 
+@pytest.mark.parametrize("hidden,heads,ffn,pooling", [(768, 12, 3072, "cls"), (768, 12, 3072, "mean"), (384, 12, 1536, "cls")])
+def test_native_provider_other_model_shapes(world, hidden, heads, ffn, pooling):
+    """bge-base / contriever shape (hidden 768, head_dim 64: lm_bert_forward_packed behind lm_recompute_create_general) and bge-small
+    (hidden 384, CLS pooling: the fused kernels + the CLS pooling kernel), two layers deep: the library-side provider, the Python
+    provider's one-call forward and its per-kernel launch path return the same bits; close to the same weights in fp32 on the CPU;
+    a recompute-mode search over the library-side provider equals the oracle over the table of those embeddings."""
+    torch = world["torch"]
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.synth import pad_batch
+    from oracle import oracle as orc
+
+    dev = torch.device("cuda")
+    cfg = EncoderConfig(vocab_size=30522, hidden=hidden, layers=2, heads=heads, ffn=ffn, max_pos=512, max_seq_length=256, pooling=pooling)
+    enc = BertEncoder.random_init(cfg, seed=5).to("cuda", dtype=torch.float16).eval()
+    n = 1500
+    ids = torch.arange(n, dtype=torch.int32, device="cuda")
+    nat = RecomputeProvider(enc, world["tokens"], hidden, dev, batch_size=64)  # 12k tokens per forward: sub-batched
+    py = RecomputeProvider(enc, world["tokens"], hidden, dev, batch_size=64)
+    assert nat.native() is not None
+    a = nat.embed_ids(ids)
+    with _python_form():
+        b = py.embed_ids(ids)
+        with mock.patch.dict(os.environ, {"LEANN_MI355X_ONECALL": "0"}):
+            c = py.embed_ids(ids)
+    torch.cuda.synchronize()
+    assert a.shape == (n, hidden) and torch.equal(a, b) and torch.equal(b, c), (float((a - b).abs().max()), float((b - c).abs().max()))
+    assert nat.native_stats()["forwards"] > 1
+    tok, off = world["corpus"].chunks()
+    pi, pl = pad_batch(tok, off, 256)
+    with torch.no_grad():
+        ref = BertEncoder.random_init(cfg, seed=5).eval()(torch.from_numpy(pi[:200]), torch.from_numpy(pl[:200])).float()
+    assert float((a[:200].cpu() - ref).abs().max()) < 8e-3
+    # search over the library-side provider vs the oracle over the same embeddings
+    g = build_graph_gpu(a, "mips", M=10, ef_construction=50)
+    Q = (a[:12] + 0.03 * torch.randn((12, hidden), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))).contiguous()
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_provider(nat)
+    assert idx.native_provider
+    gd, gi = idx.search_device(Q, 10, idx.make_params(ef=32, beam=1, recompute=True))
+    torch.cuda.synchronize()
+    oi, od, ost = orc.search(oracle_graph(g, hidden), Q.cpu().numpy(), 10, ef=32, beam=1, table=a.cpu().numpy())
+    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od) and int(idx.stats()["ndis"]) == int(ost["ndis"])
+    idx.close()
+    nat.close()
+
+
 def test_native_provider_declines_outside_its_envelope(world):
-    """Hidden 768 / CLS pooling / per-kernel timers: native() is None and the Python provider over the general kernels runs."""
+    """A width the general kernels do not take (hidden 64) / fp32 weights / per-kernel timers on: native() is None and the Python
+    provider runs."""
     torch = world["torch"]
     from leann_amd.encoder import BertEncoder, EncoderConfig, KernelTimers
     from leann_amd.recompute import RecomputeProvider
 
     dev = torch.device("cuda")
-    cfg = EncoderConfig(vocab_size=30522, hidden=768, layers=1, heads=12, ffn=3072, max_pos=512, max_seq_length=256, pooling="cls")
-    enc768 = BertEncoder.random_init(cfg, seed=2).to("cuda", dtype=torch.float16).eval()
-    assert RecomputeProvider(enc768, world["tokens"], 768, dev).native() is None
+    cfg = EncoderConfig(vocab_size=30522, hidden=64, layers=1, heads=4, ffn=128, max_pos=512, max_seq_length=256)
+    enc64 = BertEncoder.random_init(cfg, seed=2).to("cuda", dtype=torch.float16).eval()
+    assert RecomputeProvider(enc64, world["tokens"], 64, dev).native() is None
+    enc32 = BertEncoder.random_init(world["enc"].cfg, seed=2).to("cuda").eval()  # fp32 weights
+    assert RecomputeProvider(enc32, world["tokens"], 384, dev).native() is None
     p = RecomputeProvider(world["enc"], world["tokens"], 384, dev)
     KernelTimers.active = KernelTimers()
     try:
