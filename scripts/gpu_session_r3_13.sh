@@ -9,7 +9,7 @@ set -u
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/s13; rm -rf "$OUT"; mkdir -p "$OUT"
 T0=$(date +%s)
-timeout -k 5 200 python -m pytest tests/test_gpu_native_provider.py tests/test_gpu_encoder_kernels.py tests/test_gpu_parity.py -m gpu -q -x \
+timeout -k 5 200 python -m pytest tests/test_gpu_native_provider.py tests/test_gpu_encoder_kernels.py tests/test_gpu_parity.py -m gpu -q \
     -k "native or meanpool or hidden_768 or default_forward or recompute or memo" > $OUT/pytest_new_code.log 2>&1
 echo "step1 rc=$? $(tail -1 $OUT/pytest_new_code.log) [$(( $(date +%s) - T0 )) s]"; grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest_new_code.log | head -12
 timeout -k 5 260 python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_c2_short.json 2> $OUT/bench_c2.err
