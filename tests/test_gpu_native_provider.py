@@ -64,21 +64,72 @@ def test_native_embeddings_bit_identical_to_the_python_provider(world, batch_siz
     st = nat.native_stats()
     assert st["chunks"] == ids.shape[0] and st["tokens"] == int(np.minimum(lens[ids], 256).sum())
     assert (st["forwards"] == 1) == (batch_size == 5461)
-    # a one-chunk call and an empty call
+    # a one-chunk call (a SMALL forward: the general kernels, whatever form the big call above took -- same bits as the Python provider's
+    # one-chunk call, fp16-close to the row of the big call) and an empty call
     one = nat.embed_ids(d_ids[:1])
-    assert torch.equal(one, a[:1])
+    with _python_form():
+        one_py = py.embed_ids(d_ids[:1])
+    assert torch.equal(one, one_py)
+    assert float((one - a[:1]).abs().max()) < 3e-3
     assert nat.embed_ids(d_ids[:0]).shape == (0, 384)
     nat.close()
+
+
+def _search_native_vs_python_vs_oracle(torch, nat, py, g, Q, dim, ef, beam, memo):
+    """Search over the library-side provider == search over the Python provider (labels, distances, evaluation and recompute counts:
+    both hand the same token batches to the same kernels) == the oracle replaying the Python provider's own per-round outputs (the
+    comparison that is exact whatever kernel form a forward of a given size takes; a table of embeddings computed in ONE big forward
+    is only fp16-close to what a round's small forward returns).  Returns (labels, nunique, provider sync counters before / after)."""
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_provider(nat)
+    assert idx.native_provider
+    prm = idx.make_params(ef=ef, beam=beam, recompute=True, recompute_memo=memo)
+    idx.search_device(Q, 10, prm)  # first call grows the provider's buffers
+    s0 = nat.native_stats()
+    gd, gi = idx.search_device(Q, 10, prm)
+    torch.cuda.synchronize()
+    st, s1 = idx.stats(), nat.native_stats()
+    assert s1["chunks"] - s0["chunks"] == int(st["nunique"])
+    rounds = []
+
+    def recording(d_ids, cnt, stream):
+        p = py(d_ids, cnt, stream)
+        torch.cuda.synchronize()
+        rounds.append((as_tensor(d_ids, (cnt,), "int32").cpu().numpy().copy(), as_tensor(p, (cnt, dim), "float32").cpu().numpy().copy()))
+        return p
+
+    idx.set_provider(recording)
+    assert not idx.native_provider
+    pd_, pi = idx.search_device(Q, 10, prm)
+    torch.cuda.synchronize()
+    st_py = idx.stats()
+    assert torch.equal(pi, gi) and torch.equal(pd_, gd)
+    assert int(st_py["nunique"]) == int(st["nunique"]) and int(st_py["ndis"]) == int(st["ndis"]) and int(st_py["nrounds"]) == int(st["nrounds"])
+    it = iter(rounds)
+
+    def replay(idv):
+        ids, emb = next(it)
+        assert np.array_equal(ids, idv)
+        return emb
+
+    oi, od, ost = orc.search(oracle_graph(g, dim), Q.cpu().numpy(), 10, ef=ef, beam=beam, provider=replay, memo=bool(memo) and Q.shape[0] > 1)
+    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od) and int(st["ndis"]) == int(ost["ndis"])
+    idx.close()
+    return oi, int(st["nunique"]), s0, s1
 
 
 @pytest.mark.parametrize("nq,memo", [(1, True), (24, True), (24, False)])
 def test_search_over_the_native_provider_equals_python_provider_and_oracle(world, nq, memo):
     """Recompute-mode search with the library-side provider attached (lm_index_set_recompute): labels, distances, evaluation and
-    recompute counts equal the search over the Python provider and the oracle over the table of the same embeddings; the provider adds
+    recompute counts equal the search over the Python provider and the oracle (replay of the per-round embeddings); the provider adds
     no host synchronisation of its own (the search loop's per-round copy carries the token counts)."""
     torch = world["torch"]
     from leann_amd.gpu_graph_build import build_graph_gpu
-    from leann_amd.index import Mi355xIndex
     from leann_amd.recompute import RecomputeProvider
     from leann_amd.token_store import TokenStore
     from oracle import oracle as orc
@@ -90,34 +141,11 @@ def test_search_over_the_native_provider_equals_python_provider_and_oracle(world
     qt, qo, _ = world["corpus"].queries(nq)
     qs = TokenStore(qt, qo)
     Q = RecomputeProvider(world["enc"], qs, 384, torch.device("cuda")).embed_ids(torch.arange(nq, dtype=torch.int32, device="cuda"))
-    x_np, q_np = X.cpu().numpy(), Q.cpu().numpy()
-    oi, od, ost = orc.search(oracle_graph(g, 384), q_np, 10, ef=40, beam=2, table=x_np)
-
-    idx = Mi355xIndex.from_csr(g)
-    idx.set_stream(torch.cuda.current_stream().cuda_stream)
-    idx.set_provider(nat)
-    assert idx.native_provider
-    prm = idx.make_params(ef=40, beam=2, recompute=True, recompute_memo=memo)
-    idx.search_device(Q, 10, prm)  # first call grows the provider's buffers
-    s0 = nat.native_stats()
-    gd, gi = idx.search_device(Q, 10, prm)
-    torch.cuda.synchronize()
-    st, s1 = idx.stats(), nat.native_stats()
-    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od)
-    assert int(st["ndis"]) == int(ost["ndis"])
+    oi, nunique, s0, s1 = _search_native_vs_python_vs_oracle(torch, nat, py, g, Q, 384, 40, 2, memo)
     assert s1["host_syncs"] == s0["host_syncs"], (s0, s1)
-    assert s1["chunks"] - s0["chunks"] == int(st["nunique"])
-
-    with _python_form():
-        idx.set_provider(py)
-        assert not idx.native_provider
-        pd_, pi = idx.search_device(Q, 10, prm)
-        torch.cuda.synchronize()
-    assert torch.equal(pi, gi) and torch.equal(pd_, gd)
-    assert int(idx.stats()["nunique"]) == int(st["nunique"]) and py.chunks == int(st["nunique"])
-    gt, _ = orc.bruteforce_topk(x_np, q_np, 10, 0)
+    assert py.chunks == nunique
+    gt, _ = orc.bruteforce_topk(X.cpu().numpy(), Q.cpu().numpy(), 10, 0)
     assert recall_at_k(oi, gt) > 0.9
-    idx.close()
     nat.close()
 
 
@@ -179,7 +207,7 @@ def test_native_provider_other_model_shapes(world, hidden, heads, ffn, pooling):
     """bge-base / contriever shape (hidden 768, head_dim 64: lm_bert_forward_packed behind lm_recompute_create_general) and bge-small
     (hidden 384, CLS pooling: the fused kernels + the CLS pooling kernel), two layers deep: the library-side provider, the Python
     provider's one-call forward and its per-kernel launch path return the same bits; close to the same weights in fp32 on the CPU;
-    a recompute-mode search over the library-side provider equals the oracle over the table of those embeddings."""
+    a recompute-mode search over the library-side provider equals the one over the Python provider and the oracle."""
     torch = world["torch"]
     from leann_amd.encoder import BertEncoder, EncoderConfig
     from leann_amd.gpu_graph_build import build_graph_gpu
@@ -209,18 +237,10 @@ def test_native_provider_other_model_shapes(world, hidden, heads, ffn, pooling):
     with torch.no_grad():
         ref = BertEncoder.random_init(cfg, seed=5).eval()(torch.from_numpy(pi[:200]), torch.from_numpy(pl[:200])).float()
     assert float((a[:200].cpu() - ref).abs().max()) < 8e-3
-    # search over the library-side provider vs the oracle over the same embeddings
+    # search over the library-side provider == over the Python provider == the oracle (replay)
     g = build_graph_gpu(a, "mips", M=10, ef_construction=50)
     Q = (a[:12] + 0.03 * torch.randn((12, hidden), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))).contiguous()
-    idx = Mi355xIndex.from_csr(g)
-    idx.set_stream(torch.cuda.current_stream().cuda_stream)
-    idx.set_provider(nat)
-    assert idx.native_provider
-    gd, gi = idx.search_device(Q, 10, idx.make_params(ef=32, beam=1, recompute=True))
-    torch.cuda.synchronize()
-    oi, od, ost = orc.search(oracle_graph(g, hidden), Q.cpu().numpy(), 10, ef=32, beam=1, table=a.cpu().numpy())
-    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od) and int(idx.stats()["ndis"]) == int(ost["ndis"])
-    idx.close()
+    _search_native_vs_python_vs_oracle(torch, nat, py, g, Q, hidden, 32, 1, True)
     nat.close()
 
 

@@ -141,7 +141,8 @@ def test_recompute_search_end_to_end_bit_exact_given_same_embeddings(torch_, dim
         assert np.array_equal(ids, idv)
         return emb
 
-    oi, od, _ = orc.search(oracle_graph(g, dim), Q.cpu().numpy(), 10, ef=48, beam=2, provider=replay)
+    # (the library default keeps a per-call recompute memo for a call of more than one query: the oracle restates it, oracle.py: memo=)
+    oi, od, _ = orc.search(oracle_graph(g, dim), Q.cpu().numpy(), 10, ef=48, beam=2, provider=replay, memo=True)
     assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gd.cpu().numpy(), od)
     # and the recompute path finds what the stored-embedding path finds (recall sanity)
     gt, _ = orc.bruteforce_topk(X.cpu().numpy(), Q.cpu().numpy(), 10, 0)
