@@ -68,6 +68,10 @@ class _PqStats(C.Structure):
     _fields_ = [("n_adc", C.c_int64), ("n_rerank_unique", C.c_int64), ("n_rounds", C.c_int64), ("n_expand", C.c_int64)]
 
 
+class _DiskannStats(C.Structure):
+    _fields_ = [("n_cmps", C.c_int64), ("n_hops", C.c_int64), ("n_expanded", C.c_int64), ("max_hops", C.c_int64), ("n_final_differs", C.c_int64)]
+
+
 class _FaissStats(C.Structure):
     _fields_ = [("ndis", C.c_int64), ("ndis_upper", C.c_int64), ("nstep", C.c_int64)]
 
@@ -113,6 +117,9 @@ def lib():
         _lib.orcf_search.restype = C.c_int
         _lib.orcf_search.argtypes = [C.POINTER(_Graph), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.POINTER(_FaissStats)]
+        _lib.orcd_search.restype = C.c_int
+        _lib.orcd_search.argtypes = [C.POINTER(_Graph), C.POINTER(_Pq), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(_DiskannStats)]
         _lib.orc_set_num_threads.argtypes = [C.c_int]
         _lib.orc_set_num_threads.restype = None
         _lib.orc_set_num_threads(usable_cores())
@@ -363,3 +370,26 @@ def faiss_search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, 
     if rc != 0:
         raise RuntimeError(f"orcf_search failed rc={rc}")
     return ids, dd, {"ndis": st.ndis, "ndis_upper": st.ndis_upper, "nstep": st.nstep}
+
+
+def diskann_search(graph: OracleGraph, codebooks: np.ndarray, codes: np.ndarray, queries: np.ndarray, k: int, L: int = 64, W: int = 1,
+                   table: Optional[np.ndarray] = None, rerank_final_list_only: bool = True, chunk_off=None):
+    """The second oracle of the DiskANN-style path (oracle/lm_oracle_diskann.c): a literal transcription of upstream DiskANN's
+    PQFlashIndex::cached_beam_search / NeighborPriorityQueue, one query at a time, exact distances from ``table``.
+    ``rerank_final_list_only`` = True ranks the final candidate list (the product's deferred fetch; must equal ``pq_search``),
+    False ranks upstream's full_retset (every expanded node).  Returns (ids int64 (B,k), dist float32 (B,k), stats dict)."""
+    pq, _keep, m = _pq_struct(codebooks, codes, chunk_off)
+    assert np.asarray(codes).shape == (graph.N, m)
+    q = pad64(np.atleast_2d(queries))
+    B = q.shape[0]
+    tab = pad64(table)
+    assert tab.shape == (graph.N, graph.Dp) and q.shape[1] == graph.Dp
+    ids = np.empty((B, k), dtype=np.int64)
+    dd = np.empty((B, k), dtype=np.float32)
+    st = _DiskannStats()
+    g = graph.cstruct()
+    rc = lib().orcd_search(C.byref(g), C.byref(pq), _ptr(tab), _ptr(q), B, k, L, W, 1 if rerank_final_list_only else 0, _ptr(ids), _ptr(dd),
+                           C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orcd_search failed rc={rc}")
+    return ids, dd, {f: int(getattr(st, f)) for f, _ in _DiskannStats._fields_}
