@@ -983,6 +983,10 @@ if __name__ == "__main__":
 
     torch.set_num_threads(1)
     _orc.set_num_threads(1)  # libgomp's own synchronisation is invisible to ThreadSanitizer (false positives in the ORACLE)
+    import time
+
     for name in (sys.argv[2:] or list(CASES)):
+        t0 = time.time()
         CASES[name]()
+        print(f"[case {name}: {time.time() - t0:.1f} s]", flush=True)
     print("ALL CASES OK")

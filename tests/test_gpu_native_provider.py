@@ -211,10 +211,8 @@ def test_native_provider_other_model_shapes(world, hidden, heads, ffn, pooling):
     torch = world["torch"]
     from leann_amd.encoder import BertEncoder, EncoderConfig
     from leann_amd.gpu_graph_build import build_graph_gpu
-    from leann_amd.index import Mi355xIndex
     from leann_amd.recompute import RecomputeProvider
     from leann_amd.synth import pad_batch
-    from oracle import oracle as orc
 
     dev = torch.device("cuda")
     cfg = EncoderConfig(vocab_size=30522, hidden=hidden, layers=2, heads=heads, ffn=ffn, max_pos=512, max_seq_length=256, pooling=pooling)
