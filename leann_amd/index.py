@@ -107,6 +107,8 @@ class Mi355xIndex:
             self._provider_keepalive = fn
             check(self._lib.lm_index_set_recompute(self._h, h), "lm_index_set_recompute")
             self.native_provider = True
+            if hasattr(fn, "_attached"):  # the provider detaches itself from the indexes that hold its handle before it frees it
+                fn._attached.add(self)
             self._refresh()
             return
         check(self._lib.lm_index_set_recompute(self._h, None), "lm_index_set_recompute")

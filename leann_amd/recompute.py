@@ -43,6 +43,9 @@ class RecomputeProvider:
         self.count_tokens = False
         self._native = None  # lm_recompute handle (created on first use)
         self._native_tried = False
+        import weakref
+
+        self._attached = weakref.WeakSet()  # indexes whose provider is this handle (Mi355xIndex.set_provider)
 
     # ---- the library-side form (csrc/lm_recompute.hip) ------------------------------------------------
     def native(self):
@@ -95,10 +98,16 @@ class RecomputeProvider:
         self._native_chunks0 = self.native_stats()["chunks"] if self._native is not None else 0
 
     def close(self) -> None:
+        """Free the library-side handle.  Indexes still attached to it lose their provider first (a recompute search on them then fails
+        loudly with "no embedding provider" instead of reading freed memory)."""
         if self._native is not None:
             from . import _lib
 
-            _lib.load().lm_recompute_free(self._native)  # an index it is attached to must be given another provider first
+            for idx in list(self._attached):
+                if getattr(idx, "_h", None) and getattr(idx, "native_provider", False) and idx._provider_keepalive is self:
+                    idx.set_provider(None)
+            self._attached.clear()
+            _lib.load().lm_recompute_free(self._native)
             self._native = None
         self._native_tried = False
 

@@ -964,6 +964,18 @@ def case_native_recompute(hidden=384, heads=12, pooling="mean", searches=True):
             except ValueError:
                 pass
             other.close()
+            # closing the provider while an index still holds its handle detaches it there first: the next recompute search fails loudly
+            idx4 = Mi355xIndex.from_csr(g)
+            idx4.set_provider(nat)
+            assert idx4.native_provider
+            nat.close()
+            assert not idx4.native_provider
+            try:
+                idx4.search(q[:1], 4, idx4.make_params(ef=8, beam=2, recompute=True))
+                raise AssertionError("search over a closed provider did not fail")
+            except RuntimeError as ex:
+                assert "provider" in str(ex), ex
+            idx4.close()
         for p_ in (nat, small_nat, py, small_py):
             p_.close()
     store.close()
