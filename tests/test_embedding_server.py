@@ -182,6 +182,23 @@ def test_zmtp_rep_endpoint_wire_level():
         assert s.recv(4096) == b"\x01\x00\x00\x06echo:z"
         c2.close()
         s.close()
+        # what a libzmq 4.x peer actually puts on the wire (ZMTP 3.1): minor version 1, a READY command carrying TWO properties
+        # (Socket-Type = REQ and an empty Identity), heartbeat PING commands between requests (answered with PONG + the ping's context)
+        s3 = socket.create_connection(("127.0.0.1", srv.port), timeout=10)
+        g31 = b"\xff" + bytes(8) + b"\x7f" + b"\x03\x01" + b"NULL".ljust(20, b"\x00") + b"\x00" + bytes(31)
+        ready = b"\x05READY" + b"\x0bSocket-Type" + struct.pack(">I", 3) + b"REQ" + b"\x08Identity" + struct.pack(">I", 0)
+        s3.sendall(g31[:10])
+        s3.sendall(g31[10:] + bytes([0x04, len(ready)]) + ready)
+        buf = b""
+        while len(buf) < 64 + 27:
+            buf += s3.recv(4096)
+        ping = b"\x04PING" + struct.pack(">H", 300) + b"ctx1"  # TTL (deciseconds) + context
+        s3.sendall(bytes([0x04, len(ping)]) + ping)
+        pong = s3.recv(4096)
+        assert pong == bytes([0x04, 9]) + b"\x04PONG" + b"ctx1", pong
+        s3.sendall(b"\x01\x00" + b"\x00\x03abc")
+        assert s3.recv(4096) == b"\x01\x00\x00\x08echo:abc"
+        s3.close()
     finally:
         stop.set()
         th.join(5)
