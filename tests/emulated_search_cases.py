@@ -986,6 +986,52 @@ CASES["native_recompute_h384_cls"] = lambda: case_native_recompute(384, 12, "cls
 CASES["native_recompute_general_hd64_cls"] = lambda: case_native_recompute(128, 2, "cls", searches=False)
 
 
+def case_native_recompute_long_id_list():
+    """An id list longer than one pass of the built-in provider's length scan (k_rc_lengths_scan walks 1024 ids per pass: carry between
+    passes, the next pass's lengths requested early) and, with a 768-token budget, cut into several forwards: 1100 ids (with repeats) over
+    very short chunks; embeddings bit-identical to the Python provider's, token count exact."""
+    import os
+    from unittest import mock
+
+    import torch
+
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.token_store import TokenStore
+
+    class _Stream:
+        cuda_stream = 0
+
+    cfg = EncoderConfig(vocab_size=200, hidden=128, layers=1, heads=2, ffn=128, max_pos=16, max_seq_length=8, pooling="mean")
+    enc = BertEncoder.random_init(cfg, 4).eval().half()
+    rng = np.random.default_rng(8)
+    lens = rng.integers(1, 3, 40)
+    lens[7] = 0  # an empty chunk: contributes no tokens, pools to the zero vector in both forms
+    seqs = [rng.integers(1, cfg.vocab_size, int(l)).tolist() for l in lens]
+    store = TokenStore.from_lists(seqs)
+    ids = torch.from_numpy(rng.integers(0, 40, 1100).astype(np.int32))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True):
+        for bs in (5461, 4):
+            nat = RecomputeProvider(enc, store, 128, torch.device("cpu"), batch_size=bs)
+            py = RecomputeProvider(enc, store, 128, torch.device("cpu"), batch_size=bs)
+            a = nat.embed_ids(ids)
+            st = nat.native_stats()
+            with mock.patch.dict(os.environ, {"LEANN_MI355X_NATIVE_PROVIDER": "0"}):
+                b = py.embed_ids(ids)
+            assert st["chunks"] == 1100 and st["tokens"] == int(lens[ids.numpy()].sum()), st
+            assert (st["forwards"] == 1) == (bs == 5461), st
+            assert torch.equal(a, b), float((a - b).abs().max())
+            assert not torch.isnan(a).any() and float(a[ids.numpy() == 7].abs().max()) == 0.0
+            nat.close()
+    store.close()
+    print("native provider, 1100-id list (2 scan passes), one forward and 768-token forwards: ok", flush=True)
+
+
+CASES["native_recompute_long_id_list"] = case_native_recompute_long_id_list
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     _load(sys.argv[1])
