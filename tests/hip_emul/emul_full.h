@@ -27,8 +27,15 @@ struct Barrier {
         if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
             count.store(0, std::memory_order_relaxed);
             gen.fetch_add(1, std::memory_order_release);
+            gen.notify_all();
         } else {
-            while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+            // a few polite spins (a 4- or 16-lane group meets within microseconds), then sleep on the generation word (futex): with 256-1024
+            // lane threads on a handful of cores, yielding waiters would eat the time slices the late arrivers need
+            for (int spins = 0; spins < 32; ++spins) {
+                if (gen.load(std::memory_order_acquire) != g) return;
+                std::this_thread::yield();
+            }
+            while (gen.load(std::memory_order_acquire) == g) gen.wait(g, std::memory_order_acquire);
         }
     }
 };
@@ -154,7 +161,9 @@ inline long long wall_clock() {
 
 // Persistent lane threads (creating 256 OS threads per block dominated the run time).  Worker i runs when ITS mailbox
 // go[i] changes, so a 64-lane block wakes 64 workers; the launch fields are published before the mailboxes (release) and
-// read after them (acquire).  Idle workers back off to short sleeps instead of spinning.
+// read after them (acquire).  Idle workers, lanes waiting at a barrier and the launching thread sleep on the word they wait for
+// (C++20 atomic wait = futex) after a few polite spins: with 256-1024 lane threads on a handful of cores, yielding waiters ate the
+// time slices the late arrivers needed (whole emulated suite 185 s -> 120 s on 8 cores).
 struct Pool {
     static constexpr int MAXT = 1024;
     std::vector<std::thread> th;
@@ -173,8 +182,8 @@ struct Pool {
         for (;;) {
             int spins = 0, g;
             while ((g = go[i].load(std::memory_order_acquire)) == seen) {
-                if (++spins < 256) std::this_thread::yield();
-                else std::this_thread::sleep_for(std::chrono::microseconds(100));
+                if (++spins < 64) std::this_thread::yield();
+                else go[i].wait(seen, std::memory_order_acquire);  // asleep on its mailbox (futex): an idle worker costs nothing
             }
             seen = g;
             if (g < 0 || stop.load(std::memory_order_relaxed)) return;  // -1 in the mailbox: this worker is being retired
@@ -184,19 +193,14 @@ struct Pool {
             tls.gdim.x = grid.x;
             (*body)();
             done.fetch_add(1, std::memory_order_release);
+            done.notify_one();
         }
     }
     void run_block(unsigned bx_, dim3 grid_, dim3 block_, const std::function<void()>& f) {
         const int n = (int)block_.x;
         if (n > MAXT) std::abort();
-        // A 1024-thread workgroup (the PQ traversal) leaves 1024 idle workers behind, each polling its mailbox every 100 us: on a small
-        // host that alone eats the machine and every later launch crawls.  Retire the surplus as soon as an ordinary launch follows.
-        if ((int)th.size() > 512 && n <= 256) {
-            for (int i = n; i < (int)th.size(); ++i) go[i].store(-1, std::memory_order_release);
-            for (int i = n; i < (int)th.size(); ++i) th[i].join();
-            th.resize(n);
-            for (int i = n; i < MAXT; ++i) go[i].store(0, std::memory_order_relaxed);
-        }
+        // (Idle workers sleep on their mailboxes: the 1024 lane threads a 1024-wide workgroup -- the PQ traversal, the provider's length
+        // scan -- leaves behind cost nothing while later launches use the first 64 ... 256 of them.)
         while ((int)th.size() < n) {
             const int i = (int)th.size();
             th.emplace_back([this, i] { worker(i); });
@@ -207,12 +211,18 @@ struct Pool {
         body = &f;
         done.store(0, std::memory_order_relaxed);
         ++gen;
-        for (int i = 0; i < n; ++i) go[i].store(gen, std::memory_order_release);
-        while (done.load(std::memory_order_acquire) != n) std::this_thread::yield();
+        for (int i = 0; i < n; ++i) {
+            go[i].store(gen, std::memory_order_release);
+            go[i].notify_one();
+        }
+        for (int d; (d = done.load(std::memory_order_acquire)) != n;) done.wait(d, std::memory_order_acquire);
     }
     ~Pool() {
         stop.store(true);
-        for (size_t i = 0; i < th.size(); ++i) go[i].store(-1, std::memory_order_release);
+        for (size_t i = 0; i < th.size(); ++i) {
+            go[i].store(-1, std::memory_order_release);
+            go[i].notify_one();
+        }
         for (auto& t : th) t.join();
     }
 };
