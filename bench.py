@@ -556,7 +556,7 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle + fp32 CPU encoder on a bounded sample ---------
     if world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(args, g, Q, tok, off, cfg, ef, args.beam)
+            result["cpu_baseline"] = cpu_baseline(args, g, Q, tok, off, cfg, ef, args.beam, X)
         except Exception as ex:  # noqa: BLE001 - report, never lose the line
             result["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
     if rank == 0:
@@ -668,10 +668,27 @@ def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 2
     return rows, lo
 
 
-def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
+def cpu_traversal_only(orc, og, Q, X, ef, beam, ncores):
+    """SURVEY 8(d), first CPU figure: the oracle's traversal + distances alone over STORED embeddings (what faiss does once the
+    embeddings exist), 256 queries on the host cores.  Never raises: an optional figure may not cost the line."""
+    try:
+        nq = int(min(256, Q.shape[0]))
+        xt, qt = X.cpu().numpy(), Q[:nq].cpu().numpy()
+        orc.search(og, qt[:8], 10, ef=ef, beam=beam, table=xt)  # page the table in
+        t0 = time.perf_counter()
+        _, _, st = orc.search(og, qt, 10, ef=ef, beam=beam, table=xt)
+        el = time.perf_counter() - t0
+        return {"value": round(nq / el, 2), "unit": "queries/s", "cores": ncores, "kind": "port",
+                "sample": f"{nq} queries, stored embeddings (no encoder): {st['ndis'] / nq:.0f} distance evaluations per query in {el:.2f}s"}
+    except Exception as ex:  # noqa: BLE001
+        return {"value": None, "unit": "queries/s", "sample": "failed: " + repr(ex)[:200]}
+
+
+def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam, X=None):
     """The reference path on the host cores: oracle traversal (oracle/lm_oracle.c, kind "port") with
     embeddings recomputed per round by the SAME encoder in fp32 on the CPU
-    (embedding_compute.py:148-154 uses fp32 on CPU).  Bounded to ~cpu_baseline_seconds."""
+    (embedding_compute.py:148-154 uses fp32 on CPU).  Bounded to ~cpu_baseline_seconds.  With ``X`` (the corpus embeddings) the
+    traversal-only figure of SURVEY 8(d) is reported next to it (``traversal_only``)."""
     import torch
 
     from leann_amd.encoder import BertEncoder
@@ -685,6 +702,7 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     lens_all = np.diff(off.astype(np.int64))
     T = int(lens_all.max())
     stat = {"chunks": 0, "enc_s": 0.0}
+    trav = cpu_traversal_only(orc, og, Q, X, ef, beam, ncores) if X is not None else None
 
     def provider(idv):
         t0 = time.perf_counter()
@@ -721,7 +739,7 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
         return {"value": round(1.0 / one, 5), "unit": "queries/s", "cores": ncores, "kind": "port",
                 "sample": f"1 query (the calibration query: {one:.1f}s exceeds the {budget:.0f}s budget), oracle traversal + fp32 CPU encoder; "
                           f"{stat['chunks']} chunks recomputed in {stat['enc_s']:.1f}s",
-                "chunks_per_s_encoder": round(stat["chunks"] / max(stat["enc_s"], 1e-9), 1)}
+                "chunks_per_s_encoder": round(stat["chunks"] / max(stat["enc_s"], 1e-9), 1), "traversal_only": trav}
     stat = {"chunks": 0, "enc_s": 0.0}
     t0 = time.perf_counter()
     _, _, st = orc.search(og, q[1 : 1 + nq], 10, ef=ef, beam=beam, provider=provider, memo=True)  # same per-call memo as the GPU default
@@ -729,7 +747,7 @@ def cpu_baseline(args, g, Q, tok, off, cfg, ef, beam):
     return {"value": round(nq / el, 5), "unit": "queries/s", "cores": ncores, "kind": "port",
             "sample": f"{nq} queries (batched lock-step, same graph/ef/beam, per-call memo as on the GPU), oracle traversal + fp32 CPU encoder; "
                       f"{st['nunique']} chunks recomputed in {stat['enc_s']:.1f}s of {el:.1f}s",
-            "chunks_per_s_encoder": round(stat["chunks"] / max(stat["enc_s"], 1e-9), 1)}
+            "chunks_per_s_encoder": round(stat["chunks"] / max(stat["enc_s"], 1e-9), 1), "traversal_only": trav}
 
 
 if __name__ == "__main__":
