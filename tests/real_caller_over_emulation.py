@@ -1,4 +1,4 @@
-"""SURVEY 8 row a12 on the CPU box: the REAL caller -- leann.api.LeannSearcher(index).search("...") from the reference's own
+"""SURVEY 8 rows a12 (+ a1, a9) on the CPU box: the REAL caller -- leann.api.LeannSearcher(index).search("...") from the reference's own
 leann-core (api.py:623-642 factory, :644-796 search) -- driving our backend plugin down through the C ABI into the product's
 kernel sources, compiled for the host by tests/hip_emul (libleann_mi355x_emul.so).  Run as a script by
 tests/test_emulated_search.py:
@@ -119,6 +119,35 @@ def main(lib_path: str, leann_src: str, tmp: str) -> None:
         assert any(u.startswith(name) for u in used), (name, sorted(set(used)))
     print(json.dumps({"ids": [r.id for r in res], "scores": [round(float(r.score), 5) for r in res], "stats": {k: st[k] for k in ("nrounds", "nunique", "ndis")},
                       "abi_calls": len(used)}))
+
+    # ---- row a9 through the same real caller: a DiskANN-style bundle (meta.json backend_name "mi355x_diskann", recompute mode: pruned
+    #      index + product quantiser) -> LeannSearcher -> Mi355xDiskannSearcher -> lm_pq_batch_search: PQ traversal kernel + ONE deferred
+    #      exact rerank through the built-in provider (diskann_backend.py:444-449, 453-467) ----
+    from leann_amd.backend import Mi355xDiskannSearcher
+
+    p2 = str(Path(tmp) / "real_diskann.leann")
+    write_leann_bundle(p2, texts, emb, model, backend_name="mi355x_diskann", distance_metric="mips", graph_degree=8, complexity=24, pq_bytes=48,
+                       is_recompute=True)
+    used.clear()
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), \
+            mock.patch.object(Mi355xSearcher, "_torch_device", new=lambda self: cpu), \
+            mock.patch.object(_lib, "check", new=recording_check):
+        s2 = LeannSearcher(p2)
+        assert isinstance(s2.backend_impl, Mi355xDiskannSearcher)
+        q2 = 23
+        res2 = s2.search(texts[q2], top_k=3, complexity=24, beam_width=4, recompute_embeddings=True)
+        st2 = s2.backend_impl.last_stats()
+        s2.cleanup()
+    assert len(res2) == 3 and res2[0].id == str(q2) and all(r.text == texts[int(r.id)] for r in res2)
+    assert res2[0].score >= res2[1].score >= res2[2].score
+    exact2 = emb @ emb[q2]
+    assert abs(res2[0].score - float(exact2[q2])) < 5e-3 * max(1.0, abs(float(exact2[q2])))
+    assert 0 < st2["nunique"] <= 24 and st2["ndis"] >= st2["nunique"] and st2["update_launches"] == 1, st2  # PQ evaluations along the path (ndis), ONE exact rerank of the <= complexity final candidates
+    for name in ("lm_index_read", "lm_pq_attach", "lm_recompute_create", "lm_index_set_recompute", "lm_pq_batch_search"):
+        assert any(u.startswith(name) for u in used), (name, sorted(set(used)))
+    print(json.dumps({"diskann_style": {"ids": [r.id for r in res2], "scores": [round(float(r.score), 5) for r in res2],
+                                        "stats": {k: st2[k] for k in ("ndis", "nunique", "nrounds")}, "abi_calls": len(used)}}))
     print("REAL CALLER OK")
 
 
