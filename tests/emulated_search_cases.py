@@ -1032,6 +1032,59 @@ def case_native_recompute_long_id_list():
 CASES["native_recompute_long_id_list"] = case_native_recompute_long_id_list
 
 
+def case_embedding_service():
+    """SURVEY 8 rows a4 / a5 / f1 on the CPU box: the wire handlers of the ZMQ-compatible server (leann_amd/embedding_server.py: the
+    reference's hnsw_embedding_server.py:119-284 msgpack protocol and diskann_embedding_server.py:258-334 protobuf protocol) over the
+    emulated library -- embeddings by id through the built-in recompute provider (general-width model), distances through lm_dist_gather,
+    unknown ids, malformed requests."""
+    import os
+    from unittest import mock
+
+    import msgpack
+    import torch
+
+    from leann_amd import embedding_server as es
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+    from leann_amd.token_store import TokenStore
+
+    class _Stream:
+        cuda_stream = 0
+
+    cfg = EncoderConfig(vocab_size=300, hidden=128, layers=1, heads=2, ffn=128, max_pos=32, max_seq_length=16, pooling="cls")
+    enc = BertEncoder.random_init(cfg, 6).eval().half()
+    rng = np.random.default_rng(2)
+    seqs = [rng.integers(1, cfg.vocab_size, int(l)).tolist() for l in rng.integers(1, 12, 30)]
+    store = TokenStore.from_lists(seqs)
+    with torch.no_grad():
+        ref = BertEncoder.random_init(cfg, 6).eval()(torch.tensor([s_ + [0] * (16 - len(s_)) for s_ in seqs], dtype=torch.int32),
+                                                    torch.tensor([len(s_) for s_ in seqs], dtype=torch.int32)).float().numpy()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True):
+        svc = es.Mi355xEmbeddingService("test-model", enc, store, None, "mips", device=torch.device("cpu"))
+        assert msgpack.unpackb(svc.handle_msgpack(msgpack.packb(["__QUERY_MODEL__"]))) == ["test-model"]
+        dims, flat = msgpack.unpackb(svc.handle_msgpack(msgpack.packb([[3, 29, 1000]])))  # an unknown id -> zero row
+        e = np.asarray(flat, np.float32).reshape(dims)
+        assert dims == [3, 128] and np.allclose(e[:2], ref[[3, 29]], atol=4e-3) and np.all(e[2] == 0)
+        assert svc.provider.native_stats()["chunks"] == 2  # the embeddings came from the library-side provider
+        q = ref[7].tolist()
+        (d,) = msgpack.unpackb(svc.handle_msgpack(msgpack.packb([[7, 8, 12345], q])))  # distances: -e.q for mips, 1e9 for the unknown id
+        assert np.allclose(d[:2], -(ref[[7, 8]] @ ref[7]), atol=8e-3) and abs(d[2] - 1e9) < 1.0
+        svc.distance_metric = "l2"
+        (d2,) = msgpack.unpackb(svc.handle_msgpack(msgpack.packb([[[7, 8]], q])))
+        assert np.allclose(d2, ((ref[[7, 8]] - ref[7]) ** 2).sum(1), atol=8e-3)
+        assert msgpack.unpackb(svc.handle_msgpack(b"\xc1")) == [[0, 128], []]  # malformed request -> shape-correct fallback
+        data, dims, missing = es.decode_node_embedding_response(svc.handle_diskann(es.encode_node_embedding_request([1, 2, 3])))
+        assert dims == [3, 128] and missing == [] and np.allclose(np.frombuffer(data, np.float32).reshape(3, 128), ref[1:4], atol=4e-3)
+        assert svc.handle_diskann(b"") == b""
+        svc.provider.close()
+    store.close()
+    print("embedding service handlers over the emulated library (msgpack + protobuf protocols): ok", flush=True)
+
+
+CASES["embedding_service"] = case_embedding_service
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     _load(sys.argv[1])
