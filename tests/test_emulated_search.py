@@ -52,6 +52,28 @@ def test_real_leann_searcher_drives_the_product_library_on_the_cpu(emul_dir, tmp
     assert r.returncode == 0 and "REAL CALLER OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_two_rank_gloo_over_the_emulated_library(emul_dir):
+    """SURVEY 8(e) with the product's own kernels on the CPU box: broadcast_graph + PartitionedSearch + ShardedSearch (incl. the
+    lm_topk_merge kernel) on two gloo ranks, each over the emulated library -- the scenario tests/test_distributed.py runs over RCCL
+    where two GPUs are visible (tests/emulated_two_rank.py)."""
+    import socket
+
+    import build_emul_lib
+    import torch.multiprocessing as mp
+
+    from tests.emulated_two_rank import worker
+
+    lib = build_emul_lib.build(emul_dir)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(worker, args=(2, port, str(lib), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def test_plain_c_host_known_answer_against_the_emulated_library(emul_dir):
     """tests/abi/abi_host.c (C11, no Python) linked against the host build: with a "device" present it takes the same
     branch as on the GPU box and checks the hand-traced known-answer search through lm_index_search."""
