@@ -1085,6 +1085,42 @@ def case_embedding_service():
 CASES["embedding_service"] = case_embedding_service
 
 
+def case_gpu_graph_builder():
+    """Row f4 on the CPU box: leann_amd/gpu_graph_build.build_graph_gpu with its DEFAULT candidate search -- the product's stored-embedding
+    search kernel (hip_search_fn: lm_index_search_device, persistent k_search_table) -- over the emulated library, then the paper's
+    Algorithm 3 pruning: the graph is valid, and a search over it finds the exact neighbours."""
+    from unittest import mock
+
+    import torch
+
+    from leann_amd.gpu_graph_build import build_graph_gpu, prune_preserving_hubs
+    from oracle import oracle as orc
+    from tests.util import clustered, oracle_graph, queries_near, recall_at_k
+
+    class _Stream:
+        cuda_stream = 0
+
+    x = clustered(320, 32, 4, n_centers=4, sigma=0.6)
+    with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+            mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch("torch.cuda.synchronize", new=lambda *a, **k: None):
+        g = build_graph_gpu(torch.from_numpy(x), "mips", M=8, ef_construction=40, seed_nodes=128)
+    g.validate()
+    assert g.ntotal == 320 and g.level0_degrees().max() <= 16 and g.level0_degrees().min() >= 1
+    q = queries_near(x, 30, 5)
+    gt, _ = orc.bruteforce_topk(x, q, 10, 0)
+    ids, _, _ = orc.search(oracle_graph(g, 32), q, 10, ef=48, table=x)
+    r = recall_at_k(ids, gt)
+    g2 = prune_preserving_hubs(g, torch.from_numpy(x), M=8, m_low=4, hub_fraction=0.05)
+    g2.validate()
+    ids2, _, _ = orc.search(oracle_graph(g2, 32), q, 10, ef=48, table=x)
+    r2 = recall_at_k(ids2, gt)
+    print(f"graph builder over the emulated search kernel: recall@10 {r:.3f}; after hub-preserving pruning ({g2.neighbors.shape[0]} of {g.neighbors.shape[0]} links) {r2:.3f}", flush=True)
+    assert r > 0.92 and r2 > 0.9 and g2.neighbors.shape[0] < g.neighbors.shape[0]
+
+
+CASES["gpu_graph_builder"] = case_gpu_graph_builder
+
+
 if __name__ == "__main__":
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
     _load(sys.argv[1])
