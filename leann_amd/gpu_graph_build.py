@@ -51,9 +51,10 @@ def _bruteforce_knn(xs: torch.Tensor, k: int, metric: int):
 
 
 @torch.no_grad()
-def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
-    """HNSW select-neighbours heuristic, vectorised over rows.  cand [n,K] (-1 = empty), sim [n,K]
-    sorted best first.  Returns keep mask [n,K] with <= m True per row."""
+def _select_heuristic_scan(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+    """The heuristic as a scan over the K candidates (the form every graph measured up to GPU session r3-15 was built with: ~10 small
+    launches per candidate).  Kept as the reference the selection form below is tested against, and as its stand-in should a torch build
+    reject one of the selection form's indexing ops."""
     n, K = cand.shape
     keep = torch.zeros((n, K), dtype=torch.bool, device=xs.device)
     cd = _cdtype(xs)
@@ -74,6 +75,56 @@ def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m
             ok = (~conflict) & (cnt < m) & valid[:, j]
             kb[:, j] = ok
             cnt += ok.int()
+        keep[b0:b1] = kb
+    return keep
+
+
+def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+    try:
+        return _select_heuristic_selection(xs, cand, sim, m, metric, block)
+    except (RuntimeError, NotImplementedError, IndexError) as ex:  # build-time torch code: same result through the scan form
+        import logging
+
+        logging.getLogger(__name__).warning(f"select heuristic: selection form failed ({type(ex).__name__}: {ex}); using the candidate scan")
+        return _select_heuristic_scan(xs, cand, sim, m, metric, block)
+
+
+@torch.no_grad()
+def _select_heuristic_selection(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+    """HNSW select-neighbours heuristic, vectorised over rows.  cand [n,K] (-1 = empty), sim [n,K]
+    sorted best first.  Returns keep mask [n,K] with <= m True per row.
+
+    The rule (faiss shrink_neighbor_list / HNSW Alg. 4): scan the candidates best first; keep candidate j unless an already kept i is
+    at least as close to j as the base node is (cc[j, i] >= sim[j]), until m are kept.  Written as a loop over SELECTIONS rather than
+    over candidates: take the first candidate still alive, keep it, strike every candidate it dominates -- <= m steps of ~8 small
+    launches instead of K steps of ~10 (K = 2 m at level 0), and the same keep mask bit for bit (everything before the first alive
+    candidate is already decided; tests/test_host_helpers.py compares with the candidate-by-candidate scan above).  A row keeps ~10-20
+    neighbours in practice, so the loop ends after that many steps (one host check per step) instead of K = 128 scan steps."""
+    n, K = cand.shape
+    keep = torch.zeros((n, K), dtype=torch.bool, device=xs.device)
+    cd = _cdtype(xs)
+    for b0 in range(0, n, block):
+        b1 = min(n, b0 + block)
+        cb = cand[b0:b1]
+        B = b1 - b0
+        cv = xs[cb.clamp(min=0)].to(cd)
+        cc = torch.bmm(cv, cv.transpose(1, 2)).float()
+        if metric == METRIC_L2:
+            sq = (cv.float() ** 2).sum(-1)
+            cc = 2 * cc - sq[:, :, None] - sq[:, None, :]
+        dom = cc >= sim[b0:b1, :, None]  # dom[b, t, i]: kept i rules out candidate t
+        alive = cb >= 0
+        kb = torch.zeros_like(alive)
+        rows = torch.arange(B, device=xs.device)
+        for _ in range(min(m, K)):
+            has = alive.any(1)
+            if not bool(has.any()):
+                break
+            first = alive.int().argmax(1)  # first alive candidate of every row (0 where none: masked by `has`)
+            kb[rows, first] |= has
+            struck = dom[rows, :, first]  # [B, K]: candidates the new neighbour dominates (itself included or cleared below)
+            alive &= ~(struck & has[:, None])
+            alive[rows, first] = False
         keep[b0:b1] = kb
     return keep
 

@@ -90,6 +90,33 @@ def test_batched_graph_builder_with_injected_search(built_libs):
     assert recall_at_k(ids, gt) > 0.97
 
 
+def test_select_heuristic_selection_form_equals_the_candidate_scan():
+    """gpu_graph_build._select_heuristic: the loop over selections (first alive candidate, strike what it dominates) returns the keep
+    mask of the candidate-by-candidate scan bit for bit -- inner product and L2, exact ties (duplicate vectors), empty slots in the
+    middle and at the tail of a row, m larger / smaller than the number of survivors."""
+    from leann_amd import gpu_graph_build as gb
+    from leann_amd.csr_format import METRIC_INNER_PRODUCT, METRIC_L2
+
+    gen = torch.Generator().manual_seed(0)
+    for metric in (METRIC_INNER_PRODUCT, METRIC_L2):
+        for N, D, n, K, m in ((500, 16, 300, 24, 8), (200, 8, 150, 16, 16), (50, 4, 40, 12, 3), (300, 32, 500, 64, 32), (300, 8, 300, 64, 64), (64, 2, 200, 32, 5)):
+            xs = torch.randn(N, D, generator=gen)
+            nd = N // 7
+            xs[:nd] = xs[nd : 2 * nd]  # duplicates: exact ties
+            base = torch.randint(0, N, (n,), generator=gen)
+            cand = torch.stack([torch.randperm(N, generator=gen)[:K] for _ in range(n)])
+            s = (xs[base][:, None, :] * xs[cand]).sum(-1) if metric == METRIC_INNER_PRODUCT else -((xs[base][:, None, :] - xs[cand]) ** 2).sum(-1)
+            s, o = torch.sort(s, dim=1, descending=True)
+            cand = torch.gather(cand, 1, o)
+            empty = (torch.arange(K)[None, :] >= torch.randint(0, K + 1, (n,), generator=gen)[:, None]) | (torch.rand(n, K, generator=gen) < 0.05)
+            cand[empty] = -1
+            s[empty] = -float("inf")
+            a = gb._select_heuristic_scan(xs, cand, s, m, metric, block=128)
+            b = gb._select_heuristic_selection(xs, cand, s, m, metric, block=128)
+            assert torch.equal(a, b) and int(a.sum(1).max()) <= m, (metric, N, D, n, K, m)
+            assert torch.equal(gb._select_heuristic(xs, cand, s, m, metric), a)
+
+
 def test_packed_weight_caches_follow_the_source_weights():
     """leann_amd/encoder.py: _packed keys every packed-weight copy on (device, storage address, in-place version, dtype) of its
     sources: an in-place update (load_state_dict, optimiser step) or a dtype change must rebuild the pack, an untouched module
