@@ -50,8 +50,19 @@ def _bruteforce_knn(xs: torch.Tensor, k: int, metric: int):
     return ti, ts
 
 
+def _domination_threshold(sim: torch.Tensor, metric: int, alpha: float) -> torch.Tensor:
+    """thr[t]: a kept neighbour i rules candidate t out when cc[t, i] >= thr[t].  alpha = 1 is the HNSW rule (i at least as close to t as
+    the base node is: thr = sim, bit for bit the historic behaviour).  alpha > 1 is Vamana's relaxation (DiskANN, Subramanya et al. 2019,
+    RobustPrune: alpha * d(i, t) <= d(t, base)), which keeps more and longer edges: on squared L2 (similarity = -d^2)
+    thr = sim / alpha^2; on inner products of UNIT vectors (d^2 = 2 - 2 ip) thr = 1 - (1 - sim) / alpha^2."""
+    if alpha == 1.0:
+        return sim
+    a2 = float(alpha) * float(alpha)
+    return sim / a2 if metric == METRIC_L2 else 1.0 - (1.0 - sim) / a2
+
+
 @torch.no_grad()
-def _select_heuristic_scan(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+def _select_heuristic_scan(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048, alpha: float = 1.0):
     """The heuristic as a scan over the K candidates (the form every graph measured up to GPU session r3-15 was built with: ~10 small
     launches per candidate).  Kept as the reference the selection form below is tested against, and as its stand-in should a torch build
     reject one of the selection form's indexing ops."""
@@ -75,22 +86,29 @@ def _select_heuristic_scan(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tens
             ok = (~conflict) & (cnt < m) & valid[:, j]
             kb[:, j] = ok
             cnt += ok.int()
+        if alpha != 1.0:  # second pass (DiskANN occlude_list: alpha 1, then the relaxed rule over what is left, while slots remain)
+            sa = _domination_threshold(sb, metric, alpha)
+            for j in range(K):
+                conflict = ((cc[:, j, :] >= sa[:, j : j + 1]) & kb).any(1)
+                ok = (~conflict) & (cnt < m) & valid[:, j] & ~kb[:, j]
+                kb[:, j] |= ok
+                cnt += ok.int()
         keep[b0:b1] = kb
     return keep
 
 
-def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+def _select_heuristic(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048, alpha: float = 1.0):
     try:
-        return _select_heuristic_selection(xs, cand, sim, m, metric, block)
+        return _select_heuristic_selection(xs, cand, sim, m, metric, block, alpha)
     except (RuntimeError, NotImplementedError, IndexError) as ex:  # build-time torch code: same result through the scan form
         import logging
 
         logging.getLogger(__name__).warning(f"select heuristic: selection form failed ({type(ex).__name__}: {ex}); using the candidate scan")
-        return _select_heuristic_scan(xs, cand, sim, m, metric, block)
+        return _select_heuristic_scan(xs, cand, sim, m, metric, block, alpha)
 
 
 @torch.no_grad()
-def _select_heuristic_selection(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048):
+def _select_heuristic_selection(xs: torch.Tensor, cand: torch.Tensor, sim: torch.Tensor, m: int, metric: int, block: int = 2048, alpha: float = 1.0):
     """HNSW select-neighbours heuristic, vectorised over rows.  cand [n,K] (-1 = empty), sim [n,K]
     sorted best first.  Returns keep mask [n,K] with <= m True per row.
 
@@ -112,19 +130,25 @@ def _select_heuristic_selection(xs: torch.Tensor, cand: torch.Tensor, sim: torch
         if metric == METRIC_L2:
             sq = (cv.float() ** 2).sum(-1)
             cc = 2 * cc - sq[:, :, None] - sq[:, None, :]
-        dom = cc >= sim[b0:b1, :, None]  # dom[b, t, i]: kept i rules out candidate t
         alive = cb >= 0
         kb = torch.zeros_like(alive)
         rows = torch.arange(B, device=xs.device)
-        for _ in range(min(m, K)):
-            has = alive.any(1)
-            if not bool(has.any()):
-                break
-            first = alive.int().argmax(1)  # first alive candidate of every row (0 where none: masked by `has`)
-            kb[rows, first] |= has
-            struck = dom[rows, :, first]  # [B, K]: candidates the new neighbour dominates (itself included or cleared below)
-            alive &= ~(struck & has[:, None])
-            alive[rows, first] = False
+        for a in ((1.0,) if alpha == 1.0 else (1.0, alpha)):  # DiskANN occlude_list: the strict rule first, then the relaxed one over what is left
+            dom = cc >= _domination_threshold(sim[b0:b1], metric, a)[:, :, None]  # dom[b, t, i]: kept i rules out candidate t
+            relaxed = a != 1.0
+            if relaxed:  # not kept, not ruled out (relaxed rule) by anything kept so far, rows with slots left only
+                alive = (cb >= 0) & ~kb & ~(dom & kb[:, None, :]).any(2) & (kb.sum(1) < m)[:, None]
+            for _ in range(min(m, K)):  # (strict pass: every step keeps one candidate per live row, so m steps bound every row by m)
+                has = alive.any(1)
+                if not bool(has.any()):
+                    break
+                first = alive.int().argmax(1)  # first alive candidate of every row (0 where none: masked by `has`)
+                kb[rows, first] |= has
+                struck = dom[rows, :, first]  # [B, K]: candidates the new neighbour dominates (itself included or cleared below)
+                alive &= ~(struck & has[:, None])
+                alive[rows, first] = False
+                if relaxed:  # rows enter this pass with different counts
+                    alive &= (kb.sum(1) < m)[:, None]
         keep[b0:b1] = kb
     return keep
 
@@ -139,6 +163,7 @@ class _LevelGraph:
         self.adj = torch.full((n, cap), -1, dtype=torch.int64, device=sub.device)
         self.sim = torch.full((n, cap), -float("inf"), dtype=torch.float32, device=sub.device)
         self.deg = torch.zeros((n,), dtype=torch.int64, device=sub.device)
+        self.alpha = 1.0  # neighbour-selection relaxation (_domination_threshold); build_graph_gpu(alpha=...) sets it
 
     @torch.no_grad()
     def add_links(self, xs: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, w: torch.Tensor, metric: int):
@@ -185,7 +210,7 @@ class _LevelGraph:
         new_sim = csim[:, :cap].clone()
         if bool(over.any()):
             oi = torch.nonzero(over).flatten()
-            keep = _select_heuristic(xs, cand[oi], csim[oi], cap, metric)
+            keep = _select_heuristic(xs, cand[oi], csim[oi], cap, metric, alpha=self.alpha)
             # compact kept entries to the front (stable)
             order = torch.argsort((~keep).int(), dim=1, stable=True)
             kc = torch.gather(cand[oi], 1, order)[:, :cap]
@@ -267,8 +292,10 @@ def hip_search_fn(device_index: int = 0, beam: int = 2) -> SearchFn:
 @torch.no_grad()
 def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, ef_construction: int = 200, seed: int = 12345,
                     search_fn: Optional[SearchFn] = None, growth: float = 1.5, k_cand: int = 0,
-                    seed_nodes: int = 2048, refine: bool = True, verbose: bool = False) -> HnswCsr:
-    """x: [N, D] float tensor on the build device.  Returns the compact-CSR HNSW graph (host)."""
+                    seed_nodes: int = 2048, refine: bool = True, verbose: bool = False, alpha: float = 1.0) -> HnswCsr:
+    """x: [N, D] float tensor on the build device.  Returns the compact-CSR HNSW graph (host).  ``alpha`` > 1 relaxes the neighbour
+    selection the way Vamana does (denser lists with longer edges: what a PQ-guided walk over a flat graph needs at 10M nodes -- DESIGN 8;
+    inner-product metrics then assume unit vectors); 1.0 = the HNSW rule, the graphs every measurement so far was taken on."""
     metric = metric.lower()
     if metric not in ("mips", "cosine", "l2"):
         raise ValueError(f"Unsupported distance_metric '{metric}'.")
@@ -296,6 +323,7 @@ def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, ef_const
         xs = x[sub]
         cap = 2 * M if l == 0 else M
         G = _LevelGraph(sub, cap)
+        G.alpha = alpha
         inserted = torch.zeros(nl, dtype=torch.bool, device=dev)
         if finished and finished[0].sub.shape[0] >= 2:
             # seed with the level above (its nodes are a subset of this level)
@@ -316,7 +344,7 @@ def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, ef_const
                 perm0 = torch.unique(torch.cat([torch.searchsorted(sub, finished[0].sub), perm0]))
             ci, cs = _bruteforce_knn(xs[perm0], min(k_cand, perm0.shape[0] - 1), mt)
             if ci.shape[1] > 0:
-                keep = _select_heuristic(xs[perm0], ci, cs, M, mt)
+                keep = _select_heuristic(xs[perm0], ci, cs, M, mt, alpha=alpha)
                 src = perm0[torch.arange(perm0.shape[0], device=dev)[:, None].expand_as(ci)[keep]]
                 dst = perm0[ci[keep]]
                 w = cs[keep]
@@ -356,7 +384,7 @@ def build_graph_gpu(x: torch.Tensor, metric: str = "mips", M: int = 32, ef_const
                 o = torch.argsort(sim, dim=1, descending=True, stable=True)
                 ids, sim = torch.gather(ids, 1, o), torch.gather(sim, 1, o)
             ids = ids.masked_fill(~torch.isfinite(sim), -1)
-            keep = _select_heuristic(xs, ids, sim, M, mt)
+            keep = _select_heuristic(xs, ids, sim, M, mt, alpha=alpha)
             src = batch[:, None].expand_as(ids)[keep]
             dst = ids[keep]
             w = sim[keep]

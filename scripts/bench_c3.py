@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--pq-bytes", type=int, default=96)
     ap.add_argument("--M", type=int, default=16, help="graph degree / 2 of the Vamana-style flat graph (degree 32)")
     ap.add_argument("--efc", type=int, default=128)
+    ap.add_argument("--alpha", type=float, default=1.0, help="neighbour-selection relaxation of the graph builder (1.0 = the HNSW rule; 1.2 = Vamana's, denser lists)")
     ap.add_argument("--cpu-baseline-queries", type=int, default=8)
     ap.add_argument("--pq-threads", type=int, default=1024, choices=[256, 512, 1024], help="workgroup width of the traversal kernel (A/B)")
     ap.add_argument("--pooling", default="mean", choices=["mean", "cls"],
@@ -80,7 +81,7 @@ def main():
     t_embed = time.time() - t0
     log(f"embedded in {t_embed:.0f}s ({n / t_embed:.0f} chunks/s)")
     t0 = time.time()
-    g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc)
+    g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc, alpha=args.alpha)
     fg = flat_graph(g, X)
     t_graph = time.time() - t0
     log(f"flat graph (degree <= {2 * args.M}) in {t_graph:.0f}s, mean degree {fg.level0_degrees().mean():.1f}")

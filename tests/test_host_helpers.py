@@ -115,6 +115,21 @@ def test_select_heuristic_selection_form_equals_the_candidate_scan():
             b = gb._select_heuristic_selection(xs, cand, s, m, metric, block=128)
             assert torch.equal(a, b) and int(a.sum(1).max()) <= m, (metric, N, D, n, K, m)
             assert torch.equal(gb._select_heuristic(xs, cand, s, m, metric), a)
+            # Vamana-style relaxation (alpha > 1: the strict pass first, then the relaxed rule over what is left while slots remain): both
+            # forms agree, the strict pass's neighbours all stay, the cap holds
+            xn = torch.nn.functional.normalize(xs, dim=1)
+            sn = (xn[base][:, None, :] * xn[cand.clamp(min=0)]).sum(-1) if metric == METRIC_INNER_PRODUCT else s
+            if metric == METRIC_INNER_PRODUCT:
+                sn[empty] = -float("inf")
+                sn, o2 = torch.sort(sn, dim=1, descending=True)
+                cn = torch.gather(cand, 1, o2)
+            else:
+                cn = cand
+            base1 = gb._select_heuristic_scan(xn, cn, sn, m, metric, block=128)
+            for alpha in (1.2, 1.5):
+                ra = gb._select_heuristic_scan(xn, cn, sn, m, metric, block=128, alpha=alpha)
+                rb = gb._select_heuristic_selection(xn, cn, sn, m, metric, block=128, alpha=alpha)
+                assert torch.equal(ra, rb) and int(ra.sum(1).max()) <= m and bool((ra | base1).eq(ra).all()) and int(ra.sum()) >= int(base1.sum())
 
 
 def test_packed_weight_caches_follow_the_source_weights():
