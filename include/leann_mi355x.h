@@ -278,6 +278,23 @@ int lm_attn_out_mlp_fused_h384_f16(const void *d_attn, const void *d_resid, cons
                                    const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
                                    const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps, void *stream);
 
+/* Fourth generation of the fused layer tail (csrc/lm_layer_tail_h384.hip) -- same operation and operands as
+ * lm_attn_out_mlp_fused_h384_f16, but the three weight matrices are passed as ready-made LDS IMAGES (written once per model by
+ * lm_layer_tail_pack_h384 from the packings above), so that the kernel's weight stream is a linear LDS-DMA copy, and the two
+ * products of the feed-forward block alternate MFMA by MFMA on single accumulator chains (no partial sums, no stage arithmetic:
+ * ~290 instead of ~470 instructions per 48 MFMAs on its one wave per SIMD).  ffn a multiple of 192 in [192, 2496]; other shapes:
+ * the general GEMM path.  DEFAULT path of the hidden-384 forward.  Part of the BERT forward in compute_embeddings
+ * (leann/embedding_compute.py:229-239). */
+int lm_layer_tail_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_img, const float *d_bo,
+                           const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1_img, const float *d_b1,
+                           const void *d_w2_img, const float *d_b2, const void *d_gamma, const void *d_beta, void *d_out,
+                           int64_t tokens, int32_t ffn, float eps, void *stream);
+/* d_wo_slabs [12][384][32] (pack_wo_slabs), d_w1_acc [ffn][384] (pack_w1_acc_order), d_w2_slabs [ffn/32][384][32]
+ * (pack_w2_fused_mlp) -> the images lm_layer_tail_h384_f16 streams (same sizes; XOR-swizzled 16-byte chunks: what makes the
+ * kernel's ds_read_b128 fragment reads bank-conflict free).  Device to device, on `stream`. */
+int lm_layer_tail_pack_h384(const void *d_wo_slabs, const void *d_w1_acc, const void *d_w2_slabs, int32_t ffn, void *d_wo_img,
+                            void *d_w1_img, void *d_w2_img, void *stream);
+
 /* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
  *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
  *   d_out[tokens][384]   = LayerNorm(residual + x W^T + b) gamma+beta (d_residual != NULL, n_out == 384)

@@ -522,6 +522,9 @@ class Mi355xDiskannSearcher(Mi355xSearcher):
         return all(Path(pre + sfx).exists() for sfx in ("_pq_pivots.bin", "_pq_compressed.bin", "_disk.index"))
 
     def __init__(self, index_path: str, **kwargs):
+        # the base class warms up at the end of ITS constructor, which would run this class' _ensure_index_loaded before _stock / pq_file
+        # exist (LeannSearcher forwards enable_warmup to the backend searcher, api.py:623-642): warm up at the end of this one instead
+        warm = bool(kwargs.pop("enable_warmup", False))
         super().__init__(index_path, **kwargs)
         self.num_threads = kwargs.get("num_threads", 8)
         self.pq_file = self.index_dir / f"{self.index_path.stem}_pq.npz"
@@ -533,6 +536,8 @@ class Mi355xDiskannSearcher(Mi355xSearcher):
         if Path(self._stock_prefix() + "_disk_graph.index").exists() and self._stock and not self._has_alternative_index_files():
             raise FileNotFoundError("this is a recompute-mode bundle of the stock DiskANN backend: its graph (_disk_graph.index / _partition.bin) is in "
                                     "the fork's private format, which leann-backend-mi355x does not read")
+        if warm:
+            self._ensure_index_loaded()
 
     def _ensure_index_loaded(self):
         if self._stock and self._index is None:

@@ -241,11 +241,8 @@ static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int
 #define CASEA(n)                                                                                                                         \
     case n: {                                                                                                                            \
         if (shmem > 48 * 1024) {                                                                                                         \
-            static size_t attr_bytes = 0;                                                                                                \
-            if (shmem > attr_bytes) {                                                                                                    \
-                LM_HIP(hipFuncSetAttribute((const void*)k_attn_varlen_hd32_v2<n, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-                attr_bytes = shmem;                                                                                                      \
-            }                                                                                                                            \
+            static DynLdsAttr attr;                                                                                                      \
+            LM_HIP(ensure_dyn_lds(attr, (const void*)k_attn_varlen_hd32_v2<n, HD>, shmem));                                              \
         }                                                                                                                                \
         hipLaunchKernelGGL((k_attn_varlen_hd32_v2<n, HD>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units);     \
     } break

@@ -324,25 +324,23 @@ static int gemm_launch_var(const void* d_x, const void* d_w, const float* d_bias
 #ifdef LM_EMULATED_DEVICE
     static const int cus_per_xcd = 1;  // host emulation: tiny grids, so that every test walks multi-tile lists
 #else
-    static const int cus_per_xcd = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t pr;
-            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount;
-        }
-        return cus / 8;
-    }();
+    static int cus_by_dev[32] = {};  // per device: a process may search on more than one GPU
+    int dev_now = 0;
+    if (hipGetDevice(&dev_now) != hipSuccess || dev_now < 0) dev_now = 0;
+    int& cus_cached = cus_by_dev[dev_now & 31];
+    if (cus_cached == 0) {
+        int cus = 0;
+        cus_cached = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_now) == hipSuccess && cus >= 8 ? cus : 256;
+    }
+    const int cus_per_xcd = cus_cached / 8;
 #endif
     int64_t slots = std::min<int64_t>(per_xcd, cus_per_xcd * (S::LDS <= 80 * 1024 ? 2 : 1));
 #ifdef LM_DIAG
     static const bool one_per_tile = [] { const char* v = getenv("LEANN_MI355X_GEMM_GRID"); return v && !strcmp(v, "tiles"); }();
     if (one_per_tile) slots = per_xcd;
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
-        LM_HIP(hipFuncSetAttribute((const void*)k_gemm_f16<S, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS));
-        attr_set = true;
-    }
+    static DynLdsAttr attr;
+    LM_HIP(ensure_dyn_lds(attr, (const void*)k_gemm_f16<S, EPI, VAR>, S::LDS));
     hipLaunchKernelGGL((k_gemm_f16<S, EPI, VAR>), dim3((unsigned)(8 * slots)), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
                        (const __half*)d_resid, (__half*)d_out, (int)tokens, n_out, k_in);
     LM_HIP(hipGetLastError());

@@ -189,11 +189,8 @@ extern "C" int lm_gemm_ws_h384_f16(const void* d_x, const void* d_w, const float
     if (n_out <= 0 || n_out % WS_ROWS || n_out / WS_ROWS > 32) LM_FAIL(LM_EINVAL, "n_out must be a multiple of 192, at most 6144");
 #define WS_GO(S)                                                                                                                          \
     do {                                                                                                                                  \
-        static bool attr_set = false; /* once per process, not per launch */                                                              \
-        if (!attr_set) {                                                                                                                  \
-            LM_HIP(hipFuncSetAttribute((const void*)k_gemm_ws_h384<S>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_TOTAL));        \
-            attr_set = true;                                                                                                              \
-        }                                                                                                                                 \
+        static DynLdsAttr attr; /* once per process and device, not per launch */                                                        \
+        LM_HIP(ensure_dyn_lds(attr, (const void*)k_gemm_ws_h384<S>, WS_LDS_TOTAL));                                                       \
         hipLaunchKernelGGL(k_gemm_ws_h384<S>, dim3(256), dim3(512), WS_LDS_TOTAL, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w, \
                            d_bias, (__half*)d_out, (int)tokens, n_out / WS_ROWS);                                                          \
     } while (0)

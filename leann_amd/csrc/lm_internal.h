@@ -52,6 +52,22 @@ void set_error(const std::string& msg);
         return (code);            \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that searches on a second GPU must raise
+// it there too.  One of these per kernel instantiation (a function-local static), keyed by the current device; set again only
+// when the request grows.  (Two threads racing on the first launch set the attribute twice: harmless.)
+struct DynLdsAttr {
+    size_t bytes[32] = {};
+};
+inline hipError_t ensure_dyn_lds(DynLdsAttr& a, const void* fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    size_t& have = a.bytes[dev & 31];
+    if (bytes <= have && dev < 32) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
 // ---- query phases (same state machine as oracle/lm_oracle.c) ----
 enum : int32_t { PH_SEED = 0, PH_UPPER = 1, PH_BEAM = 2, PH_DONE = 3 };
 

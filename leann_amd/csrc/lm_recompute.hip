@@ -349,6 +349,7 @@ int lm_recompute_provider(void* user, const int32_t* d_ids, int32_t n, void** d_
     using namespace lm;
     lm_recompute* rc = (lm_recompute*)user;
     if (!rc || !d_out || n < 0 || (n > 0 && !d_ids)) LM_FAIL(LM_EINVAL, "lm_recompute_provider: bad arguments");
+    LM_HIP(hipSetDevice(rc->device));  // buffers and launches belong to the handle's device, whatever the caller's current one is
     hipStream_t st = (hipStream_t)stream;
     // first allocation: 4096 rows (6 MB) -- the rounds of a small-batch search grow from one chunk to a few hundred, and every
     // re-allocation costs a synchronisation
@@ -361,6 +362,7 @@ int lm_recompute_provider(void* user, const int32_t* d_ids, int32_t n, void** d_
 int lm_recompute_embed(lm_recompute* rc, const int32_t* d_ids, int32_t n, float* d_out, void* stream) {
     using namespace lm;
     if (!rc || n < 0 || (n > 0 && (!d_ids || !d_out))) LM_FAIL(LM_EINVAL, "lm_recompute_embed: bad arguments");
+    LM_HIP(hipSetDevice(rc->device));
     return rc_embed(rc, d_ids, n, d_out, (hipStream_t)stream);
 }
 

@@ -588,6 +588,63 @@ int main(int argc, char** argv) {
         }
         unsetenv("LEANN_MI355X_ABLATE");
         unsetenv("LEANN_MI355X_MLP_VARIANT");
+        if (want("tail4")) {  // generation 4 (lm_layer_tail_h384.hip): every schedule variant of the diagnosis library, interleaved with generation 3
+            Dev<__half> woi((size_t)H * H), w1i((size_t)F * H), w2i((size_t)H * F), out4((size_t)T * H);
+            LM(lm_layer_tail_pack_h384(wop.p, w1a.p, w2p.p, F, woi.p, w1i.p, w2i.p, st));
+            auto run4 = [&] {
+                LM(lm_layer_tail_h384_f16(x.p, res.p, woi.p, bo.p, gamma1.p, beta1.p, 1e-12f, w1i.p, b1.p, w2i.p, b2.p, gamma.p, beta.p, out4.p, T, F,
+                                          1e-12f, st));
+            };
+            // LEANN_MI355X_TAIL4 = 1000 DM + 100 RD/4 + 10 GF + WM (DM: DMA pieces 0 at slot 0 / 1 three groups / 2 singles; RD 4 / 8; GF 1 C, 4 asm; WM 1 batched LDS waits)
+            const char* vars[] = {"0", "110", "1110", "2110", "210", "1210", "2210", "211", "1211", "2211", "2140", "2241", "1241"};
+            for (const char* v : vars) {  // correctness of every variant first (sampled rows against the fp32 reference, all rows against generation 3)
+                setenv("LEANN_MI355X_TAIL4", v, 1);
+                CK(hipMemsetAsync(out4.p, 0xFF, out4.n * sizeof(__half), st));
+                run4();
+                CK(hipStreamSynchronize(st));
+                auto a = outf.host(), b = out4.host();
+                double d4 = 0;
+                for (size_t i = 0; i < a.size(); ++i) {
+                    double d = fabs((double)__half2float(a[i]) - (double)__half2float(b[i]));
+                    if (!(d <= d4)) d4 = d;
+                }
+                printf("{\"kernel\": \"lm_layer_tail_h384_f16\", \"variant\": \"%s\", \"max_abs_err\": %.3g, \"max_abs_diff_vs_generation_3_all_rows\": %.3g}\n", v,
+                       max_err_rows(b, H, 0, H, rows, ref), d4);
+                fflush(stdout);
+            }
+            for (int round = 0; round < 3; ++round) {
+                const float usf = time_us(st, reps, runf);
+                printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 (generation 3)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f}\n", round, usf, gflop / usf * 1e-3);
+                for (const char* v : vars) {
+                        setenv("LEANN_MI355X_TAIL4", v, 1);
+                    const float us4 = time_us(st, reps, run4);
+                    printf("{\"kernel\": \"lm_layer_tail_h384_f16\", \"variant\": \"%s\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f}\n", v, round, us4, gflop / us4 * 1e-3);
+                    fflush(stdout);
+                }
+            }
+            for (const char* v : {"10110", "12110", "12211", "11211", "12241"}) {  // stamps (10000 +)
+                setenv("LEANN_MI355X_TAIL4", v, 1);
+                const int nwg = (T + 127) / 128;
+                for (int rep = 0; rep < 3; ++rep) run4();
+                CK(hipStreamSynchronize(st));
+                const float us = time_us(st, reps, run4);
+                auto ho = out4.host();
+                double sum[10] = {0};
+                for (int b = 0; b < nwg; ++b) {
+                    unsigned long long tt[10];
+                    memcpy(tt, (const char*)ho.data() + (size_t)b * 128 * H * 2, 80);
+                    // stamp order in time: 0 start, 1 prologue done, 8 out-projection done, 9 LayerNorm 1 done, 2 first product, 3 iteration 0, 4 (s = 19), 5 steady done, 6 final, 7 end
+                    const int ord[10] = {0, 1, 8, 9, 2, 3, 4, 5, 6, 7};
+                    for (int i = 1; i < 10; ++i) sum[i] += (double)(tt[ord[i]] - tt[ord[i - 1]]);
+                }
+                printf("{\"kernel\": \"lm_layer_tail_h384_f16 stamps\", \"variant\": \"%s\", \"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"out-projection (12 slabs)\": %.0f, \"LayerNorm 1 in registers\": %.0f, "
+                       "\"first product of slab 0\": %.0f, \"iteration 0\": %.0f, \"per steady iteration s = 1..18\": %.0f, \"per steady iteration s = 19..46\": %.0f, "
+                       "\"last iteration + final second product\": %.0f, \"epilogue\": %.0f}}\n",
+                       v, us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg / 18, sum[7] / nwg / 28, sum[8] / nwg, sum[9] / nwg);
+                fflush(stdout);
+            }
+            unsetenv("LEANN_MI355X_TAIL4");
+        }
         fflush(stdout);
     }
     if (want("attn")) {

@@ -61,7 +61,7 @@ using hipEvent_t = void*;
 enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
-enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate };
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate, hipDeviceAttributeMultiprocessorCount };
 inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 inline hipError_t hipMalloc(void** p, size_t n) {
     *p = nullptr;  // exact size (AddressSanitizer then sees every byte past the end), 256-byte aligned like hipMalloc
@@ -78,6 +78,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n)
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }

@@ -146,6 +146,12 @@ def test_diskann_style_backend_host_logic(tmp_path, built_libs):
     if _lib.device_count() == 0:
         with pytest.raises(_lib.LeannMi355xError, match="no HIP device"):
             s.search(x[:1], 3)
+        # enable_warmup (forwarded by LeannSearcher, api.py:623-642) loads the index from the constructor: on this box that is the
+        # same "no HIP device" error -- not an AttributeError from the subclass' half-built state (round-3 advisor finding)
+        with pytest.raises(_lib.LeannMi355xError, match="no HIP device"):
+            Mi355xDiskannSearcher(p, enable_warmup=True)
+    else:
+        assert Mi355xDiskannSearcher(p, enable_warmup=True)._index is not None
     os.remove(tmp_path / "d_pq.npz")
     with pytest.raises(FileNotFoundError):
         Mi355xDiskannSearcher(p)
