@@ -15,11 +15,14 @@ survives a call: every step starts from an empty memo, ids and distances are bit
 this run on the timed queries themselves).  The memo-less rate (dedup per lock-step round only -- what rounds 1 and 2 reported
 as `value`) is timed in the same run on the same queries and printed as `without_call_memo`.
 
-Encoder kernels: the default set (the one `pytest -m gpu` tests).  Instrumentation inside the timed region: ONE HIP event
-pair around each launch of the dominant kernel (the contract's "measured live with HIP events over the timed region"; ~4k
-pairs per step, ~2 us each against ~1.4 ms launches -- stated in the JSON line as roofline.instrumentation); the search
-library's own per-launch profiling (event pairs + device span stamps around the distance kernels) is OFF in the timed steps
-and ON only in one extra profiled step, which is where roofline_distance_kernel / roofline_encoder come from.
+The timed steps run the PRODUCT DEFAULT path end to end: the library-side recompute provider (csrc/lm_recompute.hip: ids -> token
+store -> packed forward inside lm_index_search_device, no interpreter in the search loop) over the default kernel set (the one
+`pytest -m gpu` tests).  Instrumentation inside the timed region: ONE HIP event pair around each launch of the dominant kernel,
+recorded BY THE LIBRARY on the launch stream (csrc/lm_timing.cpp, lm_kernel_timing_enable; ~1k pairs per step, ~2 us each
+against ~1.7 ms launches -- stated in the JSON line as roofline.instrumentation); the search library's own per-launch profiling
+(event pairs + device span stamps around the distance kernels) and the event pairs of the other encoder kernels are OFF in the
+timed steps and ON only in one extra profiled step, which is where roofline_distance_kernel / roofline_encoder /
+encoder_kernels_profiled_step come from.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 For N > 1 the driver launches one rank per GPU through torch.distributed.run; the graph and the
@@ -71,7 +74,46 @@ def main():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
     ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows")
     ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
+    ap.add_argument("--dry-run-emulated", default=None, metavar="LIB",
+                    help="TEST ONLY (tests/test_bench_dry_run.py): run this script's control flow -- incl. every world > 1 branch, over gloo -- on the CPU against "
+                         "the thread-per-lane build of the library (tests/hip_emul), with a tiny model and corpus; the line says data = dry-run and measures nothing")
     args = ap.parse_args()
+    if args.dry_run_emulated:
+        import contextlib
+
+        with contextlib.ExitStack() as stack:
+            _enter_dry_run(args, stack)
+            return _main(args, ap)
+    return _main(args, ap)
+
+
+def _enter_dry_run(args, stack):
+    """Everything the CPU dry run needs: the emulated library instead of the product's, host tensors pretending to be device tensors
+    (as tests/emulated_two_rank.py does for the library's own multi-GPU classes), a tiny general-width model preset and corpus."""
+    from unittest import mock
+
+    import torch
+
+    from leann_amd import _lib, encoder
+
+    _lib.LIB_PATH = Path(args.dry_run_emulated)
+    _lib._lib = None
+
+    class _Stream:
+        cuda_stream = 0
+
+    stack.enter_context(mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)))
+    stack.enter_context(mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()))
+    stack.enter_context(mock.patch("torch.cuda.synchronize", new=lambda *a, **k: None))
+    stack.enter_context(mock.patch("torch.cuda.set_device", new=lambda *a, **k: None))
+    encoder.PRESETS["dry-run-tiny"] = encoder.EncoderConfig(vocab_size=2000, hidden=128, layers=1, heads=4, ffn=128, max_pos=32, pooling="mean",
+                                                            max_seq_length=24)
+    args.model = "dry-run-tiny"
+    torch.set_num_threads(1)
+
+
+def _main(args, ap):
+    dry = bool(args.dry_run_emulated)
     if args.config in ("c3", "c4"):  # own entry points (different index type / sharded index); same JSON contract
         import runpy
 
@@ -110,27 +152,43 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if not dry else torch.device("cpu")
+    lib_dev = local_rank if not dry else 0  # (the emulated library is one "device")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     K, W, B = args.steps, args.warmup, args.batch
-    # HIP-event pairs around every launch of the dominant kernel (the fused feed-forward block) for the WHOLE process, labelled by
-    # phase: the roofline line uses the launches of the timed region; the all-launch average is what a rocprofv3 --kernel-trace
-    # --stats table of this same command reports for the kernel (profiles/r2_bench_c2_kernel_stats.csv).
-    from leann_amd.encoder import KernelTimers
+    # HIP-event pairs around every launch of the dominant kernel for the WHOLE process, recorded by the library itself (csrc/lm_timing.cpp)
+    # and read out phase by phase: the roofline line uses the launches of the timed region; the all-launch average is what a rocprofv3
+    # --kernel-trace --stats table of this same command reports for the kernel.
+    kt_dominant = _lib.KT_LAYER_TAIL if config_for(args.model).hidden == 384 and config_for(args.model).ffn % 192 == 0 else _lib.KT_GEMM_F16
+    KT_NAMES = {_lib.KT_LAYER_TAIL: "lm::k_layer_tail_h384", _lib.KT_GEMM_WS: "lm::k_gemm_ws_h384", _lib.KT_ATTN: "lm::k_attn_varlen", _lib.KT_GEMM_F16: "lm::k_gemm_f16"}
+    _lib.kernel_timing_enable(1 << kt_dominant)
+    kt_phase = {}  # phase -> {kernel: {"launches", "ms", "work"}}
 
-    ktm = KernelTimers.active = KernelTimers()
-    EXTRA_ROWS = 8192  # small-batch latency rows (library-side provider, then the Python provider) + parity-check queries (fresh, after every step's block)
+    def kt_close(phase):  # fold everything recorded since the previous call into `phase`
+        cur = _lib.kernel_timing_read(reset=True)
+        acc = kt_phase.setdefault(phase, {})
+        for k_, v_ in cur.items():
+            a_ = acc.setdefault(k_, {"launches": 0, "ms": 0.0, "work": 0.0})
+            for f_ in a_:
+                a_[f_] += v_[f_]
+        return acc
+
+    EXTRA_ROWS = 8192 if not dry else 32  # small-batch latency rows (library-side provider, then the Python provider) + parity-check queries (fresh, after every step's block)
     n_q = B * (K + W + 5) + EXTRA_ROWS  # +5: the profiled step and the extra steps (smallest ef reaching recall 0.9; hub cache; two-level search; one spare)
     t_setup = time.time()
 
     # ---- corpus -> HBM token store ------------------------------------------------------------
-    spec = (CorpusSpec(n_chunks=args.chunks, seed=1234) if not args.fixed_len else
+    spec = (CorpusSpec(n_chunks=args.chunks, seed=1234, vocab_size=2000, n_topics=8, len_mean=10.0, len_std=3.0, len_min=4, len_max=20) if dry else
+            CorpusSpec(n_chunks=args.chunks, seed=1234) if not args.fixed_len else
             CorpusSpec(n_chunks=args.chunks, seed=1234, len_mean=float(args.fixed_len), len_std=0.0, len_min=args.fixed_len, len_max=args.fixed_len))
     corpus = SyntheticCorpus(spec)
     tok, off = corpus.chunks()
-    tokens = TokenStore(tok, off, device=local_rank)
+    tokens = TokenStore(tok, off, device=lib_dev)
     log(f"corpus: {args.chunks} chunks, {int(off[-1])} tokens ({time.time() - t_setup:.1f}s)")
 
     # ---- encoder ------------------------------------------------------------------------------
@@ -165,12 +223,12 @@ def main():
         log(f"index replicated to {world} ranks in {time.time() - t0:.1f}s")
     deg0 = g.level0_degrees()
     log(f"graph built in {t_graph:.1f}s: max_level={g.max_level} mean level-0 degree={deg0.mean():.1f} edges={g.neighbors.shape[0]}")
-    idx = Mi355xIndex.from_csr(g, device=local_rank)
+    idx = Mi355xIndex.from_csr(g, device=lib_dev)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # ---- queries + exact ground truth ------------------------------------------------------------
     qt, qo, _ = corpus.queries(n_q * world, seed=4321)
-    qstore = TokenStore(qt, qo, device=local_rank)
+    qstore = TokenStore(qt, qo, device=lib_dev)
     Q_all = RecomputeProvider(enc, qstore, provider.dp, dev).embed_ids(torch.arange(n_q * world, dtype=torch.int32, device=dev))
     Q = Q_all[rank * n_q : (rank + 1) * n_q].contiguous()
     gt = torch.empty((n_q, 10), dtype=torch.int64, device=dev)
@@ -260,13 +318,13 @@ def main():
 
     batches = [global_batch(w) for w in range(W + K)]
     out_labels = []
-    ktm.phase = "warmup"
+    kt_close("setup")
     for w in range(W):
         ps.search(batches[w], 10)
     agg = {"ndis": 0, "nunique": 0, "nrounds": 0, "update_launches": 0}
     provider.chunks = 0
     barrier()
-    ktm.phase = "timed"
+    kt_close("warmup")
     t0 = time.perf_counter()
     for s in range(K):
         _, l = ps.search(batches[W + s], 10)
@@ -276,18 +334,18 @@ def main():
             agg[k_] += st[k_]
     barrier()
     elapsed = time.perf_counter() - t0
+    ktimes = kt_close("timed")  # (reading waits for the last pairs: after the clock has stopped)
     # ---- the same steps WITHOUT the per-call memo (dedup per lock-step round only: rounds 1 / 2's `value`), on the same queries:
     #      K2 = min(K, 3) steps after one warm-up step, same bracketing; labels must be identical to the memo steps' ----------
     K2 = min(K, 3)
     prm_nomemo = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=B, recompute_memo=False)
     ps_nm = PartitionedSearch(lambda qq, k: idx.search_device(qq, k, prm_nomemo))
-    ktm.phase = "warmup_no_memo"
     if K2:
         ps_nm.search(batches[0], 10)
     agg_nm = {"ndis": 0, "nunique": 0, "nrounds": 0}
     same_labels = True
     barrier()
-    ktm.phase = "timed_no_memo"
+    kt_close("warmup_no_memo")
     t0 = time.perf_counter()
     nm_labels = []
     for s in range(K2):
@@ -301,7 +359,7 @@ def main():
     for s in range(K2):
         same_labels &= bool(torch.equal(nm_labels[s], out_labels[s]))
     del nm_labels
-    ktm.phase = "profiled"
+    kt_close("timed_no_memo")
     del batches
     if world > 1:
         t = torch.tensor([elapsed, elapsed_nm, 0.0 if same_labels else 1.0], dtype=torch.float64, device=dev)
@@ -310,6 +368,7 @@ def main():
     # ---- one more step of the same workload WITH profiling (HIP event pairs + device span stamps per launch): the
     #      source of the roofline figures; not part of `value` ----------------------------------------------------
     idx.set_profiling(True)
+    _lib.kernel_timing_enable((1 << _lib.KT_COUNT) - 1)  # every instrumented encoder kernel, this one step only
     lo = (W + K) * B
     torch.cuda.synchronize()
     t1p = time.perf_counter()
@@ -317,7 +376,8 @@ def main():
     torch.cuda.synchronize()
     prof_step_s = time.perf_counter() - t1p
     prof = idx.stats()
-    ktm.phase = "extras"
+    kprof = kt_close("profiled")
+    _lib.kernel_timing_enable(1 << kt_dominant)
     idx.set_profiling(False)
     # ---- extras (NOT `value`; single-GPU runs only -- they contain no collectives and may never cost the headline
     #      line): one extra step each, on fresh queries ----------------------------------------------------------
@@ -375,18 +435,14 @@ def main():
     # ---- small-batch latency (B = 1, 16, 64, 256) and the parity check on this very index: untimed extras, rank 0 / N = 1 ----
     latency_rows = parity = None
     next_row = B * (K + W + 5)
-    ktimes, kall = ktm.totals("timed"), ktm.totals()
-    KernelTimers.active = None  # from here on the product's default launch path (one library call per forward), no event pairs
-    # The timed steps above ran over the Python form of the provider (the event pairs around the dominant kernel need the per-kernel
-    # launch path); with the timers off, re-attaching the provider resolves to the product default: the LIBRARY-side provider
-    # (csrc/lm_recompute.hip -- no interpreter in the search loop, one host synchronisation per round).
+    # The timed steps above already ran over the product default: the LIBRARY-side provider (csrc/lm_recompute.hip -- no interpreter
+    # in the search loop, one host synchronisation per round).  The Python form of the provider is the A/B here.
     latency_python_provider = provider_ab = None
-    idx.set_provider(provider)
     if world == 1 and not args.no_latency_rows:
         try:
             latency_rows, next_row = small_batch_latency(
                 idx, Q, lambda b: idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b), recall, next_row)
-            if idx.native_provider:  # A/B in the same run: the same batch sizes over the Python provider (round 3's path until now)
+            if idx.native_provider:  # A/B in the same run: the same batch sizes over the Python provider
                 os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
                 try:
                     idx.set_provider(provider)
@@ -398,18 +454,53 @@ def main():
                     idx.set_provider(provider)
         except Exception as ex:  # noqa: BLE001
             extras_errors["small_batch_latency"] = repr(ex)[:300]
-    if world == 1 and idx.native_provider and K:  # one full-size step over the library-side provider, on a timed step's own queries: same labels
+    if world == 1 and idx.native_provider and K:  # one full-size step over the PYTHON provider, on a timed step's own queries: same labels
+        os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
         try:
+            idx.set_provider(provider)
             lo_ = W * B
+            idx.search_device(Q[:B], 10, prm)  # warm-up of that path
             torch.cuda.synchronize()
             t1_ = time.perf_counter()
             _, lx = idx.search_device(Q[lo_ : lo_ + B], 10, prm)
             torch.cuda.synchronize()
-            provider_ab = {"queries_per_s_native_provider": round(B / (time.perf_counter() - t1_), 3), "steps": 1,
+            provider_ab = {"queries_per_s_python_provider": round(B / (time.perf_counter() - t1_), 3), "steps": 1,
                            "labels_identical_to_the_timed_step": bool(torch.equal(lx, out_labels[0])),
-                           "native_provider_stats": provider.native_stats()}
+                           "library_side_provider_stats_of_the_run": provider.native_stats()}
         except Exception as ex:  # noqa: BLE001
             extras_errors["provider_ab"] = repr(ex)[:300]
+        finally:
+            os.environ.pop("LEANN_MI355X_NATIVE_PROVIDER", None)
+            idx.set_provider(provider)
+    # ---- value by batch size, with and without the per-call memo (one step each, fresh queries): `value` is a B = 2048 / N = 1M figure --
+    #      the memo's gain is a property of B / N (it is what cross-query dedup buys when a call re-embeds a large part of the corpus) ----
+    value_by_batch = None
+    chunks_per_s = (args.chunks / t_embed) if t_embed > 0 else None  # encoder throughput of this run (corpus embedding at index-build time)
+    if world == 1 and not args.no_latency_rows:
+        try:
+            value_by_batch = []
+            for b in (64, 256, 8192):
+                row = {"batch": b}
+                for memo in (True, False):
+                    if next_row + b > Q.shape[0]:
+                        next_row = B * (K + W + 5)  # re-use the latency rows' queries (values only; recall is not reported here)
+                    pb = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b, recompute_memo=memo)
+                    qb = Q[next_row : next_row + b].contiguous() if next_row + b <= Q.shape[0] else Q_all[:b].contiguous()
+                    next_row += b
+                    torch.cuda.synchronize()
+                    t1_ = time.perf_counter()
+                    idx.search_device(qb, 10, pb)
+                    torch.cuda.synchronize()
+                    e_ = time.perf_counter() - t1_
+                    st_ = idx.stats()
+                    row["memo" if memo else "no_memo"] = {
+                        "queries_per_s": round(b / e_, 2), "recomputed_chunks_per_query": round(st_["nunique"] / b, 1),
+                        "fraction_of_corpus_reembedded": round(st_["nunique"] / args.chunks, 4)}
+                if chunks_per_s:
+                    row["brute_force_bound_queries_per_s"] = round(b * chunks_per_s / args.chunks, 2)
+                value_by_batch.append(row)
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["value_by_batch"] = repr(ex)[:300]
     if world == 1 and not args.no_parity_check:
         try:
             t1 = time.time()
@@ -438,9 +529,10 @@ def main():
     traffic = None
     traffic_src = None
     try:  # HBM bytes per launch from the separate PMC pass (profiles/r1_pmc_k_update.json), scaled to this run's launch size
-        pmc = json.loads((ROOT / "profiles" / "r1_pmc_k_update.json").read_text())
+        pmc_file = next(f for f in ("r4_pmc_k_update.json", "r1_pmc_k_update.json") if (ROOT / "profiles" / f).exists())
+        pmc = json.loads((ROOT / "profiles" / pmc_file).read_text())
         traffic = round(pmc["hbm_bytes_per_eval_corrected_x1.08"] * prof["ndis"] / max(prof["update_launches"], 1))
-        traffic_src = "rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/r1_pmc_k_update.json), x1.08 calibration, scaled by evals/launch"
+        traffic_src = f"rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/{pmc_file}), x1.08 calibration, scaled by evals/launch"
     except Exception:  # noqa: BLE001
         pass
     roofline_dist = {"bound": "hbm", "kernel": "lm::k_update<6,false,false,1,256> (fused gather + distance + beam update, recompute mode)", "achieved": round(achieved, 2),
@@ -463,26 +555,30 @@ def main():
     # LayerNorm, feed-forward block, LayerNorm: 70 % of the encoder's flops, the largest share of the step's time), MFMA bound;
     # duration = HIP event pairs around every one of its launches in the timed region (torch's current stream = the stream it is
     # launched on).  Algorithmic flops per token: 4 * ffn * hidden + 2 * hidden^2.
-    kname, kdesc, fpt = "attn_out_mlp_h384", ("lm::k_attn_out_mlp_h384<0> (attention output projection + residual + LayerNorm + fc1 + GELU + fc2 + "
-                                              "residual + LayerNorm in one kernel)"), 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden
-    if not ktimes.get(kname, {}).get("launches"):  # LEANN_MI355X_TAIL=0: the feed-forward block alone
-        kname, kdesc, fpt = "mlp_fused_h384", "lm::k_mlp_fused_h384_v3<0> (fc1 + GELU + fc2 + residual + LayerNorm in one kernel)", 4 * cfg.ffn * cfg.hidden
-    if not ktimes.get(kname, {}).get("launches") and ktimes.get("gemm_f16", {}).get("launches"):  # hidden != 384: the general GEMM is the dominant kernel
-        kname, fpt = "gemm_f16", None
+    kt_extras = kt_close("extras")
+    kname = KT_NAMES[kt_dominant]
+    if kt_dominant == _lib.KT_LAYER_TAIL:
+        kdesc = ("lm::k_layer_tail_h384<0,2,4,1,0> (attention output projection + residual + LayerNorm + fc1 + GELU + fc2 + residual + LayerNorm in one kernel, "
+                 "generation 4)")
+        fpt = 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden
+    else:  # hidden != 384: the general GEMM is the dominant kernel
+        fpt = None
         kdesc = ("lm::k_gemm_f16<GemmShape<2,4,4,2>, *> (general 256 x 256-tile MFMA GEMM with bias / GELU / residual epilogues: the QKV, "
                  "attention-output and both feed-forward projections of every layer)")
-    mlp, mlp_all = ktimes.get(kname), kall.get(kname)
+    mlp = ktimes.get(kname)
+    mlp_all = {"launches": 0, "ms": 0.0, "work": 0.0}
+    for ph_ in kt_phase.values():
+        for f_ in mlp_all:
+            mlp_all[f_] += ph_.get(kname, {}).get(f_, 0)
     if mlp and mlp["ms"] > 0:
         mlp_tf = mlp["work"] / (mlp["ms"] * 1e-3) / 1e12
         tpl = mlp["work"] / fpt / max(mlp["launches"], 1) if fpt else None  # tokens per launch
         ktraffic = ktraffic_src = None
-        try:  # HBM-side bytes per launch: the separate PMC passes of this kernel (profiles/r2_pmc_layer_tail.json), per token x this run's launch size
-            pmc_t = json.loads((ROOT / "profiles" / "r2_pmc_layer_tail.json").read_text())
-            if kname == "attn_out_mlp_h384":
-                ktraffic = round(pmc_t["k_attn_out_mlp_h384"]["hbm_bytes_per_token"] * tpl)
-                ktraffic_src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over scripts/kbench.cpp (262107 tokens), FETCH_SIZE x2 as calibrated on a "
-                                "streaming read of known size in the same pass (profiles/r2_pmc_layer_tail.json): 2958 B/token = 1.28 x the algorithmic 2314 B/token "
-                                "(two row blocks in, one out, weights once), scaled by tokens/launch")
+        try:  # HBM-side bytes per launch: the separate PMC passes of this kernel (profiles/r4_pmc_layer_tail.json), per token x this run's launch size
+            pmc_t = json.loads((ROOT / "profiles" / "r4_pmc_layer_tail.json").read_text())
+            if kt_dominant == _lib.KT_LAYER_TAIL:
+                ktraffic = round(pmc_t["k_layer_tail_h384"]["hbm_bytes_per_token"] * tpl)
+                ktraffic_src = pmc_t["k_layer_tail_h384"].get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/kbench.cpp (profiles/r4_pmc_layer_tail.json), scaled by tokens/launch")
         except Exception:  # noqa: BLE001
             pass
         roofline = {"bound": "mfma", "kernel": kdesc,
@@ -494,11 +590,11 @@ def main():
                     "gflop_per_launch": round(mlp["work"] / max(mlp["launches"], 1) / 1e9, 2),
                     "share_of_timed_region": round(mlp["ms"] / (elapsed * 1e3), 4),
                     "all_launches_of_the_process": {"launches": mlp_all["launches"], "avg_launch_us": round(1e3 * mlp_all["ms"] / max(mlp_all["launches"], 1), 1),
-                                                    "TFLOPs": round(mlp_all["work"] / (mlp_all["ms"] * 1e-3) / 1e12, 2),
+                                                    "TFLOPs": round(mlp_all["work"] / max(mlp_all["ms"] * 1e-3, 1e-12) / 1e12, 2),
                                                     "note": "corpus embedding, warm-up, timed, profiled and extra steps together: the population a rocprofv3 --kernel-trace --stats table of this command averages"},
-                    "timing": "HIP event pairs around every launch of the timed region (torch's current stream = the launch stream)",
-                    "instrumentation": f"the timed region contains these {mlp['launches']} event pairs (2 records per launch of this kernel, nothing else); "
-                                       "the per-kernel launch path they require (one-call forward off) is throughput-identical at this batch size"}
+                    "timing": "library-side: HIP event pairs recorded by the library around every launch of this kernel in the timed region, on the launch stream "
+                              "(csrc/lm_timing.cpp); the timed region is the product default path (library-side recompute provider, one-call forwards)",
+                    "instrumentation": f"the timed region contains these {mlp['launches']} event pairs (2 records per launch of this kernel, nothing else)"}
     else:  # encoder without the fused block (hidden != 384): fall back to the distance kernel's line
         roofline = roofline_dist
     result = {
@@ -506,14 +602,17 @@ def main():
                    f"queries/sec at recall@10>=0.9, {args.chunks}-chunk HNSW, {args.model} fp16 recompute (BASELINE.json configs[4])"),
         "value": round(qps, 3), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * elapsed / max(K, 1), 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp16", "dtype_detail": "encoder (99.9 % of the arithmetic): fp16 MFMA with fp32 accumulation = the reference's CUDA precision (embedding_compute.py:157-162); distances, beam update and top-k: f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "fp16", "dry_run": dry, "dtype_detail": "encoder (99.9 % of the arithmetic): fp16 MFMA with fp32 accumulation = the reference's CUDA precision (embedding_compute.py:157-162); distances, beam update and top-k: f32", "data": "synthetic" if not dry else "dry-run (emulated library on the CPU: control flow only, nothing here is a measurement)",
         "config": {"workload": f"{args.chunks} synthetic chunks (topic model, {'len~N(180,50)' if not args.fixed_len else 'every chunk ' + str(args.fixed_len) + ' tokens'}), HNSW M={args.M} GPU-built, "
                                f"{args.model} shape (random init), ef_search={ef}, beam={args.beam}, top-10, "
                                f"{B} queries/step/GPU, queries partitioned over {world} GPU(s), graph replicated; library-default search parameters "
                                f"(per-call recompute memo on: within one step no chunk is encoded twice; nothing is kept between steps)",
                    "baseline_config": args.config, "n_chunks": args.chunks, "ef_search": ef, "beam_width": args.beam, "queries_per_step": B * world,
                    "parallelism": f"queries-dp{world}", "rccl_ranks": world, "recompute_memo": 1,
-                   "multi_gpu_path": "leann_amd.distributed.PartitionedSearch (index built on rank 0 and broadcast; per-step all_gather of the results)"},
+                   "multi_gpu_path": "leann_amd.distributed.PartitionedSearch (index built on rank 0 and broadcast; per-step all_gather of the results)",
+                   "workload_note": "topic-model corpus (1000 topics, 16 chunks per document), queries = held-out chunks of existing documents: recall@10 >= 0.9 is already "
+                                    "reached at a smaller ef than BASELINE's 64 (ef_sweep, at_min_ef) -- ef=64 is over-provisioned for this corpus and `value` is the rate AT ef=64",
+                   "timed_path": "library-side recompute provider (csrc/lm_recompute.hip), one-call forwards: the product default"},
         "recall_at_10": round(rec, 4),
         "without_call_memo": {
             "value": round(world * K2 * B / elapsed_nm, 3) if K2 and elapsed_nm > 0 else None, "unit": "queries/s", "steps": K2, "warmup": 1 if K2 else 0,
@@ -543,7 +642,19 @@ def main():
     if latency_python_provider:
         result["small_batch_latency_python_provider"] = latency_python_provider
     if provider_ab:
-        result["full_step_over_the_library_side_provider"] = provider_ab
+        result["full_step_over_the_python_provider"] = provider_ab
+    if value_by_batch:
+        result["value_by_batch"] = {"rows": value_by_batch, "timed_batch": B, "encoder_chunks_per_s": round(chunks_per_s, 1) if chunks_per_s else None,
+                                    "what": "one search call per row on fresh queries, library defaults except the memo switch; brute_force_bound = B x (encoder chunks/s) / N: "
+                                            "the rate of embedding the WHOLE corpus once per call and scanning it (no graph) -- the per-call memo's gain over `no_memo` is a "
+                                            "property of B / N (fraction_of_corpus_reembedded), ~0 at B = 1"}
+    if kprof:
+        tot_ms = sum(v["ms"] for v in kprof.values())
+        result["encoder_kernels_profiled_step"] = {
+            k_: {"launches": v["launches"], "ms": round(v["ms"], 1), "share_of_step": round(v["ms"] / (prof_step_s * 1e3), 4),
+                 "TFLOPs": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["work"] and v["ms"] else None}
+            for k_, v in kprof.items() if v["launches"]}
+        result["encoder_kernels_profiled_step"]["instrumented_ms_of_step_ms"] = [round(tot_ms, 1), round(prof_step_s * 1e3, 1)]
     if parity:
         result["parity_check"] = parity
     if table_roof:

@@ -162,8 +162,14 @@ int lm_index_event_overhead_us(lm_index *idx, double *out_us);
  * wave / a workgroup per query.  "persistent_table" 1 (default) = stored-embedding searches run as ONE persistent
  * launch per batch, 0 = lock-step rounds; "persistent_wave" -1 (auto) / 0 / 1 = its workgroup- or wave-per-query form.
  * "pq_threads" 256 / 512 / 1024 (default) = workgroup width of the PQ traversal.  "memo_initial_rows" = first allocation of the
- * per-call recompute memo in rows (0 = default: max(65536, 1024 per query of the pass)); it doubles on demand, never beyond N. */
+ * per-call recompute memo in rows (0 = default: max(65536, 1024 per query of the pass)); it doubles on demand, never beyond N.
+ * "pq_rerank_expanded" 0 (default) / 1: which set the DiskANN-style path's exact rerank ranks -- 0 the final candidate list (what
+ * diskann_backend.py:444-449 describes: "fetch embeddings for the final candidate set only"), 1 EVERY node the traversal expanded
+ * (upstream DiskANN's full_retset, PQFlashIndex::cached_beam_search: a superset of the final list; up to 4 x complexity <= 8192 nodes
+ * per query are recorded, a query that expands more falls back to its final list and is counted in "pq_rerank_overflow").
+ * lm_index_get_option reads a value back ("pq_rerank_overflow": queries that fell back since the option was last set). */
 int lm_index_set_option(lm_index *idx, const char *name, int64_t value);
+int lm_index_get_option(const lm_index *idx, const char *name, int64_t *value);
 
 /* ---- DiskANN-style path: PQ-ADC traversal + deferred exact rerank ---------------------------------
  * Replaces _diskannpy.StaticDiskFloatIndex(metric, prefix, threads, cache, mechanism, zmq_port,
@@ -191,11 +197,16 @@ typedef struct {
     int32_t num_threads;         /* accepted, unused                       :459 */
     int32_t use_deferred_fetch;  /* = recompute_embeddings                 :450,460 */
     int32_t skip_search_reorder; /* return PQ order / distances            :461 */
-    int32_t recompute_neighbors; /* accepted, must be 0 (as the reference passes) :451,462 */
-    int32_t dedup_node_dis;      /* accepted, unused                       :463 */
-    float prune_ratio;           /* accepted, unused                       :464 */
-    int32_t batch_recompute;     /* accepted, unused (the rerank IS one batch) :465 */
-    int32_t use_global_pruning;  /* accepted, unused                       :466 */
+    int32_t recompute_neighbors; /* must be 0 -- what the reference passes (:451,462); non-zero: LM_EINVAL */
+    /* The four knobs below parametrise the PER-HOP neighbour recomputation of the fork's batch_search (which neighbours' exact distances
+     * are recomputed, and how those recomputations are cached / batched).  The reference switches that recomputation OFF for every
+     * search ("Do not recompute neighbor distances along the path", :444-451: recompute_neighors = False), so they cannot change its
+     * results; here the traversal is PQ-only by construction and they are accepted and have NO effect (the Python host logs that
+     * once when a non-default value arrives: leann_amd/backend.py).  The exact rerank is a single batch whatever batch_recompute says. */
+    int32_t dedup_node_dis;      /* :463 inert (see above) */
+    float prune_ratio;           /* :464 inert */
+    int32_t batch_recompute;     /* :465 inert */
+    int32_t use_global_pruning;  /* :466 inert */
 } lm_pq_search_params;
 void lm_pq_search_params_default(lm_pq_search_params *p);
 int lm_pq_batch_search(lm_index *idx, int64_t n, const float *x, int32_t k, const lm_pq_search_params *params,
@@ -331,19 +342,19 @@ int lm_gemm_f16(const void *d_x, const void *d_w, const float *d_bias, const voi
 /* ---- the whole packed BERT forward (hidden 384, mean or CLS pooling) in one call ---------------------
  * Replaces compute_embeddings' model.encode() (leann/embedding_compute.py:229-239) for sentence-transformers models of the
  * all-MiniLM family: embedding front end, per layer {lm_gemm_ws_h384_f16 (QKV), lm_attn_varlen_hd32_f16,
- * lm_attn_out_mlp_fused_h384_f16}, lm_meanpool_varlen_f16 / lm_clspool_varlen_f16 -- one foreign-function call per recompute round
- * instead of ~3 L + 2.
+ * lm_layer_tail_h384_f16}, lm_meanpool_varlen_f16 / lm_clspool_varlen_f16 -- one foreign-function call per recompute round
+ * instead of ~3 L + 2.  ffn a multiple of 192 in [192, 2496] (other widths: lm_bert_forward_packed).
  * All pointers are device pointers except `layers` (host array).  Weight layouts as documented at the entry points named above
- * (leann_amd/encoder.py: pack_wo_slabs, pack_w1_acc_order, pack_w2_fused_mlp).  d_out: fp32 [n_seqs][384]. */
+ * (the three images of lm_layer_tail_pack_h384; leann_amd/encoder.py: pack_tail_images).  d_out: fp32 [n_seqs][384]. */
 typedef struct lm_bert_h384_layer {
     const void *wqkv;  /* [1152][384] fp16, nn.Linear layout */
     const float *bqkv; /* [1152] */
-    const void *wo_p;  /* [12][384][32] */
+    const void *wo_img; /* lm_layer_tail_pack_h384's image of [12][384][32] */
     const float *bo;
     const void *ln1_gamma, *ln1_beta; /* fp16 [384] */
-    const void *w1acc;                /* [ffn][384], columns in accumulator order */
+    const void *w1_img;               /* ... of [ffn][384], columns in accumulator order */
     const float *b1;
-    const void *w2p; /* [ffn/32][384][32] */
+    const void *w2_img; /* ... of [ffn/32][384][32] */
     const float *b2;
     const void *ln2_gamma, *ln2_beta;
     /* Optional (all three or none): the plain nn.Linear weights [384][384], [ffn][384], [384][ffn] fp16.  With them a forward of at
@@ -445,6 +456,25 @@ int lm_recompute_provider(void *user, const int32_t *d_ids, int32_t n, void **d_
 int lm_recompute_embed(lm_recompute *rc, const int32_t *d_ids, int32_t n, float *d_out, void *stream);
 int lm_recompute_get_stats(const lm_recompute *rc, lm_recompute_stats *out);
 int lm_index_set_recompute(lm_index *idx, lm_recompute *rc);
+
+/* ---- measurement: event pairs around the library's own launches of the encoder's MFMA kernels (csrc/lm_timing.cpp) ----
+ * One HIP event pair per launch, recorded on the stream the kernel is launched on, for the kernels whose bit is set in `mask`
+ * (bit LM_KT_*); 0 = off (the default: a disabled launch pays one atomic load).  Works on every launch path -- the one-call forwards,
+ * the built-in recompute provider inside lm_index_search*, single entry points.  lm_kernel_timing_read waits for the pairs recorded
+ * so far and returns, per kernel, launches / summed milliseconds / summed algorithmic flops since the last reset (work 0 where the
+ * launcher cannot know it: attention).  bench.py's `roofline` is built from these over its timed region. */
+#define LM_KT_LAYER_TAIL 0 /* lm_layer_tail_h384_f16 */
+#define LM_KT_GEMM_WS 1    /* lm_gemm_ws_h384_f16 */
+#define LM_KT_ATTN 2       /* lm_attn_varlen_hd32_f16 / lm_attn_varlen_f16 */
+#define LM_KT_GEMM_F16 3   /* lm_gemm_f16 */
+#define LM_KT_COUNT 4
+typedef struct lm_kernel_time {
+    const char *name;
+    int64_t launches;
+    double ms, work;
+} lm_kernel_time;
+int lm_kernel_timing_enable(uint32_t mask);
+int lm_kernel_timing_read(lm_kernel_time *out /* [LM_KT_COUNT] */, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ class PqSearchParams(C.Structure):
 
 
 class BertH384Layer(C.Structure):  # include/leann_mi355x.h: lm_bert_h384_layer
-    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo_p", "bo", "ln1_gamma", "ln1_beta", "w1acc", "b1", "w2p", "b2", "ln2_gamma", "ln2_beta",
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo_img", "bo", "ln1_gamma", "ln1_beta", "w1_img", "b1", "w2_img", "b2", "ln2_gamma", "ln2_beta",
                                           "wo", "w1", "w2")]
 
 
@@ -84,6 +84,13 @@ class Bert(C.Structure):  # include/leann_mi355x.h: lm_bert
                 ("layers", C.POINTER(BertLayer))]
 
 
+class KernelTime(C.Structure):  # include/leann_mi355x.h: lm_kernel_time
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("ms", C.c_double), ("work", C.c_double)]
+
+
+KT_LAYER_TAIL, KT_GEMM_WS, KT_ATTN, KT_GEMM_F16, KT_COUNT = 0, 1, 2, 3, 4
+
+
 class RecomputeStats(C.Structure):  # include/leann_mi355x.h: lm_recompute_stats
     _fields_ = [(n, C.c_int64) for n in ("calls", "chunks", "tokens", "forwards", "host_syncs")]
 
@@ -96,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "lm_index_read", "lm_index_create_from_csr", "lm_index_free", "lm_index_info",
     "lm_index_attach_table", "lm_index_set_provider", "lm_index_set_hub_cache", "lm_index_set_stream",
     "lm_search_params_default", "lm_index_search", "lm_index_search_device",
-    "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_event_overhead_us",
+    "lm_index_get_stats", "lm_index_set_profiling", "lm_index_set_option", "lm_index_get_option", "lm_index_event_overhead_us",
     "lm_dist_gather", "lm_topk_merge",
     "lm_pq_attach", "lm_pq_attach_chunked", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
     "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_attn_varlen_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
@@ -105,6 +112,7 @@ EXPORTED_SYMBOLS = [
     "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
     "lm_bert_workspace_bytes", "lm_bert_forward_packed", "lm_clspool_varlen_f16",
     "lm_recompute_create", "lm_recompute_create_general", "lm_recompute_free", "lm_recompute_provider", "lm_recompute_embed", "lm_recompute_get_stats", "lm_index_set_recompute",
+    "lm_kernel_timing_enable", "lm_kernel_timing_read",
 ]
 
 _lib = None
@@ -141,6 +149,7 @@ def load() -> C.CDLL:
     lib.lm_index_get_stats.argtypes = [vp, C.POINTER(SearchStats)]
     lib.lm_index_set_profiling.argtypes = [vp, i32]
     lib.lm_index_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.lm_index_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     lib.lm_index_event_overhead_us.argtypes = [vp, C.POINTER(C.c_double)]
     lib.lm_dist_gather.argtypes = [vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]
     lib.lm_topk_merge.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
@@ -185,6 +194,8 @@ def load() -> C.CDLL:
     lib.lm_recompute_embed.argtypes = [vp, vp, i32, vp, vp]
     lib.lm_recompute_get_stats.argtypes = [vp, C.POINTER(RecomputeStats)]
     lib.lm_index_set_recompute.argtypes = [vp, vp]
+    lib.lm_kernel_timing_enable.argtypes = [C.c_uint32]
+    lib.lm_kernel_timing_read.argtypes = [C.POINTER(KernelTime), i32]
     _lib = lib
     return lib
 
@@ -204,6 +215,18 @@ def check(rc: int, what: str = "") -> None:
     if rc == LM_ENOENT:
         raise FileNotFoundError(msg)
     raise LeannMi355xError(msg)
+
+
+def kernel_timing_enable(mask: int) -> None:
+    """Event pairs around the library's own launches of the encoder kernels whose bit (1 << KT_*) is set; 0 = off (lm_timing.cpp)."""
+    check(load().lm_kernel_timing_enable(int(mask)), "lm_kernel_timing_enable")
+
+
+def kernel_timing_read(reset: bool = False) -> dict:
+    """{kernel name: {"launches", "ms", "work"}} accumulated since the last reset (waits for the pairs recorded so far)."""
+    arr = (KernelTime * KT_COUNT)()
+    check(load().lm_kernel_timing_read(arr, 1 if reset else 0), "lm_kernel_timing_read")
+    return {a.name.decode(): {"launches": int(a.launches), "ms": float(a.ms), "work": float(a.work)} for a in arr}
 
 
 def device_count() -> int:

@@ -566,6 +566,13 @@ class Mi355xDiskannSearcher(Mi355xSearcher):
         if pruning_strategy == "proportional":
             raise NotImplementedError(
                 "DiskANN backend does not support 'proportional' pruning strategy. Use 'global' or 'local' instead.")
+        if (prune_ratio or batch_recompute or dedup_node_dis or pruning_strategy == "local") and not getattr(self, "_inert_knobs_logged", False):
+            # These parametrise the per-hop neighbour recomputation of the fork's batch_search, which the reference switches off for every
+            # search (recompute_neighors = False, diskann_backend.py:444-451): the traversal is PQ-only there and here, so they change nothing.
+            logger.warning("prune_ratio / pruning_strategy='local' / batch_recompute / dedup_node_dis have no effect on the DiskANN-style path: "
+                           "the traversal never recomputes neighbour distances (as in the reference, diskann_backend.py:444-451); accepted for "
+                           "interface compatibility")
+            self._inert_knobs_logged = True
         query = np.atleast_2d(np.asarray(query))
         if query.dtype != np.float32:
             query = query.astype(np.float32)

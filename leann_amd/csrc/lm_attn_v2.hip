@@ -237,6 +237,7 @@ static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int
     hipStream_t st = (hipStream_t)stream;
     const __half* q = (const __half*)d_qkv;
     __half* o = (__half*)d_out;
+    KtScope kt(LM_KT_ATTN, stream, 0.0);  // the flops depend on the sequence lengths (device memory): time only
     switch (nt) {
 #define CASEA(n)                                                                                                                         \
     case n: {                                                                                                                            \

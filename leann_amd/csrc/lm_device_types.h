@@ -56,7 +56,7 @@ struct WsDev {
 };
 // C_RC_TOKENS / C_RC_MAXLEN: total tokens and longest chunk of the round's unique list, written by the built-in recompute provider's
 // length scan (lm_recompute.hip) so that the loop's one device-to-host copy per round carries them
-enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_RC_TOKENS = 5, C_NADC = 6, C_RC_MAXLEN = 7, C_NCOUNTERS = 8 };
+enum { C_LIVE = 0, C_NUNIQ = 1, C_NDIS = 2, C_NEXPAND = 3, C_ROUNDS = 4, C_RC_TOKENS = 5, C_NADC = 6, C_RC_MAXLEN = 7, C_PQ_OVERFLOW = 8, C_NCOUNTERS = 9 };
 
 constexpr int UNIQ_TILE = 4096;  // words per block in the uniq scan
 constexpr int AQ_CAP = 512;       // capacity of the approximate queue (== ORC_AQ_CAP in oracle/lm_oracle.c)

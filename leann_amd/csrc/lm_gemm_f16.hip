@@ -369,6 +369,7 @@ extern "C" int lm_gemm_f16(const void* d_x, const void* d_w, const float* d_bias
     if ((epilogue & GM_EPI_RESID) && !d_residual) LM_FAIL(LM_EINVAL, "lm_gemm_f16: residual epilogue without a residual");
     if ((uint64_t)n_out * (uint64_t)k_in * 2 >= (1ull << 32)) LM_FAIL(LM_EINVAL, "lm_gemm_f16: a weight matrix of 4 GiB or more");
     hipStream_t st = (hipStream_t)stream;
+    KtScope kt(LM_KT_GEMM_F16, stream, 2.0 * (double)tokens * n_out * k_in);
 #define GM_GO(S)                                                                                                             \
     switch (epilogue) {                                                                                                      \
         case 0: return gemm_launch<S, 0>(d_x, d_w, d_bias, d_residual, d_out, tokens, n_out, k_in, st);                       \

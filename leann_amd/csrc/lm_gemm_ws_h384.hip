@@ -187,6 +187,7 @@ extern "C" int lm_gemm_ws_h384_f16(const void* d_x, const void* d_w, const float
     if (tokens == 0) return LM_OK;
     if (!d_x || !d_w || !d_bias || !d_out || tokens < 0 || tokens > 0x7fffffff) LM_FAIL(LM_EINVAL, "bad linear arguments");
     if (n_out <= 0 || n_out % WS_ROWS || n_out / WS_ROWS > 32) LM_FAIL(LM_EINVAL, "n_out must be a multiple of 192, at most 6144");
+    KtScope kt(LM_KT_GEMM_WS, stream, 2.0 * (double)tokens * n_out * ML_H);
 #define WS_GO(S)                                                                                                                          \
     do {                                                                                                                                  \
         static DynLdsAttr attr; /* once per process and device, not per launch */                                                        \

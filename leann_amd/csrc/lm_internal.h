@@ -68,6 +68,19 @@ inline hipError_t ensure_dyn_lds(DynLdsAttr& a, const void* fn, size_t bytes) {
     return e;
 }
 
+// lm_timing.cpp: an event pair around one launch of kernel `kid` (LM_KT_*) on `stream` when that kernel's bit is on in
+// lm_kernel_timing_enable's mask; `work` = the launch's algorithmic flops.  Put one in front of the launch: { KtScope kt(...); launch; }
+struct KtScope {
+    int kid;
+    void* st;
+    double work;
+    void* a;
+    KtScope(int kid, void* stream, double work);
+    ~KtScope();
+    KtScope(const KtScope&) = delete;
+    KtScope& operator=(const KtScope&) = delete;
+};
+
 // ---- query phases (same state machine as oracle/lm_oracle.c) ----
 enum : int32_t { PH_SEED = 0, PH_UPPER = 1, PH_BEAM = 2, PH_DONE = 3 };
 

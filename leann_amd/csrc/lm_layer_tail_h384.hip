@@ -855,6 +855,7 @@ extern "C" int lm_layer_tail_h384_f16(const void* d_attn, const void* d_resid, c
     static const int stagger_env = [] { const char* sg = getenv("LEANN_MI355X_STAGGER"); return sg ? atoi(sg) : 40; }();  // spread of the first round's start times, x 1024 cycles (0 = off)
     const T4Pre pre = {(const __half*)d_attn, (const __half*)d_wo_img, d_bo, (const __half*)d_gamma1, (const __half*)d_beta1, eps1,
                        grid.x >= 512 ? stagger_env : 0};  // a launch of fewer than two rounds has no lock-step to break: no start delay (small-batch latency)
+    KtScope kt(LM_KT_LAYER_TAIL, stream, (double)tokens * (4.0 * ffn * ML_H + 2.0 * ML_H * ML_H));
 #define T4_GO(A, DM, RD, GF, WM)                                                                                                            \
     {                                                                                                                                       \
         static DynLdsAttr attr; /* per device; the attribute only ever needs to grow */                                                     \

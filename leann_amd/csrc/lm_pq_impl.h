@@ -28,6 +28,9 @@ struct PqArgs {
     int32_t Dp, metric, L, W, maxnew, Pmax;
     unsigned long long* n_adc_q;  // per-query ADC evaluations
     int32_t* rounds_q;
+    int32_t exp_cap;  // > 0: the rerank set is EVERY expanded node (upstream DiskANN's full_retset), recorded in ws.pool (ws.ef = exp_cap
+                      // entries per query); a query that expands more than exp_cap nodes falls back to its final list (counted)
+    unsigned long long* n_exp_overflow;
 };
 
 // dynamic LDS: lut[m*256] f32 | lpool[L] u64 | out[L] u64 | newk[Pmax] u64 | s_new[maxnew] i32
@@ -139,6 +142,8 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
         const int np = s_npop;
         if (np == 0) break;
         rounds++;
+        if (a.exp_cap > 0 && tid < np && nexp + tid < a.exp_cap)  // the expanded nodes, in expansion order (s_pop is stable until the next pop selection)
+            ws.pool[(size_t)q * ws.ef + nexp + tid] = make_key(0.0f, s_pop[tid]);
         nexp += np;
         const uint32_t totalc = s_off[np];
         // ---- flattened expansion over the workgroup, visited test-and-set, ordered compaction ----
@@ -206,10 +211,14 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
             __syncthreads();
         }
     }
-    // ---- final candidate list -> global pool ----
+    // ---- rerank set -> global pool: the final candidate list, or (exp_cap > 0) the expanded nodes already recorded there ----
     uint64_t* pool = ws.pool + (size_t)q * ws.ef;
-    for (int i = tid; i < npool; i += NTH) pool[i] = lpool[i];
+    const bool expanded_set = a.exp_cap > 0 && nexp <= a.exp_cap;
+    if (!expanded_set)
+        for (int i = tid; i < npool; i += NTH) pool[i] = lpool[i];
     if (tid == 0) {
+        if (a.exp_cap > 0 && !expanded_set) atomicAdd(a.n_exp_overflow, 1ull);
+        if (expanded_set) npool = nexp;
         ws.npool[q] = npool;
         ws.nsteps[q] = nexp;
         a.n_adc_q[q] = n_adc;
@@ -314,7 +323,11 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     const int32_t L = std::max(prm.complexity, k);
     const int32_t W = std::max(prm.beam_width, 1);
     if (W > 64) LM_FAIL(LM_EINVAL, "beam_width > 64 is not supported by the PQ traversal kernel");
-    int rc = ensure_ws(ix, B, L, W);
+    // option "pq_rerank_expanded": the exact rerank ranks every EXPANDED node (upstream DiskANN: full_retset) instead of the final
+    // candidate list; the record holds up to 4 L (<= 8192: the rerank kernel's sort) entries per query
+    const int32_t exp_cap = ix->pq_rerank_expanded ? std::min<int32_t>(8192, 4 * L) : 0;
+    if (ix->pq_rerank_expanded && L > 8192) LM_FAIL(LM_EINVAL, "pq_rerank_expanded: complexity <= 8192");
+    int rc = ensure_ws(ix, B, exp_cap ? exp_cap : L, W);
     if (rc) return rc;
     WsDev& ws = ix->ws;
     hipStream_t st = ix->stream;
@@ -334,6 +347,8 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     pa.Q = d_q; pa.Dp = ix->Dp; pa.metric = ix->metric; pa.L = L; pa.W = W; pa.maxnew = ws.maxnew;
     pa.Pmax = next_pow2(ws.maxnew);
     pa.n_adc_q = ix->d_pq_nadc; pa.rounds_q = ix->d_pq_rounds;
+    pa.exp_cap = exp_cap;
+    pa.n_exp_overflow = ws.counters + C_PQ_OVERFLOW;
     size_t shmem = (size_t)ix->pq_m * 256 * 4 + (size_t)2 * L * 8 + (size_t)pa.Pmax * 8 + (size_t)ws.maxnew * 4;
     if (shmem > 158 * 1024)  // 160 KiB per workgroup minus the kernel's ~1.1 KiB of static LDS
         LM_FAIL(LM_EINVAL, "PQ search state does not fit the 160 KB LDS (reduce m, complexity or beam_width)");
@@ -358,12 +373,12 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     if (rerank) {
         UpdateArgs ua{};
         ua.Q = d_q;
-        ua.P2 = next_pow2(L);
+        ua.P2 = next_pow2(exp_cap ? exp_cap : L);
         if ((size_t)ua.P2 * 8 > 64 * 1024) LM_FAIL(LM_EINVAL, "complexity too large for the rerank kernel (<= 8192 candidates per query)");
         if (prm.use_deferred_fetch && ix->provider) {
             // ONE deferred fetch for the union of all candidate lists
             const int ntiles = (int)((ws.nw + UNIQ_TILE - 1) / UNIQ_TILE);
-            hipLaunchKernelGGL(k_pq_mark, dim3((B * L + 255) / 256), dim3(256), 0, st, ws);
+            hipLaunchKernelGGL(k_pq_mark, dim3((unsigned)(((int64_t)B * ws.ef + 255) / 256)), dim3(256), 0, st, ws);
             hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
             hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
             LM_HIP(hipMemcpyAsync(hc, ws.counters, C_NCOUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -395,6 +410,7 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     ix->stats.ndis += (int64_t)hc[C_NDIS];
     ix->stats.nexpand += (int64_t)hc[C_NEXPAND];
     ix->stats.nrounds = std::max<int64_t>(ix->stats.nrounds, (int64_t)hc[C_ROUNDS]);
+    ix->pq_overflow += (int64_t)hc[C_PQ_OVERFLOW];
     return LM_OK;
 }
 
@@ -447,6 +463,8 @@ static int pq_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
                             int64_t* d_labels, float* d_dist) {
     if (!ix || !params || n < 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad search arguments");
     if (params->complexity <= 0) LM_FAIL(LM_EINVAL, "complexity must be positive");
+    if (params->recompute_neighbors)
+        LM_FAIL(LM_EINVAL, "recompute_neighbors != 0 is not supported: the traversal runs on PQ distances only, as the reference runs it (diskann_backend.py:444-451)");
     if (!ix->d_pq_codes) LM_FAIL(LM_ESTATE, "no PQ codes attached (lm_pq_attach)");
     if (params->use_deferred_fetch && !ix->provider && !ix->d_table)
         LM_FAIL(LM_ESTATE, "deferred fetch requested but neither an embedding provider nor stored embeddings are attached");

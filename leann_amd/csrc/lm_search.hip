@@ -101,6 +101,8 @@ struct lm_index {
     int update_variant = 0;  // 0: auto, 3: wave (64 lanes) per query, 4: workgroup (256 threads) per query   (1, 2: removed A/B forms)
     int persistent_table = 1;  // stored-embedding mode: one persistent launch per batch (0: lock-step rounds, for A/B)
     int pq_threads = 1024;     // workgroup width of the PQ traversal kernel (option "pq_threads": 256 / 512 / 1024)
+    bool pq_rerank_expanded = false;  // option "pq_rerank_expanded": rerank every expanded node (upstream DiskANN's full_retset), not the final list
+    int64_t pq_overflow = 0;   // queries (since the option was last set) whose expansions outgrew the record and fell back to the final list
     int persistent_wave = -1;  // persistent search: 1 = one wave per query, 0 = one 256-thread workgroup per query, -1 = auto
     int wave_maxnew = 0;     // auto rule threshold on beam x mean level-0 degree; 0 = never: on the 1M-chunk HNSW graph
                              // (max degree 64, mean 9.3) the workgroup form is 1.5x faster (profiles/r1_bench_default_1M_b2048.json
@@ -866,6 +868,11 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
         ix->pq_threads = (int)value;
         return LM_OK;
     }
+    if (!std::strcmp(name, "pq_rerank_expanded")) {
+        ix->pq_rerank_expanded = value != 0;
+        ix->pq_overflow = 0;
+        return LM_OK;
+    }
     if (!std::strcmp(name, "persistent_wave")) {
         if (value < -1 || value > 1) LM_FAIL(LM_EINVAL, "persistent_wave must be -1 (auto), 0 or 1");
         ix->persistent_wave = (int)value;
@@ -881,6 +888,15 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
         return LM_OK;
     }
     LM_FAIL(LM_EINVAL, std::string("unknown option: ") + name);
+}
+
+int lm_index_get_option(const lm_index* ix, const char* name, int64_t* value) {
+    if (!ix || !name || !value) LM_FAIL(LM_EINVAL, "NULL argument");
+    if (!std::strcmp(name, "pq_rerank_overflow")) *value = ix->pq_overflow;
+    else if (!std::strcmp(name, "pq_rerank_expanded")) *value = ix->pq_rerank_expanded ? 1 : 0;
+    else if (!std::strcmp(name, "pq_threads")) *value = ix->pq_threads;
+    else LM_FAIL(LM_EINVAL, std::string("unknown readable option: ") + name);
+    return LM_OK;
 }
 
 // Mean HIP-event-pair time around an EMPTY kernel on the index' stream: the fixed dispatch + event cost that

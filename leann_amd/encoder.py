@@ -354,10 +354,26 @@ def pack_w1_acc_order(w1: torch.Tensor) -> torch.Tensor:
     return w1.reshape(f, h // 32, 32)[:, :, perm].reshape(f, h).contiguous()
 
 
+def pack_tail_images(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> tuple:
+    """The three weight matrices of a layer tail as the LDS IMAGES csrc/lm_layer_tail_h384.hip streams (fp16, on the weights' device):
+    pack_wo_slabs / pack_w1_acc_order / pack_w2_fused_mlp, then the library's own chunk swizzle (lm_layer_tail_pack_h384) -- one
+    definition of the image layout, next to the kernel that reads it."""
+    import ctypes as C
+
+    from . import _lib
+
+    wos, w1a, w2p = pack_wo_slabs(wo.detach()), pack_w1_acc_order(w1.detach()), pack_w2_fused_mlp(w2.detach())
+    imgs = tuple(torch.empty_like(s) for s in (wos, w1a, w2p))
+    st = C.c_void_p(torch.cuda.current_stream(wo.device).cuda_stream) if wo.is_cuda else None
+    _lib.check(_lib.load().lm_layer_tail_pack_h384(C.c_void_p(wos.data_ptr()), C.c_void_p(w1a.data_ptr()), C.c_void_p(w2p.data_ptr()), int(w1.shape[0]),
+                                                   *(C.c_void_p(i.data_ptr()) for i in imgs), st), "lm_layer_tail_pack_h384")
+    return imgs  # (the packed sources die with this frame: the kernels above run on the stream the caching allocator orders their reuse on)
+
+
 def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
-    """LayerNorm2(x + fc2(GELU(fc1(x)))) with x = LayerNorm1(resid + out(a)) in ONE kernel (csrc/lm_mlp_fused_v3.hip:
-    k_attn_out_mlp_h384) for hidden 384, fp16 on the GPU.  LEANN_MI355X_TAIL=0 = the three-kernel path (A/B); None = the caller
-    takes that path."""
+    """LayerNorm2(x + fc2(GELU(fc1(x)))) with x = LayerNorm1(resid + out(a)) in ONE kernel (csrc/lm_layer_tail_h384.hip:
+    k_layer_tail_h384, generation 4 of the fused layer tail) for hidden 384, fp16 on the GPU, ffn a multiple of 192.
+    LEANN_MI355X_TAIL=0 = the three-kernel path (A/B); None = the caller takes that path."""
     import os
 
     if os.environ.get("LEANN_MI355X_TAIL", "1") != "1" or os.environ.get("LEANN_MI355X_MLP", "1") != "1":
@@ -366,27 +382,26 @@ def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") ->
         return None  # an explicitly selected older kernel generation is an A/B run of THAT kernel
     f, h = layer.fc1.weight.shape
     if not (a.is_cuda and a.dtype == torch.float16 and a.is_contiguous() and resid.is_contiguous() and resid.dtype == torch.float16
-            and h == 384 and f % 32 == 0 and 128 <= f <= 2560 and layer.out.bias is not None):
+            and h == 384 and f % 192 == 0 and 192 <= f <= 2496 and layer.out.bias is not None):
         return None
     import ctypes as C
 
     from . import _lib
 
-    wo_p, bo, w1a, b1, w2p, b2 = _packed(
+    wo_i, bo, w1_i, b1, w2_i, b2 = _packed(
         layer, "_tail_pack", (layer.out.weight, layer.out.bias, layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias),
-        lambda: (pack_wo_slabs(layer.out.weight.detach()), layer.out.bias.detach().float().contiguous(),
-                 pack_w1_acc_order(layer.fc1.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
-                 pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc2.bias.detach().float().contiguous()))
+        lambda: (lambda im: (im[0], layer.out.bias.detach().float().contiguous(), im[1], layer.fc1.bias.detach().float().contiguous(), im[2],
+                             layer.fc2.bias.detach().float().contiguous()))(pack_tail_images(layer.out.weight, layer.fc1.weight, layer.fc2.weight)))
     out = torch.empty_like(resid)
     vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     tm = KernelTimers.active
-    ev = tm.span("attn_out_mlp_h384", a.shape[0] * (4.0 * f * h + 2.0 * h * h)) if tm is not None else None
+    ev = tm.span("layer_tail_h384", a.shape[0] * (4.0 * f * h + 2.0 * h * h)) if tm is not None else None
     if ev:
         ev[0].record()
-    _lib.check(_lib.load().lm_attn_out_mlp_fused_h384_f16(
-        vp(a), vp(resid), vp(wo_p), vp(bo), vp(layer.ln1.weight), vp(layer.ln1.bias), float(layer.ln1.eps), vp(w1a), vp(b1), vp(w2p), vp(b2),
+    _lib.check(_lib.load().lm_layer_tail_h384_f16(
+        vp(a), vp(resid), vp(wo_i), vp(bo), vp(layer.ln1.weight), vp(layer.ln1.bias), float(layer.ln1.eps), vp(w1_i), vp(b1), vp(w2_i), vp(b2),
         vp(layer.ln2.weight), vp(layer.ln2.bias), vp(out), a.shape[0], f, float(layer.ln2.eps),
-        C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "lm_attn_out_mlp_fused_h384_f16")
+        C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "lm_layer_tail_h384_f16")
     if ev:
         ev[1].record()
     return out
@@ -696,11 +711,12 @@ class BertEncoder(nn.Module):
     def onecall_model(self) -> Optional[dict]:
         """``{"model": lm_bert_h384 struct, ...}`` over this encoder's weights (packed copies cached, rebuilt when a weight changes: _packed)
         -- the argument of lm_bert_h384_forward_packed and of the built-in recompute provider (lm_recompute_create) -- or None when the
-        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights, mean or CLS pooling, 128 <= ffn <= 2560, ffn % 32 == 0."""
+        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights on the GPU, mean or CLS pooling, ffn a multiple of 192 in
+        [192, 2496] (the fused layer tail's shapes; other widths: general_model)."""
         cfg = self.cfg
         w = self.word.weight
-        if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling in ("mean", "cls") and cfg.ffn % 32 == 0
-                and 128 <= cfg.ffn <= 2560):
+        if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling in ("mean", "cls") and cfg.ffn % 192 == 0
+                and 192 <= cfg.ffn <= 2496):
             return None
         from . import _lib
 
@@ -708,9 +724,10 @@ class BertEncoder(nn.Module):
             keep, layers = [], (_lib.BertH384Layer * cfg.layers)()
             ptr = lambda t: (keep.append(t), t.data_ptr())[1]  # noqa: E731 - tensors stay referenced for the life of the pack
             for li, L in enumerate(self.layers):
-                vals = (L.qkv.weight.detach().contiguous(), L.qkv.bias.detach().float().contiguous(), pack_wo_slabs(L.out.weight.detach()),
+                wo_i, w1_i, w2_i = pack_tail_images(L.out.weight, L.fc1.weight, L.fc2.weight)
+                vals = (L.qkv.weight.detach().contiguous(), L.qkv.bias.detach().float().contiguous(), wo_i,
                         L.out.bias.detach().float().contiguous(), L.ln1.weight.detach().contiguous(), L.ln1.bias.detach().contiguous(),
-                        pack_w1_acc_order(L.fc1.weight.detach()), L.fc1.bias.detach().float().contiguous(), pack_w2_fused_mlp(L.fc2.weight.detach()),
+                        w1_i, L.fc1.bias.detach().float().contiguous(), w2_i,
                         L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous(),
                         L.out.weight.detach().contiguous(), L.fc1.weight.detach().contiguous(), L.fc2.weight.detach().contiguous())
                 for (name, _), v in zip(_lib.BertH384Layer._fields_, vals):
@@ -776,7 +793,7 @@ class BertEncoder(nn.Module):
         tot, n = tok.shape[0], cu.shape[0] - 1
         pk = self.onecall_model() if max_len <= 256 else None
         if pk is None:  # other widths (768: bge-base, contriever): the general kernels, also strung together on the C++ side
-            gk = self.general_model() if self.cfg.hidden != 384 and max_len <= (256 if self.cfg.hidden == self.cfg.heads * 32 else 512) else None
+            gk = self.general_model() if max_len <= (256 if self.cfg.hidden == self.cfg.heads * 32 else 512) else None
             if gk is None:
                 return None
             need = int(lib.lm_bert_workspace_bytes(C.byref(gk["model"]), tot))

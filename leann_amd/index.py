@@ -142,6 +142,11 @@ class Mi355xIndex:
     def set_option(self, name: str, value: int) -> None:
         check(self._lib.lm_index_set_option(self._h, name.encode(), int(value)), "lm_index_set_option")
 
+    def get_option(self, name: str) -> int:
+        out = C.c_int64()
+        check(self._lib.lm_index_get_option(self._h, name.encode(), C.byref(out)), "lm_index_get_option")
+        return int(out.value)
+
     def event_overhead_us(self) -> float:
         out = C.c_double()
         check(self._lib.lm_index_event_overhead_us(self._h, C.byref(out)), "lm_index_event_overhead_us")

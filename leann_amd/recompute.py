@@ -62,7 +62,7 @@ class RecomputeProvider:
         # cached packs; a NEW pack object means the weights changed: the handle holds the old pointers
         pk = self.encoder.onecall_model() if fused else None
         if pk is None:
-            fused, pk = False, (self.encoder.general_model() if cfg.hidden != 384 else None)
+            fused, pk = False, self.encoder.general_model()  # also hidden 384 with an ffn the fused layer tail does not take
         if self._native_tried and pk is getattr(self, "_native_pack", None):
             return self._native
         self.close()

@@ -39,6 +39,12 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0, help="neighbour-selection relaxation of the graph builder (1.0 = the HNSW rule; 1.2 = Vamana's, denser lists)")
     ap.add_argument("--cpu-baseline-queries", type=int, default=8)
     ap.add_argument("--pq-threads", type=int, default=1024, choices=[256, 512, 1024], help="workgroup width of the traversal kernel (A/B)")
+    ap.add_argument("--rerank-expanded", type=int, default=-1, choices=[-1, 0, 1],
+                    help="rerank set of the deferred fetch: 0 the final candidate list, 1 every expanded node (upstream DiskANN's full_retset; index option "
+                         "pq_rerank_expanded), -1 (default) sweep both and time the one that reaches recall 0.9 with the smaller list (ties: the final list)")
+    ap.add_argument("--diagnose", action="store_true",
+                    help="before the sweep: (1) recall of the EXACT-distance beam search on the same flat graph (is the graph the limit?), (2) how much of the "
+                         "true top-10 a brute-force ADC scan ranks inside its top-L (is the quantiser the limit?), for 64 queries")
     ap.add_argument("--pooling", default="mean", choices=["mean", "cls"],
                     help="sentence pooling of the RANDOM-INIT stand-in encoder.  bge-small pools the [CLS] row, but with random weights the [CLS] rows of "
                          "different chunks are nearly parallel (mean pairwise cosine 0.997 on this corpus: attention is ~uniform, so [CLS] sees the same "
@@ -102,25 +108,71 @@ def main():
     for b0 in range(0, nq, 256):
         gt[b0 : b0 + 256] = torch.topk(Q[b0 : b0 + 256] @ X.T, 10, dim=1).indices
     gt = gt.cpu().numpy()
-    # ---- complexity sweep (untimed, the last 256 queries): recall@10 after the deferred rerank per candidate-list size ----
-    sweep = {}
     nsw = min(256, B)
     qs = Q[nq - nsw :].contiguous()
-    for L in (64, 128, 256, 512, 1024, 2048):
-        try:
-            ls, _ = idx.pq_search_device(qs, 10, idx.make_pq_params(L, args.beam, use_deferred_fetch=True))
-        except Exception as ex:  # noqa: BLE001 - the candidate list + frontier no longer fit the LDS next to the lookup table
-            log(f"complexity {L}: {ex!r}"[:200])
-            break
-        st = idx.stats()
-        lsn = ls.cpu().numpy()
-        sweep[L] = {"recall_at_10": round(float(np.mean([len(set(lsn[i]) & set(gt[nq - nsw + i])) / 10 for i in range(nsw)])), 4),
-                    "adc_evals_per_query": round(st["ndis"] / nsw, 1), "reranked_chunks_per_query": round(st["nunique"] / nsw, 1)}
-        if args.complexity == 0 and sweep[L]["recall_at_10"] >= 0.9:
-            break
-    log("complexity sweep:", json.dumps(sweep))
+    diag = None
+    if args.diagnose:
+        diag = {}
+        # (1) exact distances on the same graph: stored-embedding beam search (no quantiser in the loop)
+        idx.attach_table(X)
+        for ef_ in (64, 256, 1024):
+            _, le = idx.search_device(qs, 10, idx.make_params(ef=ef_, beam=1, recompute=False))
+            le = le.cpu().numpy()
+            diag[f"exact_distance_search_ef{ef_}_recall_at_10"] = round(float(np.mean([len(set(le[i]) & set(gt[nq - nsw + i])) / 10 for i in range(nsw)])), 4)
+        # (2) brute-force ADC ranking of the whole corpus (no graph in the loop): share of the true top-10 inside the ADC top-L
+        nd = 64
+        Ls = (64, 256, 1024, 2048)
+        hit = {L_: 0 for L_ in Ls}
+        m_ = args.pq_bytes
+        dsub = D // m_
+        cbt = cb.to(dev)  # (m, 256, dsub)
+        for qi in range(nd):
+            qv = Q[nq - nsw + qi].view(m_, 1, dsub)
+            lut = -(cbt * qv).sum(-1)  # (m, 256): -<q_j, c>  (mips)
+            adc = torch.zeros((n,), dtype=torch.float32, device=dev)
+            for c0 in range(0, n, 2_000_000):
+                cc = codes[c0 : c0 + 2_000_000].long()  # (chunk, m)
+                adc[c0 : c0 + cc.shape[0]] = lut[torch.arange(m_, device=dev)[None, :], cc].sum(1)  # sum_j lut[j, code_j]
+            top = torch.topk(adc, max(Ls), largest=False).indices.cpu().numpy()
+            truth = set(gt[nq - nsw + qi].tolist())
+            for L_ in Ls:
+                hit[L_] += len(truth & set(top[:L_].tolist()))
+        for L_ in Ls:
+            diag[f"true_top10_inside_bruteforce_adc_top{L_}"] = round(hit[L_] / (10 * nd), 4)
+        log("diagnosis:", json.dumps(diag))
+    # ---- complexity sweep (untimed, the last 256 queries): recall@10 after the deferred rerank per candidate-list size, for both rerank sets ----
+    sweeps = {}
+    for mode in ((0, 1) if args.rerank_expanded < 0 else (args.rerank_expanded,)):
+        idx.set_option("pq_rerank_expanded", mode)
+        sweep = {}
+        for L in (64, 128, 256, 512, 1024, 2048):
+            try:
+                ls, _ = idx.pq_search_device(qs, 10, idx.make_pq_params(L, args.beam, use_deferred_fetch=True))
+            except Exception as ex:  # noqa: BLE001 - the candidate list + frontier no longer fit the LDS next to the lookup table
+                log(f"complexity {L}: {ex!r}"[:200])
+                break
+            st = idx.stats()
+            lsn = ls.cpu().numpy()
+            sweep[L] = {"recall_at_10": round(float(np.mean([len(set(lsn[i]) & set(gt[nq - nsw + i])) / 10 for i in range(nsw)])), 4),
+                        "adc_evals_per_query": round(st["ndis"] / nsw, 1), "reranked_chunks_per_query": round(st["nunique"] / nsw, 1)}
+            if args.complexity == 0 and sweep[L]["recall_at_10"] >= 0.9:
+                break
+        sweeps["expanded_nodes" if mode else "final_list"] = sweep
+        log(f"complexity sweep (rerank set = {'expanded nodes' if mode else 'final list'}):", json.dumps(sweep))
+        if mode:
+            log("queries whose expansions outgrew the record:", idx.get_option("pq_rerank_overflow"))
+
+    def first_ok(sw):
+        return next((L for L in sorted(sw) if sw[L]["recall_at_10"] >= 0.9), None)
+
+    cand = {k_: first_ok(v_) for k_, v_ in sweeps.items()}
+    use_mode = "final_list" if "final_list" in sweeps else "expanded_nodes"
+    if cand.get("expanded_nodes") and (not cand.get("final_list") or cand["expanded_nodes"] < cand["final_list"]):
+        use_mode = "expanded_nodes"
+    sweep = sweeps[use_mode]
+    idx.set_option("pq_rerank_expanded", 1 if use_mode == "expanded_nodes" else 0)
     if args.complexity == 0:
-        args.complexity = next((L for L in sorted(sweep) if sweep[L]["recall_at_10"] >= 0.9), max(sweep))
+        args.complexity = cand.get(use_mode) or max(sweep)
     prm = idx.make_pq_params(args.complexity, args.beam, use_deferred_fetch=True)
     setup_s = time.time() - t_all
     log(f"setup {setup_s:.0f}s; timing {K} steps x {B} queries")
@@ -168,7 +220,7 @@ def main():
                                f"beam_width {args.beam}, top-10, {B} queries/step, one deferred rerank through the recompute provider; "
                                f"{args.model} shape, random init, {enc.cfg.pooling} pooling",
                    "baseline_config": "c3", "n_chunks": n, "queries_per_step": B},
-        "recall_at_10": round(rec, 4), "complexity_sweep": sweep,
+        "recall_at_10": round(rec, 4), "complexity_sweep": sweeps, "rerank_set": use_mode, "diagnosis": diag,
         "roofline": {"bound": "hbm", "kernel": "lm::k_pq_traverse (persistent PQ-ADC traversal, one launch per batch; codes gathered from HBM, LUT in LDS)",
                      "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None,
                      "bytes_per_adc_eval": bytes_eval, "adc_evals_per_launch": pst["ndis"], "us_per_launch": round(1e3 * trav_ms, 1),

@@ -34,12 +34,26 @@ def main():
     ap.add_argument("--efc", type=int, default=200)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-emulated", default=None, metavar="LIB", help="TEST ONLY (tests/test_bench_dry_run.py): as bench.py's switch of this name")
     args = ap.parse_args()
+    dry = bool(args.dry_run_emulated)
+    if dry:
+        import contextlib
+
+        import bench as _bench
+
+        with contextlib.ExitStack() as stack:
+            _bench._enter_dry_run(args, stack)
+            return _main(args, dry)
+    return _main(args, dry)
+
+
+def _main(args, dry):
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
     from leann_amd import _lib
     from leann_amd.distributed import ShardedSearch, all_gather_results, shard_bounds
-    from leann_amd.encoder import BertEncoder, KernelTimers, config_for
+    from leann_amd.encoder import BertEncoder, config_for
     from leann_amd.gpu_graph_build import build_graph_gpu
     from leann_amd.index import Mi355xIndex
     from leann_amd.recompute import RecomputeProvider
@@ -48,23 +62,30 @@ def main():
 
     _lib.require_gpu()
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local) if not dry else torch.device("cpu")
+    lib_dev = local if not dry else 0
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def log(*a):
         if rank == 0:
             print("[c4]", *a, file=sys.stderr, flush=True)
 
     B, K, W = args.batch, args.steps, args.warmup
-    ktm = KernelTimers.active = KernelTimers()  # HIP-event pairs around the dominant encoder kernel, labelled by phase (as bench.py)
+    cfg0 = config_for(args.model)
+    kt_dominant = _lib.KT_LAYER_TAIL if cfg0.hidden == 384 and cfg0.ffn % 192 == 0 else _lib.KT_GEMM_F16
+    _lib.kernel_timing_enable(1 << kt_dominant)  # event pairs around the dominant encoder kernel, recorded by the library (as bench.py)
     lo, hi = shard_bounds(args.chunks, world)[rank]
     ns = hi - lo
     t_all = time.time()
     # the shard's chunks: an independent corpus per shard (seed = 1234 + rank), ids local to the shard + id_base = lo
-    corpus = SyntheticCorpus(CorpusSpec(n_chunks=ns, seed=1234 + rank))
+    corpus = SyntheticCorpus(CorpusSpec(n_chunks=ns, seed=1234 + rank) if not dry else
+                             CorpusSpec(n_chunks=ns, seed=1234 + rank, vocab_size=2000, n_topics=8, len_mean=10.0, len_std=3.0, len_min=4, len_max=20))
     tok, off = corpus.chunks_torch(dev)
-    tokens = TokenStore(tok, off, device=local)
+    tokens = TokenStore(tok, off, device=lib_dev)
     cfg = config_for(args.model)
     enc = BertEncoder.load(args.model, allow_random=True).to(dev, dtype=torch.float16).eval()
     D = cfg.hidden
@@ -75,14 +96,14 @@ def main():
         X[b0 : b0 + ids.shape[0]] = provider.embed_ids(ids)
     g = build_graph_gpu(X, "mips", M=args.M, ef_construction=args.efc)
     log(f"shard of {ns} chunks ready in {time.time() - t_all:.0f}s (mean level-0 degree {g.level0_degrees().mean():.1f})")
-    idx = Mi355xIndex.from_csr(g, device=local)
+    idx = Mi355xIndex.from_csr(g, device=lib_dev)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
     idx.set_provider(provider)
     # queries: identical on every rank (drawn from shard 0's documents; broadcast from rank 0)
     nq = B * (K + W)
     if rank == 0:
         qt, qo, _ = corpus.queries(nq, seed=4321)
-        Q = RecomputeProvider(enc, TokenStore(qt, qo, device=local), provider.dp, dev).embed_ids(torch.arange(nq, dtype=torch.int32, device=dev)).contiguous()
+        Q = RecomputeProvider(enc, TokenStore(qt, qo, device=lib_dev), provider.dp, dev).embed_ids(torch.arange(nq, dtype=torch.int32, device=dev)).contiguous()
     else:
         Q = torch.empty((nq, D), dtype=torch.float32, device=dev)
     if world > 1:
@@ -115,13 +136,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ktm.phase = "warmup"
     for w in range(W):
         ss.search(Q[w * B : (w + 1) * B].contiguous(), 10)
     labels = []
     agg = {"ndis": 0, "nunique": 0, "nrounds": 0}
     barrier()
-    ktm.phase = "timed"
+    _lib.kernel_timing_read(reset=True)
     t0 = time.perf_counter()
     for st in range(K):
         _, l = ss.search(Q[(W + st) * B : (W + st + 1) * B].contiguous(), 10)
@@ -131,7 +151,8 @@ def main():
             agg[k_] += st_[k_]
     barrier()
     elapsed = time.perf_counter() - t0
-    ktm.phase = "after"
+    kt_timed = _lib.kernel_timing_read(reset=True)
+    _lib.kernel_timing_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,17 +172,17 @@ def main():
     barrier()
     coll_us = (time.perf_counter() - t0) / 20 * 1e6
     # roofline of the dominant kernel of the timed region (the fused layer tail, MFMA bound), as in bench.py
-    kt = ktm.totals("timed").get("attn_out_mlp_h384")
-    KernelTimers.active = None
+    kname = "lm::k_layer_tail_h384" if kt_dominant == _lib.KT_LAYER_TAIL else "lm::k_gemm_f16"
+    kt = kt_timed.get(kname)
     roofline = None
     if kt and kt["ms"] > 0:
         tf = kt["work"] / (kt["ms"] * 1e-3) / 1e12
-        fpt = 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden
-        roofline = {"bound": "mfma", "kernel": "lm::k_attn_out_mlp_h384<0> (attention output projection + LayerNorm + feed-forward block + LayerNorm)",
+        fpt = 4 * cfg.ffn * cfg.hidden + 2 * cfg.hidden * cfg.hidden if kt_dominant == _lib.KT_LAYER_TAIL else None
+        roofline = {"bound": "mfma", "kernel": kname + (" (attention output projection + LayerNorm + feed-forward block + LayerNorm, generation 4)" if fpt else " (general MFMA GEMM)"),
                     "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5), "traffic": None,
                     "flops_per_token": fpt, "launches": kt["launches"], "avg_launch_us": round(1e3 * kt["ms"] / kt["launches"], 1),
-                    "tokens_per_launch": round(kt["work"] / fpt / kt["launches"]), "share_of_timed_region": round(kt["ms"] / (elapsed * 1e3), 4),
-                    "timing": "HIP event pairs around every launch of the timed region, rank 0 (one pair per launch inside the timed region)"}
+                    "tokens_per_launch": round(kt["work"] / fpt / kt["launches"]) if fpt else None, "share_of_timed_region": round(kt["ms"] / (elapsed * 1e3), 4),
+                    "timing": "library-side HIP event pairs around every launch of the timed region, rank 0 (csrc/lm_timing.cpp); library-side recompute provider"}
     cpu_base = None
     if rank == 0 and not args.no_cpu_baseline:  # the oracle traversal + fp32 CPU encoder on shard 0, a bounded sample of the same queries
         try:
@@ -182,7 +203,8 @@ def main():
             "metric": f"queries/sec, {args.chunks}-chunk HNSW sharded {world}-way, query batch {B}, RCCL all_gather of per-shard top-k + merge",
             "value": round(K * B / elapsed, 3), "unit": "queries/s", "n_gpus": world, "rccl_ranks": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16",
-            "dtype_detail": "encoder fp16 MFMA with fp32 accumulation; distances / merge f32", "data": "synthetic",
+            "dtype_detail": "encoder fp16 MFMA with fp32 accumulation; distances / merge f32",
+            "data": "synthetic" if not dry else "dry-run (emulated library on the CPU: control flow only, nothing here is a measurement)", "dry_run": dry,
             "roofline": roofline, "cpu_baseline": cpu_base,
             "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),
                           "rounds_per_step": round(agg["nrounds"] / max(K, 1), 1)},

@@ -596,7 +596,10 @@ int main(int argc, char** argv) {
                                           1e-12f, st));
             };
             // LEANN_MI355X_TAIL4 = 1000 DM + 100 RD/4 + 10 GF + WM (DM: DMA pieces 0 at slot 0 / 1 three groups / 2 singles; RD 4 / 8; GF 1 C, 4 asm; WM 1 batched LDS waits)
-            const char* vars[] = {"0", "110", "1110", "2110", "210", "1210", "2210", "211", "1211", "2211", "2140", "2241", "1241"};
+            // KBENCH_TAIL4_ONLY=1: the product instance alone, no stamps (the PMC passes: scripts/pmc_sq.sh, scripts/pmc_tail.sh)
+            const bool only0 = getenv("KBENCH_TAIL4_ONLY") != nullptr;
+            std::vector<const char*> vars = {"0", "110", "1110", "2110", "210", "1210", "2210", "211", "1211", "2211", "2140", "2241", "1241"};
+            if (only0) vars = {"0"};
             for (const char* v : vars) {  // correctness of every variant first (sampled rows against the fp32 reference, all rows against generation 3)
                 setenv("LEANN_MI355X_TAIL4", v, 1);
                 CK(hipMemsetAsync(out4.p, 0xFF, out4.n * sizeof(__half), st));
@@ -623,6 +626,7 @@ int main(int argc, char** argv) {
                 }
             }
             for (const char* v : {"10110", "12110", "12211", "11211", "12241"}) {  // stamps (10000 +)
+                if (only0) break;
                 setenv("LEANN_MI355X_TAIL4", v, 1);
                 const int nwg = (T + 127) / 128;
                 for (int rep = 0; rep < 3; ++rep) run4();

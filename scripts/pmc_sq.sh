@@ -26,7 +26,7 @@ if f:
         a[1] += float(r["Counter_Value"])
 res = {}
 for k, cs in agg.items():
-    if not any(s in k for s in ("k_attn_out_mlp", "k_gemm_f16", "k_gemm_ws", "k_attn_varlen")):
+    if not any(s in k for s in ("k_attn_out_mlp", "k_layer_tail", "k_gemm_f16", "k_gemm_ws", "k_attn_varlen")):
         continue
     d = {c: round(v / n) for c, (n, v) in cs.items()}
     d["dispatches"] = max(n for n, _ in cs.values())

@@ -3,12 +3,13 @@
 # `kbench 262107 3 bwtail`, calibrated in the same passes on kbench's streaming read / write probes of a known byte count
 # (MI355X_MICROARCH.md, HBM: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950; WRITE_SIZE uncalibrated).  --kernel-trace only.
 set -u
+export KBENCH_TAIL4_ONLY=1
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/$1; mkdir -p "$OUT"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- $ROOT/leann_amd/lib/bin/kbench 262107 3 bwtail > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- $ROOT/leann_amd/lib/bin/kbench 262107 3 bwtail4 > $OUT/pmc_$c.log 2>&1
   echo "$c rc=$?"
 done
 python - "$OUT" <<'PY'

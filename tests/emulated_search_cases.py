@@ -179,6 +179,22 @@ def case_pq(deferred=True):
         el2, ed2, ost2 = orc.pq_search(og, cb.numpy(), codes.numpy(), q, 5, L=24, W=40, table=x)
         _check("pq traversal, beam 40 on a 24-entry list", (d2, l2), (el2, ed2))
         assert int(st2["ndis"]) == int(ost2["n_adc"]), (st2, ost2)
+        # option "pq_rerank_expanded": the exact rerank over EVERY expanded node = upstream DiskANN's full_retset -- the second oracle
+        # (oracle/lm_oracle_diskann.c, the transcription of cached_beam_search) with rerank_final_list_only off, ids and distances;
+        # with the option off the same oracle's final-list form (= lm_oracle_pq.c) must come back
+        idx.set_option("pq_rerank_expanded", 1)
+        differs = 0
+        for L, Wb in ((12, 2), (24, 40), (6, 1)):
+            l3, d3 = idx.pq_search(q, 5, idx.make_pq_params(L, Wb))
+            ui, ud, ust = orc.diskann_search(og, cb.numpy(), codes.numpy(), q, 5, L=L, W=Wb, table=x, rerank_final_list_only=False)
+            _check(f"pq traversal, rerank set = expanded nodes (upstream full_retset) L={L} W={Wb}", (d3, l3), (ui, ud))
+            differs += ust["n_final_differs"]
+        assert differs > 0  # (on at least one query the expanded set is a strict superset of the final list: the option is exercised)
+        assert idx.get_option("pq_rerank_overflow") == 0 and idx.get_option("pq_rerank_expanded") == 1
+        idx.set_option("pq_rerank_expanded", 0)
+        l4, d4 = idx.pq_search(q, 5, idx.make_pq_params(12, 2))
+        fi, fd, _ = orc.diskann_search(og, cb.numpy(), codes.numpy(), q, 5, L=12, W=2, table=x, rerank_final_list_only=True)
+        _check("pq traversal, rerank set = final list again", (d4, l4), (fi, fd))
     idx.close()
 
 
@@ -474,6 +490,35 @@ def case_encoder_abi():
         assert np.abs(o3.astype(np.float64) - ot.astype(np.float64)).max() < 1.5e-2, (Tt, F3)
     assert lib.lm_attn_out_mlp_fused_h384_f16(vp(at), vp(rs), vp(wos), vp(bo), vp(gamma1), vp(beta1), 1e-12, vp(w1a), vp(b1t), vp(w2pt), vp(b2),
                                               vp(gamma), vp(beta), vp(ot), Tt, 96, 1e-12, None) == -1  # ffn < 128
+    # generation 4 (lm_layer_tail_h384.hip): weight images, alternating products; ffn a multiple of 192; ragged token counts
+    for Tt, F4 in ((130, 192), (257, 384)):
+        at = rng.standard_normal((Tt, H)).astype(np.float16)
+        rs = rng.standard_normal((Tt, H)).astype(np.float16)
+        w1t = (rng.standard_normal((F4, H)) / np.sqrt(H)).astype(np.float16)
+        w2t = (rng.standard_normal((H, F4)) / np.sqrt(F4)).astype(np.float16)
+        b1t = (0.2 * rng.standard_normal(F4)).astype(np.float32)
+        x1 = ln_with(rs.astype(np.float64) + at.astype(np.float64) @ wo.astype(np.float64).T + bo, gamma1, beta1).astype(np.float16)
+        hidt = x1.astype(np.float64) @ w1t.astype(np.float64).T + b1t
+        p16t = (0.5 * hidt * (1 + erf(hidt / np.sqrt(2)))).astype(np.float16).astype(np.float64)
+        reft = ln(p16t @ w2t.astype(np.float64).T + b2 + x1.astype(np.float64))
+        wos = pack_wo_slabs(torch.from_numpy(wo)).numpy()
+        w1a = pack_w1_acc_order(torch.from_numpy(w1t)).numpy()
+        w2pt = pack_w2_fused_mlp(torch.from_numpy(w2t)).numpy()
+        woi, w1i, w2i = np.zeros_like(wos), np.zeros_like(w1a), np.zeros_like(w2pt)
+        _lib.check(lib.lm_layer_tail_pack_h384(vp(wos), vp(w1a), vp(w2pt), F4, vp(woi), vp(w1i), vp(w2i), None), "tail images")
+        for src, img in ((wos, woi), (w1a, w1i), (w2pt, w2i)):  # an image is a permutation of 16-byte chunks
+            assert np.array_equal(np.sort(src.view(np.uint64).reshape(-1, 2), axis=0), np.sort(img.view(np.uint64).reshape(-1, 2), axis=0))
+        o4 = np.zeros((Tt, H), np.float16)
+        _lib.check(lib.lm_layer_tail_h384_f16(vp(at), vp(rs), vp(woi), vp(bo), vp(gamma1), vp(beta1), 1e-12, vp(w1i), vp(b1t), vp(w2i), vp(b2),
+                                              vp(gamma), vp(beta), vp(o4), Tt, F4, 1e-12, None), "tail4")
+        err4 = np.abs(o4.astype(np.float64) - reft).max()
+        assert err4 < 1.2e-2, (Tt, F4, err4)
+        o3 = np.zeros((Tt, H), np.float16)  # generation 3 on the same operands: agreement to fp16 rounding
+        _lib.check(lib.lm_attn_out_mlp_fused_h384_f16(vp(at), vp(rs), vp(wos), vp(bo), vp(gamma1), vp(beta1), 1e-12, vp(w1a), vp(b1t), vp(w2pt), vp(b2),
+                                                      vp(gamma), vp(beta), vp(o3), Tt, F4, 1e-12, None), "tail3")
+        assert np.abs(o3.astype(np.float64) - o4.astype(np.float64)).max() < 8e-3, (Tt, F4)
+    assert lib.lm_layer_tail_h384_f16(vp(at), vp(rs), vp(woi), vp(bo), vp(gamma1), vp(beta1), 1e-12, vp(w1i), vp(b1t), vp(w2i), vp(b2),
+                                      vp(gamma), vp(beta), vp(o4), Tt, 224, 1e-12, None) == -1  # ffn % 192
     # add + LayerNorm: both generations through the same entry point
     for gen in ("1", "2"):
         os.environ["LEANN_MI355X_LN"] = gen
@@ -786,7 +831,7 @@ def case_encoder_python_wiring():
             got2 = enc16.encode_tokens_packed(ti, tl, 4096)
     assert float((got2.float() - ref).abs().max()) < 6e-3
     # the DEFAULT kernel set (weight-stationary QKV GEMM, attention revision 2, fused layer tail)
-    for ffn, extra, want in ((128, {}, {"lm_gemm_ws_h384_f16": 2, "lm_attn_out_mlp_fused_h384_f16": 2}),):
+    for ffn, extra, want in ((384, {}, {"lm_gemm_ws_h384_f16": 2, "lm_layer_tail_h384_f16": 2}),):
         cfg3 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=ffn, max_pos=64, max_seq_length=48)
         e32 = BertEncoder.random_init(cfg3, 5).eval()
         with torch.no_grad():
@@ -807,7 +852,7 @@ def case_encoder_python_wiring():
         err3 = float((got3.float() - ref3).abs().max())
         assert err3 < 6e-3, (ffn, err3)
     # the default launch path: the whole forward as ONE library call (csrc/lm_encoder_forward.cpp) -- same kernels, same result as the default path
-    cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=128, max_pos=64, max_seq_length=48)
+    cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=384, max_pos=64, max_seq_length=48)
     e1 = BertEncoder.random_init(cfg1, 5).eval().half()
     outs = {}
     for onecall, small in (("0", "0"), ("1", "0"), ("0", None), ("1", None)):  # large-forward form, then the small-forward form (general kernels)
@@ -824,9 +869,9 @@ def case_encoder_python_wiring():
         if onecall == "1":
             assert used.count("lm_bert_h384_forward_packed") == 1 and "lm_gemm_ws_h384_f16" not in used, sorted(set(used))
         elif small is None:
-            assert used.count("lm_gemm_f16") == 4 * cfg1.layers and "lm_attn_out_mlp_fused_h384_f16" not in used, sorted(set(used))
+            assert used.count("lm_gemm_f16") == 4 * cfg1.layers and "lm_layer_tail_h384_f16" not in used, sorted(set(used))
         else:
-            assert used.count("lm_attn_out_mlp_fused_h384_f16") == cfg1.layers and "lm_gemm_f16" not in used, sorted(set(used))
+            assert used.count("lm_layer_tail_h384_f16") == cfg1.layers and "lm_gemm_f16" not in used, sorted(set(used))
     print("one-call vs per-kernel: large form max|diff|", float((outs[("0", "0")] - outs[("1", "0")]).abs().max()), "small form", float((outs[("0", None)] - outs[("1", None)]).abs().max()), flush=True)
     assert torch.equal(outs[("0", "0")], outs[("1", "0")]) and torch.equal(outs[("0", None)], outs[("1", None)])
     with torch.no_grad():
@@ -866,7 +911,7 @@ def case_native_recompute(hidden=384, heads=12, pooling="mean", searches=True):
         cuda_stream = 0
 
     torch.manual_seed(1)
-    cfg = EncoderConfig(vocab_size=300, hidden=hidden, layers=1, heads=heads, ffn=128, max_pos=32, max_seq_length=24, pooling=pooling)
+    cfg = EncoderConfig(vocab_size=300, hidden=hidden, layers=1, heads=heads, ffn=384 if hidden == 384 else 128, max_pos=32, max_seq_length=24, pooling=pooling)
     enc = BertEncoder.random_init(cfg, 7).eval().half()
     rng = np.random.default_rng(5)
     n = 72

@@ -34,7 +34,7 @@ def test_bench_c4_one_shard_small():
     assert r["config"]["baseline_config"] == "c4" and r["rccl_ranks"] == 1 and r["value"] > 0
     assert r["recall_at_10"] >= 0.9
     assert r["allgather_plus_merge_us"] > 0
-    assert r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0 and "k_attn_out_mlp_h384" in r["roofline"]["kernel"]
+    assert r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0 and "k_layer_tail_h384" in r["roofline"]["kernel"]
     assert r["cpu_baseline"]["value"] and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port"
 
 

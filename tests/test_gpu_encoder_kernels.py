@@ -211,12 +211,12 @@ def test_default_forward_vs_cpu_fp32_and_one_call_vs_per_kernel(monkeypatch):
     used.clear()
     monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
     per = enc.encode_tokens_packed(ti, tl)
-    assert "lm_bert_h384_forward_packed" not in used and used.count("lm_attn_out_mlp_fused_h384_f16") == cfg.layers
+    assert "lm_bert_h384_forward_packed" not in used and used.count("lm_layer_tail_h384_f16") == cfg.layers
     assert torch.equal(one, per)
     # a SMALL forward (what a one-query search round is: a handful of chunks) takes the general kernels in both launch paths
     used.clear()
     per_s = enc.encode_tokens_packed(ti[:7], tl[:7])
-    assert used.count("lm_gemm_f16") == 4 * cfg.layers and "lm_attn_out_mlp_fused_h384_f16" not in used
+    assert used.count("lm_gemm_f16") == 4 * cfg.layers and "lm_layer_tail_h384_f16" not in used
     monkeypatch.delenv("LEANN_MI355X_ONECALL")
     used.clear()
     one_s = enc.encode_tokens_packed(ti[:7], tl[:7])
@@ -262,9 +262,9 @@ def test_fused_mlp_h384(tokens, ffn, variant, monkeypatch):
     assert (got.float() - dflt.float()).abs().max().item() <= 1.2e-2 * scale
 
 
-@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (300, 128), (300, 160), (300, 2560)])
+@pytest.mark.parametrize("tokens,ffn", [(128, 1536), (1, 1536), (129, 1536), (5000, 1536), (70000, 1536), (300, 192), (300, 384), (300, 2496)])
 def test_fused_attention_output_projection_and_mlp_h384(tokens, ffn, monkeypatch):
-    """lm_attn_out_mlp_fused_h384_f16 (the second half of a layer in one kernel; default, LEANN_MI355X_TAIL=0 for A/B) vs a plain
+    """lm_layer_tail_h384_f16 (the second half of a layer in one kernel, generation 4; default, LEANN_MI355X_TAIL=0 for A/B) vs a plain
     PyTorch fp32 reference of the same ops and vs the three-kernel path it replaces (weight-stationary GEMM, add + LayerNorm, fused MLP)."""
     import torch
     import torch.nn.functional as F

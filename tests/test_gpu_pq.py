@@ -76,6 +76,20 @@ def test_pq_search_parity(metric, L, W):
     gt, _ = orc.bruteforce_topk(x, q, 10, 1 if metric == "l2" else 0)
     if L >= 64:
         assert recall_at_k(gi, gt) > 0.9
+    # (4) option "pq_rerank_expanded": the rerank set = every expanded node = upstream DiskANN's full_retset; the second oracle
+    # (oracle/lm_oracle_diskann.c, a transcription of PQFlashIndex::cached_beam_search) with rerank_final_list_only off -- through the
+    # table and through the deferred fetch (ONE provider call over the union of the expanded sets)
+    idx.set_option("pq_rerank_expanded", 1)
+    ui, ud, ust = orc.diskann_search(og, cb, codes, q, 10, L=L, W=W, table=x, rerank_final_list_only=False)
+    gi2, gd2 = idx.pq_search(q, 10, idx.make_pq_params(L, W))
+    assert np.array_equal(gi2, ui) and np.array_equal(gd2.view(np.uint32), ud.view(np.uint32))
+    calls.clear()
+    idx.set_provider(provider)
+    gi3, gd3 = idx.pq_search(q, 10, idx.make_pq_params(L, W, use_deferred_fetch=True))
+    assert len(calls) == 1 and np.array_equal(gi3, ui) and np.array_equal(gd3.view(np.uint32), ud.view(np.uint32))
+    assert idx.get_option("pq_rerank_overflow") == 0
+    assert recall_at_k(gi2, gt) >= recall_at_k(gi, gt)  # a superset of the final list can only rank better
+    idx.set_option("pq_rerank_expanded", 0)
     idx.close()
 
 
@@ -97,5 +111,9 @@ def test_pq_errors_and_edge_cases():
         idx.pq_search(x[:1], 3, idx.make_pq_params(16, 1, use_deferred_fetch=True))
     with pytest.raises(ValueError):  # beam > 64
         idx.pq_search(x[:1], 3, idx.make_pq_params(16, 65, skip_search_reorder=True))
+    with pytest.raises(ValueError, match="recompute_neighbors"):  # the reference passes 0; anything else is refused, not ignored
+        prm_rn = idx.make_pq_params(16, 1, skip_search_reorder=True)
+        prm_rn.recompute_neighbors = 1
+        idx.pq_search(x[:1], 3, prm_rn)
     l, d = idx.pq_search(x[:2], 5000, idx.make_pq_params(16, 1, skip_search_reorder=True))  # k > N reachable
     assert (l[:, 4000:] == -1).all()
