@@ -293,7 +293,7 @@ int lm_attn_out_mlp_fused_h384_f16(const void *d_attn, const void *d_resid, cons
  * lm_attn_out_mlp_fused_h384_f16, but the three weight matrices are passed as ready-made LDS IMAGES (written once per model by
  * lm_layer_tail_pack_h384 from the packings above), so that the kernel's weight stream is a linear LDS-DMA copy, and the two
  * products of the feed-forward block alternate MFMA by MFMA on single accumulator chains (no partial sums, no stage arithmetic:
- * ~290 instead of ~470 instructions per 48 MFMAs on its one wave per SIMD).  ffn a multiple of 192 in [192, 2496]; other shapes:
+ * ~290 instead of ~470 instructions per 48 MFMAs on its one wave per SIMD).  ffn a multiple of 192 in [192, 1728]; other shapes:
  * the general GEMM path.  DEFAULT path of the hidden-384 forward.  Part of the BERT forward in compute_embeddings
  * (leann/embedding_compute.py:229-239). */
 int lm_layer_tail_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_img, const float *d_bo,
@@ -305,6 +305,15 @@ int lm_layer_tail_h384_f16(const void *d_attn, const void *d_resid, const void *
  * kernel's ds_read_b128 fragment reads bank-conflict free).  Device to device, on `stream`. */
 int lm_layer_tail_pack_h384(const void *d_wo_slabs, const void *d_w1_acc, const void *d_w2_slabs, int32_t ffn, void *d_wo_img,
                             void *d_w1_img, void *d_w2_img, void *stream);
+
+/* Weight-STREAMING form of the 384-input linear layer (csrc/lm_qkv_h384.hip): d_out[tokens][n_out] = x W^T + b, n_out a multiple of
+ * 128 in [256, 6144], d_w_img = lm_qkv_pack_h384's image of the nn.Linear weight [n_out][384] (same size).  x is read once (a wave holds
+ * its 32 token rows as MFMA B fragments for the whole kernel), W streams through a four-stage LDS ring shared by eight waves -- two per
+ * SIMD, ~230 registers each -- and a slab's 32 x 32 results leave through a per-wave LDS tile as full 128-byte lines.  The QKV projection
+ * of the hidden-384 forward (leann/embedding_compute.py:229-239). */
+int lm_qkv_h384_f16(const void *d_x, const void *d_w_img, const float *d_bias, int32_t n_out, void *d_out, int64_t tokens,
+                    void *stream);
+int lm_qkv_pack_h384(const void *d_w, int32_t n_out, void *d_w_img, void *stream); /* device to device, on `stream` */
 
 /* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
  *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
@@ -343,7 +352,7 @@ int lm_gemm_f16(const void *d_x, const void *d_w, const float *d_bias, const voi
  * Replaces compute_embeddings' model.encode() (leann/embedding_compute.py:229-239) for sentence-transformers models of the
  * all-MiniLM family: embedding front end, per layer {lm_gemm_ws_h384_f16 (QKV), lm_attn_varlen_hd32_f16,
  * lm_layer_tail_h384_f16}, lm_meanpool_varlen_f16 / lm_clspool_varlen_f16 -- one foreign-function call per recompute round
- * instead of ~3 L + 2.  ffn a multiple of 192 in [192, 2496] (other widths: lm_bert_forward_packed).
+ * instead of ~3 L + 2.  ffn a multiple of 192 in [192, 1728] (other widths: lm_bert_forward_packed).
  * All pointers are device pointers except `layers` (host array).  Weight layouts as documented at the entry points named above
  * (the three images of lm_layer_tail_pack_h384; leann_amd/encoder.py: pack_tail_images).  d_out: fp32 [n_seqs][384]. */
 typedef struct lm_bert_h384_layer {
@@ -363,6 +372,9 @@ typedef struct lm_bert_h384_layer {
      * layer tail, whose 128-token workgroup is one ~77 us dependency chain however few tokens it holds (MI355X, 200k-chunk index,
      * B = 1 search: p50 59.7 -> 47.2 ms).  Same arithmetic up to fp16 rounding of the intermediate activations. */
     const void *wo, *w1, *w2;
+    /* Optional: lm_qkv_pack_h384's image of wqkv.  With it the large-forward QKV projection runs on the weight-streaming kernel
+     * (lm_qkv_h384_f16: x read once, two waves per SIMD); NULL = the weight-stationary one (lm_gemm_ws_h384_f16 on wqkv). */
+    const void *wqkv_img;
 } lm_bert_h384_layer;
 #define LM_BERT_SMALL_TOKENS 6144
 

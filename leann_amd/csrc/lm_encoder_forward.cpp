@@ -33,8 +33,8 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     if (n_seqs == 0 || total_tokens == 0) return LM_OK;
     if (!m || !m->layers || !d_tok || !d_pos || !d_cu_seqlens || !d_workspace || !d_out || n_seqs < 0 || total_tokens < 0)
         LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: bad arguments");
-    if (m->n_layers <= 0 || m->heads * 32 != 384 || m->ffn < 192 || m->ffn > 2496 || m->ffn % 192)
-        LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: needs hidden 384 = heads x 32 and ffn a multiple of 192 in [192, 2496]");
+    if (m->n_layers <= 0 || m->heads * 32 != 384 || m->ffn < 192 || m->ffn > 1728 || m->ffn % 192)
+        LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: needs hidden 384 = heads x 32 and ffn a multiple of 192 in [192, 1728]");
     if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: sequence lengths 1..256");
     if (m->pooling != 0 && m->pooling != 1) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: pooling 0 (mean) or 1 (CLS)");
     if (workspace_bytes < lm_bert_h384_workspace_bytes(total_tokens)) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: workspace too small");
@@ -61,7 +61,9 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
             if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln2_gamma, L.ln2_beta, x, total_tokens, 384, m->ln_eps, stream))) return rc;
             continue;
         }
-        if ((rc = lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream))) return rc;
+        if ((rc = L.wqkv_img ? lm_qkv_h384_f16(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, stream)
+                             : lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream)))
+            return rc;
         if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
         if ((rc = lm_layer_tail_h384_f16(a, x, L.wo_img, L.bo, L.ln1_gamma, L.ln1_beta, m->ln_eps, L.w1_img, L.b1, L.w2_img, L.b2, L.ln2_gamma,
                                          L.ln2_beta, y, total_tokens, m->ffn, m->ln_eps, stream)))

@@ -28,19 +28,18 @@
 //   * GELU micro-operations as before (8.5 per value, one transcendental), three behind each MFMA.
 // Budget of an iteration: 48 MFMA + 48 ds_read + 136 GELU + 16 accumulator reads + 21 DMA + waits.
 //
-// Envelope: ffn a multiple of 192 (the six-fold unrolled pipeline), 192 <= ffn <= 2496; other shapes take the general GEMM path
-// (lm_gemm_f16).  LDS map: [0, 72 K) W1 ring, [72 K, 144 K) W2 ring, then b1 (fp32), b2, b_o (fp32), gamma / beta of both norms.
+// Envelope: ffn a multiple of 192 (the six-fold unrolled pipeline), 192 <= ffn <= 1728; other shapes take the general GEMM path
+// (lm_gemm_f16).  LDS map: [0, 72 K) W1 ring, [72 K, 144 K) W2 ring, then b1, b2, b_o, gamma / beta of both norms (fp32).
 #include <cstdlib>
 #include <cstring>
 #include <utility>
 
-#include "lm_h384_common.h"
+#include "lm_h384_stream.h"
 
 namespace lm {
 
 typedef _Float16 t4_half2 __attribute__((ext_vector_type(2)));
 
-constexpr int T4_SLAB = 24576;  // bytes of a W1 slab (32 hidden x 384 k), a W2 slab (384 rows x 32 hidden) and a W_o slab (384 rows x 32 k)
 constexpr int T4_W1_OFF = 0;
 constexpr int T4_W2_OFF = 3 * T4_SLAB;
 constexpr int T4_B1_OFF = 6 * T4_SLAB;
@@ -58,73 +57,6 @@ constexpr int T4_B1_OFF = 6 * T4_SLAB;
 #ifndef LM_T4_WM
 #define LM_T4_WM 0
 #endif
-
-#ifdef LM_EMULATED_DEVICE
-#define T4_WAIT_VM(n) ((void)0)
-#define T4_WAIT_LGKM0() ((void)0)
-#define T4_BARRIER() __syncthreads()
-#else
-#define T4_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define T4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define T4_BARRIER() __builtin_amdgcn_s_barrier()
-#endif
-
-// ---- LDS-DMA -------------------------------------------------------------------------------------------------------------------
-// NP consecutive 1 KB pieces: LDS [dst + 1024 p + 16 lane, +16) <- global [sbase + voff + 1024 p, +16), p = 0 .. NP-1.  dst and sbase
-// are wave uniform.  ONE M0 write serves the group: the instruction offset is added to the global AND to the LDS address.
-// Inline assembly for the reason given in lm_h384_common.h (lm_dma16); M0 is written in the statement that uses it.
-template <int NP>
-__device__ __forceinline__ void t4_dma_group(const void* sbase, unsigned voff, unsigned char* dst) {
-    static_assert(NP >= 1 && NP <= 4, "instruction offsets reach 3072");
-#ifdef LM_EMULATED_DEVICE
-    for (int p = 0; p < NP; ++p) std::memcpy(dst + 1024 * p + 16 * (threadIdx.x & 63), (const unsigned char*)sbase + voff + 1024 * p, 16);
-#else
-    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);  // low half of the flat address = LDS offset
-    if constexpr (NP == 4)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
-    else if constexpr (NP == 2)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
-    else if constexpr (NP == 1)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
-    else
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
-#endif
-}
-// piece Q (0 .. 3) of a group ALONE: the variants that spread the pieces over the MFMA gaps issue Q = 0 with the M0 write and
-// Q = 1 .. 3 on the M0 it left behind (nothing else in this kernel writes M0: scripts/isa_report.sh checks the disassembly)
-template <int Q>
-__device__ __forceinline__ void t4_dma_piece(const void* sbase, unsigned voff, unsigned char* dst) {
-#ifdef LM_EMULATED_DEVICE
-    std::memcpy(dst + 1024 * Q + 16 * (threadIdx.x & 63), (const unsigned char*)sbase + voff + 1024 * Q, 16);
-#else
-    if constexpr (Q == 0) {
-        const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
-    } else if constexpr (Q == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
-    else if constexpr (Q == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
-    else asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
-#endif
-}
-// a wave's quarter (6 KB: pieces 6 wv .. 6 wv + 5) of a 24 KB image -> the same place of a stage: prologue fills and the W_o ring
-__device__ __forceinline__ void t4_copy_quarter(const unsigned char* img, unsigned char* stage, int wv, unsigned voff) {
-    t4_dma_group<4>(img + 6144 * wv, voff, stage + 6144 * wv);
-    t4_dma_group<2>(img + 6144 * wv + 4096, voff, stage + 6144 * wv + 4096);
-}
-
-// A wave's 32 token rows -- one contiguous 24 KB block of a [T][384] fp16 matrix -- into a 24 KB stage as the image of a W1 slab
-// (row r, 16-byte chunk c at position (c & ~15) | ((c ^ r) & 15)): 24 fully coalesced 1 KB pieces.  Rows >= rows_valid (past the
-// end of the matrix) repeat the last valid row.  (Activations cannot be pre-swizzled: the permutation is in the source offsets.)
-__device__ __forceinline__ void t4_issue_rows(const unsigned char* rows, int rows_valid, unsigned char* stage, int lane) {
-    LM_KEEP_LOCAL(lane);  // the 24 source offsets are a few VALU operations each: recomputed per call, not kept alive between the two calls
-#pragma unroll
-    for (int p = 0; p < 24; ++p) {
-        const int L = 64 * p + lane, row = L / 48, pos = L - 48 * row;
-        const int rc = row < rows_valid ? row : rows_valid - 1;
-        lm_dma16_sv(rows, (unsigned)(rc * 768 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)), stage + 1024 * p);
-    }
-}
 
 // ---- GELU ------------------------------------------------------------------------------------------------------------------------
 // exact (erf) GELU in scalar fp32, 8.5 instructions per value, ONE transcendental:
@@ -249,26 +181,6 @@ template <int DM>
 constexpr int t4_pieces_before(int slot) {  // pieces a wave has requested in this iteration when it arrives at `slot`
     return DM == 0 ? 12 : (DM == 1 ? 4 * ((slot + 12) / 16) : (DM == 2 ? slot / 4 : 0));
 }
-template <int N>
-__device__ __forceinline__ void t4_wait_vm() {
-#ifndef LM_EMULATED_DEVICE
-    static_assert(N == 0 || N == 8 || N == 10 || N == 11 || N == 12, "add the count");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#endif
-}
-// s_waitcnt lgkmcnt(N) alone (vmcnt 63, expcnt 7): a BUILTIN, so the compiler's own wait insertion sees it and drops the per-MFMA
-// waits it covers
-template <int N>
-__device__ __forceinline__ void t4_wait_lgkm() {
-#ifndef LM_EMULATED_DEVICE
-    __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
-#endif
-}
-
 // Carried from iteration to iteration: the fragment ring and the bias vector of the NEXT first product.
 template <int RD>
 struct T4Carry {
@@ -366,10 +278,13 @@ __device__ __forceinline__ void t4_outproj_slab(const unsigned char* b20, const 
 // (leann_amd/encoder.py: pack_w1_acc_order), so x never leaves the registers.  The residual (the layer's input rows, fragments in
 // natural order) is brought into accumulator order with lane swaps: lane (token, g) owns features 16 ks + 8 g + e and needs
 // 32 j + 8 q + 4 g + i, i.e. half of every fragment register pair trades places with the partner lane (token, g ^ 1).
-__device__ __forceinline__ void t4_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[ML_KS], half8 (&xf)[ML_KS], const _Float16* gam_s,
-                                       const _Float16* bet_s, int g, float eps) {
+__device__ __forceinline__ void t4_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[ML_KS], half8 (&xf)[ML_KS], const float* gam_s,
+                                       const float* bet_s, int g, float eps) {
+    // ONE pass for both moments (sum and sum of squares of v = o + residual; var = E[v^2] - mean^2 in fp32 over 384 values of order 1),
+    // then y = (v rstd - mean rstd) gamma + beta as two packed fused multiply-adds per pair; gamma / beta are fp32 in LDS (no conversions).
+    // 4.75 instructions per value against the 8.25 of the two-pass form with fp16 parameters: this phase runs with the matrix pipe idle.
     __builtin_amdgcn_sched_barrier(0);
-    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f}, qa = {0.f, 0.f}, qb = {0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < ML_KS; ++ks) {
         u32x4 d = __builtin_bit_cast(u32x4, rf[ks]);
@@ -393,39 +308,32 @@ __device__ __forceinline__ void t4_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[M
         o[j][4 * qe + 7] = v3[1];
         sa += v0 + v2;
         sb += v1 + v3;
+        qa = __builtin_elementwise_fma(v0, v0, qa);
+        qb = __builtin_elementwise_fma(v1, v1, qb);
+        qa = __builtin_elementwise_fma(v2, v2, qa);
+        qb = __builtin_elementwise_fma(v3, v3, qb);
     }
-    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]);
+    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]), sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
     sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / ML_H);
-    const float2v nm = {-mean, -mean};
-    float2v qa = {0.f, 0.f}, qb = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < ML_NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {
-            float2v d0 = (float2v){o[j][r], o[j][r + 1]} + nm, d1 = (float2v){o[j][r + 2], o[j][r + 3]} + nm;
-            qa = __builtin_elementwise_fma(d0, d0, qa);
-            qb = __builtin_elementwise_fma(d1, d1, qb);
-        }
-    float sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
     sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
-    const float2v rs = {rstd, rstd};
-    // gamma / beta of tile j + 1 are read while tile j is normalised (left to itself the compiler emits read, read, wait, use: 48
-    // exposed LDS round trips)
-    half4 gv[4], bv[4], gn[4], bn[4];
+    const float mean = sum * (1.0f / ML_H);
+    const float var = __builtin_fmaxf(__builtin_fmaf(-mean, mean, sq * (1.0f / ML_H)), 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    const float2v rs = {rstd, rstd}, nmr = {-mean * rstd, -mean * rstd};
+    // gamma / beta of tile j + 1 are read while tile j is normalised (left to itself the compiler emits read, read, wait, use)
+    float4v gv[4], bv[4], gn[4], bn[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        gv[q] = *(const half4*)(gam_s + 8 * q + 4 * g);
-        bv[q] = *(const half4*)(bet_s + 8 * q + 4 * g);
+        gv[q] = *(const float4v*)(gam_s + 8 * q + 4 * g);
+        bv[q] = *(const float4v*)(bet_s + 8 * q + 4 * g);
     }
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j) {
         if (j + 1 < ML_NJ) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                gn[q] = *(const half4*)(gam_s + 32 * (j + 1) + 8 * q + 4 * g);
-                bn[q] = *(const half4*)(bet_s + 32 * (j + 1) + 8 * q + 4 * g);
+                gn[q] = *(const float4v*)(gam_s + 32 * (j + 1) + 8 * q + 4 * g);
+                bn[q] = *(const float4v*)(bet_s + 32 * (j + 1) + 8 * q + 4 * g);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -435,10 +343,10 @@ __device__ __forceinline__ void t4_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[M
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int q = 2 * u + qq;
-                float2v n0 = ((float2v){o[j][4 * q], o[j][4 * q + 1]} + nm) * rs;
-                float2v n1 = ((float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + nm) * rs;
-                float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[q][0], (float)gv[q][1]}, (float2v){(float)bv[q][0], (float)bv[q][1]});
-                float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[q][2], (float)gv[q][3]}, (float2v){(float)bv[q][2], (float)bv[q][3]});
+                const float2v n0 = __builtin_elementwise_fma((float2v){o[j][4 * q], o[j][4 * q + 1]}, rs, nmr);
+                const float2v n1 = __builtin_elementwise_fma((float2v){o[j][4 * q + 2], o[j][4 * q + 3]}, rs, nmr);
+                const float2v y0 = __builtin_elementwise_fma(n0, (float2v){gv[q][0], gv[q][1]}, (float2v){bv[q][0], bv[q][1]});
+                const float2v y1 = __builtin_elementwise_fma(n1, (float2v){gv[q][2], gv[q][3]}, (float2v){bv[q][2], bv[q][3]});
                 const t4_half2 h0 = __builtin_convertvector(y0, t4_half2), h1 = __builtin_convertvector(y1, t4_half2);
                 h[4 * qq] = h0[0];
                 h[4 * qq + 1] = h0[1];
@@ -464,11 +372,11 @@ __device__ __forceinline__ void t4_ln1(float16v (&o)[ML_NJ], const half8 (&rf)[M
 //   * the fp16 results go through the wave's own 24 KB of the (now idle) weight stages -- [32 tokens][48 chunks of 16 B], chunk c
 //     of row r at position (c & ~15) | ((c ^ r) & 15): conflict-free ds_write_b64 in, ds_read_b128 out -- and leave as 24 fully
 //     coalesced 1 KB stores per wave (a wave's 32 token rows are one contiguous 24 KB block of the output).
-__device__ __forceinline__ void t4_epilogue(float16v (&o)[ML_NJ], const half8 (&xf)[ML_KS], const _Float16* gam_s, const _Float16* bet_s,
+__device__ __forceinline__ void t4_epilogue(float16v (&o)[ML_NJ], const half8 (&xf)[ML_KS], const float* gam_s, const float* bet_s,
                                             unsigned char* tile, __half* __restrict__ out, int64_t token0, int T, int r31, int g, int lane,
                                             float eps) {
     __builtin_amdgcn_sched_barrier(0);
-    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f};
+    float2v sa = {0.f, 0.f}, sb = {0.f, 0.f}, qa = {0.f, 0.f}, qb = {0.f, 0.f};  // one pass for both moments, as t4_ln1
 #pragma unroll
     for (int ks = 0; ks < ML_KS; ++ks) {
         const int j = ks >> 1, r0 = 8 * (ks & 1);
@@ -487,48 +395,42 @@ __device__ __forceinline__ void t4_epilogue(float16v (&o)[ML_NJ], const half8 (&
         o[j][r0 + 7] = v3[1];
         sa += v0 + v2;
         sb += v1 + v3;
+        qa = __builtin_elementwise_fma(v0, v0, qa);
+        qb = __builtin_elementwise_fma(v1, v1, qb);
+        qa = __builtin_elementwise_fma(v2, v2, qa);
+        qb = __builtin_elementwise_fma(v3, v3, qb);
     }
-    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]);
+    float sum = (sa[0] + sa[1]) + (sb[0] + sb[1]), sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
     sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / ML_H);
-    const float2v nm = {-mean, -mean};
-    float2v qa = {0.f, 0.f}, qb = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < ML_NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {
-            float2v d0 = (float2v){o[j][r], o[j][r + 1]} + nm, d1 = (float2v){o[j][r + 2], o[j][r + 3]} + nm;
-            qa = __builtin_elementwise_fma(d0, d0, qa);
-            qb = __builtin_elementwise_fma(d1, d1, qb);
-        }
-    float sq = (qa[0] + qa[1]) + (qb[0] + qb[1]);
     sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq * (1.0f / ML_H) + eps);
-    const float2v rs = {rstd, rstd};
+    const float mean = sum * (1.0f / ML_H);
+    const float var = __builtin_fmaxf(__builtin_fmaf(-mean, mean, sq * (1.0f / ML_H)), 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    const float2v rs = {rstd, rstd}, nmr = {-mean * rstd, -mean * rstd};
     unsigned char* trow = tile + r31 * 768 + 8 * g;
-    half4 gv[4], bv[4], gn[4], bn[4];
+    float4v gv[4], bv[4], gn[4], bn[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        gv[q] = *(const half4*)(gam_s + 8 * q + 4 * g);
-        bv[q] = *(const half4*)(bet_s + 8 * q + 4 * g);
+        gv[q] = *(const float4v*)(gam_s + 8 * q + 4 * g);
+        bv[q] = *(const float4v*)(bet_s + 8 * q + 4 * g);
     }
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j) {
         if (j + 1 < ML_NJ) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                gn[q] = *(const half4*)(gam_s + 32 * (j + 1) + 8 * q + 4 * g);
-                bn[q] = *(const half4*)(bet_s + 32 * (j + 1) + 8 * q + 4 * g);
+                gn[q] = *(const float4v*)(gam_s + 32 * (j + 1) + 8 * q + 4 * g);
+                bn[q] = *(const float4v*)(bet_s + 32 * (j + 1) + 8 * q + 4 * g);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 4 * j + q;
-            float2v n0 = ((float2v){o[j][4 * q], o[j][4 * q + 1]} + nm) * rs;
-            float2v n1 = ((float2v){o[j][4 * q + 2], o[j][4 * q + 3]} + nm) * rs;
-            float2v y0 = __builtin_elementwise_fma(n0, (float2v){(float)gv[q][0], (float)gv[q][1]}, (float2v){(float)bv[q][0], (float)bv[q][1]});
-            float2v y1 = __builtin_elementwise_fma(n1, (float2v){(float)gv[q][2], (float)gv[q][3]}, (float2v){(float)bv[q][2], (float)bv[q][3]});
+            const float2v n0 = __builtin_elementwise_fma((float2v){o[j][4 * q], o[j][4 * q + 1]}, rs, nmr);
+            const float2v n1 = __builtin_elementwise_fma((float2v){o[j][4 * q + 2], o[j][4 * q + 3]}, rs, nmr);
+            const float2v y0 = __builtin_elementwise_fma(n0, (float2v){gv[q][0], gv[q][1]}, (float2v){bv[q][0], bv[q][1]});
+            const float2v y1 = __builtin_elementwise_fma(n1, (float2v){gv[q][2], gv[q][3]}, (float2v){bv[q][2], bv[q][3]});
             const t4_half2 h0 = __builtin_convertvector(y0, t4_half2), h1 = __builtin_convertvector(y1, t4_half2);
             const half4 y = {h0[0], h0[1], h1[0], h1[1]};
             *(half4*)(trow + ((c & ~15) | ((c ^ r31) & 15)) * 16) = y;
@@ -608,12 +510,12 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
 #endif
     T4_STAMP(0);
     float* b1s = (float*)(smem + T4_B1_OFF);
-    float* b2s = b1s + F;  // b2 (384 floats), gamma, beta (384 halfs each) behind b1
-    _Float16* gam_s = (_Float16*)(b2s + ML_H);
-    _Float16* bet_s = gam_s + ML_H;
-    float* bos = (float*)(bet_s + ML_H);  // b_o (384 floats), gamma1, beta1 (384 halfs each) behind them
-    _Float16* gam1_s = (_Float16*)(bos + ML_H);
-    _Float16* bet1_s = gam1_s + ML_H;
+    float* b2s = b1s + F;  // behind b1: b2, gamma, beta, b_o, gamma1, beta1 -- 384 floats each (the LayerNorm parameters converted once per workgroup)
+    float* gam_s = b2s + ML_H;
+    float* bet_s = gam_s + ML_H;
+    float* bos = bet_s + ML_H;
+    float* gam1_s = bos + ML_H;
+    float* bet1_s = gam1_s + ML_H;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef LM_EMULATED_DEVICE
     const int wv = tid >> 6;
@@ -629,22 +531,29 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
     const unsigned char* go = (const unsigned char*)pre.wo_img;
     const unsigned voff0 = (unsigned)lane * 16u;
 
-    // ---- prologue.  LDS = four 24 KB row tiles (stages 0..3 = W1 ring + W2 stage 0; wave w owns tile w: its attention rows, then its
-    //      residual rows, at the end its output rows) + a two-stage ring for the W_o slabs (W2 stages 1, 2; slab s in stage 1 + (s & 1)) ----
+    // ---- prologue + attention output projection.  Six 24 KB stages (0 .. 5).  The wave's attention rows come into stage wv (24 coalesced
+    //      1 KB pieces) and from there into the B fragments; then all six stages are the ring of the twelve W_o slabs -- slab s in stage
+    //      OST[s % 6], OST = {4, 5, 0, 1, 2, 3}: slabs 0, 1 arrive with the prologue, 2 .. 5 as soon as the attention rows are in registers,
+    //      slab s + 5 at the top of slab s >= 1 (the stage slab s - 1 has just left): FIVE slabs of lead.  (Generation 3 and the first form of
+    //      this kernel kept the residual rows in four of the stages during the projection, leaving a two-stage ring with ONE slab of lead:
+    //      1.46 k cycles per slab against a 0.77 k matrix-pipe floor, the L2 -> LDS latency exposed twelve times.)  The residual rows
+    //      (needed by the LayerNorm behind the projection) follow in the last four refill slots: the rows of wave r go to stage RST[r] =
+    //      {4, 5, 0, 1}[r] at the top of slab 7 + r -- six pieces per wave, ALL waves sharing the work, so that every top issues exactly six
+    //      pieces per wave and one counted wait fits all: vmcnt(24) = the four youngest requests may still be in flight. ----
     unsigned char* mytile = smem + wv * T4_SLAB;
     const int tok0c = (int)blockIdx.x * 128 + wv * 32 < T ? (int)blockIdx.x * 128 + wv * 32 : T - 1;  // wave uniform
     const int rows_valid = T - tok0c < 32 ? T - tok0c : 32;
-    t4_copy_quarter(go, smem + T4_W2_OFF + T4_SLAB, wv, voff0);
-    t4_copy_quarter(go + T4_SLAB, smem + T4_W2_OFF + 2 * T4_SLAB, wv, voff0);
-    t4_issue_rows((const unsigned char*)pre.attn + (int64_t)tok0c * (ML_H * 2), rows_valid, mytile, lane);
+    t4_copy_quarter(go, smem + 4 * T4_SLAB, wv, voff0);
+    t4_copy_quarter(go + T4_SLAB, smem + 5 * T4_SLAB, wv, voff0);
+    t4_issue_rows<0, 24>((const unsigned char*)pre.attn + (int64_t)tok0c * (ML_H * 2), rows_valid, mytile, lane);
     for (int i = tid; i < F; i += 256) b1s[i] = b1[i];
     for (int i = tid; i < ML_H; i += 256) {
         b2s[i] = b2[i];
-        gam_s[i] = ((const _Float16*)gamma)[i];
-        bet_s[i] = ((const _Float16*)beta)[i];
+        gam_s[i] = (float)((const _Float16*)gamma)[i];
+        bet_s[i] = (float)((const _Float16*)beta)[i];
         bos[i] = pre.bo[i];
-        gam1_s[i] = ((const _Float16*)pre.gamma1)[i];
-        bet1_s[i] = ((const _Float16*)pre.beta1)[i];
+        gam1_s[i] = (float)((const _Float16*)pre.gamma1)[i];
+        bet1_s[i] = (float)((const _Float16*)pre.beta1)[i];
     }
 
     // fragment addresses inside a slab image.  W1 (and row tiles): row r31, chunk c = 2 ks + g at position (c & ~15) | ((c ^ r31) & 15):
@@ -682,7 +591,7 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
     __syncthreads();  // LDS fills written, every wave's DMA pieces landed (nothing is in flight: a plain barrier is fine here)
     T4_STAMP(1);
     {
-        // attention rows: tile -> B fragments (the reads of a W1 fragment: conflict free); then the tile takes the residual rows
+        // attention rows: tile -> B fragments (the reads of a W1 fragment: conflict free)
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < ML_KS; ++ks) {
@@ -691,11 +600,11 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
         }
     }
     T4_WAIT_LGKM0();
-    LM_WAVE_SYNC();  // the tile is re-filled by this wave's own DMA: program order on the GPU
-    t4_issue_rows((const unsigned char*)resid + (int64_t)tok0c * (ML_H * 2), rows_valid, mytile, lane);
-    // ---- attention output projection: o = attn W_o^T + b_o, twelve 32-wide k slabs through the two-stage ring.  Top of slab s >= 1:
-    //      slab s has landed (s >= 2: vmcnt(0) -- it is the youngest request; slabs 0, 1 came with the prologue), every wave is done
-    //      with slab s - 1 (barrier), whose stage takes slab s + 1. ----
+    T4_BARRIER();  // every wave has its rows in registers: stages 0 .. 3 join the W_o ring
+    t4_copy_quarter(go + 2 * T4_SLAB, smem + 0 * T4_SLAB, wv, voff0);
+    t4_copy_quarter(go + 3 * T4_SLAB, smem + 1 * T4_SLAB, wv, voff0);
+    t4_copy_quarter(go + 4 * T4_SLAB, smem + 2 * T4_SLAB, wv, voff0);
+    t4_copy_quarter(go + 5 * T4_SLAB, smem + 3 * T4_SLAB, wv, voff0);
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
@@ -704,24 +613,39 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
         }
+    constexpr int OST[6] = {4, 5, 0, 1, 2, 3}, RST[4] = {4, 5, 0, 1};
 #pragma unroll
     for (int s = 0; s < ML_H / 32; ++s) {
         if (s > 0) {
-            if (s > 1) T4_WAIT_VM(0);
-            T4_BARRIER();
-            if (s + 1 < ML_H / 32) t4_copy_quarter(go + (int64_t)(s + 1) * T4_SLAB, smem + T4_W2_OFF + (1 + ((s + 1) & 1)) * T4_SLAB, wv, voff0);
+            if (s > 1) t4_wait_vm<24>();  // slab s has landed: the four requests behind it (6 pieces each) may be in flight
+            T4_BARRIER();                 // ... for every wave; and every wave is done with slab s - 1, whose stage is refilled:
+            unsigned char* freed = smem + OST[(s - 1) % 6] * T4_SLAB;
+            if (s + 5 < ML_H / 32) t4_copy_quarter(go + (int64_t)(s + 5) * T4_SLAB, freed, wv, voff0);
+            else if (s - 7 < 4) {  // s = 7 .. 10: the residual rows of wave r = s - 7 into stage RST[r] (= the stage just freed), a quarter per wave
+                const int r = s - 7;
+                const int tr = (int)blockIdx.x * 128 + r * 32 < T ? (int)blockIdx.x * 128 + r * 32 : T - 1;
+                const int rv = T - tr < 32 ? T - tr : 32;
+                const unsigned char* rrows = (const unsigned char*)resid + (int64_t)tr * (ML_H * 2);
+                if (wv == 0) t4_issue_rows<0, 6>(rrows, rv, freed, lane);
+                else if (wv == 1) t4_issue_rows<6, 6>(rrows, rv, freed, lane);
+                else if (wv == 2) t4_issue_rows<12, 6>(rrows, rv, freed, lane);
+                else t4_issue_rows<18, 6>(rrows, rv, freed, lane);
+            }
         }
-        const unsigned char* stg = smem + T4_W2_OFF + (1 + (s & 1)) * T4_SLAB;
+        const unsigned char* stg = smem + OST[s % 6] * T4_SLAB;
         t4_outproj_slab(stg + b20, stg + b21, xf[2 * s], xf[2 * s + 1], o);
     }
     T4_STAMP(8);
+    T4_WAIT_VM(0);
+    T4_BARRIER();  // the residual rows have landed (every wave's share of every tile)
     {
-        // residual rows: tile -> fragments (their DMA is older than every W_o slab waited for above).  Then all six stages are idle once
-        // every wave is here: the feed-forward block's first weights (W1 slabs 0..2, W2 slab 0) arrive under the LayerNorm
+        // residual rows: the wave's tile (stage RST[wv]) -> fragments.  Then all six stages are idle once every wave is here: the
+        // feed-forward block's first weights (W1 slabs 0..2, W2 slab 0) arrive under the LayerNorm
+        const unsigned char* rtile = smem + (wv < 2 ? 4 + wv : wv - 2) * T4_SLAB;
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < ML_KS; ++ks) {
-            const half8 v = *(const half8*)(mytile + a1[ks & 7] + 256 * (ks >> 3));
+            const half8 v = *(const half8*)(rtile + a1[ks & 7] + 256 * (ks >> 3));
             rf[ks] = valid ? v : z;
         }
     }
@@ -839,6 +763,16 @@ extern "C" int lm_layer_tail_pack_h384(const void* d_wo_slabs, const void* d_w1_
     return LM_OK;
 }
 
+// W [n_out][384] (nn.Linear layout, device) -> the image lm_qkv_h384_f16 streams: 32-row slabs in the W1 form above
+extern "C" int lm_qkv_pack_h384(const void* d_w, int32_t n_out, void* d_w_img, void* stream) {
+    using namespace lm;
+    if (!d_w || !d_w_img || n_out <= 0 || n_out % 32) LM_FAIL(LM_EINVAL, "lm_qkv_pack_h384: bad arguments");
+    const int64_t nw = (int64_t)n_out * ML_H / 8;
+    hipLaunchKernelGGL(k_tail_image, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_w, (uint4*)d_w_img, nw, 0);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 extern "C" int lm_layer_tail_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_img, const float* d_bo, const void* d_gamma1,
                                       const void* d_beta1, float eps1, const void* d_w1_img, const float* d_b1, const void* d_w2_img,
                                       const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out, int64_t tokens, int32_t ffn,
@@ -848,8 +782,8 @@ extern "C" int lm_layer_tail_h384_f16(const void* d_attn, const void* d_resid, c
     if (!d_attn || !d_resid || !d_wo_img || !d_bo || !d_gamma1 || !d_beta1 || !d_w1_img || !d_b1 || !d_w2_img || !d_b2 || !d_gamma || !d_beta ||
         !d_out || tokens < 0 || tokens > 0x7fffffff)
         LM_FAIL(LM_EINVAL, "bad fused layer-tail arguments");
-    const size_t shmem = (size_t)T4_B1_OFF + (size_t)(ffn > 0 ? ffn : 0) * 4 + ML_H * 16;  // + b2, b_o (fp32), gamma, beta, gamma1, beta1 (fp16)
-    if (ffn < 192 || ffn % 192 || shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "fused layer tail: ffn must be a multiple of 192 in [192, 2496]");
+    const size_t shmem = (size_t)T4_B1_OFF + (size_t)(ffn > 0 ? ffn : 0) * 4 + ML_H * 24;  // + b2, b_o, gamma, beta, gamma1, beta1 (fp32)
+    if (ffn < 192 || ffn % 192 || shmem > 160 * 1024) LM_FAIL(LM_EINVAL, "fused layer tail: ffn must be a multiple of 192 in [192, 1728]");
     dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
     // environment switches are read once per process (the launch path of a B = 1 search runs this ~600 times per query)
     static const int stagger_env = [] { const char* sg = getenv("LEANN_MI355X_STAGGER"); return sg ? atoi(sg) : 40; }();  // spread of the first round's start times, x 1024 cycles (0 = off)

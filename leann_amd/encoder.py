@@ -156,7 +156,7 @@ def _packed(owner, attr: str, sources: tuple, make):
 
 # environment variables that select a particular kernel generation for an A/B run (everything else under LEANN_MI355X_* --
 # ALLOW_RANDOM_WEIGHTS, ATTN_XCD, STAGGER ... -- does not change which kernels a forward is made of)
-KERNEL_SELECTION_KEYS = ("LEANN_MI355X_ATTN", "LEANN_MI355X_LN", "LEANN_MI355X_POOL", "LEANN_MI355X_EMBED", "LEANN_MI355X_PACK",
+KERNEL_SELECTION_KEYS = ("LEANN_MI355X_QKV", "LEANN_MI355X_ATTN", "LEANN_MI355X_LN", "LEANN_MI355X_POOL", "LEANN_MI355X_EMBED", "LEANN_MI355X_PACK",
                          "LEANN_MI355X_LINEAR", "LEANN_MI355X_MLP", "LEANN_MI355X_MLP_VARIANT", "LEANN_MI355X_TAIL", "LEANN_MI355X_ABLATE",
                          "LEANN_MI355X_GEMM")
 
@@ -382,7 +382,7 @@ def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") ->
         return None  # an explicitly selected older kernel generation is an A/B run of THAT kernel
     f, h = layer.fc1.weight.shape
     if not (a.is_cuda and a.dtype == torch.float16 and a.is_contiguous() and resid.is_contiguous() and resid.dtype == torch.float16
-            and h == 384 and f % 192 == 0 and 192 <= f <= 2496 and layer.out.bias is not None):
+            and h == 384 and f % 192 == 0 and 192 <= f <= 1728 and layer.out.bias is not None):
         return None
     import ctypes as C
 
@@ -481,13 +481,36 @@ def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.
     return out
 
 
+def pack_qkv_image(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [n_out, 384] -> the LDS image csrc/lm_qkv_h384.hip streams (lm_qkv_pack_h384; same size, on the weight's device)."""
+    import ctypes as C
+
+    from . import _lib
+
+    src = w.detach().contiguous()
+    img = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream) if w.is_cuda else None
+    _lib.check(_lib.load().lm_qkv_pack_h384(C.c_void_p(src.data_ptr()), int(src.shape[0]), C.c_void_p(img.data_ptr()), st), "lm_qkv_pack_h384")
+    return img
+
+
 def _linear_ws_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor], ln: Optional[nn.LayerNorm]) -> Optional[torch.Tensor]:
     n, k = lin.weight.shape
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n % 192 == 0 and n <= 6144 and lin.bias is not None):
         return None
     import ctypes as C
+    import os
 
     from . import _lib
+
+    if ln is None and n % 128 == 0 and n >= 256 and os.environ.get("LEANN_MI355X_QKV", "1") == "1":
+        # the weight-STREAMING form (csrc/lm_qkv_h384.hip: x read once, two waves per SIMD); LEANN_MI355X_QKV=0 = the weight-stationary kernel (A/B)
+        pk = _packed(lin, "_qkv_pack", (lin.weight, lin.bias), lambda: (pack_qkv_image(lin.weight), lin.bias.detach().float().contiguous()))
+        out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
+        _lib.check(_lib.load().lm_qkv_h384_f16(C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), n,
+                                               C.c_void_p(out.data_ptr()), x.shape[0], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+                   "lm_qkv_h384_f16")
+        return out
 
     pk = _packed(lin, "_ws_pack", (lin.weight, lin.bias), lambda: (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous()))
     out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
@@ -712,12 +735,14 @@ class BertEncoder(nn.Module):
         """``{"model": lm_bert_h384 struct, ...}`` over this encoder's weights (packed copies cached, rebuilt when a weight changes: _packed)
         -- the argument of lm_bert_h384_forward_packed and of the built-in recompute provider (lm_recompute_create) -- or None when the
         model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights on the GPU, mean or CLS pooling, ffn a multiple of 192 in
-        [192, 2496] (the fused layer tail's shapes; other widths: general_model)."""
+        [192, 1728] (the fused layer tail's shapes; other widths: general_model)."""
         cfg = self.cfg
         w = self.word.weight
         if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling in ("mean", "cls") and cfg.ffn % 192 == 0
-                and 192 <= cfg.ffn <= 2496):
+                and 192 <= cfg.ffn <= 1728):
             return None
+        import os
+
         from . import _lib
 
         def make():
@@ -729,9 +754,10 @@ class BertEncoder(nn.Module):
                         L.out.bias.detach().float().contiguous(), L.ln1.weight.detach().contiguous(), L.ln1.bias.detach().contiguous(),
                         w1_i, L.fc1.bias.detach().float().contiguous(), w2_i,
                         L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous(),
-                        L.out.weight.detach().contiguous(), L.fc1.weight.detach().contiguous(), L.fc2.weight.detach().contiguous())
+                        L.out.weight.detach().contiguous(), L.fc1.weight.detach().contiguous(), L.fc2.weight.detach().contiguous(),
+                        pack_qkv_image(L.qkv.weight) if os.environ.get("LEANN_MI355X_QKV", "1") == "1" else None)
                 for (name, _), v in zip(_lib.BertH384Layer._fields_, vals):
-                    setattr(layers[li], name, ptr(v))
+                    setattr(layers[li], name, ptr(v) if v is not None else None)
             m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, 1 if cfg.pooling == "cls" else 0, float(self.ln.eps), ptr(w.detach()),
                               ptr(self.pos.weight.detach()), ptr(self.tok_type.weight[0].detach().contiguous()), ptr(self.ln.weight.detach()),
                               ptr(self.ln.bias.detach()), layers)

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--rerank-expanded", type=int, default=-1, choices=[-1, 0, 1],
                     help="rerank set of the deferred fetch: 0 the final candidate list, 1 every expanded node (upstream DiskANN's full_retset; index option "
                          "pq_rerank_expanded), -1 (default) sweep both and time the one that reaches recall 0.9 with the smaller list (ties: the final list)")
+    ap.add_argument("--pq-bytes-extra", type=int, default=0, help="after the timed steps: train a second quantiser with this many bytes per vector and repeat the "
+                    "(untimed) complexity sweeps with it -- reported as extra_pq_sweep")
     ap.add_argument("--diagnose", action="store_true",
                     help="before the sweep: (1) recall of the EXACT-distance beam search on the same flat graph (is the graph the limit?), (2) how much of the "
                          "true top-10 a brute-force ADC scan ranks inside its top-L (is the quantiser the limit?), for 64 queries")
@@ -228,6 +230,33 @@ def main():
         "per_query": {"adc_evals": round(agg["ndis"] / (K * B), 1), "reranked_unique_chunks": round(agg["nunique"] / (K * B), 1)},
         "setup_s": {"total": round(setup_s), "embed_corpus": round(t_embed), "build_graph": round(t_graph), "pq": round(t_pq)},
     }
+    if args.pq_bytes_extra:
+        try:
+            t0 = time.time()
+            cb2 = train_pq(X, args.pq_bytes_extra, iters=10)
+            codes2 = encode_pq(X, cb2)
+            idx.attach_pq(cb2.cpu().numpy(), codes2.cpu().numpy())
+            ex = {"pq_bytes": args.pq_bytes_extra, "train_encode_s": round(time.time() - t0, 1)}
+            for mode in (0, 1):
+                idx.set_option("pq_rerank_expanded", mode)
+                sw2 = {}
+                for L in (64, 128, 256, 512, 1024, 2048):
+                    try:
+                        ls, _ = idx.pq_search_device(qs, 10, idx.make_pq_params(L, args.beam, use_deferred_fetch=True))
+                    except Exception as ex_:  # noqa: BLE001
+                        log(f"extra PQ, complexity {L}: {ex_!r}"[:200])
+                        break
+                    st = idx.stats()
+                    lsn = ls.cpu().numpy()
+                    sw2[L] = {"recall_at_10": round(float(np.mean([len(set(lsn[i]) & set(gt[nq - nsw + i])) / 10 for i in range(nsw)])), 4),
+                              "adc_evals_per_query": round(st["ndis"] / nsw, 1), "reranked_chunks_per_query": round(st["nunique"] / nsw, 1)}
+                    if sw2[L]["recall_at_10"] >= 0.9:
+                        break
+                ex["expanded_nodes" if mode else "final_list"] = sw2
+            result["extra_pq_sweep"] = ex
+            log("extra PQ sweep:", json.dumps(ex))
+        except Exception as ex_:  # noqa: BLE001
+            result["extra_pq_sweep"] = {"error": repr(ex_)[:300]}
     # CPU baseline: the PQ oracle (traversal + deferred rerank through the fp32 CPU encoder) on a few queries
     try:
         from oracle import oracle as orc

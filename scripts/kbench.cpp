@@ -465,6 +465,38 @@ int main(int argc, char** argv) {
                gflop / (us1 + us2));
         fflush(stdout);
     }
+    if (want("qkv")) {  // QKV projection: the weight-stationary kernel (x read six times) vs the weight-streaming one with two waves per SIMD (lm_qkv_h384.hip)
+        const int N = 3 * H;
+        auto hw = rand_half((size_t)N * H, 0.05f, 60);
+        Dev<__half> w(hw), wimg((size_t)N * H), outa((size_t)T * N), outb((size_t)T * N);
+        Dev<float> b(rand_float(N, 0.2f, 61));
+        Dev<float> zref((size_t)nr * N);
+        LM(lm_qkv_pack_h384(w.p, N, wimg.p, st));
+        hipLaunchKernelGGL(ref_linear, dim3((nr * N + 255) / 256), dim3(256), 0, st, x.p, w.p, b.p, d_rows.p, nr, N, zref.p);
+        auto runa = [&] { LM(lm_gemm_ws_h384_f16(x.p, w.p, b.p, N, outa.p, T, st)); };
+        auto runb = [&] { LM(lm_qkv_h384_f16(x.p, wimg.p, b.p, N, outb.p, T, st)); };
+        CK(hipMemsetAsync(outb.p, 0xFF, outb.n * sizeof(__half), st));
+        runa();
+        runb();
+        CK(hipStreamSynchronize(st));
+        auto ref = zref.host();
+        double dmax = 0;
+        {
+            auto a = outa.host(), c = outb.host();
+            for (size_t i = 0; i < a.size(); ++i) {
+                double d = fabs((double)__half2float(a[i]) - (double)__half2float(c[i]));
+                if (!(d <= dmax)) dmax = d;
+            }
+            printf("{\"kernel\": \"lm_qkv_h384_f16\", \"max_abs_err\": %.3g, \"ws_max_abs_err\": %.3g, \"max_abs_diff_all_rows\": %.3g}\n", max_err_rows(c, N, 0, N, rows, ref),
+                   max_err_rows(a, N, 0, N, rows, ref), dmax);
+        }
+        for (int round = 0; round < 3; ++round) {
+            const float ua = time_us(st, reps, runa), ub = time_us(st, reps, runb);
+            printf("{\"kernel\": \"lm_gemm_ws_h384_f16 (weight stationary)\", \"mode\": \"N=1152\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, ua, 2.0 * T * N * H / ua * 1e-6);
+            printf("{\"kernel\": \"lm_qkv_h384_f16 (weight streaming, 2 waves per SIMD)\", \"mode\": \"N=1152\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, ub, 2.0 * T * N * H / ub * 1e-6);
+            fflush(stdout);
+        }
+    }
     if (want("wsgemm")) {  // weight-stationary GEMM alone: timing + where a wave's cycles go (LEANN_MI355X_ABLATE=64 / 65: phase stamps)
         for (int N : {3 * H, H}) {
             auto hw = rand_half((size_t)N * H, 0.05f, 50 + N);

@@ -451,6 +451,17 @@ def case_encoder_abi():
         _lib.check(lib.lm_gemm_ws_h384_f16(vp(xw), vp(np.ascontiguousarray(wmat)), vp(bvec), wmat.shape[0], vp(ow), Tw, None), "gemm_ws")
         assert np.abs(ow.astype(np.float64) - (xw.astype(np.float64) @ wmat.astype(np.float64).T + bvec)).max() < 6e-3, wmat.shape
     assert lib.lm_gemm_ws_h384_f16(vp(xw), vp(w), vp(b), 200, vp(ow), Tw, None) == -1  # n_out % 192
+    # weight-streaming form (lm_qkv_h384.hip: x read once, W through a four-stage ring, 8 waves = two per SIMD): ragged token counts, several workgroups
+    for Tq, Nq in ((300, 1152), (513, 256), (31, 384)):
+        xq = rng.standard_normal((Tq, H)).astype(np.float16)
+        wq = (rng.standard_normal((Nq, H)) / np.sqrt(H)).astype(np.float16)
+        bq = (0.3 * rng.standard_normal(Nq)).astype(np.float32)
+        wqi = np.zeros_like(wq)
+        _lib.check(lib.lm_qkv_pack_h384(vp(wq), Nq, vp(wqi), None), "qkv image")
+        oq = np.full((Tq, Nq), 7.0, np.float16)
+        _lib.check(lib.lm_qkv_h384_f16(vp(xq), vp(wqi), vp(bq), Nq, vp(oq), Tq, None), "qkv")
+        assert np.abs(oq.astype(np.float64) - (xq.astype(np.float64) @ wq.astype(np.float64).T + bq)).max() < 6e-3, (Tq, Nq)
+    assert lib.lm_qkv_h384_f16(vp(xq), vp(wqi), vp(bq), 200, vp(oq), Tq, None) == -1  # n_out % 128
     # attention output projection + LayerNorm + feed-forward block + LayerNorm in one kernel (lm_mlp_fused_v3.hip: k_attn_out_mlp_h384)
     from leann_amd.encoder import pack_w1_acc_order, pack_wo_slabs
 
@@ -831,7 +842,7 @@ def case_encoder_python_wiring():
             got2 = enc16.encode_tokens_packed(ti, tl, 4096)
     assert float((got2.float() - ref).abs().max()) < 6e-3
     # the DEFAULT kernel set (weight-stationary QKV GEMM, attention revision 2, fused layer tail)
-    for ffn, extra, want in ((384, {}, {"lm_gemm_ws_h384_f16": 2, "lm_layer_tail_h384_f16": 2}),):
+    for ffn, extra, want in ((384, {}, {"lm_qkv_h384_f16": 2, "lm_layer_tail_h384_f16": 2}), (384, {"LEANN_MI355X_QKV": "0"}, {"lm_gemm_ws_h384_f16": 2, "lm_layer_tail_h384_f16": 2})):
         cfg3 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=ffn, max_pos=64, max_seq_length=48)
         e32 = BertEncoder.random_init(cfg3, 5).eval()
         with torch.no_grad():
