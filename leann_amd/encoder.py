@@ -582,11 +582,14 @@ class _Layer(nn.Module):
         if y is None:
             return None
         x1 = fused_add_layernorm(y, None, self.ln1)
+        if x1 is None:  # LEANN_MI355X_LN=0 / a width outside the LayerNorm kernel's envelope: the torch LayerNorm
+            x1 = self.ln1(y)
         hmid = fused_gemm(x1, self.fc1, GEMM_EPI_GELU)
         y2 = fused_gemm(hmid, self.fc2, GEMM_EPI_RESIDUAL, x1) if hmid is not None else None
         if y2 is None:
             return None
-        return fused_add_layernorm(y2, None, self.ln2)
+        out = fused_add_layernorm(y2, None, self.ln2)
+        return out if out is not None else self.ln2(y2)
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
         n, t, h = x.shape
