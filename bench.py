@@ -72,7 +72,8 @@ def main():
                          "query batch 1024 split over the ranks; c3 (configs[2], 10M DiskANN-style) and c4 (configs[3], 60M sharded over the "
                          "ranks, all_gather + merge timed) run scripts/bench_c3.py / scripts/bench_c4.py with this command's --steps/--warmup")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
-    ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows")
+    ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows and value_by_batch")
+    ap.add_argument("--no-provider-ab", action="store_true", help="skip the extra full-size step over the Python form of the provider")
     ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
     ap.add_argument("--dry-run-emulated", default=None, metavar="LIB",
                     help="TEST ONLY (tests/test_bench_dry_run.py): run this script's control flow -- incl. every world > 1 branch, over gloo -- on the CPU against "
@@ -454,7 +455,7 @@ def _main(args, ap):
                     idx.set_provider(provider)
         except Exception as ex:  # noqa: BLE001
             extras_errors["small_batch_latency"] = repr(ex)[:300]
-    if world == 1 and idx.native_provider and K:  # one full-size step over the PYTHON provider, on a timed step's own queries: same labels
+    if world == 1 and idx.native_provider and K and not args.no_provider_ab:  # one full-size step over the PYTHON provider, on a timed step's own queries: same labels
         os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
         try:
             idx.set_provider(provider)

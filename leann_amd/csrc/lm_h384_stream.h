@@ -80,14 +80,8 @@ __device__ __forceinline__ void t4_issue_rows(const unsigned char* rows, int row
 template <int N>
 __device__ __forceinline__ void t4_wait_vm() {
 #ifndef LM_EMULATED_DEVICE
-    static_assert(N == 0 || N == 3 || N == 8 || N == 10 || N == 11 || N == 12 || N == 24, "add the count");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
 }
 // s_waitcnt lgkmcnt(N) alone (vmcnt 63, expcnt 7): a BUILTIN, so the compiler's own wait insertion sees it and drops the per-MFMA

@@ -66,11 +66,14 @@ __device__ __forceinline__ void qk_epilogue_step(const float16v& a, const float1
     } else if constexpr (ODD && STEP == 4) {
         LM_WAVE_SYNC();  // the rows were written by other lanes of this wave (lock-step on the GPU: program order is enough)
     } else if constexpr (ODD && (STEP == 5 || STEP == 6)) {
+        if (rows_valid > 0) {  // wave uniform
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int id = 64 * (2 * (STEP - 5) + jj) + lane, row = id >> 3, c16 = id & 7;
-            const u32x4 v = *(const u32x4*)(tile + row * 128 + ((c16 ^ (row & 7)) << 4));
-            if (row < rows_valid) *(u32x4*)((unsigned char*)out + ((tok0 + row) * N + feat0) * 2 + 16 * c16) = v;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int id = 64 * (2 * (STEP - 5) + jj) + lane, c16 = id & 7;
+                const int row = (id >> 3) < rows_valid ? (id >> 3) : rows_valid - 1;  // past the end: the last valid row once more (same bytes): the
+                const u32x4 v = *(const u32x4*)(tile + row * 128 + ((c16 ^ (row & 7)) << 4));  // number of stores is what the counted waits assume
+                *(u32x4*)((unsigned char*)out + ((tok0 + row) * N + feat0) * 2 + 16 * c16) = v;
+            }
         }
     }
 }
@@ -85,11 +88,13 @@ __device__ __forceinline__ void qk_slot(const QkAddr& c, const float* bs_next, c
                                         unsigned char* tile, __half* __restrict__ out, int64_t tok0, int rows_valid, int N, int feat0_prev, int r31, int g,
                                         int lane, const unsigned char* dsrc, unsigned voff, unsigned char* ddst) {
     if constexpr (I == 24 - RD && NEXT) {
-        // Counted wait for the pieces of slab s + 1 .. s + 2 (requested one and two slabs ago).  This slab's own vector-memory operations so far:
-        // its DMA group (3 pieces, behind slot 1), then -- every other slab, and fewer at the ragged end of the matrix -- the stores of the
-        // previous slab's epilogue (slots 13, 15).  Operations retire in issue order, so "at most 3 in flight" covers every case: with no store
-        // issued the three are this slab's pieces, otherwise they are stores and even this slab's pieces have landed.
-        t4_wait_vm<DMA ? 3 : 0>();
+        // Counted wait for the pieces of slab s + 1 (requested in slab s - 2).  Behind them in this wave's queue, in issue order: the four
+        // stores of slab s - 2's slots (if it had them), the three pieces of slab s - 1 (slab s + 2), its stores, this slab's three pieces
+        // (slab s + 3) and its stores.  A slab's slots carry stores when the slab before it completed a 64-feature tile, i.e. in EVEN
+        // slabs: two of the three slabs s - 2, s - 1, s when s is even (P = 0), one when it is odd.  The stores are issued unconditionally
+        // (rows past the end of the matrix repeat the last valid row: qk_epilogue_step), except by a wave with no valid row at all.
+        if (rows_valid > 0) t4_wait_vm<DMA ? (P == 0 ? 14 : 10) : 0>();
+        else t4_wait_vm<DMA ? 6 : 0>();
         T4_BARRIER();
     }
     if constexpr (I == 0) acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cy.ring[0], xf[0], cy.biasv, 0, 0, 0);

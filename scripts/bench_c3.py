@@ -42,6 +42,12 @@ def main():
     ap.add_argument("--rerank-expanded", type=int, default=-1, choices=[-1, 0, 1],
                     help="rerank set of the deferred fetch: 0 the final candidate list, 1 every expanded node (upstream DiskANN's full_retset; index option "
                          "pq_rerank_expanded), -1 (default) sweep both and time the one that reaches recall 0.9 with the smaller list (ties: the final list)")
+    ap.add_argument("--chunks-per-topic", type=int, default=1000,
+                    help="density of the synthetic corpus: the generator's topic count is chunks / this (never below its default 1000 topics), so that a "
+                         "10M-chunk corpus has the local density of the 1M-chunk headline corpus (1000 chunks per topic).  0 = the generator's fixed 1000 "
+                         "topics at every size: at 10M chunks that puts ~10,000 near-equidistant chunks around each query, and neither the exact-distance "
+                         "walk on the graph (recall@10 0.87 at ef 1024) nor a brute-force 96-byte ADC ranking (0.86 of the true top-10 inside its top-2048) "
+                         "separates the true top-10 any more (profiles/r4_bench_c3_10M_chunks_1000_topics_with_diagnosis.json)")
     ap.add_argument("--pq-bytes-extra", type=int, default=0, help="after the timed steps: train a second quantiser with this many bytes per vector and repeat the "
                     "(untimed) complexity sweeps with it -- reported as extra_pq_sweep")
     ap.add_argument("--diagnose", action="store_true",
@@ -68,7 +74,8 @@ def main():
     dev = torch.device("cuda", 0)
     n, B, K, W = args.chunks, args.batch, args.steps, args.warmup
     t_all = time.time()
-    corpus = SyntheticCorpus(CorpusSpec(n_chunks=n, seed=1234))
+    n_topics = max(1000, n // args.chunks_per_topic) if args.chunks_per_topic > 0 else 1000
+    corpus = SyntheticCorpus(CorpusSpec(n_chunks=n, seed=1234, n_topics=n_topics))
     tok, off = corpus.chunks_torch(dev)
     tokens = TokenStore(tok, off)
     log(f"corpus: {n} chunks, {int(off[-1])} tokens ({time.time() - t_all:.0f}s)")
@@ -220,7 +227,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 codes / f32 LUT; fp16 encoder", "data": "synthetic",
         "config": {"workload": f"{n} synthetic chunks, flat graph degree<={2 * args.M} (GPU-built), PQ {args.pq_bytes} B/vector, complexity {args.complexity}, "
                                f"beam_width {args.beam}, top-10, {B} queries/step, one deferred rerank through the recompute provider; "
-                               f"{args.model} shape, random init, {enc.cfg.pooling} pooling",
+                               f"{args.model} shape, random init, {enc.cfg.pooling} pooling; topic-model corpus with {n_topics} topics ({n // n_topics} chunks per topic)",
                    "baseline_config": "c3", "n_chunks": n, "queries_per_step": B},
         "recall_at_10": round(rec, 4), "complexity_sweep": sweeps, "rerank_set": use_mode, "diagnosis": diag,
         "roofline": {"bound": "hbm", "kernel": "lm::k_pq_traverse (persistent PQ-ADC traversal, one launch per batch; codes gathered from HBM, LUT in LDS)",

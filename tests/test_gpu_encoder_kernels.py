@@ -316,12 +316,13 @@ def test_encoder_forward_with_and_without_the_fused_layer_tail(monkeypatch):
     assert (d - t0).abs().max() < 2e-3 and not torch.isnan(d).any()
 
 
-@pytest.mark.parametrize("gen", ["1", "2", "3"])
-@pytest.mark.parametrize("tokens", [1, 128, 129, 257, 5000])
+@pytest.mark.parametrize("gen", ["1", "2", "3", "3ws"])
+@pytest.mark.parametrize("tokens", [1, 128, 129, 257, 5000, 70001])
 def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
-    """The three hand-written 384-input linear kernels -- LEANN_MI355X_LINEAR=3 (default: weight-stationary lm_gemm_ws_h384_f16 +
-    add/LayerNorm), 2 (lm_gemm_h384_f16), 1 (lm_linear_h384_f16): QKV projection (n_out = 1152) and output projection with the
-    residual + LayerNorm epilogue, vs plain PyTorch fp32 references of the same ops."""
+    """The hand-written 384-input linear kernels -- LEANN_MI355X_LINEAR=3 (default): the QKV projection on the weight-STREAMING kernel
+    with two waves per SIMD (lm_qkv_h384_f16; "3ws" = LEANN_MI355X_QKV=0: the weight-stationary lm_gemm_ws_h384_f16), the output projection
+    on the weight-stationary one + add/LayerNorm; 2 (lm_gemm_h384_f16), 1 (lm_linear_h384_f16): QKV projection (n_out = 1152) and output
+    projection with the residual + LayerNorm epilogue, vs plain PyTorch fp32 references of the same ops."""
     import torch
     import torch.nn as nn
     import torch.nn.functional as F
@@ -337,9 +338,18 @@ def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
         ln.bias.copy_(0.1 * torch.randn(384))
     x = torch.randn((tokens, 384), device="cuda").half()
     res = torch.randn((tokens, 384), device="cuda").half()
-    monkeypatch.setenv("LEANN_MI355X_LINEAR", gen)
+    monkeypatch.setenv("LEANN_MI355X_LINEAR", gen[0])
+    if gen == "3ws":
+        monkeypatch.setenv("LEANN_MI355X_QKV", "0")
+    from leann_amd import _lib
+
+    used = []
+    real = _lib.check
+    monkeypatch.setattr(_lib, "check", lambda rc, what="": (used.append(what), real(rc, what))[1])
     with torch.no_grad():
         got = fused_linear_h384(x, qkv)
+        if gen[0] == "3":
+            assert ("lm_qkv_h384_f16" in used) == (gen == "3") and ("lm_gemm_ws_h384_f16" in used) == (gen == "3ws"), used
         assert got is not None and got.shape == (tokens, 1152)
         ref = x.float() @ qkv.weight.float().t() + qkv.bias.float()
         assert (got.float() - ref).abs().max().item() <= 4e-3 * max(1.0, float(ref.abs().max()))
