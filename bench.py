@@ -232,11 +232,9 @@ def _main(args, ap):
     qstore = TokenStore(qt, qo, device=lib_dev)
     Q_all = RecomputeProvider(enc, qstore, provider.dp, dev).embed_ids(torch.arange(n_q * world, dtype=torch.int32, device=dev))
     Q = Q_all[rank * n_q : (rank + 1) * n_q].contiguous()
-    gt = torch.empty((n_q, 10), dtype=torch.int64, device=dev)
-    for b0 in range(0, n_q, 1024):
-        s = Q[b0 : b0 + 1024] @ X.T
-        gt[b0 : b0 + 1024] = torch.topk(s, 10, dim=1).indices
-    gt_np = gt.cpu().numpy()
+    from leann_amd.exact import exact_topk_ip
+
+    gt_np = exact_topk_ip(Q, X, 10)[1].cpu().numpy()  # blocked: no GEMM call with more than 2^28 output elements (leann_amd/exact.py says why)
 
     def recall(labels_np, rows):
         hit = 0

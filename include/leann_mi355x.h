@@ -229,7 +229,7 @@ int lm_topk_merge(const int64_t *d_in_ids, const float *d_in_dist, int32_t S, in
  * out = LayerNorm(x + residual) * gamma + beta over the last dim; fp16 in/out, fp32 arithmetic;
  * residual may be NULL.  Part of the BERT forward inside compute_embeddings
  * (leann/embedding_compute.py:229-239).  The GEMMs and the attention of that forward are the hand-written MFMA kernels below
- * (hidden 384: lm_gemm_ws_h384_f16, lm_attn_varlen_hd32_f16, lm_attn_out_mlp_fused_h384_f16); no library call is on the default path. */
+ * (hidden 384: lm_qkv_h384_f16, lm_attn_varlen_hd32_f16, lm_layer_tail_h384_f16); no library call is on the default path. */
 int lm_add_layernorm_f16(const void *d_x, const void *d_residual, const void *d_gamma, const void *d_beta,
                          void *d_out, int64_t rows, int32_t hidden, float eps, void *stream);
 
@@ -263,45 +263,25 @@ int lm_pack_tokens(const int32_t *d_ids, const int32_t *d_lens, const int32_t *d
 int lm_meanpool_varlen_f16(const void *d_x, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t hidden,
                            int32_t normalize, float *d_out, void *stream);
 
-/* The feed-forward block of a BERT layer with hidden size 384 in one kernel:
- *   d_out = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2) * gamma + beta,   x / d_out [tokens][384] fp16,
- * d_w1 [ffn][384] fp16 (nn.Linear layout), d_w2p = W2 packed as [ffn/32][384][32] fp16 with the k order of
- * leann_amd/encoder.py: fused_mlp_k_permutation, biases fp32, GELU = exact erf form, ffn % 32 == 0.
- * MFMA 32x32x16 f16 with the 1536-wide intermediate held in accumulators (never written to HBM).  Part of the
- * BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).  Used when the fused layer tail below is switched off
- * (LEANN_MI355X_TAIL=0, A/B); LEANN_MI355X_MLP=0 = library GEMMs (A/B). */
-int lm_mlp_fused_h384_f16(const void *d_x, const void *d_w1, const float *d_b1, const void *d_w2p, const float *d_b2,
-                          const void *d_gamma, const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps,
-                          void *stream);
-
-/* The second half of a BERT layer with hidden size 384 in one kernel -- attention output projection, residual,
- * LayerNorm, then the feed-forward block of lm_mlp_fused_h384_f16:
+/* The second half of a BERT layer with hidden size 384 in ONE kernel (csrc/lm_layer_tail_h384.hip) -- attention output projection,
+ * residual, LayerNorm, then the feed-forward block with its residual and LayerNorm:
  *   x     = LayerNorm(resid + attn W_o^T + b_o) * gamma1 + beta1          (never written to HBM)
  *   d_out = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2) * gamma + beta,    attn / resid / d_out [tokens][384] fp16,
- * d_wo_p = W_o packed as [12][384][32] fp16 (slab s = input features 32 s .. 32 s + 31, natural order),
- * d_w1acc = W1 [ffn][384] with its COLUMNS in accumulator order (leann_amd/encoder.py: pack_w1_acc_order),
- * d_w2p as for lm_mlp_fused_h384_f16; biases fp32; 128 <= ffn <= 2560, ffn % 32 == 0.  Replaces
- * lm_gemm_ws_h384_f16 (n_out 384) + lm_add_layernorm_f16 + lm_mlp_fused_h384_f16: two launches and three passes
- * over the activations fewer.  Part of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).
- * DEFAULT path of the Python host for hidden 384 (LEANN_MI355X_TAIL=0 = the three-launch form, A/B). */
-int lm_attn_out_mlp_fused_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_p, const float *d_bo,
-                                   const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1acc,
-                                   const float *d_b1, const void *d_w2p, const float *d_b2, const void *d_gamma,
-                                   const void *d_beta, void *d_out, int64_t tokens, int32_t ffn, float eps, void *stream);
-
-/* Fourth generation of the fused layer tail (csrc/lm_layer_tail_h384.hip) -- same operation and operands as
- * lm_attn_out_mlp_fused_h384_f16, but the three weight matrices are passed as ready-made LDS IMAGES (written once per model by
- * lm_layer_tail_pack_h384 from the packings above), so that the kernel's weight stream is a linear LDS-DMA copy, and the two
- * products of the feed-forward block alternate MFMA by MFMA on single accumulator chains (no partial sums, no stage arithmetic:
- * ~290 instead of ~470 instructions per 48 MFMAs on its one wave per SIMD).  ffn a multiple of 192 in [192, 1728]; other shapes:
- * the general GEMM path.  DEFAULT path of the hidden-384 forward.  Part of the BERT forward in compute_embeddings
- * (leann/embedding_compute.py:229-239). */
+ * biases fp32, GELU = exact erf form, MFMA 32x32x16 f16 with the ffn-wide intermediate held in accumulators (never written to HBM).
+ * The three weight matrices are passed as ready-made LDS IMAGES (written once per model by lm_layer_tail_pack_h384), so that the
+ * kernel's weight stream is a linear LDS-DMA copy, and the two products of the feed-forward block alternate MFMA by MFMA on single
+ * accumulator chains (no partial sums, no stage arithmetic: ~290 instructions per 48 MFMAs on its one wave per SIMD).  ffn a multiple
+ * of 192 in [192, 1728]; other shapes: the general GEMM path (lm_gemm_f16).  DEFAULT path of the hidden-384 forward
+ * (LEANN_MI355X_TAIL=0 in the Python host = lm_gemm_ws_h384_f16 + lm_add_layernorm_f16 + lm_gemm_f16 x 2 + lm_add_layernorm_f16, A/B).
+ * Part of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).  (Generations 1-3 of this kernel are history:
+ * generation 3 survives only in the diagnosis build, csrc/diag/, as scripts/kbench.cpp's A/B reference.) */
 int lm_layer_tail_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo_img, const float *d_bo,
                            const void *d_gamma1, const void *d_beta1, float eps1, const void *d_w1_img, const float *d_b1,
                            const void *d_w2_img, const float *d_b2, const void *d_gamma, const void *d_beta, void *d_out,
                            int64_t tokens, int32_t ffn, float eps, void *stream);
-/* d_wo_slabs [12][384][32] (pack_wo_slabs), d_w1_acc [ffn][384] (pack_w1_acc_order), d_w2_slabs [ffn/32][384][32]
- * (pack_w2_fused_mlp) -> the images lm_layer_tail_h384_f16 streams (same sizes; XOR-swizzled 16-byte chunks: what makes the
+/* d_wo_slabs = W_o as [12][384][32] (slab s = input features 32 s .. 32 s + 31, natural order: leann_amd/encoder.py pack_wo_slabs),
+ * d_w1_acc = W1 [ffn][384] with its COLUMNS in accumulator order (pack_w1_acc_order), d_w2_slabs = W2 as [ffn/32][384][32] with the k
+ * order of fused_mlp_k_permutation (pack_w2_fused_mlp) -> the images lm_layer_tail_h384_f16 streams (same sizes; XOR-swizzled 16-byte chunks: what makes the
  * kernel's ds_read_b128 fragment reads bank-conflict free).  Device to device, on `stream`. */
 int lm_layer_tail_pack_h384(const void *d_wo_slabs, const void *d_w1_acc, const void *d_w2_slabs, int32_t ffn, void *d_wo_img,
                             void *d_w1_img, void *d_w2_img, void *stream);
@@ -315,27 +295,11 @@ int lm_qkv_h384_f16(const void *d_x, const void *d_w_img, const float *d_bias, i
                     void *stream);
 int lm_qkv_pack_h384(const void *d_w, int32_t n_out, void *d_w_img, void *stream); /* device to device, on `stream` */
 
-/* Linear layer with 384 input features, n_out = 384 P outputs (QKV projection: P = 3):
- *   d_out[tokens][n_out] = x W^T + b                                  (d_residual == NULL)
- *   d_out[tokens][384]   = LayerNorm(residual + x W^T + b) gamma+beta (d_residual != NULL, n_out == 384)
- * x / out / residual fp16, bias fp32, d_wp = W packed as [P][12][384][32] fp16 (leann_amd/encoder.py:
- * pack_w_linear_h384).  MFMA 32x32x16 f16 with the token slice of x held in registers.  The attention
- * projections of the BERT forward in compute_embeddings (leann/embedding_compute.py:229-239).
- * First generation, kept for A/B runs: LEANN_MI355X_LINEAR=1. */
-int lm_linear_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
-                       const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
-
-/* Same operation, same arguments and weight packing, second-generation kernel (csrc/lm_gemm_h384.hip): 64 tokens x 192
- * features per wave (every weight fragment read from LDS feeds two MFMAs), weight slabs streamed L2 -> LDS by
- * global_load_lds through four stages with counted waits.  Second generation, kept for A/B runs: LEANN_MI355X_LINEAR=2. */
-int lm_gemm_h384_f16(const void *d_x, const void *d_wp, const float *d_bias, int32_t n_out, const void *d_residual,
-                     const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
-
 /* Weight-stationary form of the 384-input linear layer (csrc/lm_gemm_ws_h384.hip): d_out[tokens][n_out] = x W^T + b with
  * d_w = the nn.Linear weight itself, [n_out][384] fp16 row major (no packing), n_out a multiple of 192 (<= 6144).  A
  * workgroup keeps its 192 x 384 weight block resident in LDS and streams token tiles past it (no per-slab barriers, two
- * waves per SIMD).  DEFAULT for the QKV projection at hidden 384 (LEANN_MI355X_LINEAR=3 is the default value; with the layer tail
- * switched off also the output projection, followed by lm_add_layernorm_f16). */
+ * waves per SIMD).  The QKV projection of lm_bert_h384_forward_packed when the model carries no wqkv_img (and of the Python host under
+ * LEANN_MI355X_QKV=0, A/B); with the layer tail switched off also the output projection, followed by lm_add_layernorm_f16. */
 int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, int32_t n_out, void *d_out, int64_t tokens,
                         void *stream);
 

@@ -1,4 +1,6 @@
-// lm_mlp_fused_v3.hip -- third variant of the fused feed-forward block (hidden 384):
+// lm_mlp_fused_v3.hip -- generation 3 of the fused layer tail (hidden 384).  SUPERSEDED by csrc/lm_layer_tail_h384.hip (generation 4) and built
+// ONLY into the diagnosis library (make EXTRA_DEFS=-DLM_DIAG), where scripts/kbench.cpp's `tail` / `tail4` modes use its entry point
+// lm_attn_out_mlp_fused_h384_f16 as the A/B reference; the product library does not contain it.  The feed-forward block it was built around:
 //
 //     y = LayerNorm( x + GELU(x W1^T + b1) W2^T + b2 ) * gamma + beta          x, y: [T, 384] fp16
 //
@@ -887,37 +889,6 @@ extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_
     switch (0) { M3P_GO(0); }
 #endif
 #undef M3P_GO
-    LM_HIP(hipGetLastError());
-    return LM_OK;
-}
-
-int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
-                           const void* d_beta, void* d_out, int64_t tokens, int32_t ffn, float eps, void* stream) {
-    using namespace lm;
-    const size_t shmem = (size_t)M3_B1_OFF + (size_t)ffn * 4 + ML_H * 8;  // + b2 (fp32), gamma, beta (fp16)
-    if (ffn < 128 || shmem > 160 * 1024) return 1;  // not applicable: the caller takes variant 2
-    dim3 grid((unsigned)((tokens + 127) / 128)), block(256);
-#define M3_GO(A)                                                                                                                     \
-    case A: {                                                                                                                         \
-        static size_t attr_bytes = 0;                                                                                                 \
-        if (shmem > attr_bytes) {                                                                                                     \
-            LM_HIP(hipFuncSetAttribute((const void*)k_mlp_fused_h384_v3<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-            attr_bytes = shmem;                                                                                                       \
-        }                                                                                                                             \
-        hipLaunchKernelGGL(k_mlp_fused_h384_v3<A>, grid, block, shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w1, \
-                           d_b1, (const __half*)d_w2p, d_b2, (const __half*)d_gamma, (const __half*)d_beta, (__half*)d_out,            \
-                           (int)tokens, ffn, eps);                                                                                      \
-    } break
-#ifdef LM_DIAG
-    static const int abl = [] { const char* ab = getenv("LEANN_MI355X_ABLATE"); return ab ? atoi(ab) : 0; }();
-    switch (abl) {
-        M3_GO(0); M3_GO(1); M3_GO(2); M3_GO(3); M3_GO(4); M3_GO(7); M3_GO(8); M3_GO(16); M3_GO(32); M3_GO(48); M3_GO(64); M3_GO(65); M3_GO(66); M3_GO(68); M3_GO(71); M3_GO(128); M3_GO(192); M3_GO(96); M3_GO(224);
-        default: LM_FAIL(LM_EINVAL, "LEANN_MI355X_ABLATE: unknown combination");
-    }
-#else
-    switch (0) { M3_GO(0); }
-#endif
-#undef M3_GO
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -1,13 +1,15 @@
-// lm_attn_v2.hip -- second revision of the hd=32 packed-sequence attention kernel (see lm_encoder_ops.hip for
-// the first one and the algorithm: swapped S^T = K Q^T, P registers reused as the B operand of O^T = V^T P^T).
+// lm_attn_v2.hip -- fused self-attention for packed variable-length sequences, fp16 in/out: head_dim 32 (MiniLM-L6 / bge-small:
+// 384 / 12, lengths <= 256) and 64 (bge-base / contriever, lengths <= 512).
 //
-// STATUS: default since round 2 (round-1 driver bench on an MI355X: 23.62 -> 21.68 ms per 2048-chunk forward,
-// max|diff| 3.1e-5); LEANN_MI355X_ATTN=1 selects revision 1 for A/B (tests/test_gpu_encoder_kernels.py).
+// One 256-thread workgroup per (sequence, head).  K rows and V^T are staged once in LDS (row strides padded: conflict-free fragment
+// reads); each wave owns 32-row Q blocks.  Scores are computed SWAPPED, S^T = K Q^T with v_mfma_f32_32x32x16_f16, so that a lane
+// holds 16 keys x 1 query row per 32-key tile: softmax max / sum are in-lane reductions plus one exchange with lane ^ 32, and the
+// packed P registers are directly the B operand of the second MFMA  O^T = V^T P^T  (the k-slot -> key assignment of an MFMA operand
+// is free as long as A and B use the same one): no cross-lane movement.  Online softmax over chunks of two 32-key tiles.
+// Role in the reference: part of compute_embeddings' BERT forward (leann/embedding_compute.py:229-239).
 //
-// Why a revision: the ISA of revision 1 spends ~17 VALU issue slots per score (2234 instructions per 32-query
-// block, 32 of them MFMA): at head_dim 32 a 32x32 score tile costs 2 MFMAs (64 cycles) but 16 registers x 17
-// VALU operations, so the kernel is VALU bound, not MFMA / LDS / HBM bound.  This revision puts the softmax
-// on a diet:
+// At head_dim 32 a 32 x 32 score tile costs 2 MFMAs (64 cycles) against 16 registers of softmax: the kernel is VALU bound, not
+// MFMA / LDS / HBM bound (the first revision of this kernel spent ~17 VALU issue slots per score; it is gone).  The softmax diet:
 //   * key masking (compare + select per score) only in tiles that straddle the sequence end -- a
 //     workgroup-uniform branch; full tiles need none because K rows are real;
 //   * (s - max) * c  ->  one fused multiply-add with a per-chunk constant, issued as v_pk_fma_f32 on pairs;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void k_attn_varlen_hd32_v2(const __half* __res
 }  // namespace lm
 
 #ifndef LM_HOST_EMULATION
-// launched by lm_attn_varlen_hd32_f16 / lm_attn_varlen_f16 (lm_encoder_ops.hip)
+// launched by lm_attn_varlen_hd32_f16 / lm_attn_varlen_f16 (below)
 template <int HD>
 static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out,
                              void* stream) {
@@ -263,8 +265,11 @@ static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int
     return LM_OK;
 }
 
-int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len,
-                      void* d_out, void* stream) {
+extern "C" int lm_attn_varlen_hd32_f16(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len,
+                                       void* d_out, void* stream) {
+    if (n_seqs == 0) return LM_OK;
+    if (!d_qkv || !d_cu_seqlens || !d_out || n_seqs < 0 || heads <= 0) LM_FAIL(LM_EINVAL, "bad attention arguments");
+    if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
     return attn_v2_launch_hd<32>(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
 }
 

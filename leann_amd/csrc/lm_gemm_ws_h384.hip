@@ -1,7 +1,7 @@
 // lm_gemm_ws_h384.hip -- WEIGHT-STATIONARY linear layer for 384 input features:   out[T][N] = x W^T + b,   N = 192 nblk.
 //
-// Why a third form (hardware numbers, profiles/r2_kbench_encoder_kernels_262k_tokens.txt + the ablation runs of
-// lm_gemm_h384.hip): with ONE wave per SIMD nothing covers a wave's own load, barrier, DMA-issue and store phases --
+// Why this form (hardware numbers, profiles/r2_kbench_encoder_kernels_262k_tokens.txt + the ablation runs of the streaming kernel that
+// preceded it, one wave per SIMD, 64 tokens x 192 features per wave): with ONE wave per SIMD nothing covers a wave's own load, barrier, DMA-issue and store phases --
 // QKV at 262k tokens takes 406 us, of which the stores alone are 160 us, the weight DMA + per-slab waits 120 us; the bare
 // MFMA / LDS loop is 198 us.  Streaming the weights through LDS slab by slab is what forces the per-slab barriers, and
 // holding 64 tokens x 192 features of accumulators per wave is what forces one wave per SIMD.  K = 384 is small enough to

@@ -1,4 +1,4 @@
-// lm_h384_common.h -- pieces shared by the hidden-384 MFMA kernels (lm_mlp_fused.hip, lm_linear_h384.hip):
+// lm_h384_common.h -- pieces shared by the hidden-384 MFMA kernels (lm_layer_tail_h384.hip, lm_qkv_h384.hip, lm_gemm_ws_h384.hip):
 // vector typedefs, tile constants and the bias + residual + LayerNorm epilogue on the transposed accumulator layout.
 #pragma once
 #include <hip/hip_fp16.h>
@@ -43,6 +43,7 @@ __device__ __forceinline__ void lane32_swap(uint32_t& a, uint32_t& b) {
 #ifdef LM_EMULATED_DEVICE
 __device__ inline void lm_dma16(const void* gsrc, unsigned char* lds_wave_base) { std::memcpy(lds_wave_base + 16 * (threadIdx.x & 63), gsrc, 16); }
 __device__ inline void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) { lm_dma16((const unsigned char*)sbase + voff, lds_wave_base); }
+__device__ inline void lm_dma16_sv_nt(const void* sbase, unsigned voff, unsigned char* lds_wave_base) { lm_dma16((const unsigned char*)sbase + voff, lds_wave_base); }
 #else
 __device__ __forceinline__ void lm_dma16(const void* gsrc, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);  // low half of the flat address = LDS offset
@@ -53,6 +54,11 @@ __device__ __forceinline__ void lm_dma16(const void* gsrc, unsigned char* lds_wa
 __device__ __forceinline__ void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+}
+// ... with the non-temporal hint (streamed activations: read once; A/B switch LM_T4_NT of the layer tail)
+__device__ __forceinline__ void lm_dma16_sv_nt(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
 }
 #endif
 

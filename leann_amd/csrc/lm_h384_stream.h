@@ -73,7 +73,11 @@ __device__ __forceinline__ void t4_issue_rows(const unsigned char* rows, int row
     for (int p = P0; p < P0 + NP; ++p) {
         const int L = 64 * p + lane, row = L / 48, pos = L - 48 * row;
         const int rc = row < rows_valid ? row : rows_valid - 1;
+#if defined(LM_T4_NT) && LM_T4_NT
+        lm_dma16_sv_nt(rows, (unsigned)(rc * 768 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)), stage + 1024 * p);
+#else
         lm_dma16_sv(rows, (unsigned)(rc * 768 + (((pos & ~15) | ((pos ^ row) & 15)) << 4)), stage + 1024 * p);
+#endif
     }
 }
 

@@ -137,13 +137,6 @@ void rc_prepared(lm_recompute* rc, const int32_t* d_ids, int32_t n, int64_t tota
 int32_t rc_width(const lm_recompute* rc);  // floats per embedding row
 }  // namespace lm
 
-// lm_attn_v2.hip: revision 2 of the hd=32 attention kernel (opt-in, LEANN_MI355X_ATTN=2); arguments as lm_attn_varlen_hd32_f16
-int lm_attn_v2_launch(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out,
-                      void* stream);
-// lm_mlp_fused_v3.hip: third variant of the fused feed-forward block (LEANN_MI355X_MLP_VARIANT=3); returns 1 when the shape is outside
-// its envelope (ffn < 128), arguments as lm_mlp_fused_h384_f16
-int lm_mlp_fused_v3_launch(const void* d_x, const void* d_w1, const float* d_b1, const void* d_w2p, const float* d_b2, const void* d_gamma,
-                           const void* d_beta, void* d_out, int64_t tokens, int32_t ffn, float eps, void* stream);
 // lm_encoder_ops2.hip: 16-lanes-per-row LayerNorm (opt-in, LEANN_MI355X_LN=2, hidden <= 768); arguments as lm_add_layernorm_f16
 int lm_add_layernorm_r16_launch(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, void* d_out,
                                 int64_t rows, int32_t hidden, float eps, void* stream);

@@ -54,6 +54,9 @@ constexpr int T4_B1_OFF = 6 * T4_SLAB;
 #ifndef LM_T4_GF
 #define LM_T4_GF 1
 #endif
+#ifndef LM_T4_WO_RING
+#define LM_T4_WO_RING 2  // stages of the W_o ring in the prologue: 2 (product) or 6 (A/B; see the prologue comment)
+#endif
 #ifndef LM_T4_WM
 #define LM_T4_WM 0
 #endif
@@ -459,7 +462,11 @@ __device__ __forceinline__ void t4_epilogue(float16v (&o)[ML_NJ], const half8 (&
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int L = 64 * (8 * b + i) + lane;
+#if defined(LM_T4_NT) && LM_T4_NT && !defined(LM_EMULATED_DEVICE)
+            if (L < 48 * rows_valid) __builtin_nontemporal_store(v[i], (u32x4*)(obase + 16 * L));
+#else
             if (L < 48 * rows_valid) *(u32x4*)(obase + 16 * L) = v[i];
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -531,15 +538,17 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
     const unsigned char* go = (const unsigned char*)pre.wo_img;
     const unsigned voff0 = (unsigned)lane * 16u;
 
-    // ---- prologue + attention output projection.  Six 24 KB stages (0 .. 5).  The wave's attention rows come into stage wv (24 coalesced
-    //      1 KB pieces) and from there into the B fragments; then all six stages are the ring of the twelve W_o slabs -- slab s in stage
-    //      OST[s % 6], OST = {4, 5, 0, 1, 2, 3}: slabs 0, 1 arrive with the prologue, 2 .. 5 as soon as the attention rows are in registers,
-    //      slab s + 5 at the top of slab s >= 1 (the stage slab s - 1 has just left): FIVE slabs of lead.  (Generation 3 and the first form of
-    //      this kernel kept the residual rows in four of the stages during the projection, leaving a two-stage ring with ONE slab of lead:
-    //      1.46 k cycles per slab against a 0.77 k matrix-pipe floor, the L2 -> LDS latency exposed twelve times.)  The residual rows
-    //      (needed by the LayerNorm behind the projection) follow in the last four refill slots: the rows of wave r go to stage RST[r] =
-    //      {4, 5, 0, 1}[r] at the top of slab 7 + r -- six pieces per wave, ALL waves sharing the work, so that every top issues exactly six
-    //      pieces per wave and one counted wait fits all: vmcnt(24) = the four youngest requests may still be in flight. ----
+    // ---- prologue + attention output projection.  Six 24 KB stages (0 .. 5; 0 .. 2 = the W1 ring, 3 .. 5 = the W2 ring of the feed-forward loop).
+    //      LM_T4_WO_RING == 2 (the PRODUCT form): stages 0 .. 3 are row tiles -- wave w owns tile w: its attention rows, then, re-filled by its
+    //      own DMA as soon as those are in registers, its residual rows -- and stages 4, 5 a two-stage ring for the twelve W_o slabs (slab s in
+    //      stage 4 + (s & 1); slabs 0, 1 arrive with the prologue, slab s + 1 at the top of slab s >= 1: ONE slab of lead, vmcnt(0) per slab).
+    //      LM_T4_WO_RING == 6: the attention rows leave stage w before the projection starts and all six stages carry W_o slabs (slab s in
+    //      stage OST[s % 6], FIVE slabs of lead, counted vmcnt(24)); the residual rows follow in the refill slots of slabs 7 .. 10, a quarter
+    //      per wave.  Same time as the two-stage form on most MI355X boxes (673 vs 675 us per 262k tokens), 1085 vs 731 us on the others
+    //      (profiles/r4_session4_layer_tail_bisect_same_source_two_speeds.jsonl: the deep DMA queue of one workgroup's prologue delays the
+    //      feed-forward weight stream of its neighbours) -- kept for A/B only. ----
+    constexpr int WOR = LM_T4_WO_RING;
+    static_assert(WOR == 2 || WOR == 6, "LM_T4_WO_RING: 2 or 6");
     unsigned char* mytile = smem + wv * T4_SLAB;
     const int tok0c = (int)blockIdx.x * 128 + wv * 32 < T ? (int)blockIdx.x * 128 + wv * 32 : T - 1;  // wave uniform
     const int rows_valid = T - tok0c < 32 ? T - tok0c : 32;
@@ -600,11 +609,16 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
         }
     }
     T4_WAIT_LGKM0();
-    T4_BARRIER();  // every wave has its rows in registers: stages 0 .. 3 join the W_o ring
-    t4_copy_quarter(go + 2 * T4_SLAB, smem + 0 * T4_SLAB, wv, voff0);
-    t4_copy_quarter(go + 3 * T4_SLAB, smem + 1 * T4_SLAB, wv, voff0);
-    t4_copy_quarter(go + 4 * T4_SLAB, smem + 2 * T4_SLAB, wv, voff0);
-    t4_copy_quarter(go + 5 * T4_SLAB, smem + 3 * T4_SLAB, wv, voff0);
+    if constexpr (WOR == 6) {
+        T4_BARRIER();  // every wave has its rows in registers: stages 0 .. 3 join the W_o ring
+        t4_copy_quarter(go + 2 * T4_SLAB, smem + 0 * T4_SLAB, wv, voff0);
+        t4_copy_quarter(go + 3 * T4_SLAB, smem + 1 * T4_SLAB, wv, voff0);
+        t4_copy_quarter(go + 4 * T4_SLAB, smem + 2 * T4_SLAB, wv, voff0);
+        t4_copy_quarter(go + 5 * T4_SLAB, smem + 3 * T4_SLAB, wv, voff0);
+    } else {
+        LM_WAVE_SYNC();  // the tile is re-filled by this wave's own DMA: program order on the GPU
+        t4_issue_rows<0, 24>((const unsigned char*)resid + (int64_t)tok0c * (ML_H * 2), rows_valid, mytile, lane);
+    }
 #pragma unroll
     for (int j = 0; j < ML_NJ; ++j)
 #pragma unroll
@@ -613,35 +627,46 @@ __global__ __launch_bounds__(256) LM_ONE_WAVE_PER_SIMD void k_layer_tail_h384(
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[j][4 * q + i] = bv[i];
         }
-    constexpr int OST[6] = {4, 5, 0, 1, 2, 3}, RST[4] = {4, 5, 0, 1};
+    constexpr int OST[6] = {4, 5, 0, 1, 2, 3};  // WOR == 6 (RST[r] = {4, 5, 0, 1}: where the residual rows of wave r land -- the stage slab r + 6 frees)
 #pragma unroll
     for (int s = 0; s < ML_H / 32; ++s) {
-        if (s > 0) {
-            if (s > 1) t4_wait_vm<24>();  // slab s has landed: the four requests behind it (6 pieces each) may be in flight
-            T4_BARRIER();                 // ... for every wave; and every wave is done with slab s - 1, whose stage is refilled:
-            unsigned char* freed = smem + OST[(s - 1) % 6] * T4_SLAB;
-            if (s + 5 < ML_H / 32) t4_copy_quarter(go + (int64_t)(s + 5) * T4_SLAB, freed, wv, voff0);
-            else if (s - 7 < 4) {  // s = 7 .. 10: the residual rows of wave r = s - 7 into stage RST[r] (= the stage just freed), a quarter per wave
-                const int r = s - 7;
-                const int tr = (int)blockIdx.x * 128 + r * 32 < T ? (int)blockIdx.x * 128 + r * 32 : T - 1;
-                const int rv = T - tr < 32 ? T - tr : 32;
-                const unsigned char* rrows = (const unsigned char*)resid + (int64_t)tr * (ML_H * 2);
-                if (wv == 0) t4_issue_rows<0, 6>(rrows, rv, freed, lane);
-                else if (wv == 1) t4_issue_rows<6, 6>(rrows, rv, freed, lane);
-                else if (wv == 2) t4_issue_rows<12, 6>(rrows, rv, freed, lane);
-                else t4_issue_rows<18, 6>(rrows, rv, freed, lane);
+        if constexpr (WOR == 6) {
+            if (s > 0) {
+                if (s > 1) t4_wait_vm<24>();  // slab s has landed: the four requests behind it (6 pieces each) may be in flight
+                T4_BARRIER();                 // ... for every wave; and every wave is done with slab s - 1, whose stage is refilled:
+                unsigned char* freed = smem + OST[(s - 1) % 6] * T4_SLAB;
+                if (s + 5 < ML_H / 32) t4_copy_quarter(go + (int64_t)(s + 5) * T4_SLAB, freed, wv, voff0);
+                else if (s - 7 < 4) {  // s = 7 .. 10: the residual rows of wave r = s - 7 into stage RST[r] (= the stage just freed), a quarter per wave
+                    const int r = s - 7;
+                    const int tr = (int)blockIdx.x * 128 + r * 32 < T ? (int)blockIdx.x * 128 + r * 32 : T - 1;
+                    const int rv = T - tr < 32 ? T - tr : 32;
+                    const unsigned char* rrows = (const unsigned char*)resid + (int64_t)tr * (ML_H * 2);
+                    if (wv == 0) t4_issue_rows<0, 6>(rrows, rv, freed, lane);
+                    else if (wv == 1) t4_issue_rows<6, 6>(rrows, rv, freed, lane);
+                    else if (wv == 2) t4_issue_rows<12, 6>(rrows, rv, freed, lane);
+                    else t4_issue_rows<18, 6>(rrows, rv, freed, lane);
+                }
             }
+        } else if (s > 0) {
+            // top of slab s >= 1: slab s has landed (s >= 2: vmcnt(0) -- it is the youngest request; slabs 0, 1 came with the prologue), every
+            // wave is done with slab s - 1 (barrier), whose stage takes slab s + 1
+            if (s > 1) T4_WAIT_VM(0);
+            T4_BARRIER();
+            if (s + 1 < ML_H / 32) t4_copy_quarter(go + (int64_t)(s + 1) * T4_SLAB, smem + (4 + ((s + 1) & 1)) * T4_SLAB, wv, voff0);
         }
-        const unsigned char* stg = smem + OST[s % 6] * T4_SLAB;
+        const unsigned char* stg = smem + (WOR == 6 ? OST[s % 6] : 4 + (s & 1)) * T4_SLAB;
         t4_outproj_slab(stg + b20, stg + b21, xf[2 * s], xf[2 * s + 1], o);
     }
     T4_STAMP(8);
-    T4_WAIT_VM(0);
-    T4_BARRIER();  // the residual rows have landed (every wave's share of every tile)
+    if constexpr (WOR == 6) {
+        T4_WAIT_VM(0);
+        T4_BARRIER();  // the residual rows have landed (every wave's share of every tile)
+    }
     {
-        // residual rows: the wave's tile (stage RST[wv]) -> fragments.  Then all six stages are idle once every wave is here: the
-        // feed-forward block's first weights (W1 slabs 0..2, W2 slab 0) arrive under the LayerNorm
-        const unsigned char* rtile = smem + (wv < 2 ? 4 + wv : wv - 2) * T4_SLAB;
+        // residual rows: the wave's tile -> fragments (WOR == 2: its own DMA, older than every W_o slab waited for above; WOR == 6: stage
+        // RST[wv]).  Then all six stages are idle once every wave is here: the feed-forward block's first weights (W1 slabs 0..2, W2 slab 0)
+        // arrive under the LayerNorm
+        const unsigned char* rtile = WOR == 6 ? smem + (wv < 2 ? 4 + wv : wv - 2) * T4_SLAB : mytile;
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < ML_KS; ++ks) {

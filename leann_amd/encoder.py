@@ -157,8 +157,7 @@ def _packed(owner, attr: str, sources: tuple, make):
 # environment variables that select a particular kernel generation for an A/B run (everything else under LEANN_MI355X_* --
 # ALLOW_RANDOM_WEIGHTS, ATTN_XCD, STAGGER ... -- does not change which kernels a forward is made of)
 KERNEL_SELECTION_KEYS = ("LEANN_MI355X_QKV", "LEANN_MI355X_ATTN", "LEANN_MI355X_LN", "LEANN_MI355X_POOL", "LEANN_MI355X_EMBED", "LEANN_MI355X_PACK",
-                         "LEANN_MI355X_LINEAR", "LEANN_MI355X_MLP", "LEANN_MI355X_MLP_VARIANT", "LEANN_MI355X_TAIL", "LEANN_MI355X_ABLATE",
-                         "LEANN_MI355X_GEMM")
+                         "LEANN_MI355X_LINEAR", "LEANN_MI355X_TAIL", "LEANN_MI355X_TAIL4", "LEANN_MI355X_GEMM")
 
 
 def fused_add_layernorm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
@@ -191,7 +190,7 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
     if not (qkv.is_cuda and qkv.dtype == torch.float16 and qkv.is_contiguous() and hidden == heads * hd and (
             (hd == 32 and 0 < max_len <= 256) or (hd == 64 and 0 < max_len <= 512))):
         return None
-    if os.environ.get("LEANN_MI355X_ATTN", "1") == "0":
+    if os.environ.get("LEANN_MI355X_ATTN", "1") == "0":  # torch's varlen_attn (A/B)
         return None
     import ctypes as C
 
@@ -199,7 +198,7 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
 
     out = torch.empty((tot, hidden), dtype=torch.float16, device=qkv.device)
     st = C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
-    if hd == 32:  # (also carries the revision-1 A/B switch)
+    if hd == 32:
         _lib.check(_lib.load().lm_attn_varlen_hd32_f16(C.c_void_p(qkv.data_ptr()), C.c_void_p(cu.data_ptr()), cu.shape[0] - 1, heads, int(max_len),
                                                        C.c_void_p(out.data_ptr()), st), "lm_attn_varlen_hd32_f16")
     else:
@@ -323,7 +322,7 @@ def fused_meanpool(x: torch.Tensor, cu: torch.Tensor, normalize: bool, cls: bool
 
 
 def fused_mlp_k_permutation() -> torch.Tensor:
-    """Order of the 32 hidden units of a slab inside a packed W2 row (csrc/lm_mlp_fused.hip): position
+    """Order of the 32 hidden units of a slab inside a packed W2 row (csrc/lm_layer_tail_h384.hip): position
     16u + 8g + e holds unit 16u + 4g + e (e < 4) or 16u + 8 + 4g + e - 4 (e >= 4) -- the hidden units whose GELU
     outputs lane group g already has in registers 8u .. 8u+7 of the first product's accumulator."""
     pos = torch.arange(32)
@@ -347,7 +346,7 @@ def pack_wo_slabs(wo: torch.Tensor) -> torch.Tensor:
 
 def pack_w1_acc_order(w1: torch.Tensor) -> torch.Tensor:
     """W1 [F, 384] with its columns in ACCUMULATOR order: column 32 j + p holds input feature 32 j + perm[p] (perm =
-    fused_mlp_k_permutation).  csrc/lm_mlp_fused_v3.hip: k_attn_out_mlp_h384 normalises the attention block's output inside the
+    fused_mlp_k_permutation).  csrc/lm_layer_tail_h384.hip: k_layer_tail_h384 normalises the attention block's output inside the
     MFMA accumulators and feeds those registers to the first product as they are."""
     f, h = w1.shape
     perm = fused_mlp_k_permutation().to(w1.device)
@@ -373,13 +372,12 @@ def pack_tail_images(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> tu
 def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
     """LayerNorm2(x + fc2(GELU(fc1(x)))) with x = LayerNorm1(resid + out(a)) in ONE kernel (csrc/lm_layer_tail_h384.hip:
     k_layer_tail_h384, generation 4 of the fused layer tail) for hidden 384, fp16 on the GPU, ffn a multiple of 192.
-    LEANN_MI355X_TAIL=0 = the three-kernel path (A/B); None = the caller takes that path."""
+    LEANN_MI355X_TAIL=0 = the unfused path (weight-stationary out-projection + LayerNorm, then the general GEMM for the feed-forward
+    block: A/B); None = the caller takes that path."""
     import os
 
-    if os.environ.get("LEANN_MI355X_TAIL", "1") != "1" or os.environ.get("LEANN_MI355X_MLP", "1") != "1":
+    if os.environ.get("LEANN_MI355X_TAIL", "1") != "1" or os.environ.get("LEANN_MI355X_LINEAR", "1") == "0":
         return None
-    if os.environ.get("LEANN_MI355X_MLP_VARIANT", "3") != "3" or os.environ.get("LEANN_MI355X_LINEAR", "3") != "3":
-        return None  # an explicitly selected older kernel generation is an A/B run of THAT kernel
     f, h = layer.fc1.weight.shape
     if not (a.is_cuda and a.dtype == torch.float16 and a.is_contiguous() and resid.is_contiguous() and resid.dtype == torch.float16
             and h == 384 and f % 192 == 0 and 192 <= f <= 1728 and layer.out.bias is not None):
@@ -407,78 +405,17 @@ def fused_attn_out_mlp(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer") ->
     return out
 
 
-def fused_mlp(x: torch.Tensor, layer: "_Layer") -> Optional[torch.Tensor]:
-    """LayerNorm(x + fc2(GELU(fc1(x)))) in one kernel (csrc/lm_mlp_fused.hip) for hidden 384, fp16 on the GPU.
-    Default on (LEANN_MI355X_MLP=0 = library GEMM path, A/B); None = the caller takes the default path."""
-    import os
-
-    if os.environ.get("LEANN_MI355X_MLP", "1") != "1":
-        return None
-    f, h = layer.fc1.weight.shape
-    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and h == 384 and f % 32 == 0 and f <= 13056):
-        return None
-    import ctypes as C
-
-    from . import _lib
-
-    w2p, b1, b2, w1 = _packed(
-        layer, "_mlp_pack", (layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias),
-        lambda: (pack_w2_fused_mlp(layer.fc2.weight.detach()), layer.fc1.bias.detach().float().contiguous(),
-                 layer.fc2.bias.detach().float().contiguous(), layer.fc1.weight.detach().contiguous()))
-    out = torch.empty_like(x)
-    tm = KernelTimers.active
-    ev = tm.span("mlp_fused_h384", 4.0 * x.shape[0] * f * h) if tm is not None else None
-    if ev:
-        ev[0].record()
-    _lib.check(_lib.load().lm_mlp_fused_h384_f16(
-        C.c_void_p(x.data_ptr()), C.c_void_p(w1.data_ptr()), C.c_void_p(b1.data_ptr()), C.c_void_p(w2p.data_ptr()),
-        C.c_void_p(b2.data_ptr()), C.c_void_p(layer.ln2.weight.data_ptr()), C.c_void_p(layer.ln2.bias.data_ptr()),
-        C.c_void_p(out.data_ptr()), x.shape[0], f, float(layer.ln2.eps), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
-        "lm_mlp_fused_h384_f16")
-    if ev:
-        ev[1].record()
-    return out
-
-
-def pack_w_linear_h384(w: torch.Tensor) -> torch.Tensor:
-    """nn.Linear weight [384 P, 384] -> [P, 12, 384, 32]: pass p, input-feature slab s, output row f, 32 inputs --
-    one contiguous 24 KB block per (p, s) for csrc/lm_linear_h384.hip."""
-    n, k = w.shape
-    return w.reshape(n // 384, 384, k // 32, 32).permute(0, 2, 1, 3).contiguous()
-
-
 def fused_linear_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor] = None,
                       ln: Optional[nn.LayerNorm] = None) -> Optional[torch.Tensor]:
-    """x W^T + b (and, with residual + ln, LayerNorm(residual + x W^T + b)) for 384 input features through the
-    hand-written MFMA kernels: LEANN_MI355X_LINEAR=3 (default) the weight-stationary GEMM (csrc/lm_gemm_ws_h384.hip, + the
-    add+LayerNorm kernel for the output projection), =2 the streaming second generation (csrc/lm_gemm_h384.hip), =1 the first
-    (csrc/lm_linear_h384.hip), =0 the library path (A/B).  None = the caller takes the hipBLASLt path."""
+    """x W^T + b (and, with residual + ln, LayerNorm(residual + x W^T + b)) for 384 input features through the hand-written MFMA
+    kernels: the weight-streaming QKV kernel (csrc/lm_qkv_h384.hip) or the weight-stationary GEMM (csrc/lm_gemm_ws_h384.hip, + the
+    add+LayerNorm kernel for the output projection).  LEANN_MI355X_LINEAR=0 = the library path (A/B).  None = the caller takes the
+    hipBLASLt path."""
     import os
 
-    gen = os.environ.get("LEANN_MI355X_LINEAR", "3")  # default since round 2: measured 381 / 240 us vs 405 / ~225 us (library) per 262k tokens
-    if gen == "3":  # weight-stationary GEMM (csrc/lm_gemm_ws_h384.hip) + the add+LayerNorm kernel for the output projection
-        return _linear_ws_h384(x, lin, residual, ln)
-    if gen not in ("1", "2"):
+    if os.environ.get("LEANN_MI355X_LINEAR", "1") == "0":
         return None
-    n, k = lin.weight.shape
-    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n % 384 == 0 and lin.bias is not None):
-        return None
-    if (residual is None) != (ln is None) or (ln is not None and (n != 384 or not residual.is_contiguous())):
-        return None
-    import ctypes as C
-
-    from . import _lib
-
-    pk = _packed(lin, "_h384_pack", (lin.weight, lin.bias), lambda: (pack_w_linear_h384(lin.weight.detach()), lin.bias.detach().float().contiguous()))
-    out = torch.empty((x.shape[0], n), dtype=torch.float16, device=x.device)
-    fn = _lib.load().lm_gemm_h384_f16 if gen == "2" else _lib.load().lm_linear_h384_f16
-    _lib.check(fn(
-        C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), n,
-        C.c_void_p(residual.data_ptr()) if residual is not None else None,
-        C.c_void_p(ln.weight.data_ptr()) if ln is not None else None, C.c_void_p(ln.bias.data_ptr()) if ln is not None else None,
-        float(ln.eps) if ln is not None else 0.0, C.c_void_p(out.data_ptr()), x.shape[0],
-        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_linear_h384_f16")
-    return out
+    return _linear_ws_h384(x, lin, residual, ln)
 
 
 def pack_qkv_image(w: torch.Tensor) -> torch.Tensor:
@@ -563,11 +500,11 @@ class _Layer(nn.Module):
             return y
         y = fused_linear_h384(a, self.out, residual=x, ln=self.ln1)
         x = y if y is not None else fused_add_layernorm(self.out(a), x, self.ln1)
-        y = fused_mlp(x, self)
+        hmid = fused_gemm(x, self.fc1, GEMM_EPI_GELU)  # a feed-forward width outside the fused tail's envelope, or LEANN_MI355X_TAIL=0
+        y = fused_gemm(hmid, self.fc2, GEMM_EPI_RESIDUAL, x) if hmid is not None else None
         if y is not None:
-            return y
-        x = fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
-        return x
+            return fused_add_layernorm(y, None, self.ln2)
+        return fused_add_layernorm(self.fc2(F.gelu(self.fc1(x))), x, self.ln2)
 
     def _forward_packed_general(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> Optional[torch.Tensor]:
         """The layer on the general kernels (lm_gemm_f16 + lm_attn_varlen_f16 + lm_add_layernorm_f16); None = a shape outside their

@@ -113,10 +113,11 @@ def main():
     nq = B * (K + W + 1)
     qt, qo, _ = corpus.queries(nq, seed=4321)
     Q = RecomputeProvider(enc, TokenStore(qt, qo), provider.dp, dev).embed_ids(torch.arange(nq, dtype=torch.int32, device=dev)).contiguous()
-    gt = torch.empty((nq, 10), dtype=torch.int64, device=dev)
-    for b0 in range(0, nq, 256):
-        gt[b0 : b0 + 256] = torch.topk(Q[b0 : b0 + 256] @ X.T, 10, dim=1).indices
-    gt = gt.cpu().numpy()
+    from leann_amd.exact import exact_topk_ip
+
+    # blocked: 256 queries x 10M chunks in ONE GEMM call (2.56e9 scores > 2^31) came back with rows 215 .. 255 of every block wrong, which
+    # capped every recall figure of the first two 10M runs at 0.84 (profiles/r4_bench_c3_10M_chunks_*_with_diagnosis.json; leann_amd/exact.py)
+    gt = exact_topk_ip(Q, X, 10)[1].cpu().numpy()
     nsw = min(256, B)
     qs = Q[nq - nsw :].contiguous()
     diag = None

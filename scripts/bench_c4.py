@@ -112,9 +112,9 @@ def _main(args, dry):
     # 256 x 7.5M x 4 B = 7.7 GB, and more at larger batches), gathered and merged
     ld = torch.empty((nq, 10), dtype=torch.float32, device=dev)
     li = torch.empty((nq, 10), dtype=torch.int64, device=dev)
-    for b0 in range(0, nq, 64):
-        v, ix_ = torch.topk(Q[b0 : b0 + 64] @ X.T, 10, dim=1)
-        ld[b0 : b0 + 64], li[b0 : b0 + 64] = v, ix_
+    from leann_amd.exact import exact_topk_ip
+
+    ld[:], li[:] = exact_topk_ip(Q, X, 10, q_block=64)
     li = li + lo
     if world > 1:
         gd = [torch.empty_like(ld) for _ in range(world)]

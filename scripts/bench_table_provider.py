@@ -65,10 +65,9 @@ def main():
         return keep["e"].data_ptr()
 
     idx.set_provider(provider)
-    gt = torch.empty((nq, 10), dtype=torch.int64, device=dev)
-    for b0 in range(0, nq, 1024):
-        gt[b0 : b0 + 1024] = torch.topk(Q[b0 : b0 + 1024] @ X.T, 10, dim=1).indices
-    gt = gt.cpu().numpy()
+    from leann_amd.exact import exact_topk_ip
+
+    gt = exact_topk_ip(Q, X, 10)[1].cpu().numpy()
     prm = idx.make_params(ef=args.ef, beam=args.beam, recompute=True, max_batch=B)
     for w in range(W):
         idx.search_device(Q[w * B : (w + 1) * B], 10, prm)

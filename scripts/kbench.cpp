@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|linear|mlp|attn|ln]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -22,6 +22,13 @@
 #include <vector>
 
 #include "leann_mi355x.h"
+
+// generation 3 of the fused layer tail: only in the diagnosis build of the library (csrc/diag/lm_mlp_fused_v3.hip), as the `tail` / `tail4`
+// modes' A/B reference; operands: W_o as [12][384][32] slabs, W1 with its columns in accumulator order, W2 as [ffn/32][384][32] slabs
+extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_resid, const void* d_wo_p, const float* d_bo, const void* d_gamma1,
+                                              const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1, const void* d_w2p,
+                                              const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out, int64_t tokens, int32_t ffn,
+                                              float eps, void* stream);
 
 #define CK(e)                                                                                  \
     do {                                                                                       \
@@ -199,16 +206,6 @@ static float time_us(hipStream_t st, int reps, const std::function<void()>& f) {
     return 1e3f * ms / reps;
 }
 
-// nn.Linear weight [384 P][384] -> [P][12][384][32] (leann_amd/encoder.py: pack_w_linear_h384)
-static std::vector<__half> pack_linear(const std::vector<__half>& w, int N) {
-    std::vector<__half> p(w.size());
-    const int P = N / H;
-    for (int pp = 0; pp < P; ++pp)
-        for (int s = 0; s < 12; ++s)
-            for (int r = 0; r < H; ++r)
-                for (int c = 0; c < 32; ++c) p[(((size_t)pp * 12 + s) * H + r) * 32 + c] = w[((size_t)pp * H + r) * H + s * 32 + c];
-    return p;
-}
 // W2 [384][F] -> [F/32][384][32] with the k permutation of leann_amd/encoder.py: fused_mlp_k_permutation
 static std::vector<__half> pack_w2(const std::vector<__half>& w2, int F) {
     int perm[32];
@@ -330,7 +327,7 @@ int main(int argc, char** argv) {
             const int N = mode == 0 ? 3 * H : H;
             auto hw = rand_half((size_t)N * H, 0.05f, 10 + mode);
             auto hb = rand_float(N, 0.2f, 20 + mode);
-            Dev<__half> w(hw), wp(pack_linear(hw, N));
+            Dev<__half> w(hw);
             Dev<float> b(hb);
             Dev<__half> out((size_t)T * N);
             Dev<float> zref((size_t)nr * N), lref((size_t)nr * H);
@@ -339,18 +336,6 @@ int main(int argc, char** argv) {
             CK(hipStreamSynchronize(st));
             auto ref = mode == 0 ? zref.host() : lref.host();
             const double gflop = 2.0 * T * (double)N * H * 1e-9;
-            for (int gen = 1; gen <= 2; ++gen) {
-                auto fn = gen == 1 ? lm_linear_h384_f16 : lm_gemm_h384_f16;
-                CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
-                auto run = [&] { LM(fn(x.p, wp.p, b.p, N, mode ? res.p : nullptr, mode ? gamma.p : nullptr, mode ? beta.p : nullptr, 1e-12f, out.p, T, st)); };
-                run();
-                CK(hipStreamSynchronize(st));
-                const double err = max_err_rows(out.host(), N, 0, N, rows, ref);
-                const float us = time_us(st, reps, run);
-                printf("{\"kernel\": \"%s\", \"mode\": \"%s\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
-                       gen == 1 ? "lm_linear_h384_f16" : "lm_gemm_h384_f16", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us, err);
-                fflush(stdout);
-            }
             {   // weight-stationary form (plain weight layout); the LN variant is GEMM + lm_add_layernorm_f16
                 Dev<__half> tmp((size_t)T * N);
                 CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
@@ -369,101 +354,10 @@ int main(int argc, char** argv) {
                        mode ? " + lm_add_layernorm_f16" : "", mode ? "out-proj+res+LN (N=384)" : "QKV (N=1152)", us, gflop / us, err);
                 fflush(stdout);
             }
-            if (mode == 0 && want("ablate")) {
-                for (const char* ab : {"1", "2", "3", "4", "7"}) {
-                    setenv("LEANN_MI355X_ABLATE", ab, 1);
-                    const float usa = time_us(st, reps, [&] { LM(lm_gemm_h384_f16(x.p, wp.p, b.p, N, nullptr, nullptr, nullptr, 1e-12f, out.p, T, st)); });
-                    printf("{\"kernel\": \"lm_gemm_h384_f16 QKV\", \"ablate\": \"%s (1 no DMA, 2 no wait/barrier, 4 no stores)\", \"us\": %.1f}\n", ab, usa);
-                    fflush(stdout);
-                }
-                unsetenv("LEANN_MI355X_ABLATE");
-            }
             const float us = time_us(st, reps, [&] { lib_gemm(w.p, N, H, x.p, out.p); });
             printf("{\"kernel\": \"rocblas_gemm_ex f16 (no bias / LN)\", \"mode\": \"N=%d K=384\", \"us\": %.1f, \"TFLOPs\": %.1f}\n", N, us, gflop / us);
             fflush(stdout);
         }
-    }
-    if (want("mlp")) {
-        const int F = 1536;
-        auto hw1 = rand_half((size_t)F * H, 0.05f, 30), hw2 = rand_half((size_t)H * F, 0.03f, 31);
-        Dev<__half> w1(hw1), w2(hw2), w2p(pack_w2(hw2, F));
-        Dev<float> b1(rand_float(F, 0.2f, 32)), b2(rand_float(H, 0.2f, 33));
-        Dev<__half> out((size_t)T * H), hid16((size_t)T * F);
-        Dev<float> hid((size_t)nr * F), z((size_t)nr * H), lref((size_t)nr * H);
-        hipLaunchKernelGGL(ref_gelu_fc1, dim3((nr * F + 255) / 256), dim3(256), 0, st, x.p, w1.p, b1.p, d_rows.p, nr, F, hid.p);
-        hipLaunchKernelGGL(ref_fc2, dim3((nr * H + 255) / 256), dim3(256), 0, st, hid.p, w2.p, b2.p, nr, F, z.p);
-        hipLaunchKernelGGL(ref_add_ln, dim3(nr), dim3(128), 0, st, z.p, x.p, d_rows.p, nr, gamma.p, beta.p, 1e-12f, lref.p);
-        CK(hipStreamSynchronize(st));
-        auto ref = lref.host();
-        const double gflop = 4.0 * T * (double)F * H * 1e-9;
-        for (const char* var : {"1", "2", "3"}) {
-            setenv("LEANN_MI355X_MLP_VARIANT", var, 1);
-            CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
-            auto run = [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); };
-            run();
-            CK(hipStreamSynchronize(st));
-            const double err = max_err_rows(out.host(), H, 0, H, rows, ref);
-            const float us = time_us(st, reps, run);
-            printf("{\"kernel\": \"lm_mlp_fused_h384_f16\", \"mode\": \"variant %s, ffn 1536 (fc1+GELU+fc2+res+LN)\", \"us\": %.1f, \"TFLOPs\": %.1f, \"max_abs_err\": %.3g}\n",
-                   var, us, gflop / us, err);
-            fflush(stdout);
-        }
-        if (want("ablate")) {  // diagnosis: variant 3 with pieces switched off (results wrong by construction)
-            setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
-            for (const char* ab : {"1", "2", "3", "4", "7", "8"}) {
-                setenv("LEANN_MI355X_ABLATE", ab, 1);
-                const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
-                printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"ablate\": \"%s (1 no DMA, 2 no wait/barrier, 4 no GELU, 8 = round-2 GELU form, results right)\", \"us\": %.1f}\n", ab, us);
-                fflush(stdout);
-            }
-            unsetenv("LEANN_MI355X_ABLATE");
-        }
-        if (want("stamps")) {  // where a workgroup's cycles go: LEANN_MI355X_ABLATE & 64 writes 8 s_memtime stamps per workgroup over its first output row
-            setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
-            const int nwg = (T + 127) / 128;
-            for (const char* ab : {"64", "68", "71", "65", "66", "96", "192", "224"}) {
-                setenv("LEANN_MI355X_ABLATE", ab, 1);
-                for (int rep = 0; rep < 3; ++rep) LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st));
-                CK(hipStreamSynchronize(st));
-                const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
-                auto ho = out.host();
-                double sum[8] = {0};
-                for (int b = 0; b < nwg; ++b) {
-                    unsigned long long t[8];
-                    memcpy(t, (const char*)ho.data() + (size_t)b * 128 * H * 2, 64);
-                    for (int i = 1; i < 8; ++i) sum[i] += (double)(t[i] - t[i - 1]);
-                }
-                printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3 stamps\", \"ablate\": \"%s (64 = product kernel; +4 no GELU, +7 bare MFMA/LDS loop, +1 no DMA, +2 no wait/barrier, +32 asm GELU, +128 fragment ring 8)\", "
-                       "\"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"first product of slab 0\": %.0f, \"iteration 0\": %.0f, \"per steady iteration s = 1..16\": %.0f, "
-                       "\"per steady iteration s = 17..46\": %.0f, \"last iteration + final second product\": %.0f, \"epilogue\": %.0f}}\n",
-                       ab, us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg / 16, sum[5] / nwg / 30, sum[6] / nwg, sum[7] / nwg);
-                fflush(stdout);
-            }
-            unsetenv("LEANN_MI355X_ABLATE");
-        }
-        if (want("gelu")) {  // interleaved A/B of variant 3's two GELU forms (clock / thermal state drifts between back-to-back groups)
-            setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
-            for (int round = 0; round < 3; ++round)
-                for (const char* ab : {"0", "8", "16", "32", "48"}) {
-                    setenv("LEANN_MI355X_ABLATE", ab, 1);
-                    if (round == 0) {  // results of every form against the reference rows
-                        CK(hipMemsetAsync(out.p, 0xFF, out.n * sizeof(__half), st));
-                        LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st));
-                        CK(hipStreamSynchronize(st));
-                        printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"gelu_form_ablate\": \"%s\", \"max_abs_err\": %.3g}\n", ab, max_err_rows(out.host(), H, 0, H, rows, ref));
-                    }
-                    const float us = time_us(st, reps, [&] { LM(lm_mlp_fused_h384_f16(x.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out.p, T, F, 1e-12f, st)); });
-                    printf("{\"kernel\": \"lm_mlp_fused_h384_f16 v3\", \"gelu_form\": \"%s\", \"round\": %d, \"us\": %.1f}\n", !strcmp(ab, "0") ? "1: one transcendental, C" : !strcmp(ab, "8") ? "2: Abramowitz-Stegun" : !strcmp(ab, "16") ? "3: asm, VOP2 literals" : !strcmp(ab, "32") ? "4: asm, VOP3 modifiers" : "5: asm, VOP3, 8 in flight", round, us);
-                    fflush(stdout);
-                }
-            unsetenv("LEANN_MI355X_ABLATE");
-        }
-        unsetenv("LEANN_MI355X_MLP_VARIANT");
-        const float us1 = time_us(st, reps, [&] { lib_gemm(w1.p, F, H, x.p, hid16.p); });
-        const float us2 = time_us(st, reps, [&] { lib_gemm(w2.p, H, F, hid16.p, out.p); });
-        printf("{\"kernel\": \"rocblas_gemm_ex f16 fc1 + fc2 (no GELU / LN)\", \"us\": %.1f, \"fc1_us\": %.1f, \"fc2_us\": %.1f, \"TFLOPs\": %.1f}\n", us1 + us2, us1, us2,
-               gflop / (us1 + us2));
-        fflush(stdout);
     }
     if (want("qkv")) {  // QKV projection: the weight-stationary kernel (x read six times) vs the weight-streaming one with two waves per SIMD (lm_qkv_h384.hip)
         const int N = 3 * H;
@@ -555,11 +449,13 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         auto ref = lref.host();
         const double gflop = (4.0 * F * H + 2.0 * H * H) * T * 1e-9;
-        setenv("LEANN_MI355X_MLP_VARIANT", "3", 1);
-        auto run3 = [&] {
+        Dev<__half> hmid((size_t)T * F);
+        auto run3 = [&] {  // the unfused form (LEANN_MI355X_TAIL=0 in the Python host): five launches, the intermediate through HBM
             LM(lm_gemm_ws_h384_f16(x.p, wo.p, bo.p, H, y0.p, T, st));
             LM(lm_add_layernorm_f16(y0.p, res.p, gamma1.p, beta1.p, x1.p, T, H, 1e-12f, st));
-            LM(lm_mlp_fused_h384_f16(x1.p, w1.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, out3.p, T, F, 1e-12f, st));
+            LM(lm_gemm_f16(x1.p, w1.p, b1.p, nullptr, 1, F, H, hmid.p, T, st));
+            LM(lm_gemm_f16(hmid.p, w2.p, b2.p, x1.p, 2, H, F, y0.p, T, st));
+            LM(lm_add_layernorm_f16(y0.p, nullptr, gamma.p, beta.p, out3.p, T, H, 1e-12f, st));
         };
         auto runf = [&] {
             LM(lm_attn_out_mlp_fused_h384_f16(x.p, res.p, wop.p, bo.p, gamma1.p, beta1.p, 1e-12f, w1a.p, b1.p, w2p.p, b2.p, gamma.p, beta.p, outf.p, T,
@@ -581,45 +477,10 @@ int main(int argc, char** argv) {
         }
         for (int round = 0; round < 2; ++round) {  // interleaved A/B
             const float us3 = time_us(st, reps, run3), usf = time_us(st, reps, runf);
-            printf("{\"kernel\": \"lm_gemm_ws_h384_f16 + lm_add_layernorm_f16 + lm_mlp_fused_h384_f16 (v3)\", \"mode\": \"out-proj+res+LN+MLP+res+LN, three launches\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g}\n", round, us3, gflop / us3 * 1e-3, e3);
-            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16\", \"mode\": \"out-proj+res+LN+MLP+res+LN, one launch\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g, \"max_abs_diff_vs_three_launches_all_rows\": %.3g}\n", round, usf, gflop / usf * 1e-3, ef, dmax);
+            printf("{\"kernel\": \"lm_gemm_ws_h384_f16 + lm_add_layernorm_f16 + lm_gemm_f16 x 2 + lm_add_layernorm_f16\", \"mode\": \"out-proj+res+LN+MLP+res+LN, five launches\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g}\n", round, us3, gflop / us3 * 1e-3, e3);
+            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 (generation 3, diagnosis library)\", \"mode\": \"out-proj+res+LN+MLP+res+LN, one launch\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.3f, \"max_abs_err\": %.3g, \"max_abs_diff_vs_five_launches_all_rows\": %.3g}\n", round, usf, gflop / usf * 1e-3, ef, dmax);
             fflush(stdout);
         }
-        if (want("stagger")) {  // spread of the first round's start times, x 1024 cycles (0 = off; the library's default is 40)
-            for (int round = 0; round < 2; ++round)
-                for (const char* sg : {"0", "20", "40", "80", "120", "160"}) {
-                    setenv("LEANN_MI355X_STAGGER", sg, 1);
-                    const float us = time_us(st, reps, runf);
-                    printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16\", \"stagger_kcycles\": %s, \"round\": %d, \"us\": %.1f}\n", sg, round, us);
-                    fflush(stdout);
-                }
-            unsetenv("LEANN_MI355X_STAGGER");
-        }
-        for (const char* ab : {"64", "320", "576", "1088", "1856"}) {
-            if (!want("stamps")) break;
-            if (strcmp(ab, "64") && !want("prolog")) break;  // prologue ablations (results wrong by construction): "tailstampsprolog"
-            setenv("LEANN_MI355X_ABLATE", ab, 1);
-            const int nwg = (T + 127) / 128;
-            for (int rep = 0; rep < 3; ++rep) runf();
-            CK(hipStreamSynchronize(st));
-            const float us = time_us(st, reps, runf);
-            auto ho = outf.host();
-            double sum[10] = {0};
-            for (int b = 0; b < nwg; ++b) {
-                unsigned long long t[10];
-                memcpy(t, (const char*)ho.data() + (size_t)b * 128 * H * 2, 80);
-                // stamp order in time: 0 start, 1 prologue done, 8 out-projection done, 9 LayerNorm 1 done, 2 first product, 3 iteration 0, 4 (s = 17), 5 steady done, 6 final, 7 end
-                const int ord[10] = {0, 1, 8, 9, 2, 3, 4, 5, 6, 7};
-                for (int i = 1; i < 10; ++i) sum[i] += (double)(t[ord[i]] - t[ord[i - 1]]);
-            }
-            printf("{\"kernel\": \"lm_attn_out_mlp_fused_h384_f16 stamps\", \"ablate\": \"%s (64 = product kernel; +256 no row tiles, +512 no prologue DMA, +1024 no LDS fills)\", \"us\": %.1f, \"mean_cycles\": {\"prologue\": %.0f, \"out-projection (12 slabs)\": %.0f, \"LayerNorm 1 in registers\": %.0f, "
-                   "\"first product of slab 0\": %.0f, \"iteration 0\": %.0f, \"per steady iteration s = 1..16\": %.0f, \"per steady iteration s = 17..46\": %.0f, "
-                   "\"last iteration + final second product\": %.0f, \"epilogue\": %.0f}}\n",
-                   ab, us, sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg, sum[6] / nwg / 16, sum[7] / nwg / 30, sum[8] / nwg, sum[9] / nwg);
-            fflush(stdout);
-        }
-        unsetenv("LEANN_MI355X_ABLATE");
-        unsetenv("LEANN_MI355X_MLP_VARIANT");
         if (want("tail4")) {  // generation 4 (lm_layer_tail_h384.hip): every schedule variant of the diagnosis library, interleaved with generation 3
             Dev<__half> woi((size_t)H * H), w1i((size_t)F * H), w2i((size_t)H * F), out4((size_t)T * H);
             LM(lm_layer_tail_pack_h384(wop.p, w1a.p, w2p.p, F, woi.p, w1i.p, w2i.p, st));

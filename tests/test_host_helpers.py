@@ -195,3 +195,25 @@ def test_high_degree_preserving_pruning_alg3(built_libs):
         Mi355xBuilder(M=16, efConstruction=100, hub_preserving_m=6).build(x, [str(i) for i in range(5000)], str(pathlib.Path(td) / "p.leann"))
         Mi355xBuilder(M=16, efConstruction=100).build(x, [str(i) for i in range(5000)], str(pathlib.Path(td) / "f.leann"))
         assert cf.read_index(pathlib.Path(td) / "p.index").neighbors.shape[0] < cf.read_index(pathlib.Path(td) / "f.index").neighbors.shape[0]
+
+
+def test_blocked_exact_topk_equals_one_big_matmul():
+    """leann_amd/exact.py (the benchmarks' ground truth): the blocked form -- query blocks x corpus blocks, top-k merge -- against torch.topk
+    of the whole score matrix, with block sizes forced small enough that both loops and the merge run."""
+    import torch
+
+    import leann_amd.exact as ex
+
+    torch.manual_seed(3)
+    Q, X = torch.randn(37, 16), torch.randn(1003, 16)
+    rv, ri = torch.topk(Q @ X.T, 10, dim=1)
+    old = ex.MAX_SCORES
+    try:
+        for cap, qb in ((37 * 130, 256), (16 * 64, 16), (old, 5)):
+            ex.MAX_SCORES = cap
+            v, i = ex.exact_topk_ip(Q, X, 10, q_block=qb)
+            assert torch.equal(i, ri) and torch.allclose(v, rv)
+    finally:
+        ex.MAX_SCORES = old
+    v, i = ex.exact_topk_ip(Q, X[:4], 10)  # k > n
+    assert i.shape == (37, 4) and torch.equal(i, torch.topk(Q @ X[:4].T, 4, dim=1).indices)
