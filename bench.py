@@ -436,11 +436,22 @@ def _main(args, ap):
     next_row = B * (K + W + 5)
     # The timed steps above already ran over the product default: the LIBRARY-side provider (csrc/lm_recompute.hip -- no interpreter
     # in the search loop, one host synchronisation per round).  The Python form of the provider is the A/B here.
-    latency_python_provider = provider_ab = None
+    latency_python_provider = provider_ab = latency_speculate = None
     if world == 1 and not args.no_latency_rows:
         try:
             latency_rows, next_row = small_batch_latency(
                 idx, Q, lambda b: idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b), recall, next_row)
+            # option "speculate" (k_speculate: a one-query round also embeds the neighbours of its S best unexpanded candidates; same labels,
+            # fewer forwards, more chunks): off by default, reported next to the default row
+            latency_speculate = {}
+            for S in (4, 16):
+                idx.set_option("speculate", S)
+                try:
+                    rows_s, next_row = small_batch_latency(
+                        idx, Q, lambda b: idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b), recall, next_row, batches=(1,), budget_s=4.0)
+                    latency_speculate[str(S)] = rows_s[0] if rows_s else None
+                finally:
+                    idx.set_option("speculate", 0)
             if idx.native_provider:  # A/B in the same run: the same batch sizes over the Python provider
                 os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
                 try:
@@ -640,6 +651,8 @@ def _main(args, ap):
                                                   "synchronisation per round" if latency_python_provider is not None else "Python provider")
     if latency_python_provider:
         result["small_batch_latency_python_provider"] = latency_python_provider
+        if latency_speculate:
+            result["small_batch_latency_b1_with_speculative_prefetch"] = latency_speculate
     if provider_ab:
         result["full_step_over_the_python_provider"] = provider_ab
     if value_by_batch:
@@ -755,7 +768,7 @@ def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 2
         prm = prm_of(b)
         idx.search_device(Q[lo : lo + b].contiguous(), 10, prm)  # warm-up (workspace sizing for this batch size)
         lo += b
-        lat, labels, used = [], [], []
+        lat, labels, used, chunks, rounds = [], [], [], 0, 0
         t_all = time.perf_counter()
         reps = 0
         while reps < (24 if b == 1 else 8) and time.perf_counter() - t_all < budget_s / len(batches) and lo + b <= Q.shape[0]:
@@ -764,6 +777,9 @@ def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 2
             _, l = idx.search_device(Q[lo : lo + b].contiguous(), 10, prm)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
+            st_ = idx.stats()  # (of that call)
+            chunks += int(st_["nunique"])
+            rounds += int(st_["nrounds"])
             labels.append(l)
             used.append(range(lo, lo + b))
             lo += b
@@ -774,7 +790,8 @@ def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 2
         rec = float(np.mean([recall(l.cpu().numpy(), r) for l, r in zip(labels, used)]))
         rows.append({"batch": b, "reps": len(lat), "p50_ms": round(float(np.median(lat_ms)), 2), "mean_ms": round(float(lat_ms.mean()), 2),
                      "max_ms": round(float(lat_ms.max()), 2), "queries_per_s": round(b / float(lat_ms.mean()) * 1e3, 2),
-                     "recall_at_10": round(rec, 4)})
+                     "recall_at_10": round(rec, 4), "recomputed_chunks_per_query": round(chunks / (len(lat) * b), 1),
+                     "rounds_per_call": round(rounds / len(lat), 1)})
     return rows, lo
 
 

@@ -167,6 +167,10 @@ int lm_index_event_overhead_us(lm_index *idx, double *out_us);
  * diskann_backend.py:444-449 describes: "fetch embeddings for the final candidate set only"), 1 EVERY node the traversal expanded
  * (upstream DiskANN's full_retset, PQFlashIndex::cached_beam_search: a superset of the final list; up to 4 x complexity <= 8192 nodes
  * per query are recorded, a query that expands more falls back to its final list and is counted in "pq_rerank_overflow").
+ * "speculate" S (0 = off, <= 64) / "speculate_max_batch" (default 2): speculative prefetch of a small recompute batch -- a round's forward
+ * also embeds the unvisited neighbours of the S best candidates that are not expanded yet, into the per-call memo, so that later rounds
+ * find their new nodes there and need no forward (a one-query search is ~100 rounds of ~50 dependent launches: launch latency).  Labels,
+ * distances and distance-evaluation counts are those of S = 0; only the provider's request lists differ (more ids in fewer calls).
  * lm_index_get_option reads a value back ("pq_rerank_overflow": queries that fell back since the option was last set). */
 int lm_index_set_option(lm_index *idx, const char *name, int64_t value);
 int lm_index_get_option(const lm_index *idx, const char *name, int64_t *value);

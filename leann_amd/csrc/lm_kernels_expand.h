@@ -114,6 +114,42 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
     }
 }
 
+// Speculative prefetch for small batches (option "speculate" = S; needs the per-call memo).  A one-query search is a chain of ~100 rounds
+// of ~50 dependent kernel launches each (the recompute forward of ~8 chunks): launch latency, not arithmetic.  The next nodes the search
+// will pop are, most of the time, the best candidates of the pool that are not expanded yet -- so this round's forward also embeds THEIR
+// unvisited neighbours (the request bitmap gets their bits too), the rows go into the memo, and a later round whose new nodes are all in
+// the memo needs no forward at all.  Nothing the search itself reads is touched: visited bits, new-lists, pops, the pool and the
+// distance-evaluation counts are exactly those of S = 0, and so are the results; only the provider's request lists differ (more rows in
+// fewer calls).  One wave per query; after k_expand of the same round (its visited bits are final), before k_uniq_count.
+__global__ __launch_bounds__(64) void k_speculate(GraphDev g, WsDev ws, int S, int check_rel) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (ws.phase[q] != PH_BEAM) return;
+    const uint64_t* pool = ws.pool + (size_t)q * ws.ef;
+    const uint32_t* vis = ws.visited + (size_t)q * ws.nw;
+    const int npool = ws.npool[q];
+    const int scan_n = check_rel ? min(npool, ws.efs) : npool;  // what select_pops will look at
+    int found = 0;
+    for (int base = 0; base < scan_n && found < S; base += 64) {
+        const int i = base + lane;
+        const uint64_t key = i < scan_n ? pool[i] : KEY_NONE;
+        const bool un = i < scan_n && !(key & KEY_EXPANDED);
+        unsigned long long m = __ballot(un);
+        const int32_t mine = key_id(key);
+        while (m && found < S) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int32_t c = __shfl(mine, src);
+            const L0Range r = g.l0[c];
+            for (uint32_t j = lane; j < r.count; j += 64) {
+                const int32_t v = g.neighbors[r.begin + j];
+                const uint32_t bit = 1u << (v & 31);
+                if (!(vis[v >> 5] & bit) && ws.memo_slot[v] < 0) atomicOr(&ws.rbm[v >> 5], bit);
+            }
+            ++found;
+        }
+    }
+}
+
 // round bitmap -> per-tile popcounts
 __global__ __launch_bounds__(256) void k_uniq_count(WsDev ws) {
     __shared__ int red[4];

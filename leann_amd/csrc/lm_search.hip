@@ -83,8 +83,10 @@ struct lm_index {
     hipStream_t stream = nullptr;
     // workspace
     WsDev ws{};
-    int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0;
+    int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0, ws_spec = 0;
     int64_t ws_ucap = 0;
+    int speculate = 0;            // option "speculate": candidates whose neighbours a small-batch round embeds ahead of time (k_speculate); 0 = off
+    int speculate_max_batch = 2;  // option "speculate_max_batch": ... for calls of at most this many queries (larger rounds are not launch bound)
     int32_t* d_memo_slot = nullptr;
     float* d_memo = nullptr;
     int64_t memo_cap = 0;
@@ -115,7 +117,7 @@ struct lm_index {
 static int free_ws(lm_index* ix) {
     for (void* p : ix->ws_allocs) (void)hipFree(p);
     ix->ws_allocs.clear();
-    ix->ws_B = ix->ws_ef = ix->ws_W = ix->ws_maxnew = 0;
+    ix->ws_B = ix->ws_ef = ix->ws_W = ix->ws_maxnew = ix->ws_spec = 0;
     ix->ws_ucap = 0;
     return 0;
 }
@@ -129,10 +131,10 @@ static int ws_alloc(lm_index* ix, T** p, size_t count) {
     return LM_OK;
 }
 
-static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune = false) {
+static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune = false, int32_t spec = 0) {
     int32_t maxnew = std::max({W * ix->maxdeg0, ix->maxdeg_up, 1});
     if (prune) maxnew = std::max(maxnew, (int32_t)AQ_CAP);
-    if (B <= ix->ws_B && ef == ix->ws_ef && W == ix->ws_W && maxnew == ix->ws_maxnew) {
+    if (B <= ix->ws_B && ef == ix->ws_ef && W == ix->ws_W && maxnew == ix->ws_maxnew && spec == ix->ws_spec) {
         ix->ws.B = B;
         return LM_OK;
     }
@@ -149,12 +151,12 @@ static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune 
     A(rbm, w.nw); A(rbm_snap, w.nw); A(word_rank, w.nw);
     int ntiles = (int)((w.nw + UNIQ_TILE - 1) / UNIQ_TILE);
     A(tile_sum, std::max(ntiles, 1));
-    ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * std::max(maxnew, ef));
+    ix->ws_ucap = std::min<int64_t>(ix->N, (int64_t)B * (std::max(maxnew, ef) + (int64_t)spec * ix->maxdeg0));  // + the speculative requests
     A(uniq, ix->ws_ucap);
     A(counters, C_NCOUNTERS);
 #undef A
     LM_HIP(hipMemsetAsync(w.rbm, 0, w.nw * 4, ix->stream));
-    ix->ws_B = B; ix->ws_ef = ef; ix->ws_W = W; ix->ws_maxnew = maxnew;
+    ix->ws_B = B; ix->ws_ef = ef; ix->ws_W = W; ix->ws_maxnew = maxnew; ix->ws_spec = spec;
     return LM_OK;
 }
 
@@ -351,12 +353,15 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         if (!ix->d_pq_codes) LM_FAIL(LM_ESTATE, "pq_pruning_ratio > 0 needs a product quantiser (lm_pq_attach)");
         if (prm.pq_pruning_ratio >= 1.0f) LM_FAIL(LM_EINVAL, "pq_pruning_ratio must be < 1");
     }
-    int rc = ensure_ws(ix, B, ef, W, prune);
+    const bool recompute = prm.recompute != 0;
+    // speculative prefetch (k_speculate): small recompute batches with the per-call memo; not with the two-level search (its new-lists are
+    // finished by k_prune)
+    const int spec = (recompute && prm.recompute_memo != 0 && !prune && B <= ix->speculate_max_batch) ? ix->speculate : 0;
+    int rc = ensure_ws(ix, B, ef, W, prune, spec);
     if (rc) return rc;
     WsDev& ws = ix->ws;
     ws.efs = prm.efSearch;
     hipStream_t st = ix->stream;
-    const bool recompute = prm.recompute != 0;
     PruneArgs pa{};
     size_t prune_shmem = 0;
     if (prune) {
@@ -378,8 +383,8 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     }
     const bool hub = recompute && ix->hub_n > 0;
     // Per-call memo (the default): a node's embedding is recomputed at most once per pass and stays in HBM until the pass returns.
-    // A one-query pass never meets a node twice (visited set), so it skips the memo's bookkeeping.
-    const bool memo_call = recompute && prm.recompute_memo != 0 && B > 1;
+    // A one-query pass never meets a node twice (visited set), so it skips the memo's bookkeeping -- unless it prefetches (spec > 0).
+    const bool memo_call = recompute && prm.recompute_memo != 0 && (B > 1 || spec > 0);
     const bool memo = memo_call || hub;                                       // rows are addressed through memo_slot
     int64_t memo_used = 0;
     if (memo) {
@@ -439,6 +444,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
                 pa.use_rbm = recompute ? (memo ? 2 : 1) : 0;
                 hipLaunchKernelGGL(k_prune, dim3(B), dim3(256), prune_shmem, st, ws, pa);
             }
+            if (spec > 0) hipLaunchKernelGGL(k_speculate, dim3(B), dim3(64), 0, st, g, ws, spec, (int)prm.check_relative_distance);
             if (recompute) {
                 hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
                 hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
@@ -882,6 +888,16 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
         ix->wave_maxnew = (int)value;
         return LM_OK;
     }
+    if (!std::strcmp(name, "speculate")) {  // k_speculate: neighbours of the S best unexpanded candidates are embedded ahead of time (small batches)
+        if (value < 0 || value > 64) LM_FAIL(LM_EINVAL, "speculate must be in [0, 64]");
+        ix->speculate = (int)value;
+        return LM_OK;
+    }
+    if (!std::strcmp(name, "speculate_max_batch")) {
+        if (value < 1) LM_FAIL(LM_EINVAL, "speculate_max_batch must be >= 1");
+        ix->speculate_max_batch = (int)std::min<int64_t>(value, 1 << 20);
+        return LM_OK;
+    }
     if (!std::strcmp(name, "memo_initial_rows")) {  // first allocation of the per-call recompute memo (it doubles on demand); 0 = default
         if (value < 0) LM_FAIL(LM_EINVAL, "memo_initial_rows must not be negative");
         ix->memo_initial_rows = value;
@@ -895,6 +911,8 @@ int lm_index_get_option(const lm_index* ix, const char* name, int64_t* value) {
     if (!std::strcmp(name, "pq_rerank_overflow")) *value = ix->pq_overflow;
     else if (!std::strcmp(name, "pq_rerank_expanded")) *value = ix->pq_rerank_expanded ? 1 : 0;
     else if (!std::strcmp(name, "pq_threads")) *value = ix->pq_threads;
+    else if (!std::strcmp(name, "speculate")) *value = ix->speculate;
+    else if (!std::strcmp(name, "speculate_max_batch")) *value = ix->speculate_max_batch;
     else LM_FAIL(LM_EINVAL, std::string("unknown readable option: ") + name);
     return LM_OK;
 }

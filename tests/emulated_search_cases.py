@@ -115,6 +115,64 @@ def case_recompute(variant=0, memo=False, initial_rows=0, nq=3):
     idx.close()
 
 
+def case_speculative_prefetch():
+    """Option "speculate" (k_speculate): a small recompute batch embeds the neighbours of its best unexpanded candidates ahead of time.
+    Labels, distances, rounds and distance-evaluation counts must be those of the oracle and of S = 0 (bit for bit); the provider is called
+    less often, never twice for a node, and is asked for at least as many ids."""
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    for metric, nq, beam, check in (("mips", 1, 1, True), ("l2", 1, 2, False), ("mips", 2, 1, True)):
+        x, q = _data(400, 48, 23, nq=nq)
+        g = build_hnsw(x, metric, M=6, ef_construction=30)
+        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 48)
+        exp = orc.search(og, q, 5, ef=24, beam=beam, check_relative_distance=check, table=x)
+        runs = {}
+        for S in (0, 1, 3, 64):
+            idx = Mi355xIndex.from_csr(g)
+            prov = NumpyProvider(x, idx.info.d_padded)
+            seen = []
+            inner = prov.__call__
+
+            def logging_provider(d_ids_ptr, n, stream_ptr, seen=seen, inner=inner):
+                seen.append(np.ctypeslib.as_array(C.cast(d_ids_ptr, C.POINTER(C.c_int32)), shape=(n,)).copy())
+                return inner(d_ids_ptr, n, stream_ptr)
+
+            idx.set_provider(logging_provider)
+            idx.set_option("speculate", S)
+            assert idx.get_option("speculate") == S and idx.get_option("speculate_max_batch") == 2
+            got = idx.search(q, 5, idx.make_params(ef=24, beam=beam, recompute=True, check_relative_distance=check))
+            st = idx.stats()
+            _check(f"speculative prefetch S={S} metric={metric} nq={nq} beam={beam} check={check}", got, exp[:2], st, exp[2])
+            allids = np.concatenate(seen)
+            assert int(st["nunique"]) == allids.shape[0]
+            if S > 0 or nq > 1:
+                assert np.unique(allids).shape[0] == allids.shape[0], "a node reached the provider twice"
+            runs[S] = (got, int(st["nrounds"]), int(st["ndis"]), len(seen), np.unique(allids))
+            idx.close()
+        for S in (1, 3, 64):
+            assert np.array_equal(runs[S][0][0], runs[0][0][0]) and np.array_equal(runs[S][0][1], runs[0][0][1]) and runs[S][1:3] == runs[0][1:3], S
+            assert runs[S][3] <= runs[0][3] and np.isin(runs[0][4], runs[S][4]).all(), (S, runs[S][3], runs[0][3])  # a superset of the ids, in fewer calls
+        assert runs[3][3] < runs[0][3], ("the prefetch saved no provider call", {s: r[3] for s, r in runs.items()})
+        print(f"speculative prefetch {metric} nq={nq}: (provider calls, distinct ids requested) by S:", {s: (r[3], r[4].shape[0]) for s, r in runs.items()}, flush=True)
+    # a batch above speculate_max_batch does not prefetch; the two-level search does not either
+    x, q = _data(300, 48, 29, nq=3)
+    g = build_hnsw(x, "mips", M=6, ef_construction=30)
+    og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 48)
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_provider(NumpyProvider(x, idx.info.d_padded))
+    base = idx.search(q, 5, idx.make_params(ef=14, beam=1, recompute=True))
+    n0 = int(idx.stats()["nunique"])
+    idx.set_option("speculate", 4)
+    again = idx.search(q, 5, idx.make_params(ef=14, beam=1, recompute=True))
+    assert np.array_equal(base[0], again[0]) and np.array_equal(base[1], again[1]) and int(idx.stats()["nunique"]) == n0
+    idx.set_option("speculate_max_batch", 8)
+    spec = idx.search(q, 5, idx.make_params(ef=14, beam=1, recompute=True))
+    assert np.array_equal(base[0], spec[0]) and np.array_equal(base[1], spec[1]) and int(idx.stats()["nunique"]) >= n0
+    idx.close()
+
+
 def case_stop_rules():
     """Both faiss stop rules against the oracle (itself pinned by the literal transcription, tests/test_oracle_faiss.py):
     k > efSearch (count_below(d0) >= efSearch ends the search although the pool holds k entries) and
@@ -537,6 +595,7 @@ CASES = {
     "recompute_one_query_skips_memo": lambda: case_recompute(0, memo=True, nq=1),
     "recompute_wave_variant": lambda: case_recompute(3),
     "stop_rules": case_stop_rules,
+    "speculative_prefetch": case_speculative_prefetch,
     "pq_deferred": lambda: case_pq(True),
     "pq_table": lambda: case_pq(False),
     "two_level": case_two_level,

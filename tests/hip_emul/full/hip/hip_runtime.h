@@ -118,6 +118,7 @@ inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 #define __popc(x) __builtin_popcount(x)
 #define __popcll(x) __builtin_popcountll(x)
 #define __ffs(x) __builtin_ffs(x)
+#define __ffsll(x) __builtin_ffsll(x)
 #define atomicOr(p, v) emul::atomic_or((p), (v))
 #define atomicMin(p, v) emul::atomic_min((p), (v))
 #define atomicAdd(p, v) emul::atomic_add((p), (v))

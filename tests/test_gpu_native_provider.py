@@ -149,6 +149,42 @@ def test_search_over_the_native_provider_equals_python_provider_and_oracle(world
     nat.close()
 
 
+def test_speculative_prefetch_over_the_native_provider(world):
+    """Option "speculate" with the real encoder behind the search: a one-query search asks the built-in provider for more chunks in fewer
+    forwards.  With a table-lookup provider the results are those of S = 0 bit for bit (tests/test_gpu_parity.py); with the encoder a
+    chunk's embedding can come from a different launch form (a prefetching round may exceed the small-forward limit of 6144 tokens and
+    take the fused kernels): fp16-close distances, and labels that may differ only where two candidates are that close."""
+    torch = world["torch"]
+    from leann_amd.gpu_graph_build import build_graph_gpu
+    from leann_amd.index import Mi355xIndex
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.token_store import TokenStore
+
+    nat, _ = _providers(world)
+    n = world["n"]
+    X = nat.embed_ids(torch.arange(n, dtype=torch.int32, device="cuda"))
+    g = build_graph_gpu(X, "mips", M=12, ef_construction=60)
+    qt, qo, _ = world["corpus"].queries(4)
+    Q = RecomputeProvider(world["enc"], TokenStore(qt, qo), 384, torch.device("cuda")).embed_ids(torch.arange(4, dtype=torch.int32, device="cuda"))
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_provider(nat)
+    assert idx.native_provider
+    out = {}
+    for S in (0, 8):
+        idx.set_option("speculate", S)
+        f0 = nat.native_stats()["forwards"]
+        res = [idx.search_device(Q[i : i + 1].contiguous(), 10, idx.make_params(ef=48, beam=1, recompute=True)) for i in range(4)]
+        torch.cuda.synchronize()
+        out[S] = ([r[1].cpu().numpy() for r in res], [r[0].cpu().numpy() for r in res], nat.native_stats()["forwards"] - f0)
+    for i in range(4):
+        assert len(set(out[0][0][i].ravel().tolist()) & set(out[8][0][i].ravel().tolist())) >= 9, i
+        assert np.abs(out[0][1][i] - out[8][1][i]).max() < 3e-3
+    assert out[8][2] < out[0][2], (out[8][2], out[0][2])
+    idx.close()
+    nat.close()
+
+
 def test_native_provider_behind_the_pq_traversal_and_as_plain_provider_fn(world):
     """The provider interface has other callers: the DiskANN-style traversal's deferred rerank (lm_pq_batch_search) and any host that
     passes lm_recompute_provider to lm_index_set_provider itself.  Both equal the Python provider's results."""

@@ -208,6 +208,47 @@ def test_recompute_memo_same_results_fewer_recomputes(env):
     idx.set_option("memo_initial_rows", 0)
 
 
+def test_speculative_prefetch_same_results_fewer_provider_calls(env):
+    """Option "speculate" (k_speculate): a one-query search embeds the neighbours of its best unexpanded candidates ahead of time.  Labels,
+    distances and evaluation counts are the oracle's for every S; the provider is asked less often, never twice for a node."""
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    torch = env
+    x, g = _build(20000, 128, "mips", seed=5)
+    q = queries_near(x, 6, seed=31)
+    xdev = torch.from_numpy(x).cuda()
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    keep, seen = {}, []
+
+    def provider(d_ids, n, stream):
+        ids = as_tensor(d_ids, (n,), "int32")
+        seen.append(ids.cpu().numpy().copy())
+        keep["e"] = xdev.index_select(0, ids.long()).contiguous()
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+    og = oracle_graph(g, 128)
+    calls = {}
+    for S in (0, 4, 16):
+        idx.set_option("speculate", S)
+        calls[S] = 0
+        for i in range(q.shape[0]):
+            seen.clear()
+            d, l = idx.search_device(torch.from_numpy(q[i : i + 1]).cuda(), 10, idx.make_params(ef=96, beam=1, recompute=True))
+            torch.cuda.synchronize()
+            oi, od, ost = orc.search(og, q[i : i + 1], 10, ef=96, beam=1, table=x)
+            assert np.array_equal(l.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od) and idx.stats()["ndis"] == ost["ndis"], (S, i)
+            allids = np.concatenate(seen)
+            if S:
+                assert len(np.unique(allids)) == len(allids)
+            calls[S] += len(seen)
+    assert calls[16] < calls[4] <= calls[0], calls
+    idx.set_option("speculate", 0)
+
+
 def test_lockstep_table_mode_still_matches(env):
     """Stored-embedding mode defaults to the persistent kernel; the lock-step path must give the same answers."""
     from leann_amd.index import Mi355xIndex
