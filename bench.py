@@ -166,7 +166,7 @@ def _main(args, ap):
     # and read out phase by phase: the roofline line uses the launches of the timed region; the all-launch average is what a rocprofv3
     # --kernel-trace --stats table of this same command reports for the kernel.
     kt_dominant = _lib.KT_LAYER_TAIL if config_for(args.model).hidden == 384 and config_for(args.model).ffn % 192 == 0 else _lib.KT_GEMM_F16
-    KT_NAMES = {_lib.KT_LAYER_TAIL: "lm::k_layer_tail_h384", _lib.KT_GEMM_WS: "lm::k_gemm_ws_h384", _lib.KT_ATTN: "lm::k_attn_varlen", _lib.KT_GEMM_F16: "lm::k_gemm_f16"}
+    KT_NAMES = {_lib.KT_LAYER_TAIL: "lm::k_layer_tail_h384", _lib.KT_GEMM_WS: "lm::k_qkv_h384 (QKV projection; k_gemm_ws_h384 under LEANN_MI355X_QKV=0)", _lib.KT_ATTN: "lm::k_attn_varlen", _lib.KT_GEMM_F16: "lm::k_gemm_f16"}
     _lib.kernel_timing_enable(1 << kt_dominant)
     kt_phase = {}  # phase -> {kernel: {"launches", "ms", "work"}}
 
@@ -651,8 +651,8 @@ def _main(args, ap):
                                                   "synchronisation per round" if latency_python_provider is not None else "Python provider")
     if latency_python_provider:
         result["small_batch_latency_python_provider"] = latency_python_provider
-        if latency_speculate:
-            result["small_batch_latency_b1_with_speculative_prefetch"] = latency_speculate
+    if latency_speculate and any(latency_speculate.values()):
+        result["small_batch_latency_b1_with_speculative_prefetch"] = latency_speculate
     if provider_ab:
         result["full_step_over_the_python_provider"] = provider_ab
     if value_by_batch:
