@@ -46,7 +46,7 @@ def attach(native: bool):
 
 forms = [("library_side_provider", True), ("python_provider", False)] if attach(True) else [("python_provider", False)]
 rows, lo, same = [], 0, True
-for b in (1, 4, 16, 64, 256):
+for b in ((1,) if "--speculate" in sys.argv else (1, 4, 16, 64, 256)):  # (the prefetch sweep below: B = 1 only)
     prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b)
     reps = 24 if b == 1 else (12 if b <= 16 else 4)
     if lo + b * (reps + 1) > Q.shape[0]:
@@ -74,5 +74,31 @@ for b in (1, 4, 16, 64, 256):
     lo += b * (reps + 1)
     rows.append(row)
 attach(True)
-print(json.dumps({"chunks": n, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
+# --speculate 0,4,16: B = 1 latency with the speculative prefetch (option "speculate": a round also embeds the neighbours of its S best
+# unexpanded candidates), same queries for every S; labels must not change
+spec_rows = []
+if "--speculate" in sys.argv:
+    svals = [int(s) for s in sys.argv[sys.argv.index("--speculate") + 1].split(",")]
+    prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=1)
+    ref_labels = None
+    for S in svals:
+        idx.set_option("speculate", S)
+        idx.search_device(Q[0:1].contiguous(), 10, prm)
+        f0 = provider.native_stats()["forwards"]
+        lat, labels, chunks = [], [], 0
+        for i in range(1, 33):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d, l = idx.search_device(Q[i : i + 1].contiguous(), 10, prm)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+            labels.append(l.cpu())
+            chunks += int(idx.stats()["nunique"])
+        if ref_labels is None:
+            ref_labels = labels
+        spec_rows.append({"speculate": S, "p50_ms": round(float(np.median(lat)), 2), "mean_ms": round(float(np.mean(lat)), 2),
+                          "recomputed_chunks_per_query": round(chunks / 32, 1), "forwards_per_query": round((provider.native_stats()["forwards"] - f0) / 32, 1),
+                          "queries_with_the_labels_of_S0": int(sum(torch.equal(a, b) for a, b in zip(ref_labels, labels)))})
+    idx.set_option("speculate", 0)
+print(json.dumps({"chunks": n, "b1_speculative_prefetch": spec_rows, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
                   "identical_results_between_the_providers": same, "library_side_provider_stats": provider.native_stats()}))
