@@ -46,7 +46,7 @@ def attach(native: bool):
 
 forms = [("library_side_provider", True), ("python_provider", False)] if attach(True) else [("python_provider", False)]
 rows, lo, same = [], 0, True
-for b in ((1,) if "--speculate" in sys.argv else (1, 4, 16, 64, 256)):  # (the prefetch sweep below: B = 1 only)
+for b in ((1,) if "--speculate" in sys.argv else tuple(int(v) for v in os.environ.get("LAT_BATCHES", "1,4,16,64,256").split(","))):  # (the prefetch sweep below: B = 1 only)
     prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b)
     reps = 24 if b == 1 else (12 if b <= 16 else 4)
     if lo + b * (reps + 1) > Q.shape[0]:
