@@ -335,16 +335,18 @@ typedef struct lm_bert_h384_layer {
     const float *b2;
     const void *ln2_gamma, *ln2_beta;
     /* Optional (all three or none): the plain nn.Linear weights [384][384], [ffn][384], [384][ffn] fp16.  With them a forward of at
-     * most LM_BERT_SMALL_TOKENS tokens (a one-query search round recomputes ~5 chunks) runs every layer on the general kernels --
+     * most LM_BERT_SMALL_TOKENS tokens (a one-query search round recomputes ~10 chunks) runs every layer on the general kernels --
      * lm_gemm_f16 x 4 + attention + lm_add_layernorm_f16 x 2: many small workgroups spread over the chip -- instead of the fused
      * layer tail, whose 128-token workgroup is one ~77 us dependency chain however few tokens it holds (MI355X, 200k-chunk index,
-     * B = 1 search: p50 59.7 -> 47.2 ms).  Same arithmetic up to fp16 rounding of the intermediate activations. */
+     * B = 1 search: p50 59.7 -> 47.2 ms with the limit at 6144 tokens in round 3; round 4 measured the crossover again -- 6144 /
+     * 16384 / 32768 tokens: B = 1 p50 44.9 / 39.3 / 40.0 ms, B = 4 70.1 / 56.5 / 56.7 ms, B = 16 115.2 / 107.9 / 108.6 ms -- and moved
+     * it to 16384).  Same arithmetic up to fp16 rounding of the intermediate activations. */
     const void *wo, *w1, *w2;
     /* Optional: lm_qkv_pack_h384's image of wqkv.  With it the large-forward QKV projection runs on the weight-streaming kernel
      * (lm_qkv_h384_f16: x read once, two waves per SIMD); NULL = the weight-stationary one (lm_gemm_ws_h384_f16 on wqkv). */
     const void *wqkv_img;
 } lm_bert_h384_layer;
-#define LM_BERT_SMALL_TOKENS 6144
+#define LM_BERT_SMALL_TOKENS 16384
 
 typedef struct lm_bert_h384 {
     int32_t n_layers, heads, ffn, normalize;

@@ -208,7 +208,7 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
 
 
 GEMM_EPI_GELU, GEMM_EPI_RESIDUAL = 1, 2
-LM_BERT_SMALL_TOKENS = 6144  # include/leann_mi355x.h
+LM_BERT_SMALL_TOKENS = 16384  # include/leann_mi355x.h
 
 
 def small_tokens_limit() -> int:
@@ -480,9 +480,10 @@ class _Layer(nn.Module):
         if h != 384 or os.environ.get("LEANN_MI355X_GEMM") == "2" or (tot <= small_tokens_limit() and "LEANN_MI355X_GEMM" not in os.environ):
             # general widths (768: bge-base, contriever): five launches of the general MFMA GEMM + attention + two LayerNorms, no
             # library call -- QKV | attention | out-projection (+ residual) | LayerNorm | fc1 (+ GELU) | fc2 (+ residual) | LayerNorm.
-            # Hidden 384 takes this form for SMALL forwards (<= LM_BERT_SMALL_TOKENS tokens: a one-query search round recomputes ~5
+            # Hidden 384 takes this form for SMALL forwards (<= LM_BERT_SMALL_TOKENS tokens: a one-query search round recomputes ~10
             # chunks): many small workgroups over the chip instead of the fused tail's one ~77 us workgroup chain (MI355X: B = 1
-            # search p50 59.7 -> 47.2 ms); LEANN_MI355X_GEMM=2 forces it at every size (A/B), =1 / =0 keep the fused kernels.
+            # search p50 59.7 -> 47.2 ms at a limit of 6144 tokens, 44.9 -> 39.3 ms with the limit moved to 16384);
+            # LEANN_MI355X_GEMM=2 forces it at every size (A/B), =1 / =0 keep the fused kernels.
             y = self._forward_packed_general(x, cu, max_len)
             if y is not None:
                 return y

@@ -480,6 +480,6 @@ def test_sub_batching_does_not_change_the_embeddings():
         assert whole.shape == (120, enc.cfg.hidden) and whole.dtype == torch.float32
         for budget in (7000, 2000, 1):
             part = enc.encode_tokens_packed(ti, tl, budget)
-            # the 384-wide model switches layer form with the sub-batch size (<= 6144 tokens: general kernels): same arithmetic up to fp16
+            # the 384-wide model switches layer form with the sub-batch size (<= 16384 tokens: general kernels): same arithmetic up to fp16
             # rounding of intermediate activations
             assert (part - whole).abs().max().item() <= 3e-3, (name, budget)
