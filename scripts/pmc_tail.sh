@@ -12,7 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- $ROOT/leann_amd/lib/bin/kbench 262107 3 ${2:-bwtail4} > $OUT/pmc_$c.log 2>&1
   echo "$c rc=$?"
 done
-python - "$OUT" <<'PY'
+python - "$OUT" "${2:-bwtail4}" <<'PY'
 import csv, glob, json, sys, collections
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -25,6 +25,6 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 agg[k][0] += 1
                 agg[k][1] += float(r["Counter_Value"])
     out[c] = {k: {"dispatches": n, "per_dispatch_KB": round(v / n, 1)} for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
-json.dump(out, open(sys.argv[1] + "/pmc_${2:-bwtail4}.json", "w"), indent=1)
+json.dump(out, open(sys.argv[1] + "/pmc_" + (sys.argv[2] if len(sys.argv) > 2 else "bwtail4") + ".json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3500])
 PY
