@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|gemmf16|gemmstamp]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|rowln|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -589,6 +589,40 @@ int main(int argc, char** argv) {
             printf("{\"kernel\": \"lm_add_layernorm_f16\", \"mode\": \"revision %s\", \"us\": %.1f, \"GBps\": %.0f}\n", rev, us, (double)T * H * 6 / us * 1e-3);
         }
         unsetenv("LEANN_MI355X_LN");
+    }
+    if (want("rowln")) {
+        // lm_rowgemm_ln_h384_f16 (row-complete 384-output GEMM + residual + LayerNorm for SMALL forwards) against the two launches it replaces
+        // (lm_gemm_f16 with the residual epilogue + lm_add_layernorm_f16), at the token counts of a small search round -- run as
+        //   kbench 1500 50 rowln      (a one-query round: ~8 chunks)         kbench 12000 50 rowln      (a round of ~8 queries)
+        for (int K : {384, 1536}) {
+            Dev<__half> xa((size_t)T * K), wa((size_t)H * K), ra((size_t)T * H), y((size_t)T * H), o2((size_t)T * H), o1((size_t)T * H);
+            dev_fill(xa.p, (size_t)T * K, 1.0f, 71, st);
+            dev_fill(wa.p, (size_t)H * K, 0.05f, 72, st);
+            dev_fill(ra.p, (size_t)T * H, 1.0f, 73, st);
+            Dev<float> ba(rand_float(H, 0.2f, 74));
+            auto two = [&] {
+                LM(lm_gemm_f16(xa.p, wa.p, ba.p, ra.p, 2, H, K, y.p, T, st));
+                LM(lm_add_layernorm_f16(y.p, nullptr, gamma.p, beta.p, o2.p, T, H, 1e-12f, st));
+            };
+            auto one = [&] { LM(lm_rowgemm_ln_h384_f16(xa.p, wa.p, ba.p, K, ra.p, gamma.p, beta.p, 1e-12f, o1.p, T, st)); };
+            two();
+            one();
+            CK(hipStreamSynchronize(st));
+            double dmax = 0;
+            {
+                auto a = o2.host(), b = o1.host();
+                for (size_t i = 0; i < a.size(); ++i) {
+                    double d = fabs((double)__half2float(a[i]) - (double)__half2float(b[i]));
+                    if (!(d <= dmax)) dmax = d;
+                }
+            }
+            for (int round = 0; round < 3; ++round) {
+                const float us2 = time_us(st, reps, two), us1 = time_us(st, reps, one);
+                printf("{\"kernel\": \"lm_rowgemm_ln_h384_f16 vs lm_gemm_f16 + lm_add_layernorm_f16\", \"tokens\": %d, \"K\": %d, \"round\": %d, \"one_launch_us\": %.1f, "
+                       "\"two_launches_us\": %.1f, \"max_abs_diff_all_rows\": %.3g}\n", T, K, round, us1, us2, dmax);
+                fflush(stdout);
+            }
+        }
     }
     if (want("gemmf16")) {
         // lm_gemm_f16 (csrc/lm_gemm_f16.hip) on the encoder's GEMM shapes, against rocBLAS (no bias / epilogue) on the same operands

@@ -606,6 +606,99 @@ CASES = {
     "dims_and_batches": case_dims_and_batches,
 }
 
+def case_rowgemm_ln():
+    """lm_rowgemm_ln_h384_f16 (csrc/lm_rowgemm_ln_h384.hip: row-complete 384-output linear layer + residual + LayerNorm for small forwards)
+    through the C ABI against numpy -- ragged token counts, K = 384 / 768 / 1536, in place, without a residual -- and the small-forward
+    form of the encoder with LEANN_MI355X_SMALL_ROWLN=1: per-kernel path == one-call path bit for bit, fp16-close to the default form."""
+    import os
+    from unittest import mock
+
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+
+    lib = _lib.load()
+    rng = np.random.default_rng(41)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    H = 384
+    for T, K in ((70, 384), (33, 768), (5, 1536)):
+        x = rng.standard_normal((T, K)).astype(np.float16)
+        w = (rng.standard_normal((H, K)) / np.sqrt(K)).astype(np.float16)
+        b = (0.2 * rng.standard_normal(H)).astype(np.float32)
+        res = rng.standard_normal((T, H)).astype(np.float16)
+        gm = (1 + 0.1 * rng.standard_normal(H)).astype(np.float16)
+        bt = (0.1 * rng.standard_normal(H)).astype(np.float16)
+
+        def ref(resid):
+            z = x.astype(np.float64) @ w.astype(np.float64).T + b + (0 if resid is None else resid.astype(np.float64))
+            mu = z.mean(1, keepdims=True)
+            var = ((z - mu) ** 2).mean(1, keepdims=True)
+            return (z - mu) / np.sqrt(var + 1e-12) * gm.astype(np.float64) + bt.astype(np.float64)
+
+        out = np.full((T, H), 7.0, np.float16)
+        _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), K, vp(res), vp(gm), vp(bt), 1e-12, vp(out), T, None), "rowgemm_ln")
+        err = np.abs(out.astype(np.float64) - ref(res)).max()
+        assert err < 6e-3, (T, K, err)
+        inpl = res.copy()  # in place on the residual
+        _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), K, vp(inpl), vp(gm), vp(bt), 1e-12, vp(inpl), T, None), "rowgemm_ln in place")
+        assert np.array_equal(inpl, out), (T, K)
+        o2 = np.zeros((T, H), np.float16)
+        _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), K, None, vp(gm), vp(bt), 1e-12, vp(o2), T, None), "rowgemm_ln no residual")
+        assert np.abs(o2.astype(np.float64) - ref(None)).max() < 6e-3, (T, K)
+    assert lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), 512, vp(res), vp(gm), vp(bt), 1e-12, vp(out), T, None) == -1  # k_in % 384
+    assert lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), 2688, vp(res), vp(gm), vp(bt), 1e-12, vp(out), T, None) == -1  # k_in > 2304
+    # the encoder's small-forward form on it
+    torch.manual_seed(0)
+    cfg = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=384, max_pos=64, max_seq_length=48)
+    e16 = BertEncoder.random_init(cfg, 5).eval().half()
+    n, t = 7, 48
+    lens = rng.integers(1, t + 1, n).astype(np.int32)
+    lens[0], lens[1] = t, 1
+    ids = np.zeros((n, t), np.int32)
+    for i in range(n):
+        ids[i, : lens[i]] = rng.integers(1, cfg.vocab_size, lens[i])
+    ti, tl = torch.from_numpy(ids), torch.from_numpy(lens)
+
+    class _Stream:
+        cuda_stream = 0
+
+    used = []
+    real_check = _lib.check
+
+    def recording_check(rc, what=""):
+        used.append(what)
+        return real_check(rc, what)
+
+    outs = {}
+    for rowln in ("0", "1"):
+        for onecall in ("0", "1"):
+            used.clear()
+            env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+            env.update({"LEANN_MI355X_ONECALL": onecall, "LEANN_MI355X_SMALL_ROWLN": rowln})
+            with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+                    mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
+                    mock.patch.object(_lib, "check", new=recording_check):
+                with torch.no_grad():
+                    outs[(rowln, onecall)] = e16.encode_tokens_packed(ti, tl, 4096)
+            if onecall == "0":
+                want = {"lm_rowgemm_ln_h384_f16": 2 * cfg.layers, "lm_add_layernorm_f16": 0, "lm_gemm_f16": 2 * cfg.layers} if rowln == "1" else \
+                    {"lm_rowgemm_ln_h384_f16": 0, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_gemm_f16": 4 * cfg.layers}
+                assert {k: used.count(k) for k in want} == want, (rowln, sorted(set(used)))
+            else:
+                assert used.count("lm_bert_h384_forward_packed") == 1, sorted(set(used))
+    assert torch.equal(outs[("1", "0")], outs[("1", "1")]) and torch.equal(outs[("0", "0")], outs[("0", "1")])
+    d = float((outs[("1", "1")].float() - outs[("0", "1")].float()).abs().max())
+    print(f"row-complete GEMM + LayerNorm: small-forward form with / without it, max|diff| = {d:.2e}", flush=True)
+    assert d < 3e-3, d
+    with torch.no_grad():
+        ref32 = BertEncoder.random_init(cfg, 5).eval()(ti, tl).float()
+    assert float((outs[("1", "1")].float() - ref32).abs().max()) < 6e-3
+    print("lm_rowgemm_ln_h384_f16 through the C ABI and in the small-forward form: ok", flush=True)
+
+
+CASES["rowgemm_ln"] = case_rowgemm_ln
+
 def case_gemm_f16():
     """lm_gemm_f16 (csrc/lm_gemm_f16.hip: the general linear layer of the hidden-768 path) vs numpy: both tile shapes, every
     epilogue, ragged token counts (clamped row loads, masked stores), more than eight row blocks (XCD-order padding)."""

@@ -322,6 +322,60 @@ def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
     assert fused_linear_h384(x, qkv) is None
 
 
+@pytest.mark.parametrize("tokens", [1, 33, 700, 5000])
+@pytest.mark.parametrize("k_in", [384, 1536])
+def test_rowgemm_ln_h384(tokens, k_in, monkeypatch):
+    """lm_rowgemm_ln_h384_f16 (row-complete 384-output linear layer + residual + LayerNorm for small forwards; LEANN_MI355X_SMALL_ROWLN=1) vs a
+    plain PyTorch fp32 reference of the same ops and vs the two launches it replaces (lm_gemm_f16 + lm_add_layernorm_f16)."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import GEMM_EPI_RESIDUAL, fused_add_layernorm, fused_gemm, fused_rowgemm_ln
+
+    torch.manual_seed(tokens + k_in)
+    lin = nn.Linear(k_in, 384).to("cuda", dtype=torch.float16)
+    ln = nn.LayerNorm(384, eps=1e-12).to("cuda", dtype=torch.float16)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(384))
+        ln.bias.copy_(0.1 * torch.randn(384))
+        lin.bias.copy_(0.2 * torch.randn(384))
+    x = torch.randn((tokens, k_in), device="cuda").half()
+    res = torch.randn((tokens, 384), device="cuda").half()
+    assert fused_rowgemm_ln(x, lin, res, ln) is None  # off by default
+    monkeypatch.setenv("LEANN_MI355X_SMALL_ROWLN", "1")
+    with torch.no_grad():
+        got = fused_rowgemm_ln(x, lin, res, ln)
+        assert got is not None and got.shape == (tokens, 384) and got.dtype == torch.float16
+        ref = F.layer_norm(res.float() + x.float() @ lin.weight.float().t() + lin.bias.float(), (384,), ln.weight.float(), ln.bias.float(), 1e-12)
+        two = fused_add_layernorm(fused_gemm(x, lin, GEMM_EPI_RESIDUAL, res), None, ln)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any()
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got.float() - ref).abs().max().item() <= 6e-3 * scale
+    assert (got.float() - two.float()).abs().max().item() <= 8e-3 * scale  # the two-launch form rounds the pre-LayerNorm row to fp16 first
+
+
+def test_small_forward_with_and_without_the_rowgemm_ln_kernel(monkeypatch):
+    """The small-forward form of the MiniLM-shape encoder (a one-query round's handful of chunks) with LEANN_MI355X_SMALL_ROWLN=1: one-call and
+    per-kernel launch paths bit-identical, fp16-close to the default small form."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=24, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    base = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_SMALL_ROWLN", "1")
+    one = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
+    per = enc.encode_tokens_packed(ti, tl)
+    assert torch.equal(one, per) and not torch.isnan(one).any()
+    assert (one - base).abs().max().item() <= 3e-3
+
+
 def test_pack_tokens_front_end(monkeypatch):
     """lm_pack_tokens (LEANN_MI355X_PACK=1) == the boolean-mask selects it replaces; whole forward unchanged."""
     import torch
