@@ -86,7 +86,8 @@ int lm_index_attach_table(lm_index *idx, const void *table, int32_t dtype, int64
 /* Recompute provider: replaces the per-hop ZMQ REQ of the faiss fork to the embedding server
  * ([[ids],[query]] -> distances / [ids] -> embeddings, hnsw_embedding_server.py:148-284).
  * Called once per search round, on the index's stream, with the SORTED, DE-DUPLICATED node ids
- * of that round in device memory.  The callback must enqueue (on `stream`) work that produces
+ * of that round in device memory.  (One opt-in exception: with the index option "single_query_direct" a ONE-query pass hands over
+ * its new-list as it is -- every id once, in discovery order, not sorted.)  The callback must enqueue (on `stream`) work that produces
  * fp32 embeddings [n][d_padded] (zero padded) in device memory and store that buffer's address
  * in *d_out; the buffer must stay valid until the next callback or the end of the search.
  * Return 0 on success; any other value aborts the search with LM_EPROVIDER. */
@@ -167,6 +168,9 @@ int lm_index_event_overhead_us(lm_index *idx, double *out_us);
  * diskann_backend.py:444-449 describes: "fetch embeddings for the final candidate set only"), 1 EVERY node the traversal expanded
  * (upstream DiskANN's full_retset, PQFlashIndex::cached_beam_search: a superset of the final list; up to 4 x complexity <= 8192 nodes
  * per query are recorded, a query that expands more falls back to its final list and is counted in "pq_rerank_overflow").
+ * "single_query_direct" 0 (default) / 1: a one-query recompute pass without a memo hands its new-list to the provider as it is (unique ids
+ * in discovery order; three launches per round fewer: no request bitmap, no unique-list kernels); same results and counts.  Written after
+ * round 4's GPU budget was spent: emulation-validated, not yet timed on hardware.
  * "speculate" S (0 = off, <= 64) / "speculate_max_batch" (default 2): speculative prefetch of a small recompute batch -- a round's forward
  * also embeds the unvisited neighbours of the S best candidates that are not expanded yet, into the per-call memo, so that later rounds
  * find their new nodes there and need no forward (a one-query search is ~100 rounds of ~50 dependent launches: launch latency).  Labels,

@@ -32,8 +32,10 @@ __device__ __forceinline__ void nbr_range(const GraphDev& g, int32_t node, int32
 // one wave (64 lanes) per query.  Level-0 expansion is FLATTENED over (pop, neighbour) so that the
 // dependent chain is pop -> l0 range -> neighbour ids -> visited atomic, once per 64 neighbours
 // instead of once per popped node.  Dynamic LDS: maxnew ints (staging of the new-list).
-__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int defer) {
+__global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm, int round_no, int defer, int single) {
     // defer != 0: the two-level pruning kernel (k_prune) finishes the new-list: it marks the dedup bitmap and counts
+    // single != 0 (a ONE-query pass, option "single_query_direct"): the new-list is the provider's id list as it is -- no request bitmap, no
+    // k_uniq_* launches; this kernel writes the list's length and the live flag itself (its grid is one workgroup)
     extern __shared__ int32_t s_new[];
     __shared__ uint32_t s_off[65];
     __shared__ uint64_t s_b[64];
@@ -41,7 +43,13 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
     const int lane = threadIdx.x;
     const int ph = ws.phase[q];
     if (ph == PH_DONE) {
-        if (lane == 0) ws.nnew[q] = 0;
+        if (lane == 0) {
+            ws.nnew[q] = 0;
+            if (single) {
+                ws.counters[C_LIVE] = 0ull;
+                ws.counters[C_NUNIQ] = 0ull;
+            }
+        }
         return;
     }
     int total = 0;
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
         // workgroup and serialises the launch tail (MI355X_MICROARCH.md, price list row "fanin")
         ws.counters[C_LIVE] = 1ull;
         ws.counters[C_ROUNDS] = (unsigned long long)round_no;
+        if (single) ws.counters[C_NUNIQ] = (unsigned long long)total;
     }
 }
 

@@ -10,6 +10,7 @@ struct UpdateArgs {
     const float* Q;       // B x Dp
     const void* E;        // embeddings: table (row = node id), provider output (row = rank) or memo (row = slot)
     int32_t by_rank;      // 0: row = node id; 1: rank of the node in this round's unique list; 2: memo slot
+    int32_t identity;     // by_rank == 1 only: row i = the query's i-th new node (a one-query pass hands its new-list to the provider as it is)
     int32_t check_rel;
     int32_t max_level;
     int32_t P2;           // k_pq_rerank only: pow2 >= candidates per query
@@ -51,7 +52,10 @@ __device__ __forceinline__ void update_body(const WsDev& ws, const UpdateArgs& a
         int32_t v0 = newid[i];
         int32_t v1 = has2 ? newid[i2] : v0;
         int64_t s0 = v0, s1 = v1;
-        if (MODE == 1) {
+        if (MODE == 1 && a.identity) {
+            s0 = i;
+            s1 = has2 ? i2 : i;
+        } else if (MODE == 1) {
             s0 = ws.word_rank[v0 >> 5] + __popc(ws.rbm_snap[v0 >> 5] & ((1u << (v0 & 31)) - 1u));
             s1 = ws.word_rank[v1 >> 5] + __popc(ws.rbm_snap[v1 >> 5] & ((1u << (v1 & 31)) - 1u));
         } else if (MODE == 2) {

@@ -85,6 +85,7 @@ struct lm_index {
     WsDev ws{};
     int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0, ws_spec = 0;
     int64_t ws_ucap = 0;
+    int single_query_direct = 0;  // option "single_query_direct": a one-query recompute pass hands its new-list to the provider as it is (no k_uniq_*)
     int speculate = 0;            // option "speculate": candidates whose neighbours a small-batch round embeds ahead of time (k_speculate); 0 = off
     int speculate_max_batch = 2;  // option "speculate_max_batch": ... for calls of at most this many queries (larger rounds are not launch bound)
     int32_t* d_memo_slot = nullptr;
@@ -401,6 +402,11 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         }
     }
     GraphDev g{ix->N, ix->entry_point, ix->max_level, ix->d_node_offsets, ix->d_level_ptr, ix->d_neighbors, ix->d_l0};
+    // A ONE-query pass without a memo needs no cross-query dedup: a new-list holds every node once (visited test-and-set; an upper-level
+    // list is one neighbour list), so it IS the provider's id list, in discovery order instead of id order -- three launches per round
+    // fewer (the live-flag memset, k_uniq_count, k_uniq_emit).  Same labels, distances and counts (a chunk's embedding does not depend on
+    // its place in the forward).  Option "single_query_direct", off by default: not yet timed on hardware.
+    const bool single = recompute && B == 1 && !memo && !prune && ix->single_query_direct != 0;
 
     LM_HIP(hipMemsetAsync(ws.visited, 0, (size_t)B * ws.nw * 4, st));
     LM_HIP(hipMemsetAsync(ws.counters, 0, C_NCOUNTERS * sizeof(unsigned long long), st));
@@ -434,18 +440,20 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     int64_t rounds = 0;
     unsigned long long* hc = ix->h_counters;
 
+    const int32_t* round_ids = single ? ws.newid : ws.uniq;  // what the provider is asked for
+    ua.identity = single ? 1 : 0;
     for (;;) {
-        LM_HIP(hipMemsetAsync(ws.counters + C_LIVE, 0, sizeof(unsigned long long), st));
+        if (!single) LM_HIP(hipMemsetAsync(ws.counters + C_LIVE, 0, sizeof(unsigned long long), st));
         {
             EvScope es(ix, &ix->ev_expand);
-            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, recompute ? (memo ? 2 : 1) : 0,
-                               (int)(rounds + 1), prune ? 1 : 0);
+            hipLaunchKernelGGL(k_expand, dim3(B), dim3(64), (size_t)ws.maxnew * sizeof(int32_t), st, g, ws, single ? 0 : recompute ? (memo ? 2 : 1) : 0,
+                               (int)(rounds + 1), prune ? 1 : 0, single ? 1 : 0);
             if (prune) {
                 pa.use_rbm = recompute ? (memo ? 2 : 1) : 0;
                 hipLaunchKernelGGL(k_prune, dim3(B), dim3(256), prune_shmem, st, ws, pa);
             }
             if (spec > 0) hipLaunchKernelGGL(k_speculate, dim3(B), dim3(64), 0, st, g, ws, spec, (int)prm.check_relative_distance);
-            if (recompute) {
+            if (recompute && !single) {
                 hipLaunchKernelGGL(k_uniq_count, dim3(ntiles), dim3(256), 0, st, ws);
                 hipLaunchKernelGGL(k_uniq_emit, dim3(ntiles), dim3(256), 0, st, ws, ntiles);
             }
@@ -454,7 +462,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         // built-in provider: lengths of the round's chunks (count still on the device) before the copy below, so that this round
         // needs no second synchronisation inside the provider
         const bool native = recompute && ix->native_rc && ix->provider == lm_recompute_provider && ix->provider_user == (void*)ix->native_rc;
-        if (native && (rc = rc_prepare(ix->native_rc, ws.uniq, ws.counters + C_NUNIQ, ix->ws_ucap, ws.counters + C_RC_TOKENS,
+        if (native && (rc = rc_prepare(ix->native_rc, round_ids, ws.counters + C_NUNIQ, single ? (int64_t)ws.maxnew : ix->ws_ucap, ws.counters + C_RC_TOKENS,
                                        ws.counters + C_RC_MAXLEN, st)) != LM_OK)
             return rc;
         bool do_sync = (rounds % sync_every) == 0;
@@ -467,10 +475,10 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
             int32_t nu = (int32_t)hc[C_NUNIQ];
             void* d_e = nullptr;
             ix->stats.nunique += nu;
-            if (native) rc_prepared(ix->native_rc, ws.uniq, nu, (int64_t)hc[C_RC_TOKENS], (int32_t)hc[C_RC_MAXLEN]);
+            if (native) rc_prepared(ix->native_rc, round_ids, nu, (int64_t)hc[C_RC_TOKENS], (int32_t)hc[C_RC_MAXLEN]);
             if (nu > 0) {
                 EvScope es(ix, &ix->ev_provider);
-                int prc = ix->provider(ix->provider_user, ws.uniq, nu, &d_e, (void*)st);
+                int prc = ix->provider(ix->provider_user, round_ids, nu, &d_e, (void*)st);
                 if (prc != 0 || !d_e) LM_FAIL(LM_EPROVIDER, "embedding provider failed (rc=" + std::to_string(prc) + ")");
             }
             if (memo) {
@@ -888,6 +896,10 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
         ix->wave_maxnew = (int)value;
         return LM_OK;
     }
+    if (!std::strcmp(name, "single_query_direct")) {
+        ix->single_query_direct = value != 0;
+        return LM_OK;
+    }
     if (!std::strcmp(name, "speculate")) {  // k_speculate: neighbours of the S best unexpanded candidates are embedded ahead of time (small batches)
         if (value < 0 || value > 64) LM_FAIL(LM_EINVAL, "speculate must be in [0, 64]");
         ix->speculate = (int)value;
@@ -912,6 +924,7 @@ int lm_index_get_option(const lm_index* ix, const char* name, int64_t* value) {
     else if (!std::strcmp(name, "pq_rerank_expanded")) *value = ix->pq_rerank_expanded ? 1 : 0;
     else if (!std::strcmp(name, "pq_threads")) *value = ix->pq_threads;
     else if (!std::strcmp(name, "speculate")) *value = ix->speculate;
+    else if (!std::strcmp(name, "single_query_direct")) *value = ix->single_query_direct;
     else if (!std::strcmp(name, "speculate_max_batch")) *value = ix->speculate_max_batch;
     else LM_FAIL(LM_EINVAL, std::string("unknown readable option: ") + name);
     return LM_OK;

@@ -30,6 +30,8 @@ g = build_graph_gpu(X, "mips", M=32, ef_construction=200)
 idx = Mi355xIndex.from_csr(g, device=0)
 idx.set_stream(torch.cuda.current_stream().cuda_stream)
 idx.set_provider(provider)
+if os.environ.get("LAT_DIRECT") == "1":  # option single_query_direct: a one-query pass hands its new-list to the provider as it is
+    idx.set_option("single_query_direct", 1)
 qt, qo, _ = corpus.queries(2048, seed=4321)
 Q = RecomputeProvider(enc, TokenStore(qt, qo, device=0), 384, dev).embed_ids(torch.arange(2048, dtype=torch.int32, device=dev)).contiguous()
 # A/B in one process on the SAME queries: the library-side provider (csrc/lm_recompute.hip, the default) against the Python provider

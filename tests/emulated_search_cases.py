@@ -21,15 +21,16 @@ def _load(lib_path: str):
 class NumpyProvider:
     """lm_provider_fn in the emulated world: 'device' pointers are host pointers."""
 
-    def __init__(self, table: np.ndarray, dp: int):
+    def __init__(self, table: np.ndarray, dp: int, sorted_ids: bool = True):
         self.x = np.zeros((table.shape[0], dp), np.float32)
         self.x[:, : table.shape[1]] = table
         self.keep = None
         self.calls = 0
+        self.sorted_ids = sorted_ids  # False: option "single_query_direct" (unique ids in discovery order)
 
     def __call__(self, d_ids_ptr: int, n: int, stream_ptr: int) -> int:
         ids = np.ctypeslib.as_array(C.cast(d_ids_ptr, C.POINTER(C.c_int32)), shape=(n,))
-        assert np.all(ids[1:] > ids[:-1])  # sorted unique, as the ABI promises
+        assert np.all(ids[1:] > ids[:-1]) if self.sorted_ids else np.unique(ids).shape[0] == n  # sorted unique, as the ABI promises
         self.keep = np.ascontiguousarray(self.x[ids])
         self.calls += 1
         return self.keep.ctypes.data
@@ -171,6 +172,56 @@ def case_speculative_prefetch():
     spec = idx.search(q, 5, idx.make_params(ef=14, beam=1, recompute=True))
     assert np.array_equal(base[0], spec[0]) and np.array_equal(base[1], spec[1]) and int(idx.stats()["nunique"]) >= n0
     idx.close()
+
+
+def case_single_query_direct():
+    """Option "single_query_direct": a one-query recompute pass hands its new-list to the provider as it is (discovery order, no request
+    bitmap, no k_uniq_* launches, k_expand writes the count and the live flag).  Labels, distances, rounds and counts must be the oracle's
+    and those of the default path; the provider sees the same ids per round, in a different order; batches of more than one query and
+    passes with a memo (hub cache, speculative prefetch) do not take the path."""
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    for metric, beam, check, k, ef in (("mips", 1, True, 5, 24), ("l2", 3, False, 5, 12), ("mips", 2, True, 9, 4)):
+        x, q = _data(400, 48, 37, nq=2)
+        g = build_hnsw(x, metric, M=6, ef_construction=30)
+        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 48)
+        exp = orc.search(og, q[:1], k, ef=ef, beam=beam, check_relative_distance=check, table=x)
+        runs = {}
+        for direct in (0, 1):
+            idx = Mi355xIndex.from_csr(g)
+            prov = NumpyProvider(x, idx.info.d_padded, sorted_ids=not direct)
+            seen = []
+            inner = prov.__call__
+
+            def logging_provider(d_ids_ptr, n, stream_ptr, seen=seen, inner=inner):
+                seen.append(np.ctypeslib.as_array(C.cast(d_ids_ptr, C.POINTER(C.c_int32)), shape=(n,)).copy())
+                return inner(d_ids_ptr, n, stream_ptr)
+
+            idx.set_provider(logging_provider)
+            idx.set_option("single_query_direct", direct)
+            assert idx.get_option("single_query_direct") == direct
+            got = idx.search(q[:1], k, idx.make_params(ef=ef, beam=beam, recompute=True, check_relative_distance=check))
+            st = idx.stats()
+            _check(f"single_query_direct={direct} metric={metric} beam={beam} check={check} k={k} ef={ef}", got, exp[:2], st, exp[2])
+            runs[direct] = (got, {f: int(st[f]) for f in ("ndis", "nunique", "nrounds", "nexpand")}, [s.copy() for s in seen])
+            if direct:  # more than one query: the ordinary path (sorted unique ids per round), same answers as without the option
+                seen.clear()
+                got2 = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=True, check_relative_distance=check))
+                exp2 = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check, table=x)
+                _check("single_query_direct set, two queries", got2, exp2[:2], idx.stats(), exp2[2])
+                assert all((np.diff(s) > 0).all() for s in seen)
+                prov.sorted_ids = True
+                idx.set_option("speculate", 4)  # a memo pass: the ordinary path again
+                got3 = idx.search(q[:1], k, idx.make_params(ef=ef, beam=beam, recompute=True, check_relative_distance=check))
+                _check("single_query_direct + speculate", got3, exp[:2], idx.stats(), exp[2])
+            idx.close()
+        assert runs[0][1] == runs[1][1], (runs[0][1], runs[1][1])
+        assert len(runs[0][2]) == len(runs[1][2])
+        assert all(np.array_equal(a, np.sort(b)) for a, b in zip(runs[0][2], runs[1][2]))  # the same ids every round ...
+        assert any(not np.array_equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))      # ... in discovery order instead of id order
+    print("single_query_direct: ok", flush=True)
 
 
 def case_stop_rules():
@@ -596,6 +647,7 @@ CASES = {
     "recompute_wave_variant": lambda: case_recompute(3),
     "stop_rules": case_stop_rules,
     "speculative_prefetch": case_speculative_prefetch,
+    "single_query_direct": case_single_query_direct,
     "pq_deferred": lambda: case_pq(True),
     "pq_table": lambda: case_pq(False),
     "two_level": case_two_level,
@@ -1054,6 +1106,14 @@ def case_native_recompute(hidden=384, heads=12, pooling="mean", searches=True):
             # one synchronisation per round: the provider itself never synchronised during the search (buffers were already grown)
             assert s1["host_syncs"] == s0["host_syncs"], (s0, s1)
             assert s1["chunks"] - s0["chunks"] == int(st_n["nunique"])
+            if nq == 1:  # option "single_query_direct": the new-list goes to the provider as it is (no k_uniq_*): same answer, same counts, still one sync per round
+                idx.set_option("single_query_direct", 1)
+                s2 = nat.native_stats()
+                got_d = idx.search(q[:1], 4, idx.make_params(ef=8, beam=2, recompute=True))
+                st_d, s3 = idx.stats(), nat.native_stats()
+                _check(f"{tag} nq=1 single_query_direct vs oracle", got_d, exp[:2], st_d, exp[2])
+                assert s3["host_syncs"] == s2["host_syncs"] and s3["chunks"] - s2["chunks"] == int(st_d["nunique"]) == int(st_n["nunique"])
+                assert int(st_d["nrounds"]) == int(st_n["nrounds"])
             idx.close()
             if not searches or nq == 1:
                 continue

@@ -249,6 +249,47 @@ def test_speculative_prefetch_same_results_fewer_provider_calls(env):
     idx.set_option("speculate", 0)
 
 
+def test_single_query_direct_same_results(env):
+    """Option "single_query_direct": a one-query recompute pass hands its new-list to the provider as it is (no k_uniq_* launches).  Labels,
+    distances and counts are the oracle's; the provider sees the same ids per round in discovery order."""
+    from leann_amd.devmem import as_tensor
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    torch = env
+    x, g = _build(20000, 128, "l2", seed=9, normalize=False)
+    q = queries_near(x, 5, seed=33, normalize=False)
+    xdev = torch.from_numpy(x).cuda()
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    keep, seen = {}, []
+
+    def provider(d_ids, n, stream):
+        ids = as_tensor(d_ids, (n,), "int32")
+        seen.append(ids.cpu().numpy().copy())
+        keep["e"] = xdev.index_select(0, ids.long()).contiguous()
+        return keep["e"].data_ptr()
+
+    idx.set_provider(provider)
+    og = oracle_graph(g, 128)
+    per_round = {}
+    for direct in (0, 1):
+        idx.set_option("single_query_direct", direct)
+        per_round[direct] = []
+        for i in range(q.shape[0]):
+            seen.clear()
+            d, l = idx.search_device(torch.from_numpy(q[i : i + 1]).cuda(), 10, idx.make_params(ef=64, beam=2, recompute=True))
+            torch.cuda.synchronize()
+            oi, od, ost = orc.search(og, q[i : i + 1], 10, ef=64, beam=2, table=x)
+            st = idx.stats()
+            assert np.array_equal(l.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od) and st["ndis"] == ost["ndis"], (direct, i)
+            per_round[direct].append(([s.copy() for s in seen], int(st["nunique"]), int(st["nrounds"])))
+    for a, b in zip(per_round[0], per_round[1]):
+        assert a[1:] == b[1:] and len(a[0]) == len(b[0])
+        assert all(np.array_equal(u, np.sort(v)) for u, v in zip(a[0], b[0]))
+    idx.set_option("single_query_direct", 0)
+
+
 def test_lockstep_table_mode_still_matches(env):
     """Stored-embedding mode defaults to the persistent kernel; the lock-step path must give the same answers."""
     from leann_amd.index import Mi355xIndex
