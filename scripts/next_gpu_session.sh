@@ -1,6 +1,7 @@
 #!/bin/bash
 # What to run FIRST in the next round's first GPU session (~14 GPU-minutes), in this order.
-#   1. `pytest -m gpu` on the tree as it is, then the driver's bench command under rocprofv3 (reference line + per-kernel table).
+#   1. `pytest -m gpu` on the tree as it is (the tests marked NOT_YET_ON_HARDWARE / xfail(strict=False) are the ones of 3b / 3c: XPASS
+#      = remove the marker), then the driver's bench command under rocprofv3 (reference line + per-kernel table).
 #   2. Is this box in the layer tail's slow mode?  `kbench tail4` on the product form next to the six-stage / non-temporal
 #      builds; on a SLOW box additionally the TCC hit / miss counters of the same command (one --pmc pass, --kernel-trace only): the
 #      first experiment towards knowing what the slow boxes have in common.

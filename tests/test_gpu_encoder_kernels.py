@@ -322,6 +322,11 @@ def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
     assert fused_linear_h384(x, qkv) is None
 
 
+NOT_YET_ON_HARDWARE = pytest.mark.xfail(strict=False, reason="written after round 4's GPU budget was spent: validated in thread-per-lane emulation only; "
+                                                      "the feature is off by default -- remove this marker after the first hardware run (scripts/next_gpu_session.sh)")
+
+
+@NOT_YET_ON_HARDWARE
 @pytest.mark.parametrize("tokens", [1, 33, 700, 5000])
 @pytest.mark.parametrize("k_in", [384, 1536])
 def test_rowgemm_ln_h384(tokens, k_in, monkeypatch):
@@ -356,6 +361,7 @@ def test_rowgemm_ln_h384(tokens, k_in, monkeypatch):
     assert (got.float() - two.float()).abs().max().item() <= 8e-3 * scale  # the two-launch form rounds the pre-LayerNorm row to fp16 first
 
 
+@NOT_YET_ON_HARDWARE
 def test_small_forward_with_and_without_the_rowgemm_ln_kernel(monkeypatch):
     """The small-forward form of the MiniLM-shape encoder (a one-query round's handful of chunks) with LEANN_MI355X_SMALL_ROWLN=1: one-call and
     per-kernel launch paths bit-identical, fp16-close to the default small form."""
