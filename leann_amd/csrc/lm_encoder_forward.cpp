@@ -53,8 +53,21 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     // (lm_rowgemm_ln_h384_f16, in place on x: 5 launches per layer instead of 7).  Off by default until it has been timed on hardware.
     const char* rowln_env = getenv("LEANN_MI355X_SMALL_ROWLN");
     const bool rowln = small && rowln_env && rowln_env[0] == '1' && m->ffn % 384 == 0 && m->ffn <= 2304;
+    // LEANN_MI355X_SMALL_LAYER=1: everything of a small-forward layer behind its attention -- and the NEXT layer's QKV projection -- in one
+    // launch (lm_small_layer_h384_f16, in place on x): 2 launches per layer instead of 7.  Off by default until timed on hardware.
+    const char* slayer_env = getenv("LEANN_MI355X_SMALL_LAYER");
+    const bool slayer = small && slayer_env && slayer_env[0] == '1' && m->ffn % 384 == 0 && m->ffn <= 1536;
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
+        if (small && slayer) {  // attention + ONE launch for the rest of the layer and the next layer's QKV projection
+            if (l == 0 && (rc = lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 1152, 384, qkv, total_tokens, stream))) return rc;
+            if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
+            const lm_bert_h384_layer* nx = l + 1 < m->n_layers ? &m->layers[l + 1] : nullptr;
+            if ((rc = lm_small_layer_h384_f16(a, x, L.wo, L.bo, L.ln1_gamma, L.ln1_beta, m->ln_eps, L.w1, L.b1, L.w2, L.b2, L.ln2_gamma, L.ln2_beta, m->ln_eps,
+                                              m->ffn, x, nx ? nx->wqkv : nullptr, nx ? nx->bqkv : nullptr, nx ? qkv : nullptr, total_tokens, stream)))
+                return rc;
+            continue;
+        }
         if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x
             if ((rc = lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 1152, 384, qkv, total_tokens, stream))) return rc;
             if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;

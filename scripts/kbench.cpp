@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|rowln|gemmf16|gemmstamp]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|rowln|slayer|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -622,6 +622,47 @@ int main(int argc, char** argv) {
                        "\"two_launches_us\": %.1f, \"max_abs_diff_all_rows\": %.3g}\n", T, K, round, us1, us2, dmax);
                 fflush(stdout);
             }
+        }
+    }
+    if (want("slayer")) {
+        // lm_small_layer_h384_f16 (the rest of a small-forward layer behind its attention + the next layer's QKV projection in ONE launch)
+        // against the six launches of the default small form (out-projection GEMM, LayerNorm, fc1 GEMM, fc2 GEMM, LayerNorm, next QKV GEMM):
+        //   kbench 1500 50 slayer      kbench 6000 50 slayer      kbench 12000 50 slayer
+        const int F = 1536;
+        Dev<__half> at((size_t)T * H), rs((size_t)T * H), wo((size_t)H * H), w1((size_t)F * H), w2((size_t)H * F), wq((size_t)1152 * H);
+        dev_fill(at.p, (size_t)T * H, 1.0f, 81, st);
+        dev_fill(rs.p, (size_t)T * H, 1.0f, 82, st);
+        dev_fill(wo.p, (size_t)H * H, 0.05f, 83, st);
+        dev_fill(w1.p, (size_t)F * H, 0.05f, 84, st);
+        dev_fill(w2.p, (size_t)H * F, 0.03f, 85, st);
+        dev_fill(wq.p, (size_t)1152 * H, 0.05f, 86, st);
+        Dev<float> bo(rand_float(H, 0.2f, 87)), b1(rand_float(F, 0.2f, 88)), b2(rand_float(H, 0.2f, 89)), bq(rand_float(1152, 0.2f, 90));
+        Dev<__half> y((size_t)T * H), x1((size_t)T * H), hid((size_t)T * F), o6((size_t)T * H), q6((size_t)T * 1152), o1((size_t)T * H), q1((size_t)T * 1152);
+        auto six = [&] {
+            LM(lm_gemm_f16(at.p, wo.p, bo.p, rs.p, 2, H, H, y.p, T, st));
+            LM(lm_add_layernorm_f16(y.p, nullptr, gamma.p, beta.p, x1.p, T, H, 1e-12f, st));
+            LM(lm_gemm_f16(x1.p, w1.p, b1.p, nullptr, 1, F, H, hid.p, T, st));
+            LM(lm_gemm_f16(hid.p, w2.p, b2.p, x1.p, 2, H, F, y.p, T, st));
+            LM(lm_add_layernorm_f16(y.p, nullptr, gamma.p, beta.p, o6.p, T, H, 1e-12f, st));
+            LM(lm_gemm_f16(o6.p, wq.p, bq.p, nullptr, 0, 1152, H, q6.p, T, st));
+        };
+        auto one = [&] {
+            LM(lm_small_layer_h384_f16(at.p, rs.p, wo.p, bo.p, gamma.p, beta.p, 1e-12f, w1.p, b1.p, w2.p, b2.p, gamma.p, beta.p, 1e-12f, F, o1.p, wq.p, bq.p, q1.p, T, st));
+        };
+        six();
+        one();
+        CK(hipStreamSynchronize(st));
+        double dx = 0, dq = 0;
+        {
+            auto a = o6.host(), b = o1.host(), c = q6.host(), d = q1.host();
+            for (size_t i = 0; i < a.size(); ++i) dx = std::max(dx, fabs((double)__half2float(a[i]) - (double)__half2float(b[i])));
+            for (size_t i = 0; i < c.size(); ++i) dq = std::max(dq, fabs((double)__half2float(c[i]) - (double)__half2float(d[i])));
+        }
+        for (int round = 0; round < 3; ++round) {
+            const float us6 = time_us(st, reps, six), us1 = time_us(st, reps, one);
+            printf("{\"kernel\": \"lm_small_layer_h384_f16 vs the six launches of the default small form\", \"tokens\": %d, \"ffn\": %d, \"round\": %d, \"one_launch_us\": %.1f, "
+                   "\"six_launches_us\": %.1f, \"max_abs_diff_x2\": %.3g, \"max_abs_diff_qkv\": %.3g}\n", T, F, round, us1, us6, dx, dq);
+            fflush(stdout);
         }
     }
     if (want("gemmf16")) {

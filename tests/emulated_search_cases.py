@@ -751,6 +751,110 @@ def case_rowgemm_ln():
 
 CASES["rowgemm_ln"] = case_rowgemm_ln
 
+def case_small_layer():
+    """lm_small_layer_h384_f16 (csrc/lm_small_layer_h384.hip: out-projection + LayerNorm + fc1 + GELU + fc2 + LayerNorm and the next layer's QKV
+    projection in one launch, for small forwards) through the C ABI against numpy -- ragged token counts, ffn 384 / 768, with and without the
+    QKV projection, in place -- and the encoder's small-forward form with LEANN_MI355X_SMALL_LAYER=1 (one-call and per-kernel launch paths)
+    against the default small form and the fp32 reference."""
+    import os
+    from unittest import mock
+
+    import torch
+    from scipy.special import erf
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, EncoderConfig
+
+    lib = _lib.load()
+    rng = np.random.default_rng(43)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    H, f64 = 384, np.float64
+
+    def ln(z, gm, bt):
+        mu = z.mean(1, keepdims=True)
+        var = ((z - mu) ** 2).mean(1, keepdims=True)
+        return (z - mu) / np.sqrt(var + 1e-12) * gm.astype(f64) + bt.astype(f64)
+
+    for T, F, with_qkv in ((70, 384, True), (33, 768, False), (5, 768, True)):
+        at, rs = rng.standard_normal((T, H)).astype(np.float16), rng.standard_normal((T, H)).astype(np.float16)
+        wo = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float16)
+        w1 = (rng.standard_normal((F, H)) / np.sqrt(H)).astype(np.float16)
+        w2 = (rng.standard_normal((H, F)) / np.sqrt(F)).astype(np.float16)
+        wq = (rng.standard_normal((1152, H)) / np.sqrt(H)).astype(np.float16)
+        bo, b1, b2, bq = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (H, F, H, 1152)]
+        g1, g2 = [(1 + 0.1 * rng.standard_normal(H)).astype(np.float16) for _ in range(2)]
+        e1, e2 = [(0.1 * rng.standard_normal(H)).astype(np.float16) for _ in range(2)]
+        x1 = ln(rs.astype(f64) + at.astype(f64) @ wo.astype(f64).T + bo, g1, e1).astype(np.float16)
+        hid = x1.astype(f64) @ w1.astype(f64).T + b1
+        p16 = (0.5 * hid * (1 + erf(hid / np.sqrt(2)))).astype(np.float16).astype(f64)
+        x2 = ln(p16 @ w2.astype(f64).T + b2 + x1.astype(f64), g2, e2)
+        out = np.full((T, H), 7.0, np.float16)
+        qkv = np.full((T, 1152), 7.0, np.float16)
+        _lib.check(lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, F,
+                                               vp(out), vp(wq) if with_qkv else None, vp(bq) if with_qkv else None, vp(qkv) if with_qkv else None, T, None),
+                   "small layer")
+        err = np.abs(out.astype(f64) - x2).max()
+        assert err < 1.2e-2, (T, F, err)  # rare 1-ulp flips of the fp16 x1 / GELU outputs move single results
+        if with_qkv:
+            qref = out.astype(f64) @ wq.astype(f64).T + bq  # from the kernel's own fp16 x2
+            assert np.abs(qkv.astype(f64) - qref).max() < 6e-3, (T, F)
+        else:
+            assert (qkv == 7.0).all()
+        inpl = rs.copy()
+        _lib.check(lib.lm_small_layer_h384_f16(vp(at), vp(inpl), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, F,
+                                               vp(inpl), None, None, None, T, None), "small layer in place")
+        assert np.array_equal(inpl, out), (T, F)
+    assert lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, 512,
+                                       vp(out), None, None, None, T, None) == -1  # ffn % 384
+    assert lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, F,
+                                       vp(out), vp(wq), None, vp(qkv), T, None) == -1  # QKV weight without its bias
+    # the encoder's small-forward form on it
+    torch.manual_seed(0)
+    cfg = EncoderConfig(vocab_size=500, hidden=384, layers=3, heads=12, ffn=384, max_pos=64, max_seq_length=48)
+    e16 = BertEncoder.random_init(cfg, 5).eval().half()
+    n, t = 7, 48
+    lens = rng.integers(1, t + 1, n).astype(np.int32)
+    lens[0], lens[1] = t, 1
+    ids = np.zeros((n, t), np.int32)
+    for i in range(n):
+        ids[i, : lens[i]] = rng.integers(1, cfg.vocab_size, lens[i])
+    ti, tl = torch.from_numpy(ids), torch.from_numpy(lens)
+
+    class _Stream:
+        cuda_stream = 0
+
+    used = []
+    real_check = _lib.check
+
+    def recording_check(rc, what=""):
+        used.append(what)
+        return real_check(rc, what)
+
+    outs = {}
+    for slayer, onecall in (("0", "1"), ("1", "1"), ("1", "0")):
+        used.clear()
+        env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
+        env.update({"LEANN_MI355X_ONECALL": onecall, "LEANN_MI355X_SMALL_LAYER": slayer})
+        with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
+                mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
+                mock.patch.object(_lib, "check", new=recording_check):
+            with torch.no_grad():
+                outs[(slayer, onecall)] = e16.encode_tokens_packed(ti, tl, 4096)
+        if onecall == "0":  # per-kernel path: QKV GEMM + attention + the fused rest, per layer
+            want = {"lm_small_layer_h384_f16": cfg.layers, "lm_gemm_f16": cfg.layers, "lm_add_layernorm_f16": 0}
+            assert {k: used.count(k) for k in want} == want, sorted(set(used))
+    with torch.no_grad():
+        ref32 = BertEncoder.random_init(cfg, 5).eval()(ti, tl).float()
+    d_default = float((outs[("1", "1")].float() - outs[("0", "1")].float()).abs().max())
+    d_paths = float((outs[("1", "1")].float() - outs[("1", "0")].float()).abs().max())
+    print(f"small-layer kernel: one-call form vs the default small form max|diff| = {d_default:.2e}; vs the per-kernel path (QKV by lm_gemm_f16) {d_paths:.2e}", flush=True)
+    assert d_default < 3e-3 and d_paths < 3e-3, (d_default, d_paths)
+    assert float((outs[("1", "1")].float() - ref32).abs().max()) < 6e-3 and float((outs[("1", "0")].float() - ref32).abs().max()) < 6e-3
+    print("lm_small_layer_h384_f16 through the C ABI and in the small-forward form: ok", flush=True)
+
+
+CASES["small_layer"] = case_small_layer
+
 def case_gemm_f16():
     """lm_gemm_f16 (csrc/lm_gemm_f16.hip: the general linear layer of the hidden-768 path) vs numpy: both tile shapes, every
     epilogue, ragged token counts (clamped row loads, masked stores), more than eight row blocks (XCD-order padding)."""

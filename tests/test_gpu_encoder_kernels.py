@@ -382,6 +382,72 @@ def test_small_forward_with_and_without_the_rowgemm_ln_kernel(monkeypatch):
     assert (one - base).abs().max().item() <= 3e-3
 
 
+@NOT_YET_ON_HARDWARE
+@pytest.mark.parametrize("tokens,ffn,with_qkv", [(1, 1536, True), (33, 1536, True), (700, 1536, False), (5000, 1536, True), (300, 384, True), (300, 768, False)])
+def test_small_layer_h384(tokens, ffn, with_qkv, monkeypatch):
+    """lm_small_layer_h384_f16 (out-projection + LayerNorm + fc1 + GELU + fc2 + LayerNorm and the next layer's QKV projection in one launch, for
+    small forwards; LEANN_MI355X_SMALL_LAYER=1) vs a plain PyTorch fp32 reference of the same ops and vs the default small form."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from leann_amd.encoder import GEMM_EPI_GELU, GEMM_EPI_RESIDUAL, EncoderConfig, _Layer, fused_add_layernorm, fused_gemm, fused_small_layer
+
+    torch.manual_seed(tokens + ffn)
+    layer = _Layer(EncoderConfig(hidden=384, layers=1, heads=12, ffn=ffn)).to("cuda", dtype=torch.float16)
+    nq = nn.Linear(384, 1152).to("cuda", dtype=torch.float16) if with_qkv else None
+    with torch.no_grad():
+        for ln in (layer.ln1, layer.ln2):
+            ln.weight.copy_(1 + 0.1 * torch.randn(384))
+            ln.bias.copy_(0.1 * torch.randn(384))
+        layer.out.bias.copy_(0.2 * torch.randn(384))
+        layer.fc1.bias.copy_(0.2 * torch.randn(ffn))
+        layer.fc2.bias.copy_(0.2 * torch.randn(384))
+    a = torch.randn((tokens, 384), device="cuda").half()
+    res = torch.randn((tokens, 384), device="cuda").half()
+    assert fused_small_layer(a, res, layer) is None  # off by default
+    monkeypatch.setenv("LEANN_MI355X_SMALL_LAYER", "1")
+    with torch.no_grad():
+        got = fused_small_layer(a, res, layer, nq)
+        assert got is not None
+        x2, qkv = got if with_qkv else (got, None)
+        x1 = F.layer_norm(res.float() + a.float() @ layer.out.weight.float().t() + layer.out.bias.float(), (384,), layer.ln1.weight.float(),
+                          layer.ln1.bias.float(), layer.ln1.eps).half().float()
+        hid = F.gelu(x1 @ layer.fc1.weight.float().t() + layer.fc1.bias.float()).half().float()
+        ref = F.layer_norm(x1 + hid @ layer.fc2.weight.float().t() + layer.fc2.bias.float(), (384,), layer.ln2.weight.float(), layer.ln2.bias.float(), layer.ln2.eps)
+        # the default small form: five launches
+        y1 = fused_add_layernorm(fused_gemm(a, layer.out, GEMM_EPI_RESIDUAL, res), None, layer.ln1)
+        five = fused_add_layernorm(fused_gemm(fused_gemm(y1, layer.fc1, GEMM_EPI_GELU), layer.fc2, GEMM_EPI_RESIDUAL, y1), None, layer.ln2)
+    torch.cuda.synchronize()
+    assert x2.shape == (tokens, 384) and x2.dtype == torch.float16 and not torch.isnan(x2).any()
+    scale = max(1.0, float(ref.abs().max()))
+    assert (x2.float() - ref).abs().max().item() <= 1.2e-2 * scale
+    assert (x2.float() - five.float()).abs().max().item() <= 1.5e-2 * scale
+    if with_qkv:
+        qref = x2.float() @ nq.weight.float().t() + nq.bias.float()
+        assert qkv.shape == (tokens, 1152) and (qkv.float() - qref).abs().max().item() <= 4e-3 * max(1.0, float(qref.abs().max()))
+
+
+@NOT_YET_ON_HARDWARE
+def test_small_forward_with_the_small_layer_kernel(monkeypatch):
+    """The small-forward form of the MiniLM-shape encoder with LEANN_MI355X_SMALL_LAYER=1 (2 launches per layer in the one-call path): fp16-close
+    to the default small form and to the per-kernel path (which computes the QKV projection with lm_gemm_f16)."""
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
+    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=24, n_topics=4)).chunks(), 256)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    base = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_SMALL_LAYER", "1")
+    one = enc.encode_tokens_packed(ti, tl)
+    monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
+    per = enc.encode_tokens_packed(ti, tl)
+    assert not torch.isnan(one).any() and (one - base).abs().max().item() <= 3e-3 and (one - per).abs().max().item() <= 3e-3
+
+
 def test_pack_tokens_front_end(monkeypatch):
     """lm_pack_tokens (LEANN_MI355X_PACK=1) == the boolean-mask selects it replaces; whole forward unchanged."""
     import torch
