@@ -775,7 +775,7 @@ def case_small_layer():
         var = ((z - mu) ** 2).mean(1, keepdims=True)
         return (z - mu) / np.sqrt(var + 1e-12) * gm.astype(f64) + bt.astype(f64)
 
-    for T, F, with_qkv in ((70, 384, True), (33, 768, False), (5, 768, True)):
+    for T, F, with_qkv in ((70, 384, True), (33, 768, False), (5, 768, True), (1, 1536, True), (64, 1152, False)):
         at, rs = rng.standard_normal((T, H)).astype(np.float16), rng.standard_normal((T, H)).astype(np.float16)
         wo = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float16)
         w1 = (rng.standard_normal((F, H)) / np.sqrt(H)).astype(np.float16)
@@ -854,6 +854,36 @@ def case_small_layer():
 
 
 CASES["small_layer"] = case_small_layer
+
+def case_small_forward_kernels_small():
+    """lm_rowgemm_ln_h384_f16 and lm_small_layer_h384_f16 alone, two workgroups each (small enough for the ThreadSanitizer build): every LDS
+    hand-over of the two kernels -- token tile by DMA, row statistics, x1 / GELU / x2 tiles between the stages -- with real threads per lane."""
+    from leann_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(47)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    H, F, T = 384, 384, 40
+    at, rs = rng.standard_normal((T, H)).astype(np.float16), rng.standard_normal((T, H)).astype(np.float16)
+    wo = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float16)
+    w1 = (rng.standard_normal((F, H)) / np.sqrt(H)).astype(np.float16)
+    w2 = (rng.standard_normal((H, F)) / np.sqrt(F)).astype(np.float16)
+    wq = (rng.standard_normal((1152, H)) / np.sqrt(H)).astype(np.float16)
+    bo, b1, b2, bq = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (H, F, H, 1152)]
+    g1 = (1 + 0.1 * rng.standard_normal(H)).astype(np.float16)
+    e1 = (0.1 * rng.standard_normal(H)).astype(np.float16)
+    out, qkv, o2 = np.zeros((T, H), np.float16), np.zeros((T, 1152), np.float16), np.zeros((T, H), np.float16)
+    _lib.check(lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g1), vp(e1), 1e-12, F,
+                                           vp(out), vp(wq), vp(bq), vp(qkv), T, None), "small layer")
+    _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(at), vp(wo), vp(bo), H, vp(rs), vp(g1), vp(e1), 1e-12, vp(o2), T, None), "rowgemm_ln")
+    z = rs.astype(np.float64) + at.astype(np.float64) @ wo.astype(np.float64).T + bo
+    mu = z.mean(1, keepdims=True)
+    ref = (z - mu) / np.sqrt(((z - mu) ** 2).mean(1, keepdims=True) + 1e-12) * g1.astype(np.float64) + e1.astype(np.float64)
+    assert np.abs(o2.astype(np.float64) - ref).max() < 6e-3 and np.isfinite(out.astype(np.float64)).all() and np.abs(qkv).max() > 0
+    print("small-forward kernels (small): ok", flush=True)
+
+
+CASES["small_forward_kernels_small"] = case_small_forward_kernels_small
 
 def case_gemm_f16():
     """lm_gemm_f16 (csrc/lm_gemm_f16.hip: the general linear layer of the hidden-768 path) vs numpy: both tile shapes, every
