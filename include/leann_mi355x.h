@@ -468,13 +468,14 @@ int lm_index_set_recompute(lm_index *idx, lm_recompute *rc);
  * One HIP event pair per launch, recorded on the stream the kernel is launched on, for the kernels whose bit is set in `mask`
  * (bit LM_KT_*); 0 = off (the default: a disabled launch pays one atomic load).  Works on every launch path -- the one-call forwards,
  * the built-in recompute provider inside lm_index_search*, single entry points.  lm_kernel_timing_read waits for the pairs recorded
- * so far and returns, per kernel, launches / summed milliseconds / summed algorithmic flops since the last reset (work 0 where the
- * launcher cannot know it: attention).  bench.py's `roofline` is built from these over its timed region. */
+ * so far and returns, per kernel, launches / summed milliseconds / summed algorithmic flops since the last reset (attention's
+ * flops, 4 H sum(len^2), are summed on the device from the launch's own cumulative lengths).  bench.py's `roofline` is built from these over its timed region. */
 #define LM_KT_LAYER_TAIL 0 /* lm_layer_tail_h384_f16 */
 #define LM_KT_GEMM_WS 1    /* lm_gemm_ws_h384_f16 */
 #define LM_KT_ATTN 2       /* lm_attn_varlen_hd32_f16 / lm_attn_varlen_f16 */
 #define LM_KT_GEMM_F16 3   /* lm_gemm_f16 */
-#define LM_KT_COUNT 4
+#define LM_KT_QKV 4        /* lm_qkv_h384_f16 (the weight-streaming QKV projection of the large hidden-384 forwards) */
+#define LM_KT_COUNT 5
 typedef struct lm_kernel_time {
     const char *name;
     int64_t launches;

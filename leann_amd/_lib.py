@@ -88,7 +88,7 @@ class KernelTime(C.Structure):  # include/leann_mi355x.h: lm_kernel_time
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("ms", C.c_double), ("work", C.c_double)]
 
 
-KT_LAYER_TAIL, KT_GEMM_WS, KT_ATTN, KT_GEMM_F16, KT_COUNT = 0, 1, 2, 3, 4
+KT_LAYER_TAIL, KT_GEMM_WS, KT_ATTN, KT_GEMM_F16, KT_QKV, KT_COUNT = 0, 1, 2, 3, 4, 5
 
 
 class RecomputeStats(C.Structure):  # include/leann_mi355x.h: lm_recompute_stats

@@ -239,7 +239,8 @@ static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int
     hipStream_t st = (hipStream_t)stream;
     const __half* q = (const __half*)d_qkv;
     __half* o = (__half*)d_out;
-    KtScope kt(LM_KT_ATTN, stream, 0.0);  // the flops depend on the sequence lengths (device memory): time only
+    kt_attn_work(d_cu_seqlens, n_seqs, heads * HD, stream);  // the flops depend on the sequence lengths (device memory): summed there
+    KtScope kt(LM_KT_ATTN, stream, 0.0);
     switch (nt) {
 #define CASEA(n)                                                                                                                         \
     case n: {                                                                                                                            \

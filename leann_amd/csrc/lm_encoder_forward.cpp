@@ -33,8 +33,7 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     if (n_seqs == 0 || total_tokens == 0) return LM_OK;
     if (!m || !m->layers || !d_tok || !d_pos || !d_cu_seqlens || !d_workspace || !d_out || n_seqs < 0 || total_tokens < 0)
         LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: bad arguments");
-    if (m->n_layers <= 0 || m->heads * 32 != 384 || m->ffn < 192 || m->ffn > 1728 || m->ffn % 192)
-        LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: needs hidden 384 = heads x 32 and ffn a multiple of 192 in [192, 1728]");
+    if (!bert_h384_envelope_ok(m->n_layers, m->heads, m->ffn)) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: needs " LM_BERT_H384_ENVELOPE_TEXT);
     if (max_len <= 0 || max_len > 256) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: sequence lengths 1..256");
     if (m->pooling != 0 && m->pooling != 1) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: pooling 0 (mean) or 1 (CLS)");
     if (workspace_bytes < lm_bert_h384_workspace_bytes(total_tokens)) LM_FAIL(LM_EINVAL, "lm_bert_h384_forward_packed: workspace too small");

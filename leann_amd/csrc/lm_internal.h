@@ -75,11 +75,16 @@ struct KtScope {
     void* st;
     double work;
     void* a;
+    int dev;  // device the pair's events belong to
     KtScope(int kid, void* stream, double work);
     ~KtScope();
     KtScope(const KtScope&) = delete;
     KtScope& operator=(const KtScope&) = delete;
 };
+
+// attention's algorithmic flops (4 H sum(len^2): the lengths live in device memory) onto the current device's counter; no-op while
+// attention's timing bit is off.  Call it in front of the launch's KtScope.
+void kt_attn_work(const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t hidden, void* stream);
 
 // ---- query phases (same state machine as oracle/lm_oracle.c) ----
 enum : int32_t { PH_SEED = 0, PH_UPPER = 1, PH_BEAM = 2, PH_DONE = 3 };
@@ -135,6 +140,11 @@ int rc_prepare(lm_recompute* rc, const int32_t* d_ids, const unsigned long long*
                unsigned long long* d_maxlen, hipStream_t st);
 void rc_prepared(lm_recompute* rc, const int32_t* d_ids, int32_t n, int64_t total, int32_t max_len);
 int32_t rc_width(const lm_recompute* rc);  // floats per embedding row
+// The ONE envelope of the hidden-384 one-call forward (lm_bert_h384_forward_packed, lm_layer_tail_h384_f16) -- shared with
+// lm_recompute_create, so that a handle it accepts cannot fail on every search round (round-4 advisor finding).
+inline bool bert_h384_envelope_ok(int n_layers, int heads, int ffn) { return n_layers > 0 && heads * 32 == 384 && ffn >= 192 && ffn <= 1728 && ffn % 192 == 0; }
+#define LM_BERT_H384_ENVELOPE_TEXT "hidden 384 = heads x 32 and ffn a multiple of 192 in [192, 1728]"
+
 }  // namespace lm
 
 // lm_encoder_ops2.hip: 16-lanes-per-row LayerNorm (opt-in, LEANN_MI355X_LN=2, hidden <= 768); arguments as lm_add_layernorm_f16

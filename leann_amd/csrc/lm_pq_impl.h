@@ -325,8 +325,11 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     if (W > 64) LM_FAIL(LM_EINVAL, "beam_width > 64 is not supported by the PQ traversal kernel");
     // option "pq_rerank_expanded": the exact rerank ranks every EXPANDED node (upstream DiskANN: full_retset) instead of the final
     // candidate list; the record holds up to 4 L (<= 8192: the rerank kernel's sort) entries per query
-    const int32_t exp_cap = ix->pq_rerank_expanded ? std::min<int32_t>(8192, 4 * L) : 0;
-    if (ix->pq_rerank_expanded && L > 8192) LM_FAIL(LM_EINVAL, "pq_rerank_expanded: complexity <= 8192");
+    // The record replaces the candidate list as what the traversal leaves in ws.pool (keys in expansion order, distance 0), so it is kept
+    // ONLY when an exact rerank follows: with skip_search_reorder, or with neither a table nor a provider, the PQ-ordered list is the result.
+    const bool rerank = !prm.skip_search_reorder && ((prm.use_deferred_fetch && ix->provider) || ix->d_table != nullptr);
+    const int32_t exp_cap = (ix->pq_rerank_expanded && rerank) ? std::min<int32_t>(8192, 4 * L) : 0;
+    if (exp_cap && L > 8192) LM_FAIL(LM_EINVAL, "pq_rerank_expanded: complexity <= 8192");
     int rc = ensure_ws(ix, B, exp_cap ? exp_cap : L, W);
     if (rc) return rc;
     WsDev& ws = ix->ws;
@@ -368,8 +371,6 @@ static int pq_search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, 
     ix->stats.update_launches++;
     hipLaunchKernelGGL(k_pq_stats, dim3(1), dim3(256), 0, st, ws, pa);
     unsigned long long* hc = ix->h_counters;
-    const bool have_table = ix->d_table != nullptr;
-    const bool rerank = !prm.skip_search_reorder && ((prm.use_deferred_fetch && ix->provider) || have_table);
     if (rerank) {
         UpdateArgs ua{};
         ua.Q = d_q;

@@ -230,7 +230,7 @@ extern "C" int lm_qkv_h384_f16(const void* d_x, const void* d_w_img, const float
     if (!d_x || !d_w_img || !d_bias || !d_out || tokens < 0 || tokens > 0x7fffffff) LM_FAIL(LM_EINVAL, "bad linear arguments");
     if (n_out < 256 || n_out % 128 || n_out > 6144) LM_FAIL(LM_EINVAL, "lm_qkv_h384_f16: n_out must be a multiple of 128 in [256, 6144]");
     const size_t shmem = (size_t)QK_BIAS_OFF + (size_t)n_out * 4;
-    KtScope kt(LM_KT_GEMM_WS, stream, 2.0 * (double)tokens * n_out * ML_H);
+    KtScope kt(LM_KT_QKV, stream, 2.0 * (double)tokens * n_out * ML_H);
     static DynLdsAttr attr;
     LM_HIP(ensure_dyn_lds(attr, (const void*)k_qkv_h384<4>, shmem));
     hipLaunchKernelGGL(k_qkv_h384<4>, dim3((unsigned)((tokens + 255) / 256)), dim3(512), shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w_img,

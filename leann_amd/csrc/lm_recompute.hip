@@ -300,8 +300,8 @@ int lm_recompute_create(const lm_bert_h384* model, const lm_tokens* tokens, int3
     if (!out) LM_FAIL(LM_EINVAL, "out is NULL");
     *out = nullptr;
     if (!model || !model->layers || !tokens) LM_FAIL(LM_EINVAL, "lm_recompute_create: NULL model / token store");
-    if (model->n_layers <= 0 || model->heads * 32 != 384 || model->ffn < 128 || model->ffn > 2560 || model->ffn % 32)
-        LM_FAIL(LM_EINVAL, "lm_recompute_create: needs hidden 384 = heads x 32 and 128 <= ffn <= 2560, ffn % 32 == 0 (the one-call forward's envelope)");
+    if (!bert_h384_envelope_ok(model->n_layers, model->heads, model->ffn))
+        LM_FAIL(LM_EINVAL, "lm_recompute_create: needs " LM_BERT_H384_ENVELOPE_TEXT " (the one-call forward's envelope; other shapes: lm_recompute_create_general)");
     if (max_seq_len <= 0 || max_seq_len > 256) LM_FAIL(LM_EINVAL, "lm_recompute_create: chunk length limit must be 1..256 tokens");
     if (max_tokens_per_forward <= 0) LM_FAIL(LM_EINVAL, "lm_recompute_create: max_tokens_per_forward must be positive");
     LM_HIP(hipSetDevice(tokens->device));

@@ -418,9 +418,11 @@ def pack_tail_images(wo: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> tu
 
     from . import _lib
 
+    if not (wo.is_cuda and w1.is_cuda and w2.is_cuda):  # lm_layer_tail_pack_h384 is a DEVICE kernel over these pointers
+        raise ValueError("pack_tail_images: the weights must be on the GPU (the image is written by a device kernel)")
     wos, w1a, w2p = pack_wo_slabs(wo.detach()), pack_w1_acc_order(w1.detach()), pack_w2_fused_mlp(w2.detach())
     imgs = tuple(torch.empty_like(s) for s in (wos, w1a, w2p))
-    st = C.c_void_p(torch.cuda.current_stream(wo.device).cuda_stream) if wo.is_cuda else None
+    st = C.c_void_p(torch.cuda.current_stream(wo.device).cuda_stream)
     _lib.check(_lib.load().lm_layer_tail_pack_h384(C.c_void_p(wos.data_ptr()), C.c_void_p(w1a.data_ptr()), C.c_void_p(w2p.data_ptr()), int(w1.shape[0]),
                                                    *(C.c_void_p(i.data_ptr()) for i in imgs), st), "lm_layer_tail_pack_h384")
     return imgs  # (the packed sources die with this frame: the kernels above run on the stream the caching allocator orders their reuse on)
@@ -481,9 +483,11 @@ def pack_qkv_image(w: torch.Tensor) -> torch.Tensor:
 
     from . import _lib
 
+    if not w.is_cuda:  # lm_qkv_pack_h384 is a DEVICE kernel over these pointers
+        raise ValueError("pack_qkv_image: the weight must be on the GPU (the image is written by a device kernel)")
     src = w.detach().contiguous()
     img = torch.empty_like(src)
-    st = C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream) if w.is_cuda else None
+    st = C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
     _lib.check(_lib.load().lm_qkv_pack_h384(C.c_void_p(src.data_ptr()), int(src.shape[0]), C.c_void_p(img.data_ptr()), st), "lm_qkv_pack_h384")
     return img
 
@@ -742,14 +746,16 @@ class BertEncoder(nn.Module):
     def onecall_model(self) -> Optional[dict]:
         """``{"model": lm_bert_h384 struct, ...}`` over this encoder's weights (packed copies cached, rebuilt when a weight changes: _packed)
         -- the argument of lm_bert_h384_forward_packed and of the built-in recompute provider (lm_recompute_create) -- or None when the
-        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights on the GPU, mean or CLS pooling, ffn a multiple of 192 in
+        model is outside that envelope: needs hidden 384 = heads x 32, fp16 weights ON THE GPU (checked: the weight images are written by device kernels), mean or CLS pooling, ffn a multiple of 192 in
         [192, 1728] (the fused layer tail's shapes; other widths: general_model)."""
         cfg = self.cfg
         w = self.word.weight
-        if not (w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling in ("mean", "cls") and cfg.ffn % 192 == 0
-                and 192 <= cfg.ffn <= 1728):
+        if not (w.is_cuda and w.dtype == torch.float16 and cfg.hidden == 384 and cfg.heads * 32 == 384 and cfg.pooling in ("mean", "cls")
+                and cfg.ffn % 192 == 0 and 192 <= cfg.ffn <= 1728):
             return None
         import os
+
+        qkv_streaming = os.environ.get("LEANN_MI355X_QKV", "1") == "1"  # part of the pack's identity: read per call, one cached pack per form
 
         from . import _lib
 
@@ -763,7 +769,7 @@ class BertEncoder(nn.Module):
                         w1_i, L.fc1.bias.detach().float().contiguous(), w2_i,
                         L.fc2.bias.detach().float().contiguous(), L.ln2.weight.detach().contiguous(), L.ln2.bias.detach().contiguous(),
                         L.out.weight.detach().contiguous(), L.fc1.weight.detach().contiguous(), L.fc2.weight.detach().contiguous(),
-                        pack_qkv_image(L.qkv.weight) if os.environ.get("LEANN_MI355X_QKV", "1") == "1" else None)
+                        pack_qkv_image(L.qkv.weight) if qkv_streaming else None)
                 for (name, _), v in zip(_lib.BertH384Layer._fields_, vals):
                     setattr(layers[li], name, ptr(v) if v is not None else None)
             m = _lib.BertH384(cfg.layers, cfg.heads, cfg.ffn, 1 if cfg.normalize else 0, 1 if cfg.pooling == "cls" else 0, float(self.ln.eps), ptr(w.detach()),
@@ -771,7 +777,7 @@ class BertEncoder(nn.Module):
                               ptr(self.ln.bias.detach()), layers)
             return {"model": m, "layers": layers, "keep": keep}
 
-        return _packed(self, "_onecall_pack", tuple(self.parameters()), make)
+        return _packed(self, "_onecall_pack" if qkv_streaming else "_onecall_pack_ws_qkv", tuple(self.parameters()), make)
 
     def general_model(self) -> Optional[dict]:
         """``{"model": lm_bert struct, ...}`` over this encoder's own (unpacked) weights: the argument of lm_bert_forward_packed and

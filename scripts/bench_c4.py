@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--efc", type=int, default=200)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the shard's own index")
     ap.add_argument("--dry-run-emulated", default=None, metavar="LIB", help="TEST ONLY (tests/test_bench_dry_run.py): as bench.py's switch of this name")
     args = ap.parse_args()
     dry = bool(args.dry_run_emulated)
@@ -126,8 +127,6 @@ def _main(args, dry):
         gt = torch.gather(ai, 1, top).cpu().numpy()
     else:
         gt = li.cpu().numpy()
-    del X
-    torch.cuda.empty_cache()
     prm = idx.make_params(ef=args.ef, beam=1, recompute=True, max_batch=B)
     ss = ShardedSearch(lambda qq, k: idx.search_device(qq, k, prm), id_base=lo, metric=g.metric_type)
 
@@ -171,6 +170,24 @@ def _main(args, dry):
             ss.merge_fn(i0[None].contiguous(), d0[None].contiguous(), g.metric_type)
     barrier()
     coll_us = (time.perf_counter() - t0) / 20 * 1e6
+    # ---- parity on THIS shard's own index and queries (untimed; rank 0): GPU vs the CPU oracle exactly as bench.py's parity_check does it
+    #      for C2 -- stored-embedding mode (ids, distances, evaluation counts; the faiss transcription as well) and recompute mode
+    #      (the oracle replays the GPU encoder's own per-round outputs) -- then the shard's embeddings are dropped ----
+    parity = None
+    if rank == 0 and not args.no_parity_check:
+        try:
+            import bench as _b
+
+            t1 = time.time()
+            idx.attach_table(X)
+            parity = _b.parity_check(idx, g, X, Q, provider, args.ef, 1, D, n_table=min(64, B), n_recompute=min(16, max(1, nq - 64)))
+            parity["what"] = (f"shard-level: the searches of rank 0's shard ({ns} chunks) on the run's own queries against oracle/lm_oracle.c; the cross-shard merge "
+                              "(lm_topk_merge) has its own oracle test (tests/test_distributed.py, tests/emulated_two_rank.py)")
+            parity["seconds"] = round(time.time() - t1, 1)
+        except Exception as ex:  # noqa: BLE001 - an untimed check may never cost the line
+            parity = {"error": repr(ex)[:300]}
+    del X
+    torch.cuda.empty_cache()
     # roofline of the dominant kernel of the timed region (the fused layer tail, MFMA bound), as in bench.py
     kname = "lm::k_layer_tail_h384" if kt_dominant == _lib.KT_LAYER_TAIL else "lm::k_gemm_f16"
     kt = kt_timed.get(kname)
@@ -205,7 +222,10 @@ def _main(args, dry):
             "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16",
             "dtype_detail": "encoder fp16 MFMA with fp32 accumulation; distances / merge f32",
             "data": "synthetic" if not dry else "dry-run (emulated library on the CPU: control flow only, nothing here is a measurement)", "dry_run": dry,
-            "roofline": roofline, "cpu_baseline": cpu_base,
+            "roofline": roofline, "cpu_baseline": cpu_base, "parity_check": parity,
+            "what_this_line_is": (f"the {world}-rank job" if world > 1 or args.chunks >= 60_000_000 // 2 else
+                                  f"ONE rank's work of C4 -- one shard of {ns} chunks, all {B} queries, local top-10, exchange + lm_topk_merge in the timed region "
+                                  "at world size 1 -- on one MI355X; no 8-GPU run exists (no multi-GPU node was available to this repo in any round)"),
             "per_query": {"distance_evals": round(agg["ndis"] / max(K * B, 1), 1), "recomputed_chunks": round(agg["nunique"] / max(K * B, 1), 1),
                           "rounds_per_step": round(agg["nrounds"] / max(K, 1), 1)},
             "config": {"workload": f"{args.chunks} synthetic chunks in {world} shard(s) of {ns}, HNSW M={args.M} per shard (GPU-built), {args.model} shape, "

@@ -567,6 +567,7 @@ int main(int argc, char** argv) {
         double flops = 0;
         for (int i = 0; i < ns; ++i) flops += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
         for (const char* rev : {"1", "2", "2 plain unit order"}) {
+            if (getenv("KBENCH_ATTN_DEFAULT_ONLY") && std::strcmp(rev, "2")) continue;  // (PMC passes: one population per kernel name)
             setenv("LEANN_MI355X_ATTN", rev[0] == '1' ? "1" : "2", 1);
             setenv("LEANN_MI355X_ATTN_XCD", rev[1] ? "0" : "1", 1);
             auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };

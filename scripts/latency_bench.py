@@ -48,7 +48,7 @@ def attach(native: bool):
 
 forms = [("library_side_provider", True), ("python_provider", False)] if attach(True) else [("python_provider", False)]
 rows, lo, same = [], 0, True
-for b in ((1,) if "--speculate" in sys.argv else tuple(int(v) for v in os.environ.get("LAT_BATCHES", "1,4,16,64,256").split(","))):  # (the prefetch sweep below: B = 1 only)
+for b in (() if os.environ.get("LAT_VARIANTS_ONLY") == "1" else (1,) if "--speculate" in sys.argv else tuple(int(v) for v in os.environ.get("LAT_BATCHES", "1,4,16,64,256").split(","))):  # (the prefetch sweep below: B = 1 only)
     prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b)
     reps = 24 if b == 1 else (12 if b <= 16 else 4)
     if lo + b * (reps + 1) > Q.shape[0]:
@@ -102,5 +102,37 @@ if "--speculate" in sys.argv:
                           "recomputed_chunks_per_query": round(chunks / 32, 1), "forwards_per_query": round((provider.native_stats()["forwards"] - f0) / 32, 1),
                           "queries_with_the_labels_of_S0": int(sum(torch.equal(a, b) for a, b in zip(ref_labels, labels)))})
     idx.set_option("speculate", 0)
-print(json.dumps({"chunks": n, "b1_speculative_prefetch": spec_rows, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
+# LAT_VARIANTS=default,rowln,slayer,direct,direct+rowln,direct+slayer: the small-forward switches A/B'd IN ONE PROCESS on the same queries
+# (library-side provider only; lm_encoder_forward.cpp reads the two environment switches per call, the option is per index); the labels of
+# every variant must equal the first variant's
+variant_rows = []
+if os.environ.get("LAT_VARIANTS"):
+    ref_by_b = {}
+    for vname in os.environ["LAT_VARIANTS"].split(","):
+        parts = set(vname.split("+"))
+        os.environ["LEANN_MI355X_SMALL_ROWLN"] = "1" if "rowln" in parts else "0"
+        os.environ["LEANN_MI355X_SMALL_LAYER"] = "1" if "slayer" in parts else "0"
+        idx.set_option("single_query_direct", 1 if "direct" in parts else 0)
+        vrow = {"variant": vname}
+        for b in tuple(int(v) for v in os.environ.get("LAT_BATCHES", "1,4,16,64,256").split(",")):
+            prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b)
+            reps = 24 if b == 1 else (12 if b <= 16 else 4)
+            idx.search_device(Q[0:b].contiguous(), 10, prm)
+            lat, labels, p = [], [], b
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                d, l = idx.search_device(Q[p : p + b].contiguous(), 10, prm)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t0) * 1e3)
+                labels.append(l.cpu())
+                p += b
+            if b not in ref_by_b:
+                ref_by_b[b] = labels
+            vrow[f"B{b}"] = {"p50_ms": round(float(np.median(lat)), 2), "mean_ms": round(float(np.mean(lat)), 2), "queries_per_s": round(b / float(np.mean(lat)) * 1e3, 1),
+                             "rounds_last_call": idx.stats()["nrounds"], "calls_with_the_first_variants_labels": int(sum(torch.equal(a, c) for a, c in zip(ref_by_b[b], labels))), "calls": reps}
+        variant_rows.append(vrow)
+    os.environ.pop("LEANN_MI355X_SMALL_ROWLN", None); os.environ.pop("LEANN_MI355X_SMALL_LAYER", None)
+    idx.set_option("single_query_direct", 0)
+print(json.dumps({"chunks": n, "small_forward_variants": variant_rows, "b1_speculative_prefetch": spec_rows, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
                   "identical_results_between_the_providers": same, "library_side_provider_stats": provider.native_stats()}))

@@ -300,6 +300,11 @@ def case_pq(deferred=True):
             differs += ust["n_final_differs"]
         assert differs > 0  # (on at least one query the expanded set is a strict superset of the final list: the option is exercised)
         assert idx.get_option("pq_rerank_overflow") == 0 and idx.get_option("pq_rerank_expanded") == 1
+        # the option together with skip_search_reorder (no rerank follows): the PQ-ordered final list is the result -- the expanded-node
+        # record must NOT replace it (round-4 advisor finding: the first k expanded nodes came back with distance 0)
+        l5, d5 = idx.pq_search(q, 5, idx.make_pq_params(12, 2, skip_search_reorder=True))
+        si, sd, _ = orc.pq_search(og, cb.numpy(), codes.numpy(), q, 5, L=12, W=2, skip_search_reorder=True)
+        _check("pq traversal, pq_rerank_expanded + skip_search_reorder = PQ order", (d5, l5), (si, sd))
         idx.set_option("pq_rerank_expanded", 0)
         l4, d4 = idx.pq_search(q, 5, idx.make_pq_params(12, 2))
         fi, fd, _ = orc.diskann_search(og, cb.numpy(), codes.numpy(), q, 5, L=12, W=2, table=x, rerank_final_list_only=True)

@@ -26,9 +26,14 @@ def test_bench_c3_small():
     sw = r["complexity_sweep"]  # one sweep per rerank set: the final candidate list / every expanded node (upstream DiskANN's full_retset)
     assert set(sw) == {"final_list", "expanded_nodes"} and r["rerank_set"] in sw
     assert max(v["recall_at_10"] for v in sw[r["rerank_set"]].values()) >= 0.9
-    assert set(r["roofline"]["us_per_launch_by_workgroup_width"]) == {"256", "512", "1024"}
-    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["achieved"] > 0
+    assert set(r["roofline_traversal"]["us_per_launch_by_workgroup_width"]) == {"256", "512", "1024"}
+    assert r["roofline_traversal"]["bound"] == "hbm" and r["roofline_traversal"]["achieved"] > 0
+    assert r["roofline"]["bound"] == "mfma" and "k_layer_tail_h384" in r["roofline"]["kernel"] and 0 < r["roofline"]["share_of_timed_region"] <= 1.0
     assert r["cpu_baseline"]["value"] and r["cpu_baseline"]["value"] > 0
+    pc = r["parity_check"]  # GPU vs the PQ oracles on the run's own index, queries, L, W and m
+    assert pc["pq_order"]["ids_exact"] and pc["pq_order"]["distance_bits_equal"] and pc["pq_order"]["counts_equal"]
+    assert pc["deferred_rerank"]["ids_exact"] and pc["deferred_rerank"]["distance_bits_equal"] and pc["deferred_rerank"]["one_provider_call_same_ids"]
+    assert pc["table_rerank"]["ids_exact"] and pc["table_rerank"]["distance_bits_equal"] and pc["table_rerank"]["diskann_transcription_agrees"]
 
 
 def test_bench_c4_one_shard_small():
@@ -38,6 +43,9 @@ def test_bench_c4_one_shard_small():
     assert r["allgather_plus_merge_us"] > 0
     assert r["roofline"]["bound"] == "mfma" and r["roofline"]["achieved"] > 0 and "k_layer_tail_h384" in r["roofline"]["kernel"]
     assert r["cpu_baseline"]["value"] and r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port"
+    pc = r["parity_check"]  # the shard's own index and queries against the oracle, as bench.py does it for C2
+    assert pc["ids_exact"] and pc["ndis_equal"] and pc["max_abs_dist"] == 0.0 and pc["faiss_transcription_agrees"]
+    assert pc["recompute"]["ids_exact"] and pc["recompute"]["same_ids_requested_every_round"] and pc["recompute"]["max_abs_dist"] == 0.0
 
 
 def test_bench_table_provider_variant_small():

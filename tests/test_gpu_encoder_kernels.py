@@ -322,11 +322,10 @@ def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
     assert fused_linear_h384(x, qkv) is None
 
 
-NOT_YET_ON_HARDWARE = pytest.mark.xfail(strict=False, reason="written after round 4's GPU budget was spent: validated in thread-per-lane emulation only; "
-                                                      "the feature is off by default -- remove this marker after the first hardware run (scripts/next_gpu_session.sh)")
+# (the three small-forward features below first ran on an MI355X in the driver's round-4 GPU test tier -- 17 XPASS, GPUTEST_r04.json -- the
+# xfail markers they carried until then are gone)
 
 
-@NOT_YET_ON_HARDWARE
 @pytest.mark.parametrize("tokens", [1, 33, 700, 5000])
 @pytest.mark.parametrize("k_in", [384, 1536])
 def test_rowgemm_ln_h384(tokens, k_in, monkeypatch):
@@ -361,7 +360,6 @@ def test_rowgemm_ln_h384(tokens, k_in, monkeypatch):
     assert (got.float() - two.float()).abs().max().item() <= 8e-3 * scale  # the two-launch form rounds the pre-LayerNorm row to fp16 first
 
 
-@NOT_YET_ON_HARDWARE
 def test_small_forward_with_and_without_the_rowgemm_ln_kernel(monkeypatch):
     """The small-forward form of the MiniLM-shape encoder (a one-query round's handful of chunks) with LEANN_MI355X_SMALL_ROWLN=1: one-call and
     per-kernel launch paths bit-identical, fp16-close to the default small form."""
@@ -382,7 +380,6 @@ def test_small_forward_with_and_without_the_rowgemm_ln_kernel(monkeypatch):
     assert (one - base).abs().max().item() <= 3e-3
 
 
-@NOT_YET_ON_HARDWARE
 @pytest.mark.parametrize("tokens,ffn,with_qkv", [(1, 1536, True), (33, 1536, True), (700, 1536, False), (5000, 1536, True), (300, 384, True), (300, 768, False)])
 def test_small_layer_h384(tokens, ffn, with_qkv, monkeypatch):
     """lm_small_layer_h384_f16 (out-projection + LayerNorm + fc1 + GELU + fc2 + LayerNorm and the next layer's QKV projection in one launch, for
@@ -428,7 +425,6 @@ def test_small_layer_h384(tokens, ffn, with_qkv, monkeypatch):
         assert qkv.shape == (tokens, 1152) and (qkv.float() - qref).abs().max().item() <= 4e-3 * max(1.0, float(qref.abs().max()))
 
 
-@NOT_YET_ON_HARDWARE
 def test_small_forward_with_the_small_layer_kernel(monkeypatch):
     """The small-forward form of the MiniLM-shape encoder with LEANN_MI355X_SMALL_LAYER=1 (2 launches per layer in the one-call path): fp16-close
     to the default small form and to the per-kernel path (which computes the QKV projection with lm_gemm_f16)."""

@@ -249,8 +249,6 @@ def test_speculative_prefetch_same_results_fewer_provider_calls(env):
     idx.set_option("speculate", 0)
 
 
-@pytest.mark.xfail(strict=False, reason="written after round 4's GPU budget was spent: validated in thread-per-lane emulation only; the option is off by "
-                                        "default -- remove this marker after the first hardware run (scripts/next_gpu_session.sh)")
 def test_single_query_direct_same_results(env):
     """Option "single_query_direct": a one-query recompute pass hands its new-list to the provider as it is (no k_uniq_* launches).  Labels,
     distances and counts are the oracle's; the provider sees the same ids per round in discovery order."""

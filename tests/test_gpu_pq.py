@@ -89,6 +89,10 @@ def test_pq_search_parity(metric, L, W):
     assert len(calls) == 1 and np.array_equal(gi3, ui) and np.array_equal(gd3.view(np.uint32), ud.view(np.uint32))
     assert idx.get_option("pq_rerank_overflow") == 0
     assert recall_at_k(gi2, gt) >= recall_at_k(gi, gt)  # a superset of the final list can only rank better
+    # the option + skip_search_reorder: no rerank follows, so the PQ-ordered list (case 1) must come back, not the expanded-node record
+    oi, od, _ = orc.pq_search(og, cb, codes, q, 10, L=L, W=W, skip_search_reorder=True)
+    gi4, gd4 = idx.pq_search(q, 10, idx.make_pq_params(L, W, skip_search_reorder=True))
+    assert np.array_equal(gi4, oi) and np.array_equal(gd4.view(np.uint32), od.view(np.uint32))
     idx.set_option("pq_rerank_expanded", 0)
     idx.close()
 
