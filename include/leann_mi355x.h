@@ -311,27 +311,6 @@ int lm_qkv_pack_h384(const void *d_w, int32_t n_out, void *d_w_img, void *stream
 int lm_gemm_ws_h384_f16(const void *d_x, const void *d_w, const float *d_bias, int32_t n_out, void *d_out, int64_t tokens,
                         void *stream);
 
-/* Row-complete linear layer with 384 outputs + residual + LayerNorm for SMALL forwards (csrc/lm_rowgemm_ln_h384.hip):
- *   d_out[t] = LayerNorm(d_residual[t] + x[t] W^T + b) * gamma + beta,   x [tokens][k_in] fp16, d_w = the nn.Linear weight [384][k_in] fp16,
- * bias fp32, gamma / beta fp16, k_in a multiple of 384 in [384, 2304]; d_residual may be NULL, d_out may be d_residual (in place).  A workgroup
- * owns 32 tokens x all 384 features, so the LayerNorm needs no second launch: the attention output projection (k_in 384) and fc2 (k_in = ffn)
- * of a small-forward layer in one launch each instead of lm_gemm_f16 + lm_add_layernorm_f16.  Written in round 4 after the GPU budget was
- * spent: validated in emulation, not yet run on an MI355X; LEANN_MI355X_SMALL_ROWLN=1 switches the small-forward form onto it (off by default). */
-int lm_rowgemm_ln_h384_f16(const void *d_x, const void *d_w, const float *d_bias, int32_t k_in, const void *d_residual,
-                           const void *d_gamma, const void *d_beta, float eps, void *d_out, int64_t tokens, void *stream);
-
-/* Everything of a hidden-384 layer behind its attention, for SMALL forwards, in one launch (csrc/lm_small_layer_h384.hip):
- *   x1 = LayerNorm1(resid + attn W_o^T + b_o);  d_out = LayerNorm2(x1 + GELU(x1 W1^T + b1) W2^T + b2);  optionally d_qkv_out = d_out W_qkv'^T + b_qkv'
- * (the NEXT layer's QKV projection: the three arguments go together, NULL = none).  attn / resid / d_out [tokens][384] fp16 (d_out may be
- * resid), d_qkv_out [tokens][1152] fp16; every weight is the plain nn.Linear matrix (fp16, row major), biases fp32, gamma / beta fp16; ffn a
- * multiple of 384 in [384, 1536].  A 384-thread workgroup owns 32 tokens x all features of every intermediate (they stay in LDS): a small-forward
- * layer is attention + this = 2 launches instead of 7.  Written in round 4 after the GPU budget was spent: validated in emulation, not yet run on
- * an MI355X; LEANN_MI355X_SMALL_LAYER=1 switches the small-forward form of lm_bert_h384_forward_packed onto it (off by default). */
-int lm_small_layer_h384_f16(const void *d_attn, const void *d_resid, const void *d_wo, const float *d_bo, const void *d_gamma1,
-                            const void *d_beta1, float eps1, const void *d_w1, const float *d_b1, const void *d_w2, const float *d_b2,
-                            const void *d_gamma2, const void *d_beta2, float eps2, int32_t ffn, void *d_out, const void *d_wqkv_next,
-                            const float *d_bqkv_next, void *d_qkv_out, int64_t tokens, void *stream);
-
 /* General fp16 linear layer (csrc/lm_gemm_f16.hip):  d_out[tokens][n_out] = epi(x[tokens][k_in] W^T + b), d_w = the nn.Linear weight
  * itself ([n_out][k_in] fp16 row major, no packing, < 4 GiB), bias fp32, n_out % 128 == 0, k_in % 128 == 0; any token count.
  * epilogue: 0 = none, 1 = exact-erf GELU, 2 = + d_residual[tokens][n_out] (fp16), 3 = both.  256 x 256 workgroup tiles (128 x 128

@@ -107,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "lm_dist_gather", "lm_topk_merge",
     "lm_pq_attach", "lm_pq_attach_chunked", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
     "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_attn_varlen_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
-    "lm_layer_tail_h384_f16", "lm_layer_tail_pack_h384", "lm_qkv_h384_f16", "lm_qkv_pack_h384", "lm_rowgemm_ln_h384_f16", "lm_small_layer_h384_f16", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
+    "lm_layer_tail_h384_f16", "lm_layer_tail_pack_h384", "lm_qkv_h384_f16", "lm_qkv_pack_h384", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
     "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
     "lm_bert_workspace_bytes", "lm_bert_forward_packed", "lm_clspool_varlen_f16",
@@ -168,8 +168,6 @@ def load() -> C.CDLL:
     lib.lm_layer_tail_pack_h384.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     lib.lm_qkv_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
     lib.lm_qkv_pack_h384.argtypes = [vp, i32, vp, vp]
-    lib.lm_rowgemm_ln_h384_f16.argtypes = [vp, vp, vp, i32, vp, vp, vp, C.c_float, vp, i64, vp]
-    lib.lm_small_layer_h384_f16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, i64, vp]
     lib.lm_gemm_ws_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
     lib.lm_gemm_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]
     lib.lm_pack_tokens.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]

@@ -48,34 +48,11 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     bool small = total_tokens <= small_tokens_limit() && m->ffn % 128 == 0;  // (every multiple of 192 in the envelope that is one of 128: 384, 768, 1152, 1536, ...)
     for (int l = 0; small && l < m->n_layers; ++l) small = m->layers[l].wo && m->layers[l].w1 && m->layers[l].w2;
     void* hid = ws + 3 * row + (size_t)total_tokens * 1152 * 2;  // [T][ffn], small forwards only (lm_bert_h384_workspace_bytes)
-    // LEANN_MI355X_SMALL_ROWLN=1: the two 384-output products of a small-forward layer on the row-complete GEMM + LayerNorm kernel
-    // (lm_rowgemm_ln_h384_f16, in place on x: 5 launches per layer instead of 7).  Off by default until it has been timed on hardware.
-    const char* rowln_env = getenv("LEANN_MI355X_SMALL_ROWLN");
-    const bool rowln = small && rowln_env && rowln_env[0] == '1' && m->ffn % 384 == 0 && m->ffn <= 2304;
-    // LEANN_MI355X_SMALL_LAYER=1: everything of a small-forward layer behind its attention -- and the NEXT layer's QKV projection -- in one
-    // launch (lm_small_layer_h384_f16, in place on x): 2 launches per layer instead of 7.  Off by default until timed on hardware.
-    const char* slayer_env = getenv("LEANN_MI355X_SMALL_LAYER");
-    const bool slayer = small && slayer_env && slayer_env[0] == '1' && m->ffn % 384 == 0 && m->ffn <= 1536;
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
-        if (small && slayer) {  // attention + ONE launch for the rest of the layer and the next layer's QKV projection
-            if (l == 0 && (rc = lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 1152, 384, qkv, total_tokens, stream))) return rc;
-            if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
-            const lm_bert_h384_layer* nx = l + 1 < m->n_layers ? &m->layers[l + 1] : nullptr;
-            if ((rc = lm_small_layer_h384_f16(a, x, L.wo, L.bo, L.ln1_gamma, L.ln1_beta, m->ln_eps, L.w1, L.b1, L.w2, L.b2, L.ln2_gamma, L.ln2_beta, m->ln_eps,
-                                              m->ffn, x, nx ? nx->wqkv : nullptr, nx ? nx->bqkv : nullptr, nx ? qkv : nullptr, total_tokens, stream)))
-                return rc;
-            continue;
-        }
         if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x
             if ((rc = lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 1152, 384, qkv, total_tokens, stream))) return rc;
             if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
-            if (rowln) {
-                if ((rc = lm_rowgemm_ln_h384_f16(a, L.wo, L.bo, 384, x, L.ln1_gamma, L.ln1_beta, m->ln_eps, x, total_tokens, stream))) return rc;
-                if ((rc = lm_gemm_f16(x, L.w1, L.b1, nullptr, 1, m->ffn, 384, hid, total_tokens, stream))) return rc;
-                if ((rc = lm_rowgemm_ln_h384_f16(hid, L.w2, L.b2, m->ffn, x, L.ln2_gamma, L.ln2_beta, m->ln_eps, x, total_tokens, stream))) return rc;
-                continue;
-            }
             if ((rc = lm_gemm_f16(a, L.wo, L.bo, x, 2, 384, 384, y, total_tokens, stream))) return rc;
             if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln1_gamma, L.ln1_beta, x, total_tokens, 384, m->ln_eps, stream))) return rc;
             if ((rc = lm_gemm_f16(x, L.w1, L.b1, nullptr, 1, m->ffn, 384, hid, total_tokens, stream))) return rc;

@@ -10,6 +10,7 @@
 // does not report it.  Attention's flops depend on the sequence lengths, which only the device knows: the launcher adds
 // 4 H sum(len^2) to a per-device 64-bit counter with a one-workgroup kernel OUTSIDE its event pair (kt_attn_work; only while the
 // attention bit is on), lm_kernel_timing_read collects the counters.
+#include <algorithm>
 #include <atomic>
 #include <deque>
 #include <map>
@@ -24,6 +25,7 @@ struct Pair {
     hipEvent_t a, b;
     int kid, dev;
     double work;
+    void* stream;
 };
 struct Acc {
     int64_t launches = 0;
@@ -31,6 +33,12 @@ struct Acc {
 };
 struct DevState {
     std::vector<hipEvent_t> free_events;
+    // the END event of the last folded pair and its stream: a pair's START event may be stamped while the previous instrumented kernel
+    // of the same stream is still running (nothing orders the record behind it), so back-to-back launches of short kernels would be
+    // counted twice where they overlap -- round 4's C5 line summed 120.7 s of pairs inside a 115.8 s region.  A pair is therefore
+    // charged from max(its start, the previous pair's end).
+    hipEvent_t last_end = nullptr;
+    void* last_stream = nullptr;
     unsigned long long* d_attn_work = nullptr;  // sum over launches of H * sum(len^2) (x 4 = flops), added by k_kt_attn_work
 };
 std::atomic<unsigned> g_mask{0};
@@ -58,17 +66,22 @@ hipEvent_t get_event(int dev) {
     return nullptr;
 }
 void fold(const Pair& p) {
+    DevState& ds = g_dev[p.dev];
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        float over = 0.f;  // part of [a, b] that lies before the previous pair's end
+        if (ds.last_end && ds.last_stream == p.stream && hipEventElapsedTime(&over, p.a, ds.last_end) == hipSuccess && over > 0.f) ms -= std::min(over, ms);
+        (void)hipGetLastError();
         g_acc[p.kid].launches += 1;
         g_acc[p.kid].ms += ms;
         g_acc[p.kid].work += p.work;
     } else {
         (void)hipGetLastError();
     }
-    auto& fr = g_dev[p.dev].free_events;
-    fr.push_back(p.a);
-    fr.push_back(p.b);
+    ds.free_events.push_back(p.a);
+    if (ds.last_end) ds.free_events.push_back(ds.last_end);
+    ds.last_end = p.b;  // kept until the next pair of this device has been folded
+    ds.last_stream = p.stream;
 }
 
 __global__ __launch_bounds__(256) void k_kt_attn_work(const int32_t* __restrict__ cu, int32_t n_seqs, unsigned long long hidden,
@@ -106,7 +119,7 @@ KtScope::~KtScope() {
     if (!a) return;
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t b = get_event(dev);
-    if (b && hipEventRecord(b, (hipStream_t)st) == hipSuccess) g_pending.push_back(Pair{(hipEvent_t)a, b, kid, dev, work});
+    if (b && hipEventRecord(b, (hipStream_t)st) == hipSuccess) g_pending.push_back(Pair{(hipEvent_t)a, b, kid, dev, work, st});
     else {
         (void)hipGetLastError();
         g_dev[dev].free_events.push_back((hipEvent_t)a);

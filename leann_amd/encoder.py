@@ -253,63 +253,6 @@ def fused_gemm(x: torch.Tensor, lin: nn.Linear, epilogue: int = 0, residual: Opt
     return out
 
 
-def fused_rowgemm_ln(x: torch.Tensor, lin: nn.Linear, residual: torch.Tensor, ln: nn.LayerNorm) -> Optional[torch.Tensor]:
-    """LayerNorm(residual + x W^T + b) with 384 outputs in ONE launch for small forwards (csrc/lm_rowgemm_ln_h384.hip: a workgroup owns
-    32 tokens x all 384 features).  Written in round 4 after the GPU budget was spent: emulation-validated, not yet timed on an MI355X --
-    LEANN_MI355X_SMALL_ROWLN=1 switches it on (default off); None = not applicable / off."""
-    import os
-
-    if os.environ.get("LEANN_MI355X_SMALL_ROWLN", "0") != "1":
-        return None
-    n, k = lin.weight.shape
-    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and lin.weight.dtype == torch.float16 and n == 384 and k % 384 == 0 and k <= 2304
-            and lin.bias is not None and residual.is_contiguous() and residual.dtype == torch.float16 and tuple(residual.shape) == (x.shape[0], 384)
-            and ln.weight.dtype == torch.float16):
-        return None
-    import ctypes as C
-
-    from . import _lib
-
-    w, b = _packed(lin, "_gemm_pack", (lin.weight, lin.bias), lambda: (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous()))
-    out = torch.empty_like(residual)
-    _lib.check(_lib.load().lm_rowgemm_ln_h384_f16(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), int(k),
-                                                  C.c_void_p(residual.data_ptr()), C.c_void_p(ln.weight.data_ptr()), C.c_void_p(ln.bias.data_ptr()),
-                                                  float(ln.eps), C.c_void_p(out.data_ptr()), x.shape[0],
-                                                  C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_rowgemm_ln_h384_f16")
-    return out
-
-
-def fused_small_layer(a: torch.Tensor, resid: torch.Tensor, layer: "_Layer", next_qkv: Optional[nn.Linear] = None):
-    """Everything of a hidden-384 layer behind its attention in ONE launch for small forwards (csrc/lm_small_layer_h384.hip): returns x2, or
-    (x2, qkv of the next layer) with ``next_qkv``.  Written in round 4 after the GPU budget was spent: emulation-validated, not yet timed on an
-    MI355X -- LEANN_MI355X_SMALL_LAYER=1 switches it on (default off); None = not applicable / off."""
-    import os
-
-    if os.environ.get("LEANN_MI355X_SMALL_LAYER", "0") != "1":
-        return None
-    f, h = layer.fc1.weight.shape
-    if not (a.is_cuda and a.dtype == torch.float16 and a.is_contiguous() and resid.is_contiguous() and resid.dtype == torch.float16 and h == 384
-            and f % 384 == 0 and f <= 1536 and layer.out.bias is not None and layer.fc1.weight.dtype == torch.float16):
-        return None
-    import ctypes as C
-
-    from . import _lib
-
-    def plain(lin):
-        return _packed(lin, "_gemm_pack", (lin.weight, lin.bias), lambda: (lin.weight.detach().contiguous(), lin.bias.detach().float().contiguous()))
-
-    (wo, bo), (w1, b1), (w2, b2) = plain(layer.out), plain(layer.fc1), plain(layer.fc2)
-    out = torch.empty_like(resid)
-    vp = lambda t_: C.c_void_p(t_.data_ptr())  # noqa: E731
-    nq = plain(next_qkv) if next_qkv is not None else None
-    qkv = torch.empty((a.shape[0], 1152), dtype=torch.float16, device=a.device) if nq is not None else None
-    _lib.check(_lib.load().lm_small_layer_h384_f16(
-        vp(a), vp(resid), vp(wo), vp(bo), vp(layer.ln1.weight), vp(layer.ln1.bias), float(layer.ln1.eps), vp(w1), vp(b1), vp(w2), vp(b2),
-        vp(layer.ln2.weight), vp(layer.ln2.bias), float(layer.ln2.eps), int(f), vp(out), vp(nq[0]) if nq else None, vp(nq[1]) if nq else None,
-        vp(qkv) if nq else None, a.shape[0], C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)), "lm_small_layer_h384_f16")
-    return out if nq is None else (out, qkv)
-
-
 def fused_embed_layernorm(tok: torch.Tensor, pos: torch.Tensor, word: nn.Embedding, posw: nn.Embedding, type0: torch.Tensor,
                           ln: nn.LayerNorm) -> Optional[torch.Tensor]:
     """Embedding gathers + adds + LayerNorm in one kernel (csrc/lm_encoder_ops2.hip).  Default on (LEANN_MI355X_EMBED=0 = torch path, A/B); None = not applicable, the caller takes the torch path."""
@@ -577,23 +520,13 @@ class _Layer(nn.Module):
         a = fused_attention_hd32(qkv, cu, self.heads, max_len)
         if a is None:
             return None
-        if x.shape[1] == 384:
-            x2 = fused_small_layer(a, x, self)  # (LEANN_MI355X_SMALL_LAYER=1: the rest of the layer in one launch)
-            if x2 is not None:
-                return x2
-        x1 = fused_rowgemm_ln(a, self.out, x, self.ln1) if x.shape[1] == 384 else None  # (LEANN_MI355X_SMALL_ROWLN=1: one launch instead of two)
-        if x1 is None:
-            y = fused_gemm(a, self.out, GEMM_EPI_RESIDUAL, x)
-            if y is None:
-                return None
-            x1 = fused_add_layernorm(y, None, self.ln1)
-            if x1 is None:  # LEANN_MI355X_LN=0 / a width outside the LayerNorm kernel's envelope: the torch LayerNorm
-                x1 = self.ln1(y)
+        y = fused_gemm(a, self.out, GEMM_EPI_RESIDUAL, x)
+        if y is None:
+            return None
+        x1 = fused_add_layernorm(y, None, self.ln1)
+        if x1 is None:  # LEANN_MI355X_LN=0 / a width outside the LayerNorm kernel's envelope: the torch LayerNorm
+            x1 = self.ln1(y)
         hmid = fused_gemm(x1, self.fc1, GEMM_EPI_GELU)
-        if hmid is not None and x.shape[1] == 384:
-            x2 = fused_rowgemm_ln(hmid, self.fc2, x1, self.ln2)
-            if x2 is not None:
-                return x2
         y2 = fused_gemm(hmid, self.fc2, GEMM_EPI_RESIDUAL, x1) if hmid is not None else None
         if y2 is None:
             return None

@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|rowln|slayer|gemmf16|gemmstamp]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -566,20 +566,25 @@ int main(int argc, char** argv) {
         for (int i = 0; i < cu[nchk]; ++i) arows.push_back(i);
         double flops = 0;
         for (int i = 0; i < ns; ++i) flops += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
-        for (const char* rev : {"1", "2", "2 plain unit order"}) {
-            if (getenv("KBENCH_ATTN_DEFAULT_ONLY") && std::strcmp(rev, "2")) continue;  // (PMC passes: one population per kernel name)
-            setenv("LEANN_MI355X_ATTN", rev[0] == '1' ? "1" : "2", 1);
-            setenv("LEANN_MI355X_ATTN_XCD", rev[1] ? "0" : "1", 1);
-            auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };
-            run();
-            CK(hipStreamSynchronize(st));
-            const double err = max_err_rows(out.host(), H, 0, H, arows, href);
-            const float us = time_us(st, reps, run);
-            printf("{\"kernel\": \"lm_attn_varlen_hd32_f16\", \"mode\": \"revision %s, %d sequences, %d tokens\", \"us\": %.1f, \"TFLOPs\": %.1f, \"GBps_qkv_plus_out\": %.0f, \"max_abs_err\": %.3g}\n",
-                   rev, ns, tot, us, flops / us * 1e-6, (double)tot * H * 8 / us * 1e-3, err);
-            fflush(stdout);
-        }
-        unsetenv("LEANN_MI355X_ATTN");
+        // generation 2 (lm_attn_v2.hip) and the four variants of generation 3 (lm_attn_v3.hip: LEANN_MI355X_ATTN3), two rounds each (interleaved: clocks / box drift);
+        // KBENCH_ATTN_ONLY=<variant digit, 9 = generation 2> restricts the run to one kernel (PMC passes: one population per kernel name)
+        const char* only = getenv("KBENCH_ATTN_ONLY");
+        for (int round = 0; round < (only ? 1 : 2); ++round)
+            for (const char* rev : {"9", "0", "1"}) {  // generation 2; generation 3 with its score MFMAs at the top of a tile (0) / behind the previous tile's exponentials (1)
+                if (only && (only[0] != rev[0] || rev[1])) continue;
+                setenv("LEANN_MI355X_ATTN3", std::string(1, rev[0]).c_str(), 1);
+                setenv("LEANN_MI355X_ATTN_XCD", rev[1] ? "0" : "1", 1);
+                auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };
+                CK(hipMemsetAsync(out.p, 0xff, (size_t)tot * H * 2, st));
+                run();
+                CK(hipStreamSynchronize(st));
+                const double err = max_err_rows(out.host(), H, 0, H, arows, href);
+                const float us = time_us(st, reps, run);
+                printf("{\"kernel\": \"lm_attn_varlen_hd32_f16\", \"mode\": \"%s%s, %d sequences, %d tokens\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"GBps_qkv_plus_out\": %.0f, \"max_abs_err\": %.3g}\n",
+                       rev[0] == '9' ? "generation 2" : "generation 3, issue order ", rev[0] == '9' ? "" : rev, ns, tot, round, us, flops / us * 1e-6, (double)tot * H * 8 / us * 1e-3, err);
+                fflush(stdout);
+            }
+        unsetenv("LEANN_MI355X_ATTN3");
         unsetenv("LEANN_MI355X_ATTN_XCD");
     }
     if (want("ln")) {
@@ -590,81 +595,6 @@ int main(int argc, char** argv) {
             printf("{\"kernel\": \"lm_add_layernorm_f16\", \"mode\": \"revision %s\", \"us\": %.1f, \"GBps\": %.0f}\n", rev, us, (double)T * H * 6 / us * 1e-3);
         }
         unsetenv("LEANN_MI355X_LN");
-    }
-    if (want("rowln")) {
-        // lm_rowgemm_ln_h384_f16 (row-complete 384-output GEMM + residual + LayerNorm for SMALL forwards) against the two launches it replaces
-        // (lm_gemm_f16 with the residual epilogue + lm_add_layernorm_f16), at the token counts of a small search round -- run as
-        //   kbench 1500 50 rowln      (a one-query round: ~8 chunks)         kbench 12000 50 rowln      (a round of ~8 queries)
-        for (int K : {384, 1536}) {
-            Dev<__half> xa((size_t)T * K), wa((size_t)H * K), ra((size_t)T * H), y((size_t)T * H), o2((size_t)T * H), o1((size_t)T * H);
-            dev_fill(xa.p, (size_t)T * K, 1.0f, 71, st);
-            dev_fill(wa.p, (size_t)H * K, 0.05f, 72, st);
-            dev_fill(ra.p, (size_t)T * H, 1.0f, 73, st);
-            Dev<float> ba(rand_float(H, 0.2f, 74));
-            auto two = [&] {
-                LM(lm_gemm_f16(xa.p, wa.p, ba.p, ra.p, 2, H, K, y.p, T, st));
-                LM(lm_add_layernorm_f16(y.p, nullptr, gamma.p, beta.p, o2.p, T, H, 1e-12f, st));
-            };
-            auto one = [&] { LM(lm_rowgemm_ln_h384_f16(xa.p, wa.p, ba.p, K, ra.p, gamma.p, beta.p, 1e-12f, o1.p, T, st)); };
-            two();
-            one();
-            CK(hipStreamSynchronize(st));
-            double dmax = 0;
-            {
-                auto a = o2.host(), b = o1.host();
-                for (size_t i = 0; i < a.size(); ++i) {
-                    double d = fabs((double)__half2float(a[i]) - (double)__half2float(b[i]));
-                    if (!(d <= dmax)) dmax = d;
-                }
-            }
-            for (int round = 0; round < 3; ++round) {
-                const float us2 = time_us(st, reps, two), us1 = time_us(st, reps, one);
-                printf("{\"kernel\": \"lm_rowgemm_ln_h384_f16 vs lm_gemm_f16 + lm_add_layernorm_f16\", \"tokens\": %d, \"K\": %d, \"round\": %d, \"one_launch_us\": %.1f, "
-                       "\"two_launches_us\": %.1f, \"max_abs_diff_all_rows\": %.3g}\n", T, K, round, us1, us2, dmax);
-                fflush(stdout);
-            }
-        }
-    }
-    if (want("slayer")) {
-        // lm_small_layer_h384_f16 (the rest of a small-forward layer behind its attention + the next layer's QKV projection in ONE launch)
-        // against the six launches of the default small form (out-projection GEMM, LayerNorm, fc1 GEMM, fc2 GEMM, LayerNorm, next QKV GEMM):
-        //   kbench 1500 50 slayer      kbench 6000 50 slayer      kbench 12000 50 slayer
-        const int F = 1536;
-        Dev<__half> at((size_t)T * H), rs((size_t)T * H), wo((size_t)H * H), w1((size_t)F * H), w2((size_t)H * F), wq((size_t)1152 * H);
-        dev_fill(at.p, (size_t)T * H, 1.0f, 81, st);
-        dev_fill(rs.p, (size_t)T * H, 1.0f, 82, st);
-        dev_fill(wo.p, (size_t)H * H, 0.05f, 83, st);
-        dev_fill(w1.p, (size_t)F * H, 0.05f, 84, st);
-        dev_fill(w2.p, (size_t)H * F, 0.03f, 85, st);
-        dev_fill(wq.p, (size_t)1152 * H, 0.05f, 86, st);
-        Dev<float> bo(rand_float(H, 0.2f, 87)), b1(rand_float(F, 0.2f, 88)), b2(rand_float(H, 0.2f, 89)), bq(rand_float(1152, 0.2f, 90));
-        Dev<__half> y((size_t)T * H), x1((size_t)T * H), hid((size_t)T * F), o6((size_t)T * H), q6((size_t)T * 1152), o1((size_t)T * H), q1((size_t)T * 1152);
-        auto six = [&] {
-            LM(lm_gemm_f16(at.p, wo.p, bo.p, rs.p, 2, H, H, y.p, T, st));
-            LM(lm_add_layernorm_f16(y.p, nullptr, gamma.p, beta.p, x1.p, T, H, 1e-12f, st));
-            LM(lm_gemm_f16(x1.p, w1.p, b1.p, nullptr, 1, F, H, hid.p, T, st));
-            LM(lm_gemm_f16(hid.p, w2.p, b2.p, x1.p, 2, H, F, y.p, T, st));
-            LM(lm_add_layernorm_f16(y.p, nullptr, gamma.p, beta.p, o6.p, T, H, 1e-12f, st));
-            LM(lm_gemm_f16(o6.p, wq.p, bq.p, nullptr, 0, 1152, H, q6.p, T, st));
-        };
-        auto one = [&] {
-            LM(lm_small_layer_h384_f16(at.p, rs.p, wo.p, bo.p, gamma.p, beta.p, 1e-12f, w1.p, b1.p, w2.p, b2.p, gamma.p, beta.p, 1e-12f, F, o1.p, wq.p, bq.p, q1.p, T, st));
-        };
-        six();
-        one();
-        CK(hipStreamSynchronize(st));
-        double dx = 0, dq = 0;
-        {
-            auto a = o6.host(), b = o1.host(), c = q6.host(), d = q1.host();
-            for (size_t i = 0; i < a.size(); ++i) dx = std::max(dx, fabs((double)__half2float(a[i]) - (double)__half2float(b[i])));
-            for (size_t i = 0; i < c.size(); ++i) dq = std::max(dq, fabs((double)__half2float(c[i]) - (double)__half2float(d[i])));
-        }
-        for (int round = 0; round < 3; ++round) {
-            const float us6 = time_us(st, reps, six), us1 = time_us(st, reps, one);
-            printf("{\"kernel\": \"lm_small_layer_h384_f16 vs the six launches of the default small form\", \"tokens\": %d, \"ffn\": %d, \"round\": %d, \"one_launch_us\": %.1f, "
-                   "\"six_launches_us\": %.1f, \"max_abs_diff_x2\": %.3g, \"max_abs_diff_qkv\": %.3g}\n", T, F, round, us1, us6, dx, dq);
-            fflush(stdout);
-        }
     }
     if (want("gemmf16")) {
         // lm_gemm_f16 (csrc/lm_gemm_f16.hip) on the encoder's GEMM shapes, against rocBLAS (no bias / epilogue) on the same operands

@@ -102,16 +102,18 @@ if "--speculate" in sys.argv:
                           "recomputed_chunks_per_query": round(chunks / 32, 1), "forwards_per_query": round((provider.native_stats()["forwards"] - f0) / 32, 1),
                           "queries_with_the_labels_of_S0": int(sum(torch.equal(a, b) for a, b in zip(ref_labels, labels)))})
     idx.set_option("speculate", 0)
-# LAT_VARIANTS=default,rowln,slayer,direct,direct+rowln,direct+slayer: the small-forward switches A/B'd IN ONE PROCESS on the same queries
-# (library-side provider only; lm_encoder_forward.cpp reads the two environment switches per call, the option is per index); the labels of
-# every variant must equal the first variant's
+# LAT_VARIANTS=default,direct[,KEY=VALUE+KEY=VALUE ...]: switches A/B'd IN ONE PROCESS on the same queries (library-side provider only):
+# "direct" = index option single_query_direct, KEY=VALUE = an environment switch the library reads per call (e.g. LEANN_MI355X_SMALL_TOKENS=32768);
+# the labels of every variant must equal the first variant's.  (Round 5 timed the two small-forward kernels of round 4 this way -- row-complete
+# GEMM + LayerNorm: B = 1 p50 47.5 ms, whole-layer kernel: 60.5 ms, against 38.2 ms for the default -- and deleted them:
+# profiles/r5_latency_small_forward_variants_200k.json.)
 variant_rows = []
 if os.environ.get("LAT_VARIANTS"):
     ref_by_b = {}
     for vname in os.environ["LAT_VARIANTS"].split(","):
         parts = set(vname.split("+"))
-        os.environ["LEANN_MI355X_SMALL_ROWLN"] = "1" if "rowln" in parts else "0"
-        os.environ["LEANN_MI355X_SMALL_LAYER"] = "1" if "slayer" in parts else "0"
+        set_here = {kv.split("=", 1)[0]: kv.split("=", 1)[1] for kv in parts if "=" in kv}
+        os.environ.update(set_here)
         idx.set_option("single_query_direct", 1 if "direct" in parts else 0)
         vrow = {"variant": vname}
         for b in tuple(int(v) for v in os.environ.get("LAT_BATCHES", "1,4,16,64,256").split(",")):
@@ -132,7 +134,8 @@ if os.environ.get("LAT_VARIANTS"):
             vrow[f"B{b}"] = {"p50_ms": round(float(np.median(lat)), 2), "mean_ms": round(float(np.mean(lat)), 2), "queries_per_s": round(b / float(np.mean(lat)) * 1e3, 1),
                              "rounds_last_call": idx.stats()["nrounds"], "calls_with_the_first_variants_labels": int(sum(torch.equal(a, c) for a, c in zip(ref_by_b[b], labels))), "calls": reps}
         variant_rows.append(vrow)
-    os.environ.pop("LEANN_MI355X_SMALL_ROWLN", None); os.environ.pop("LEANN_MI355X_SMALL_LAYER", None)
+        for k_ in set_here:
+            os.environ.pop(k_, None)
     idx.set_option("single_query_direct", 0)
 print(json.dumps({"chunks": n, "small_forward_variants": variant_rows, "b1_speculative_prefetch": spec_rows, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
                   "identical_results_between_the_providers": same, "library_side_provider_stats": provider.native_stats()}))

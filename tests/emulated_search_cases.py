@@ -595,6 +595,68 @@ def case_encoder_abi():
     print("encoder entry points through the C ABI: ok", flush=True)
 
 
+def case_attention_v3():
+    """Generation 3 of the head_dim-32 attention kernel (csrc/lm_attn_v3.hip: K / V by LDS-DMA, transposing V reads, the running maximum
+    as the score MFMA's C operand, deferred rescaling) against float64 numpy, both issue orders (LEANN_MI355X_ATTN3), and against
+    generation 2 (LEANN_MI355X_ATTN=2).  Inputs that FORCE the rescale branch (cdna_hip_programming.md T13: the branch is rare and data
+    dependent -- a passing check on bounded random data says nothing): a key in a LATER tile whose score exceeds every earlier one by far
+    (threshold 8 in log2 units), per head and only for some query rows; rows whose maximum sits in the masked last tile; lengths 1, 31,
+    32, 33, 64, 65 and 200 (two query blocks per wave, seven key tiles)."""
+    import os
+
+    from leann_amd import _lib
+
+    lib = _lib.load()
+    vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    rng = np.random.default_rng(77)
+    heads = 2
+    for lens in (np.array([200, 1, 33], np.int32), np.array([31, 65, 32, 64], np.int32)):
+        n = lens.shape[0]
+        cu = np.zeros(n + 1, np.int32)
+        cu[1:] = np.cumsum(lens)
+        tot, Hh = int(cu[-1]), heads * 32
+        qkv = (1.2 * rng.standard_normal((tot, 3 * Hh))).astype(np.float32)
+        # spikes: in sequence 0 / head 0, key 170 (tile 5) is strongly aligned with query rows 3 and 40; key 199 (the masked last tile) with row 77;
+        # in the second batch, key 64 (the one-key last tile of the 65-token sequence) with its query row 0
+        def spike(tok_q, tok_k, h, gain):
+            qkv[tok_k, Hh + 32 * h: Hh + 32 * h + 32] = gain * qkv[tok_q, 32 * h: 32 * h + 32]
+        if lens[0] == 200:
+            spike(3, 170, 0, 3.0); spike(40, 170, 0, 3.0); spike(77, 199, 0, 4.0); spike(150, 40, 1, 3.5)
+        else:
+            spike(31, 31 + 64, 0, 4.0); spike(31 + 10, 31 + 33, 1, 3.0)
+        qkv = qkv.astype(np.float16)
+        q3 = qkv.astype(np.float64).reshape(tot, 3, heads, 32)
+        ref = np.zeros((tot, Hh))
+        grew = 0
+        for i in range(n):
+            a_, b_ = cu[i], cu[i + 1]
+            for h in range(heads):
+                sc = q3[a_:b_, 0, h] @ q3[a_:b_, 1, h].T / np.sqrt(32)
+                pr = np.exp(sc - sc.max(1, keepdims=True))
+                ref[a_:b_, h * 32:(h + 1) * 32] = (pr / pr.sum(1, keepdims=True)) @ q3[a_:b_, 2, h]
+                s2 = sc * 1.4426950408889634
+                if s2.shape[1] > 32:  # rows whose later tiles exceed the first tile's maximum by more than the threshold: the branch is exercised
+                    grew += int(((s2[:, 32:].max(1) - s2[:, :32].max(1)) > 8.0).sum())
+        assert grew > 0, "the test data does not reach the rescale branch"
+        outs = {}
+        for var in ("0", "1"):  # (where a tile's score MFMAs are issued: 1 = the default)
+            os.environ["LEANN_MI355X_ATTN3"] = var
+            o = np.zeros((tot, Hh), np.float16)
+            _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv), vp(cu), n, heads, int(lens.max()), vp(o), None), "attn v3")
+            err = np.abs(o.astype(np.float64) - ref).max()
+            assert err < 4e-3, (var, lens.tolist(), err)
+            outs[var] = o
+        os.environ.pop("LEANN_MI355X_ATTN3")
+        assert np.array_equal(outs["0"], outs["1"])  # (the same arithmetic in another issue order)
+        os.environ["LEANN_MI355X_ATTN"] = "2"
+        o2 = np.zeros((tot, Hh), np.float16)
+        _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv), vp(cu), n, heads, int(lens.max()), vp(o2), None), "attn v2")
+        os.environ.pop("LEANN_MI355X_ATTN")
+        assert np.abs(o2.astype(np.float64) - ref).max() < 4e-3
+        assert np.abs(o2.astype(np.float32) - outs["1"].astype(np.float32)).max() < 4e-3
+        print(f"attention generation 3, lengths {lens.tolist()}: max |err| vs float64 {max(np.abs(v.astype(np.float64) - ref).max() for v in outs.values()):.2e}, {grew} rows through the rescale branch: ok", flush=True)
+
+
 def case_layer_tail_small():
     """The fused layer tail alone (small enough for the ThreadSanitizer build): every LDS stage hand-over of lm_layer_tail_h384.hip -- the
     six-stage W_o ring with the residual rows behind it, the W1 / W2 rings, the continuous fragment ring, the output tiles -- with real
@@ -661,234 +723,8 @@ CASES = {
     "hub_cache_and_helpers": case_hub_cache_and_helpers,
     "encoder_abi": case_encoder_abi,
     "dims_and_batches": case_dims_and_batches,
+    "attention_v3": case_attention_v3,
 }
-
-def case_rowgemm_ln():
-    """lm_rowgemm_ln_h384_f16 (csrc/lm_rowgemm_ln_h384.hip: row-complete 384-output linear layer + residual + LayerNorm for small forwards)
-    through the C ABI against numpy -- ragged token counts, K = 384 / 768 / 1536, in place, without a residual -- and the small-forward
-    form of the encoder with LEANN_MI355X_SMALL_ROWLN=1: per-kernel path == one-call path bit for bit, fp16-close to the default form."""
-    import os
-    from unittest import mock
-
-    import torch
-
-    from leann_amd import _lib
-    from leann_amd.encoder import BertEncoder, EncoderConfig
-
-    lib = _lib.load()
-    rng = np.random.default_rng(41)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    H = 384
-    for T, K in ((70, 384), (33, 768), (5, 1536)):
-        x = rng.standard_normal((T, K)).astype(np.float16)
-        w = (rng.standard_normal((H, K)) / np.sqrt(K)).astype(np.float16)
-        b = (0.2 * rng.standard_normal(H)).astype(np.float32)
-        res = rng.standard_normal((T, H)).astype(np.float16)
-        gm = (1 + 0.1 * rng.standard_normal(H)).astype(np.float16)
-        bt = (0.1 * rng.standard_normal(H)).astype(np.float16)
-
-        def ref(resid):
-            z = x.astype(np.float64) @ w.astype(np.float64).T + b + (0 if resid is None else resid.astype(np.float64))
-            mu = z.mean(1, keepdims=True)
-            var = ((z - mu) ** 2).mean(1, keepdims=True)
-            return (z - mu) / np.sqrt(var + 1e-12) * gm.astype(np.float64) + bt.astype(np.float64)
-
-        out = np.full((T, H), 7.0, np.float16)
-        _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), K, vp(res), vp(gm), vp(bt), 1e-12, vp(out), T, None), "rowgemm_ln")
-        err = np.abs(out.astype(np.float64) - ref(res)).max()
-        assert err < 6e-3, (T, K, err)
-        inpl = res.copy()  # in place on the residual
-        _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), K, vp(inpl), vp(gm), vp(bt), 1e-12, vp(inpl), T, None), "rowgemm_ln in place")
-        assert np.array_equal(inpl, out), (T, K)
-        o2 = np.zeros((T, H), np.float16)
-        _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), K, None, vp(gm), vp(bt), 1e-12, vp(o2), T, None), "rowgemm_ln no residual")
-        assert np.abs(o2.astype(np.float64) - ref(None)).max() < 6e-3, (T, K)
-    assert lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), 512, vp(res), vp(gm), vp(bt), 1e-12, vp(out), T, None) == -1  # k_in % 384
-    assert lib.lm_rowgemm_ln_h384_f16(vp(x), vp(w), vp(b), 2688, vp(res), vp(gm), vp(bt), 1e-12, vp(out), T, None) == -1  # k_in > 2304
-    # the encoder's small-forward form on it
-    torch.manual_seed(0)
-    cfg = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=384, max_pos=64, max_seq_length=48)
-    e16 = BertEncoder.random_init(cfg, 5).eval().half()
-    n, t = 7, 48
-    lens = rng.integers(1, t + 1, n).astype(np.int32)
-    lens[0], lens[1] = t, 1
-    ids = np.zeros((n, t), np.int32)
-    for i in range(n):
-        ids[i, : lens[i]] = rng.integers(1, cfg.vocab_size, lens[i])
-    ti, tl = torch.from_numpy(ids), torch.from_numpy(lens)
-
-    class _Stream:
-        cuda_stream = 0
-
-    used = []
-    real_check = _lib.check
-
-    def recording_check(rc, what=""):
-        used.append(what)
-        return real_check(rc, what)
-
-    outs = {}
-    for rowln in ("0", "1"):
-        for onecall in ("0", "1"):
-            used.clear()
-            env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
-            env.update({"LEANN_MI355X_ONECALL": onecall, "LEANN_MI355X_SMALL_ROWLN": rowln})
-            with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
-                    mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
-                    mock.patch.object(_lib, "check", new=recording_check):
-                with torch.no_grad():
-                    outs[(rowln, onecall)] = e16.encode_tokens_packed(ti, tl, 4096)
-            if onecall == "0":
-                want = {"lm_rowgemm_ln_h384_f16": 2 * cfg.layers, "lm_add_layernorm_f16": 0, "lm_gemm_f16": 2 * cfg.layers} if rowln == "1" else \
-                    {"lm_rowgemm_ln_h384_f16": 0, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_gemm_f16": 4 * cfg.layers}
-                assert {k: used.count(k) for k in want} == want, (rowln, sorted(set(used)))
-            else:
-                assert used.count("lm_bert_h384_forward_packed") == 1, sorted(set(used))
-    assert torch.equal(outs[("1", "0")], outs[("1", "1")]) and torch.equal(outs[("0", "0")], outs[("0", "1")])
-    d = float((outs[("1", "1")].float() - outs[("0", "1")].float()).abs().max())
-    print(f"row-complete GEMM + LayerNorm: small-forward form with / without it, max|diff| = {d:.2e}", flush=True)
-    assert d < 3e-3, d
-    with torch.no_grad():
-        ref32 = BertEncoder.random_init(cfg, 5).eval()(ti, tl).float()
-    assert float((outs[("1", "1")].float() - ref32).abs().max()) < 6e-3
-    print("lm_rowgemm_ln_h384_f16 through the C ABI and in the small-forward form: ok", flush=True)
-
-
-CASES["rowgemm_ln"] = case_rowgemm_ln
-
-def case_small_layer():
-    """lm_small_layer_h384_f16 (csrc/lm_small_layer_h384.hip: out-projection + LayerNorm + fc1 + GELU + fc2 + LayerNorm and the next layer's QKV
-    projection in one launch, for small forwards) through the C ABI against numpy -- ragged token counts, ffn 384 / 768, with and without the
-    QKV projection, in place -- and the encoder's small-forward form with LEANN_MI355X_SMALL_LAYER=1 (one-call and per-kernel launch paths)
-    against the default small form and the fp32 reference."""
-    import os
-    from unittest import mock
-
-    import torch
-    from scipy.special import erf
-
-    from leann_amd import _lib
-    from leann_amd.encoder import BertEncoder, EncoderConfig
-
-    lib = _lib.load()
-    rng = np.random.default_rng(43)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    H, f64 = 384, np.float64
-
-    def ln(z, gm, bt):
-        mu = z.mean(1, keepdims=True)
-        var = ((z - mu) ** 2).mean(1, keepdims=True)
-        return (z - mu) / np.sqrt(var + 1e-12) * gm.astype(f64) + bt.astype(f64)
-
-    for T, F, with_qkv in ((70, 384, True), (33, 768, False), (5, 768, True), (1, 1536, True), (64, 1152, False)):
-        at, rs = rng.standard_normal((T, H)).astype(np.float16), rng.standard_normal((T, H)).astype(np.float16)
-        wo = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float16)
-        w1 = (rng.standard_normal((F, H)) / np.sqrt(H)).astype(np.float16)
-        w2 = (rng.standard_normal((H, F)) / np.sqrt(F)).astype(np.float16)
-        wq = (rng.standard_normal((1152, H)) / np.sqrt(H)).astype(np.float16)
-        bo, b1, b2, bq = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (H, F, H, 1152)]
-        g1, g2 = [(1 + 0.1 * rng.standard_normal(H)).astype(np.float16) for _ in range(2)]
-        e1, e2 = [(0.1 * rng.standard_normal(H)).astype(np.float16) for _ in range(2)]
-        x1 = ln(rs.astype(f64) + at.astype(f64) @ wo.astype(f64).T + bo, g1, e1).astype(np.float16)
-        hid = x1.astype(f64) @ w1.astype(f64).T + b1
-        p16 = (0.5 * hid * (1 + erf(hid / np.sqrt(2)))).astype(np.float16).astype(f64)
-        x2 = ln(p16 @ w2.astype(f64).T + b2 + x1.astype(f64), g2, e2)
-        out = np.full((T, H), 7.0, np.float16)
-        qkv = np.full((T, 1152), 7.0, np.float16)
-        _lib.check(lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, F,
-                                               vp(out), vp(wq) if with_qkv else None, vp(bq) if with_qkv else None, vp(qkv) if with_qkv else None, T, None),
-                   "small layer")
-        err = np.abs(out.astype(f64) - x2).max()
-        assert err < 1.2e-2, (T, F, err)  # rare 1-ulp flips of the fp16 x1 / GELU outputs move single results
-        if with_qkv:
-            qref = out.astype(f64) @ wq.astype(f64).T + bq  # from the kernel's own fp16 x2
-            assert np.abs(qkv.astype(f64) - qref).max() < 6e-3, (T, F)
-        else:
-            assert (qkv == 7.0).all()
-        inpl = rs.copy()
-        _lib.check(lib.lm_small_layer_h384_f16(vp(at), vp(inpl), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, F,
-                                               vp(inpl), None, None, None, T, None), "small layer in place")
-        assert np.array_equal(inpl, out), (T, F)
-    assert lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, 512,
-                                       vp(out), None, None, None, T, None) == -1  # ffn % 384
-    assert lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g2), vp(e2), 1e-12, F,
-                                       vp(out), vp(wq), None, vp(qkv), T, None) == -1  # QKV weight without its bias
-    # the encoder's small-forward form on it
-    torch.manual_seed(0)
-    cfg = EncoderConfig(vocab_size=500, hidden=384, layers=3, heads=12, ffn=384, max_pos=64, max_seq_length=48)
-    e16 = BertEncoder.random_init(cfg, 5).eval().half()
-    n, t = 7, 48
-    lens = rng.integers(1, t + 1, n).astype(np.int32)
-    lens[0], lens[1] = t, 1
-    ids = np.zeros((n, t), np.int32)
-    for i in range(n):
-        ids[i, : lens[i]] = rng.integers(1, cfg.vocab_size, lens[i])
-    ti, tl = torch.from_numpy(ids), torch.from_numpy(lens)
-
-    class _Stream:
-        cuda_stream = 0
-
-    used = []
-    real_check = _lib.check
-
-    def recording_check(rc, what=""):
-        used.append(what)
-        return real_check(rc, what)
-
-    outs = {}
-    for slayer, onecall in (("0", "1"), ("1", "1"), ("1", "0")):
-        used.clear()
-        env = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
-        env.update({"LEANN_MI355X_ONECALL": onecall, "LEANN_MI355X_SMALL_LAYER": slayer})
-        with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
-                mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env, clear=True), \
-                mock.patch.object(_lib, "check", new=recording_check):
-            with torch.no_grad():
-                outs[(slayer, onecall)] = e16.encode_tokens_packed(ti, tl, 4096)
-        if onecall == "0":  # per-kernel path: QKV GEMM + attention + the fused rest, per layer
-            want = {"lm_small_layer_h384_f16": cfg.layers, "lm_gemm_f16": cfg.layers, "lm_add_layernorm_f16": 0}
-            assert {k: used.count(k) for k in want} == want, sorted(set(used))
-    with torch.no_grad():
-        ref32 = BertEncoder.random_init(cfg, 5).eval()(ti, tl).float()
-    d_default = float((outs[("1", "1")].float() - outs[("0", "1")].float()).abs().max())
-    d_paths = float((outs[("1", "1")].float() - outs[("1", "0")].float()).abs().max())
-    print(f"small-layer kernel: one-call form vs the default small form max|diff| = {d_default:.2e}; vs the per-kernel path (QKV by lm_gemm_f16) {d_paths:.2e}", flush=True)
-    assert d_default < 3e-3 and d_paths < 3e-3, (d_default, d_paths)
-    assert float((outs[("1", "1")].float() - ref32).abs().max()) < 6e-3 and float((outs[("1", "0")].float() - ref32).abs().max()) < 6e-3
-    print("lm_small_layer_h384_f16 through the C ABI and in the small-forward form: ok", flush=True)
-
-
-CASES["small_layer"] = case_small_layer
-
-def case_small_forward_kernels_small():
-    """lm_rowgemm_ln_h384_f16 and lm_small_layer_h384_f16 alone, two workgroups each (small enough for the ThreadSanitizer build): every LDS
-    hand-over of the two kernels -- token tile by DMA, row statistics, x1 / GELU / x2 tiles between the stages -- with real threads per lane."""
-    from leann_amd import _lib
-
-    lib = _lib.load()
-    rng = np.random.default_rng(47)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    H, F, T = 384, 384, 40
-    at, rs = rng.standard_normal((T, H)).astype(np.float16), rng.standard_normal((T, H)).astype(np.float16)
-    wo = (rng.standard_normal((H, H)) / np.sqrt(H)).astype(np.float16)
-    w1 = (rng.standard_normal((F, H)) / np.sqrt(H)).astype(np.float16)
-    w2 = (rng.standard_normal((H, F)) / np.sqrt(F)).astype(np.float16)
-    wq = (rng.standard_normal((1152, H)) / np.sqrt(H)).astype(np.float16)
-    bo, b1, b2, bq = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (H, F, H, 1152)]
-    g1 = (1 + 0.1 * rng.standard_normal(H)).astype(np.float16)
-    e1 = (0.1 * rng.standard_normal(H)).astype(np.float16)
-    out, qkv, o2 = np.zeros((T, H), np.float16), np.zeros((T, 1152), np.float16), np.zeros((T, H), np.float16)
-    _lib.check(lib.lm_small_layer_h384_f16(vp(at), vp(rs), vp(wo), vp(bo), vp(g1), vp(e1), 1e-12, vp(w1), vp(b1), vp(w2), vp(b2), vp(g1), vp(e1), 1e-12, F,
-                                           vp(out), vp(wq), vp(bq), vp(qkv), T, None), "small layer")
-    _lib.check(lib.lm_rowgemm_ln_h384_f16(vp(at), vp(wo), vp(bo), H, vp(rs), vp(g1), vp(e1), 1e-12, vp(o2), T, None), "rowgemm_ln")
-    z = rs.astype(np.float64) + at.astype(np.float64) @ wo.astype(np.float64).T + bo
-    mu = z.mean(1, keepdims=True)
-    ref = (z - mu) / np.sqrt(((z - mu) ** 2).mean(1, keepdims=True) + 1e-12) * g1.astype(np.float64) + e1.astype(np.float64)
-    assert np.abs(o2.astype(np.float64) - ref).max() < 6e-3 and np.isfinite(out.astype(np.float64)).all() and np.abs(qkv).max() > 0
-    print("small-forward kernels (small): ok", flush=True)
-
-
-CASES["small_forward_kernels_small"] = case_small_forward_kernels_small
 
 def case_gemm_f16():
     """lm_gemm_f16 (csrc/lm_gemm_f16.hip: the general linear layer of the hidden-768 path) vs numpy: both tile shapes, every

@@ -132,6 +132,28 @@ inline C mfma_32x32x16(AB a, AB b, C c) {
     w.bar.arrive_and_wait();
     return d;
 }
+// ds_read_b64_tr_b16 (gfx950): every lane names an 8-byte piece (four halfwords); inside each group of 16 lanes, lane l receives
+// halfword l % 4 of the pieces named by lanes l / 4 + 4 k (k = 0..3) of its group.  Restated from a MEASUREMENT: scripts/vopbench.cpp's
+// probe on an MI355X, profiles/r5_vopbench_instruction_costs.jsonl (all 64 lanes match this rule).
+template <class H4>
+inline H4 ds_read_tr16_b64(const void* p) {
+    Wave& w = my_wave();
+    const int lane = my_lane();
+    uint64_t piece;
+    std::memcpy(&piece, p, 8);
+    w.slot[lane] = piece;
+    w.bar.arrive_and_wait();
+    H4 r;
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t src = w.slot[(lane & ~15) + ((lane & 15) >> 2) + 4 * k];
+        const uint16_t bits = (uint16_t)(src >> (16 * (lane & 3)));
+        _Float16 h;
+        std::memcpy(&h, &bits, 2);
+        r[k] = h;
+    }
+    w.bar.arrive_and_wait();
+    return r;
+}
 inline float med3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 
 inline unsigned long long ballot(bool p) {

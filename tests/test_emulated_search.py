@@ -102,7 +102,7 @@ def test_search_kernels_have_no_unmarked_lane_races(emul_dir):
     env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4", OMP_NUM_THREADS="1")
     # (the last case: the built-in recompute provider's kernels and the general-width one-call forward -- GEMM, head_dim-64 attention,
     # LayerNorm, CLS pooling)
-    cases = ["table_mips", "recompute_memo", "pq_deferred", "two_level", "degenerate_graphs", "layer_tail_small", "small_forward_kernels_small", "native_recompute_general_hd64_cls"]
+    cases = ["table_mips", "recompute_memo", "pq_deferred", "two_level", "degenerate_graphs", "layer_tail_small", "attention_v3", "native_recompute_general_hd64_cls"]
     r = subprocess.run([sys.executable, "-m", "tests.emulated_search_cases", str(lib), *cases], cwd=str(ROOT), capture_output=True,
                        text=True, timeout=3000, env=env)
     out = r.stdout + r.stderr

@@ -45,18 +45,70 @@ def _attention_case(torch, heads, maxlen, nseq=37):
 
 @pytest.mark.parametrize("heads,maxlen", [(12, 256), (12, 255), (12, 200), (12, 70), (12, 64), (4, 33), (4, 32), (2, 2), (2, 1)])
 def test_attention_matches_fp32_reference(heads, maxlen, monkeypatch):
-    """lm_attn_v2.hip vs a plain PyTorch fp32 reference of the same op."""
+    """The head_dim-32 attention kernels vs a plain PyTorch fp32 reference of the same op: generation 3 (csrc/lm_attn_v3.hip, the default;
+    both issue orders of its score MFMAs, LEANN_MI355X_ATTN3 = 0 / 1) and generation 2 (csrc/lm_attn_v2.hip, LEANN_MI355X_ATTN=2)."""
     import torch
 
     from leann_amd.encoder import fused_attention_hd32
 
     qkv, cu, mx, ref = _attention_case(torch, heads, maxlen)
-    o2 = fused_attention_hd32(qkv, cu, heads, mx)
-    torch.cuda.synchronize()
-    assert o2 is not None and o2.shape == ref.shape
-    assert not torch.isnan(o2).any()
-    err = (o2.float() - ref).abs().max().item()
-    assert err < 4e-3, err
+    for env in ({}, {"LEANN_MI355X_ATTN3": "0"}, {"LEANN_MI355X_ATTN3": "1"}, {"LEANN_MI355X_ATTN": "2"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        o2 = fused_attention_hd32(qkv, cu, heads, mx)
+        torch.cuda.synchronize()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert o2 is not None and o2.shape == ref.shape
+        assert not torch.isnan(o2).any(), env
+        err = (o2.float() - ref).abs().max().item()
+        # generations 3 / 4 round Q a second time (f16(q x scale x log2 e) is the score MFMA's operand): +40 % on generation 2's error on these
+        # inputs (|q|, |k| ~ 1.5: logits of +-11 in log2 units), still fp16-level
+        assert err < (4e-3 if env.get("LEANN_MI355X_ATTN") == "2" else 6e-3), (env, err)
+
+
+def test_attention_rescale_branch_and_masked_maximum(monkeypatch):
+    """Generation 3 defers the running maximum (a tile may exceed it by 2^8 before O is rescaled): the rescale branch is rare and data
+    dependent, so it gets inputs that force it -- keys in LATER tiles (one of them in the masked last tile) whose scores exceed everything
+    before them by far, for some query rows only -- and a count of the rows that take it.  fp32 torch reference; both issue orders."""
+    import torch
+
+    from leann_amd.encoder import fused_attention_hd32
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    heads, lens = 12, torch.tensor([200, 1, 33, 256, 97, 180], dtype=torch.int64)
+    cu = torch.zeros(lens.shape[0] + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    tot, H = int(cu[-1]), heads * 32
+    qkv = torch.randn((tot, 3 * H), generator=g) * 1.2
+
+    def spike(tok_q, tok_k, h, gain):
+        qkv[tok_k, H + 32 * h: H + 32 * h + 32] = gain * qkv[tok_q, 32 * h: 32 * h + 32]
+
+    spike(3, 170, 0, 3.0); spike(40, 170, 0, 3.0); spike(77, 199, 0, 4.0); spike(150, 40, 1, 3.5)
+    b3 = int(cu[3])
+    spike(b3 + 10, b3 + 255, 5, 4.0); spike(b3 + 200, b3 + 129, 7, 3.0); spike(b3 + 31, b3 + 32, 11, 5.0)
+    qkv = qkv.half().cuda()
+    q3 = qkv.float().view(tot, 3, heads, 32)
+    ref = torch.empty((tot, H), device="cuda")
+    grew = 0
+    for i in range(lens.shape[0]):
+        a, b = int(cu[i]), int(cu[i + 1])
+        q, k, v = (q3[a:b, j].transpose(0, 1) for j in range(3))
+        sc = q @ k.transpose(1, 2) / 32**0.5
+        ref[a:b] = (torch.softmax(sc, dim=-1) @ v).transpose(0, 1).reshape(b - a, H)
+        if b - a > 32:
+            s2 = sc * 1.4426950408889634
+            grew += int(((s2[:, :, 32:].max(-1).values - s2[:, :, :32].max(-1).values) > 8.0).sum())
+    assert grew >= 5
+    for var in ("0", "1"):
+        monkeypatch.setenv("LEANN_MI355X_ATTN3", var)
+        o = fused_attention_hd32(qkv, cu.cuda(), heads, 256)
+        torch.cuda.synchronize()
+        assert not torch.isnan(o).any(), var
+        err = (o.float() - ref).abs().max().item()
+        assert err < 5e-3, (var, err)
+    monkeypatch.delenv("LEANN_MI355X_ATTN3")
 
 
 def test_encoder_forward_with_and_without_the_attention_kernel(monkeypatch):
@@ -320,128 +372,6 @@ def test_linear_h384_qkv_and_out_projection(tokens, gen, monkeypatch):
     torch.cuda.synchronize()
     monkeypatch.setenv("LEANN_MI355X_LINEAR", "0")
     assert fused_linear_h384(x, qkv) is None
-
-
-# (the three small-forward features below first ran on an MI355X in the driver's round-4 GPU test tier -- 17 XPASS, GPUTEST_r04.json -- the
-# xfail markers they carried until then are gone)
-
-
-@pytest.mark.parametrize("tokens", [1, 33, 700, 5000])
-@pytest.mark.parametrize("k_in", [384, 1536])
-def test_rowgemm_ln_h384(tokens, k_in, monkeypatch):
-    """lm_rowgemm_ln_h384_f16 (row-complete 384-output linear layer + residual + LayerNorm for small forwards; LEANN_MI355X_SMALL_ROWLN=1) vs a
-    plain PyTorch fp32 reference of the same ops and vs the two launches it replaces (lm_gemm_f16 + lm_add_layernorm_f16)."""
-    import torch
-    import torch.nn as nn
-    import torch.nn.functional as F
-
-    from leann_amd.encoder import GEMM_EPI_RESIDUAL, fused_add_layernorm, fused_gemm, fused_rowgemm_ln
-
-    torch.manual_seed(tokens + k_in)
-    lin = nn.Linear(k_in, 384).to("cuda", dtype=torch.float16)
-    ln = nn.LayerNorm(384, eps=1e-12).to("cuda", dtype=torch.float16)
-    with torch.no_grad():
-        ln.weight.copy_(1 + 0.1 * torch.randn(384))
-        ln.bias.copy_(0.1 * torch.randn(384))
-        lin.bias.copy_(0.2 * torch.randn(384))
-    x = torch.randn((tokens, k_in), device="cuda").half()
-    res = torch.randn((tokens, 384), device="cuda").half()
-    assert fused_rowgemm_ln(x, lin, res, ln) is None  # off by default
-    monkeypatch.setenv("LEANN_MI355X_SMALL_ROWLN", "1")
-    with torch.no_grad():
-        got = fused_rowgemm_ln(x, lin, res, ln)
-        assert got is not None and got.shape == (tokens, 384) and got.dtype == torch.float16
-        ref = F.layer_norm(res.float() + x.float() @ lin.weight.float().t() + lin.bias.float(), (384,), ln.weight.float(), ln.bias.float(), 1e-12)
-        two = fused_add_layernorm(fused_gemm(x, lin, GEMM_EPI_RESIDUAL, res), None, ln)
-    torch.cuda.synchronize()
-    assert not torch.isnan(got).any()
-    scale = max(1.0, float(ref.abs().max()))
-    assert (got.float() - ref).abs().max().item() <= 6e-3 * scale
-    assert (got.float() - two.float()).abs().max().item() <= 8e-3 * scale  # the two-launch form rounds the pre-LayerNorm row to fp16 first
-
-
-def test_small_forward_with_and_without_the_rowgemm_ln_kernel(monkeypatch):
-    """The small-forward form of the MiniLM-shape encoder (a one-query round's handful of chunks) with LEANN_MI355X_SMALL_ROWLN=1: one-call and
-    per-kernel launch paths bit-identical, fp16-close to the default small form."""
-    import torch
-
-    from leann_amd.encoder import BertEncoder, config_for
-    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
-
-    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
-    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=24, n_topics=4)).chunks(), 256)
-    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
-    base = enc.encode_tokens_packed(ti, tl)
-    monkeypatch.setenv("LEANN_MI355X_SMALL_ROWLN", "1")
-    one = enc.encode_tokens_packed(ti, tl)
-    monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
-    per = enc.encode_tokens_packed(ti, tl)
-    assert torch.equal(one, per) and not torch.isnan(one).any()
-    assert (one - base).abs().max().item() <= 3e-3
-
-
-@pytest.mark.parametrize("tokens,ffn,with_qkv", [(1, 1536, True), (33, 1536, True), (700, 1536, False), (5000, 1536, True), (300, 384, True), (300, 768, False)])
-def test_small_layer_h384(tokens, ffn, with_qkv, monkeypatch):
-    """lm_small_layer_h384_f16 (out-projection + LayerNorm + fc1 + GELU + fc2 + LayerNorm and the next layer's QKV projection in one launch, for
-    small forwards; LEANN_MI355X_SMALL_LAYER=1) vs a plain PyTorch fp32 reference of the same ops and vs the default small form."""
-    import torch
-    import torch.nn as nn
-    import torch.nn.functional as F
-
-    from leann_amd.encoder import GEMM_EPI_GELU, GEMM_EPI_RESIDUAL, EncoderConfig, _Layer, fused_add_layernorm, fused_gemm, fused_small_layer
-
-    torch.manual_seed(tokens + ffn)
-    layer = _Layer(EncoderConfig(hidden=384, layers=1, heads=12, ffn=ffn)).to("cuda", dtype=torch.float16)
-    nq = nn.Linear(384, 1152).to("cuda", dtype=torch.float16) if with_qkv else None
-    with torch.no_grad():
-        for ln in (layer.ln1, layer.ln2):
-            ln.weight.copy_(1 + 0.1 * torch.randn(384))
-            ln.bias.copy_(0.1 * torch.randn(384))
-        layer.out.bias.copy_(0.2 * torch.randn(384))
-        layer.fc1.bias.copy_(0.2 * torch.randn(ffn))
-        layer.fc2.bias.copy_(0.2 * torch.randn(384))
-    a = torch.randn((tokens, 384), device="cuda").half()
-    res = torch.randn((tokens, 384), device="cuda").half()
-    assert fused_small_layer(a, res, layer) is None  # off by default
-    monkeypatch.setenv("LEANN_MI355X_SMALL_LAYER", "1")
-    with torch.no_grad():
-        got = fused_small_layer(a, res, layer, nq)
-        assert got is not None
-        x2, qkv = got if with_qkv else (got, None)
-        x1 = F.layer_norm(res.float() + a.float() @ layer.out.weight.float().t() + layer.out.bias.float(), (384,), layer.ln1.weight.float(),
-                          layer.ln1.bias.float(), layer.ln1.eps).half().float()
-        hid = F.gelu(x1 @ layer.fc1.weight.float().t() + layer.fc1.bias.float()).half().float()
-        ref = F.layer_norm(x1 + hid @ layer.fc2.weight.float().t() + layer.fc2.bias.float(), (384,), layer.ln2.weight.float(), layer.ln2.bias.float(), layer.ln2.eps)
-        # the default small form: five launches
-        y1 = fused_add_layernorm(fused_gemm(a, layer.out, GEMM_EPI_RESIDUAL, res), None, layer.ln1)
-        five = fused_add_layernorm(fused_gemm(fused_gemm(y1, layer.fc1, GEMM_EPI_GELU), layer.fc2, GEMM_EPI_RESIDUAL, y1), None, layer.ln2)
-    torch.cuda.synchronize()
-    assert x2.shape == (tokens, 384) and x2.dtype == torch.float16 and not torch.isnan(x2).any()
-    scale = max(1.0, float(ref.abs().max()))
-    assert (x2.float() - ref).abs().max().item() <= 1.2e-2 * scale
-    assert (x2.float() - five.float()).abs().max().item() <= 1.5e-2 * scale
-    if with_qkv:
-        qref = x2.float() @ nq.weight.float().t() + nq.bias.float()
-        assert qkv.shape == (tokens, 1152) and (qkv.float() - qref).abs().max().item() <= 4e-3 * max(1.0, float(qref.abs().max()))
-
-
-def test_small_forward_with_the_small_layer_kernel(monkeypatch):
-    """The small-forward form of the MiniLM-shape encoder with LEANN_MI355X_SMALL_LAYER=1 (2 launches per layer in the one-call path): fp16-close
-    to the default small form and to the per-kernel path (which computes the QKV projection with lm_gemm_f16)."""
-    import torch
-
-    from leann_amd.encoder import BertEncoder, config_for
-    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
-
-    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16)
-    ids, lens = pad_batch(*SyntheticCorpus(CorpusSpec(n_chunks=24, n_topics=4)).chunks(), 256)
-    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
-    base = enc.encode_tokens_packed(ti, tl)
-    monkeypatch.setenv("LEANN_MI355X_SMALL_LAYER", "1")
-    one = enc.encode_tokens_packed(ti, tl)
-    monkeypatch.setenv("LEANN_MI355X_ONECALL", "0")
-    per = enc.encode_tokens_packed(ti, tl)
-    assert not torch.isnan(one).any() and (one - base).abs().max().item() <= 3e-3 and (one - per).abs().max().item() <= 3e-3
 
 
 def test_pack_tokens_front_end(monkeypatch):
