@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed GPU-vs-oracle parity check on the benchmark's own index")
     ap.add_argument("--no-latency-rows", action="store_true", help="skip the small-batch (B = 1, 16, 64, 256) latency rows and value_by_batch")
     ap.add_argument("--no-provider-ab", action="store_true", help="skip the extra full-size step over the Python form of the provider")
+    ap.add_argument("--extra-batches", default="", help="comma-separated batch sizes: one extra search call each on fresh queries after the timed steps (library defaults), "
+                    "reported as extra_batch_rows -- e.g. 128 = the per-rank batch of C5 (query batch 1024) on 8 GPUs")
     ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
     ap.add_argument("--dry-run-emulated", default=None, metavar="LIB",
                     help="TEST ONLY (tests/test_bench_dry_run.py): run this script's control flow -- incl. every world > 1 branch, over gloo -- on the CPU against "
@@ -515,6 +517,28 @@ def _main(args, ap):
                 value_by_batch.append(row)
         except Exception as ex:  # noqa: BLE001
             extras_errors["value_by_batch"] = repr(ex)[:300]
+    extra_batch_rows = None
+    if world == 1 and args.extra_batches:
+        try:
+            extra_batch_rows = []
+            for b in (int(v) for v in args.extra_batches.split(",") if v):
+                lo_ = B * (K + W + 5)  # the latency rows' block of fresh queries
+                if lo_ + 2 * b > Q.shape[0]:
+                    continue
+                pb = idx.make_params(ef=ef, beam=args.beam, recompute=True, max_batch=b)
+                idx.search_device(Q[lo_ + b : lo_ + 2 * b].contiguous(), 10, pb)  # warm-up of this batch size (workspace sizing), other queries
+                qb = Q[lo_ : lo_ + b].contiguous()
+                torch.cuda.synchronize()
+                t1_ = time.perf_counter()
+                _, lx = idx.search_device(qb, 10, pb)
+                torch.cuda.synchronize()
+                e_ = time.perf_counter() - t1_
+                st_ = idx.stats()
+                extra_batch_rows.append({"batch": b, "queries_per_s": round(b / e_, 3), "ms": round(1e3 * e_, 1), "recall_at_10": round(recall(lx.cpu().numpy(), range(lo_, lo_ + b)), 4),
+                                         "recomputed_chunks_per_query": round(st_["nunique"] / b, 1), "rounds": int(st_["nrounds"]), "steps": 1,
+                                         "note": "one call after one warm-up call of the same batch size on other queries"})
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["extra_batch_rows"] = repr(ex)[:300]
     if world == 1 and not args.no_parity_check:
         try:
             t1 = time.time()
@@ -677,6 +701,8 @@ def _main(args, ap):
                  "TFLOPs": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1) if v["work"] and v["ms"] else None}
             for k_, v in kprof.items() if v["launches"]}
         result["encoder_kernels_profiled_step"]["instrumented_ms_of_step_ms"] = [round(tot_ms, 1), round(prof_step_s * 1e3, 1)]
+    if extra_batch_rows:
+        result["extra_batch_rows"] = extra_batch_rows
     if parity:
         result["parity_check"] = parity
     if table_roof:

@@ -50,6 +50,16 @@ __device__ __forceinline__ half4 a3_lds_read_tr16(const unsigned char* p) {
 #endif
 }
 
+#if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
+// diagnosis library only (scripts/build_kbench.sh; kbench `attnstamp`): VAR 2 = issue order 0 with s_memtime stamps, per-wave phase sums
+__device__ unsigned long long g_a3_stamps[16];
+#define A3_STAMPS 1
+#define A3_NOW() (VAR == 2 ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define A3_STAMPS 0
+#define A3_NOW() 0ull
+#endif
+
 constexpr float A3_THR = 8.0f;  // a tile may exceed the running maximum by 2^8 before O is rescaled (P <= 256: exact in fp16's range)
 
 // NT = number of 32-key tiles the launch's longest sequence needs (max_len <= 32 NT), 1..8.  VAR: where a tile's score MFMAs are issued (see the
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
     const int tok0 = cu[seq];
     const int len = cu[seq + 1] - tok0;
     if (len <= 0) return;
+    [[maybe_unused]] const unsigned long long ts0 = A3_NOW();
     const int H = heads * 32;
     const int rsb = 6 * H;  // bytes per token row of qkv
     constexpr int Tp = 32 * NT;
@@ -106,8 +117,12 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
         qraw[qi][0] = qrow < len ? q0 : z;
         qraw[qi][1] = qrow < len ? q1 : z;
     }
+    [[maybe_unused]] const unsigned long long ts1 = A3_NOW();
     T4_WAIT_VM(0);  // this wave's DMA pieces have landed ...
+    [[maybe_unused]] const unsigned long long ts2 = A3_NOW();
     __syncthreads();  // ... and everybody else's
+    [[maybe_unused]] const unsigned long long ts3 = A3_NOW();
+    [[maybe_unused]] unsigned long long tacc_setup = 0, tacc_loop = 0, tacc_epi = 0, nqb_done = 0;
 
     // per-lane LDS offsets: K fragment (row r31 of a tile, chunk 2 ks + g at its swizzled position), V transposing read (16-lane group:
     // rows 4 g + (lane % 16) / 4 of an 8-key half step, 8-byte piece (lane % 4) of column half (lane / 16) % 2)
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
         const int qb = wv + 4 * qi;
         if (qb >= nt) break;
         const int qrow = 32 * qb + r31;
+        [[maybe_unused]] const unsigned long long tq0 = A3_NOW();
         half8 qf0, qf1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -151,9 +167,10 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf0, cm, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf1, s, 0, 0, 0);
         }
+        [[maybe_unused]] const unsigned long long tq1 = A3_NOW();
         for (int t = 0; t < nt; ++t) {
             const bool more = t + 1 < nt;
-            if constexpr (VAR == 0) {
+            if constexpr (VAR != 1) {
                 if (t > 0) {
                     const half8 k0 = *(const half8*)(kf0 + 2048 * t), k1 = *(const half8*)(kf1 + 2048 * t);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf0, cm, 0, 0, 0);
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, p0, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, p1, o, 0, 0, 0);
         }
+        [[maybe_unused]] const unsigned long long tq2 = A3_NOW();
         float l = l2[0] + l2[1];
         {
             uint32_t a = __builtin_bit_cast(uint32_t, l), b = a;
@@ -237,10 +255,45 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
                 *(half4*)(orow + 8 * r4 + 4 * g) = w;
             }
         }
+        if constexpr (A3_STAMPS && VAR == 2) {
+            const unsigned long long tq3 = A3_NOW();
+            tacc_setup += tq1 - tq0;
+            tacc_loop += tq2 - tq1;
+            tacc_epi += tq3 - tq2;
+            nqb_done += 1;
+        }
     }
+#if A3_STAMPS
+    if constexpr (VAR == 2) {
+        if (lane == 0) {
+            const unsigned long long te = __builtin_amdgcn_s_memtime();
+            atomicAdd(g_a3_stamps + 0, ts1 - ts0);   // entry -> DMA pieces and Q loads issued
+            atomicAdd(g_a3_stamps + 1, ts2 - ts1);   // -> own DMA pieces landed
+            atomicAdd(g_a3_stamps + 2, ts3 - ts2);   // -> barrier passed
+            atomicAdd(g_a3_stamps + 3, tacc_setup);  // per query block: Q prescale, accumulator set-up, first score MFMAs issued
+            atomicAdd(g_a3_stamps + 4, tacc_loop);   // tile loops
+            atomicAdd(g_a3_stamps + 5, tacc_epi);    // normalisation + stores issued
+            atomicAdd(g_a3_stamps + 6, nqb_done);
+            atomicAdd(g_a3_stamps + 7, (unsigned long long)(nqb_done * (unsigned long long)nt));  // tiles
+            atomicAdd(g_a3_stamps + 8, 1ull);        // waves
+            atomicAdd(g_a3_stamps + 9, te - ts0);    // wave lifetime from the first stamp on
+        }
+    }
+#endif
 }
 
 }  // namespace lm
+
+#if defined(LM_DIAG) && !defined(LM_HOST_EMULATION) && !defined(LM_EMULATED_DEVICE)
+extern "C" int lm_attn_v3_stamps_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lm::g_a3_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return LM_EHIP;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lm::g_a3_stamps), z, sizeof(z)) != hipSuccess) return LM_EHIP;
+    }
+    return LM_OK;
+}
+#endif
 
 #ifndef LM_HOST_EMULATION
 // launched by lm_attn_v2.hip's attn_v2_launch_hd<32> (the default of head_dim 32 since round 5; LEANN_MI355X_ATTN=2 = generation 2)
@@ -258,14 +311,21 @@ int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32
     kt_attn_work(d_cu_seqlens, n_seqs, heads * 32, stream);  // the flops depend on the sequence lengths (device memory): summed there
     KtScope kt(LM_KT_ATTN, stream, 0.0);
     const char* ve = getenv("LEANN_MI355X_ATTN3");  // A/B of the two issue orders (0 / 1); default 1
-    const int var = (ve && ve[0] == '0') ? 0 : 1;
-    switch (nt * 2 + var) {
+    int var = (ve && ve[0] == '0') ? 0 : 1;
+#if A3_STAMPS
+    if (ve && ve[0] == '2') var = 2;
+#define A3_CASE2(n) CASEV(n, 2);
+#else
+#define A3_CASE2(n)
+#endif
+    switch (nt * 4 + var) {
 #define CASEV(n, v) \
-    case n * 2 + v: hipLaunchKernelGGL((k_attn_varlen_hd32_v3<n, v>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
-#define CASEA(n) CASEV(n, 0); CASEV(n, 1)
+    case n * 4 + v: hipLaunchKernelGGL((k_attn_varlen_hd32_v3<n, v>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
+#define CASEA(n) CASEV(n, 0); CASEV(n, 1); A3_CASE2(n)
         CASEA(1); CASEA(2); CASEA(3); CASEA(4); CASEA(5); CASEA(6); CASEA(7); CASEA(8);
 #undef CASEA
 #undef CASEV
+#undef A3_CASE2
         default: LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
     }
     LM_HIP(hipGetLastError());

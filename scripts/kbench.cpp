@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attn64|ln|gemmf16|gemmstamp]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attnstamp|attn64|ln|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "leann_mi355x.h"
+extern "C" int lm_attn_v3_stamps_read(unsigned long long* out16, int reset);  // diagnosis library only (csrc/lm_attn_v3.hip)
 
 // generation 3 of the fused layer tail: only in the diagnosis build of the library (csrc/diag/lm_mlp_fused_v3.hip), as the `tail` / `tail4`
 // modes' A/B reference; operands: W_o as [12][384][32] slabs, W1 with its columns in accumulator order, W2 as [ffn/32][384][32] slabs
@@ -586,6 +587,36 @@ int main(int argc, char** argv) {
             }
         unsetenv("LEANN_MI355X_ATTN3");
         unsetenv("LEANN_MI355X_ATTN_XCD");
+    }
+    if (want("attnstamp")) {
+        // s_memtime stamps of lm_attn_v3.hip (diagnosis library, LEANN_MI355X_ATTN3=2 = issue order 0 + stamps): where a wave's time goes
+        const int heads = 12;
+        std::mt19937 g(5);
+        std::normal_distribution<float> d(180.f, 50.f);
+        std::vector<int> cu{0};
+        while (true) {
+            int len = std::min(256, std::max(16, (int)lroundf(d(g))));
+            if (cu.back() + len > T) break;
+            cu.push_back(cu.back() + len);
+        }
+        const int ns = (int)cu.size() - 1, tot = cu.back();
+        Dev<int> dcu(cu);
+        Dev<__half> qkv(rand_half((size_t)tot * 3 * H, 1.0f, 40)), out((size_t)tot * H);
+        setenv("LEANN_MI355X_ATTN3", "2", 1);
+        auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };
+        run();
+        CK(hipStreamSynchronize(st));
+        unsigned long long z[16];
+        LM(lm_attn_v3_stamps_read(z, 1));
+        const float us = time_us(st, reps, run);
+        LM(lm_attn_v3_stamps_read(z, 1));
+        unsetenv("LEANN_MI355X_ATTN3");
+        const double w = (double)z[8], qb = (double)z[6], tl = (double)z[7];
+        printf("{\"kernel\": \"lm_attn_v3 stamps (issue order 0)\", \"us\": %.1f, \"waves\": %.0f, \"query_blocks\": %.0f, \"tiles\": %.0f, \"mean_cycles_per_wave\": {\"lifetime\": %.0f, "
+               "\"entry_to_requests_issued\": %.0f, \"own_dma_landed\": %.0f, \"barrier\": %.0f, \"query_block_setup_total\": %.0f, \"tile_loops_total\": %.0f, \"epilogues_total\": %.0f}, "
+               "\"mean_cycles\": {\"per_query_block_setup\": %.0f, \"per_tile\": %.0f, \"per_query_block_epilogue\": %.0f}}\n",
+               us, w / (reps + 0.0), qb / reps, tl / reps, z[9] / w, z[0] / w, z[1] / w, z[2] / w, z[3] / w, z[4] / w, z[5] / w, z[3] / qb, z[4] / tl, z[5] / qb);
+        fflush(stdout);
     }
     if (want("ln")) {
         Dev<__half> out((size_t)T * H);
