@@ -51,10 +51,11 @@ __device__ __forceinline__ half4 a3_lds_read_tr16(const unsigned char* p) {
 }
 
 #if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
-// diagnosis library only (scripts/build_kbench.sh; kbench `attnstamp`): VAR 2 = issue order 0 with s_memtime stamps, per-wave phase sums
-__device__ unsigned long long g_a3_stamps[16];
+// diagnosis library only (scripts/build_kbench.sh; kbench `a3stamps`): VAR 2 = issue order 0 with s_memtime stamps, per-wave phase sums
+constexpr int A3_STAMP_WAVES = 1 << 17, A3_STAMP_WORDS = 12;
+__device__ unsigned long long g_a3_stamps[A3_STAMP_WAVES * A3_STAMP_WORDS];  // one record per wave (a shared counter serialises the launch: ~12 ns per atomic)
 #define A3_STAMPS 1
-#define A3_NOW() (VAR == 2 ? __builtin_amdgcn_s_memtime() : 0ull)
+#define A3_NOW() ((VAR & 4) ? __builtin_amdgcn_s_memtime() : 0ull)
 #else
 #define A3_STAMPS 0
 #define A3_NOW() 0ull
@@ -62,8 +63,8 @@ __device__ unsigned long long g_a3_stamps[16];
 
 constexpr float A3_THR = 8.0f;  // a tile may exceed the running maximum by 2^8 before O is rescaled (P <= 256: exact in fp16's range)
 
-// NT = number of 32-key tiles the launch's longest sequence needs (max_len <= 32 NT), 1..8.  VAR: where a tile's score MFMAs are issued (see the
-// tile loop; A/B on hardware with LEANN_MI355X_ATTN3 = 0 / 1)
+// NT = number of 32-key tiles the launch's longest sequence needs (max_len <= 32 NT), 1..8.  VAR: 0 = the kernel; 4 = the same with phase stamps
+// (diagnosis library only: kbench a3stamps)
 template <int NT, int VAR>
 __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                                 __half* __restrict__ out, int heads, float scale_log2e, int n_units) {
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
     const unsigned char* base = (const unsigned char*)qkv + (int64_t)tok0 * rsb + h * 64;
 
     // ---- K and V rows -> LDS by DMA: instruction j covers rows 16 j .. 16 j + 15 (lane l: row 16 j + l / 4, chunk position l % 4);
-    //      rows past the sequence end repeat the last row (finite values; their scores are masked, their P is exactly 0) ----
+    //      rows past the sequence end repeat the last row (finite values; their scores are masked, their P is exactly 0).
+    //      (Measured equal and dropped: staging through registers -- global_load_dwordx4 x NT per thread, then ds_write_b128; the stamps
+    //      show requests issued in 2.5 k instead of 4.9 k cycles and landed 1.9 k later: the same ~7.3 k from entry to the barrier.)
     {
         const unsigned char* kbase = base + 2 * H;  // K of this head
         const unsigned char* vbase = base + 4 * H;  // V of this head
@@ -152,15 +155,13 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
             cm[r] = 0.f;
             o[r] = 0.f;
         }
-        float2v l2 = {0.f, 0.f};  // row sum of this lane's keys (two partial sums)
+        float2v l2 = {0.f, 0.f}, l2b = {0.f, 0.f};  // row sum of this lane's keys (four partial sums: two independent accumulation chains)
 
         // one tile of the online softmax: keys 32 t .. 32 t + 31 against the wave's 32 query rows.  s holds the tile's scores S'^T (keys x q:
-        // lane (q = r31, g), register r <-> key 32 t + (r & 3) + 8 (r >> 2) + 4 g) when the tile starts.
-        //   VAR 0 (the form first measured, 271-277 us per 262k tokens): the tile's score MFMAs are issued at its top;
-        //   VAR 1: the NEXT tile's K fragments are read at the top, and its two score MFMAs are issued right behind this tile's exponentials,
-        //   INTO THE SAME REGISTERS (the scores have just been consumed into P) and BEFORE this tile's two P V MFMAs: the dependent MFMA pair
-        //   (2 x 16 passes) and the LDS round trip complete under the P V MFMAs and the next tile's fragment reads instead of in front of its
-        //   row maximum -- no second score tuple (the two-tuple form cost 46 registers and a wave per SIMD, and lost: 288 us).
+        // lane (q = r31, g), register r <-> key 32 t + (r & 3) + 8 (r >> 2) + 4 g).  (Measured and dropped in round 5: the next tile's score MFMAs
+        // issued behind this tile's exponentials into the same registers -- 278 vs 271 us; two score tuples -- 288 us, a wave per SIMD less.)
+        // (Measured and dropped as well: row sums on the matrix pipe -- l^T += 1 P^T with an all-ones A operand instead of eight v_pk_add_f32 per
+        // tile: 284-297 vs 270-283 us.)
         float16v s;
         {
             const half8 k0 = *(const half8*)kf0, k1 = *(const half8*)kf1;
@@ -170,32 +171,28 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
         [[maybe_unused]] const unsigned long long tq1 = A3_NOW();
         for (int t = 0; t < nt; ++t) {
             const bool more = t + 1 < nt;
-            if constexpr (VAR != 1) {
-                if (t > 0) {
-                    const half8 k0 = *(const half8*)(kf0 + 2048 * t), k1 = *(const half8*)(kf1 + 2048 * t);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf0, cm, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf1, s, 0, 0, 0);
-                }
+            if (t > 0) {
+                const half8 k0 = *(const half8*)(kf0 + 2048 * t), k1 = *(const half8*)(kf1 + 2048 * t);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf0, cm, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf1, s, 0, 0, 0);
             }
             // V^T fragments of this tile: k-step u, slots 0..3 = keys 16 u + 4 g + {0..3}, slots 4..7 = keys 16 u + 8 + 4 g + {0..3}
             const unsigned char* vt = vf + 2048 * t;
             const half4 va0 = a3_lds_read_tr16(vt), vb0 = a3_lds_read_tr16(vt + 512), va1 = a3_lds_read_tr16(vt + 1024), vb1 = a3_lds_read_tr16(vt + 1536);
-            const int tn = more ? t + 1 : t;  // (the last tile requests its own fragments again: no branch around the reads / MFMAs below)
-            half8 kn0, kn1;
-            if constexpr (VAR == 1) {
-                kn0 = *(const half8*)(kf0 + 2048 * tn);
-                kn1 = *(const half8*)(kf1 + 2048 * tn);
-            }
             if (!more && tail) {  // keys past the sequence end (last tile only): s = min(s, (lenv - kc - 0.5) x 1e30), kc = the register's key offset
                 float lb = (lenv - 0.5f) * 1.0e30f;
                 LM_KEEP_LOCAL(lb);  // (the sixteen limits are recomputed here: hoisted out of the loops they would hold sixteen registers)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_fmed3f(s[r], lb - (float)((r & 3) + 8 * (r >> 2)) * 1.0e30f, -3.0e38f);
             }
-            float tm = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) tm = fmaxf(fmaxf(tm, s[r]), s[r + 1]);
-            tm = fmaxf(tm, s[15]);
+            // row maximum as a TREE of v_max3 (depth 3, not a chain of eight): a wave alone issues one VALU instruction per ~7 cycles when they are
+            // independent and waits ~12 per link of a dependent chain -- the stamps put a tile at 733 cycles for ~62 instructions
+            float tm;
+            {
+                const float m0 = fmaxf(fmaxf(s[0], s[1]), s[2]), m1 = fmaxf(fmaxf(s[3], s[4]), s[5]), m2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
+                const float m3 = fmaxf(fmaxf(s[9], s[10]), s[11]), m4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
+                tm = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), s[15]));
+            }
             {
                 uint32_t a = __builtin_bit_cast(uint32_t, tm), b = a;
                 lane32_swap(a, b);
@@ -209,6 +206,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[r] *= alpha;
                     l2 *= (float2v){alpha, alpha};
+                    l2b *= (float2v){alpha, alpha};
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -222,15 +220,11 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
                 const float2v e0 = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
                 const float2v e1 = {__builtin_amdgcn_exp2f(s[8 + r]), __builtin_amdgcn_exp2f(s[9 + r])};
                 l2 += e0;
-                l2 += e1;
+                l2b += e1;
                 p0[r] = (_Float16)e0[0];
                 p0[r + 1] = (_Float16)e0[1];
                 p1[r] = (_Float16)e1[0];
                 p1[r + 1] = (_Float16)e1[1];
-            }
-            if constexpr (VAR == 1) {  // the next tile's scores (the running reference cm is final for this tile: no fix-up later)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kn0, qf0, cm, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kn1, qf1, s, 0, 0, 0);
             }
             // O^T += V^T P^T : A = V^T (m = d), B = P^T (n = q); k-slots <-> the keys the lane's P registers belong to
             const half8 v0 = {va0[0], va0[1], va0[2], va0[3], vb0[0], vb0[1], vb0[2], vb0[3]};
@@ -239,7 +233,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, p1, o, 0, 0, 0);
         }
         [[maybe_unused]] const unsigned long long tq2 = A3_NOW();
-        float l = l2[0] + l2[1];
+        float l = (l2[0] + l2[1]) + (l2b[0] + l2b[1]);
         {
             uint32_t a = __builtin_bit_cast(uint32_t, l), b = a;
             lane32_swap(a, b);
@@ -255,7 +249,7 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
                 *(half4*)(orow + 8 * r4 + 4 * g) = w;
             }
         }
-        if constexpr (A3_STAMPS && VAR == 2) {
+        if constexpr (A3_STAMPS && (VAR & 4) != 0) {
             const unsigned long long tq3 = A3_NOW();
             tacc_setup += tq1 - tq0;
             tacc_loop += tq2 - tq1;
@@ -264,19 +258,22 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
         }
     }
 #if A3_STAMPS
-    if constexpr (VAR == 2) {
+    if constexpr ((VAR & 4) != 0) {
         if (lane == 0) {
             const unsigned long long te = __builtin_amdgcn_s_memtime();
-            atomicAdd(g_a3_stamps + 0, ts1 - ts0);   // entry -> DMA pieces and Q loads issued
-            atomicAdd(g_a3_stamps + 1, ts2 - ts1);   // -> own DMA pieces landed
-            atomicAdd(g_a3_stamps + 2, ts3 - ts2);   // -> barrier passed
-            atomicAdd(g_a3_stamps + 3, tacc_setup);  // per query block: Q prescale, accumulator set-up, first score MFMAs issued
-            atomicAdd(g_a3_stamps + 4, tacc_loop);   // tile loops
-            atomicAdd(g_a3_stamps + 5, tacc_epi);    // normalisation + stores issued
-            atomicAdd(g_a3_stamps + 6, nqb_done);
-            atomicAdd(g_a3_stamps + 7, (unsigned long long)(nqb_done * (unsigned long long)nt));  // tiles
-            atomicAdd(g_a3_stamps + 8, 1ull);        // waves
-            atomicAdd(g_a3_stamps + 9, te - ts0);    // wave lifetime from the first stamp on
+            unsigned long long* rec = g_a3_stamps + (size_t)(((unsigned)blockIdx.x * 4u + (unsigned)wv) & (A3_STAMP_WAVES - 1)) * A3_STAMP_WORDS;
+            rec[0] = ts1 - ts0;   // entry -> DMA pieces and Q loads issued
+            rec[1] = ts2 - ts1;   // -> own DMA pieces landed
+            rec[2] = ts3 - ts2;   // -> barrier passed
+            rec[3] = tacc_setup;  // per query block: Q prescale, accumulator set-up, first score MFMAs issued
+            rec[4] = tacc_loop;   // tile loops
+            rec[5] = tacc_epi;    // normalisation + stores issued
+            rec[6] = nqb_done;
+            rec[7] = nqb_done * (unsigned long long)nt;  // tiles
+            rec[8] = 1ull;
+            rec[9] = te - ts0;    // wave lifetime from the first stamp on
+            rec[10] = (unsigned long long)len;
+            rec[11] = ts0;        // absolute start (launch shape)
         }
     }
 #endif
@@ -285,11 +282,13 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
 }  // namespace lm
 
 #if defined(LM_DIAG) && !defined(LM_HOST_EMULATION) && !defined(LM_EMULATED_DEVICE)
-extern "C" int lm_attn_v3_stamps_read(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lm::g_a3_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return LM_EHIP;
+extern "C" int lm_attn_v3_stamps_read(unsigned long long* out, int64_t max_words, int reset) {  // out: [waves][12] records (lm::A3_STAMP_WORDS), zeroed slots = unused
+    const size_t total = (size_t)lm::A3_STAMP_WAVES * lm::A3_STAMP_WORDS;
+    const size_t n = std::min<size_t>(total, (size_t)max_words);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lm::g_a3_stamps), n * sizeof(unsigned long long)) != hipSuccess) return LM_EHIP;
     if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(lm::g_a3_stamps), z, sizeof(z)) != hipSuccess) return LM_EHIP;
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lm::g_a3_stamps)) != hipSuccess || hipMemset(p, 0, total * sizeof(unsigned long long)) != hipSuccess) return LM_EHIP;
     }
     return LM_OK;
 }
@@ -310,22 +309,22 @@ int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32
     __half* o = (__half*)d_out;
     kt_attn_work(d_cu_seqlens, n_seqs, heads * 32, stream);  // the flops depend on the sequence lengths (device memory): summed there
     KtScope kt(LM_KT_ATTN, stream, 0.0);
-    const char* ve = getenv("LEANN_MI355X_ATTN3");  // A/B of the two issue orders (0 / 1); default 1
-    int var = (ve && ve[0] == '0') ? 0 : 1;
+    int var = 0;
 #if A3_STAMPS
-    if (ve && ve[0] == '2') var = 2;
-#define A3_CASE2(n) CASEV(n, 2);
+    const char* ve = getenv("LEANN_MI355X_ATTN3");
+    if (ve && ve[0] == '4') var = 4;
+#define A3_CASE4(n) CASEV(n, 4);
 #else
-#define A3_CASE2(n)
+#define A3_CASE4(n)
 #endif
-    switch (nt * 4 + var) {
+    switch (nt * 8 + var) {
 #define CASEV(n, v) \
-    case n * 4 + v: hipLaunchKernelGGL((k_attn_varlen_hd32_v3<n, v>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
-#define CASEA(n) CASEV(n, 0); CASEV(n, 1); A3_CASE2(n)
+    case n * 8 + v: hipLaunchKernelGGL((k_attn_varlen_hd32_v3<n, v>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
+#define CASEA(n) CASEV(n, 0); A3_CASE4(n)
         CASEA(1); CASEA(2); CASEA(3); CASEA(4); CASEA(5); CASEA(6); CASEA(7); CASEA(8);
 #undef CASEA
 #undef CASEV
-#undef A3_CASE2
+#undef A3_CASE4
         default: LM_FAIL(LM_EINVAL, "lm_attn_varlen_hd32_f16 supports sequence lengths 1..256");
     }
     LM_HIP(hipGetLastError());

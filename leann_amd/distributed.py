@@ -129,6 +129,41 @@ def shard_bounds(n: int, world: int):
     return [partition(n, world, r) for r in range(world)]
 
 
+def build_fingerprint() -> int:
+    """63-bit fingerprint of what a rank runs: package version, the library's own version string, its exported-symbol list and the byte
+    size of the shared object.  Ranks of one job must agree (same checkout, same build): a rank whose library differs would otherwise
+    interpret broadcast bytes or packed results differently -- or hang in a collective the others never enter."""
+    import hashlib
+
+    from . import __version__
+
+    h = hashlib.sha256(__version__.encode())
+    try:
+        lib = _lib.load()
+        h.update(bytes(lib.lm_version() or b""))
+        h.update(",".join(_lib.EXPORTED_SYMBOLS).encode())
+        h.update(str(_lib.LIB_PATH.stat().st_size).encode())
+    except Exception as ex:  # noqa: BLE001 - a rank without the library is a different build by definition
+        h.update(("no library: " + type(ex).__name__).encode())
+    return int.from_bytes(h.digest()[:8], "little") >> 1
+
+
+def check_same_build(device: Optional[torch.device] = None, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Every rank contributes its build_fingerprint() to ONE all_gather; if they differ, EVERY rank raises the same RuntimeError (they all
+    see the same list), so a mixed job fails loudly at start-up instead of hanging in its first data-path collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dev = device if device is not None else torch.device("cpu")
+    mine = torch.tensor([build_fingerprint()], dtype=torch.int64, device=dev)
+    got = torch.empty((dist.get_world_size(group),), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(got, mine, group=group)
+    vals = [int(v) for v in got.cpu().tolist()]
+    if len(set(vals)) != 1:
+        odd = [r for r, v in enumerate(vals) if v != vals[0]]
+        raise RuntimeError(f"leann-backend-mi355x: ranks run different builds of the package / libleann_mi355x.so (fingerprints differ from rank 0's on ranks {odd}); "
+                           "every rank of a job must use the same checkout and the same built library")
+
+
 def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, group: Optional[dist.ProcessGroup] = None):
     """Rank `src` built the compact-CSR graph; every other rank passes ``g=None`` and receives a copy (the index is
     built ONCE per job and replicated, not rebuilt per rank).  Arrays travel in their own dtype as raw bytes on `device` (RCCL
@@ -141,6 +176,7 @@ def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, grou
         return g
     rank = dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
+    check_same_build(dev, group)  # (a rank with another build fails here, on every rank at once, not in the middle of the transfer)
     names = ("levels", "level_ptr", "node_offsets", "neighbors", "cum_nneighbor_per_level")
     dtypes = {"levels": np.int32, "level_ptr": np.uint64, "node_offsets": np.uint64, "neighbors": np.int32, "cum_nneighbor_per_level": np.int32}
     if rank == src:
@@ -151,6 +187,9 @@ def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, grou
         hdr = torch.zeros(6 + len(names), dtype=torch.int64, device=dev)
     dist.broadcast(hdr, src, group=group)
     h = [int(v) for v in hdr.cpu().tolist()]
+    # the header every rank now holds must describe a graph (the same check on every rank: a bad header raises everywhere, nobody waits)
+    if not (h[0] > 0 and h[1] > 0 and h[2] in (0, 1) and 0 <= h[3] < h[1] and h[4] >= 0 and h[6] == h[1] and h[8] == h[1] + 1 and h[7] >= h[1] and h[9] >= 0):
+        raise RuntimeError(f"broadcast_graph: implausible header from rank {src}: {h}")
     out = []
     for i, n in enumerate(names):
         nbytes = h[6 + i] * np.dtype(dtypes[n]).itemsize

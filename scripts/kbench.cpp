@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|attnstamp|attn64|ln|gemmf16|gemmstamp]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|a3stamps|attn64|ln|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -22,7 +22,7 @@
 #include <vector>
 
 #include "leann_mi355x.h"
-extern "C" int lm_attn_v3_stamps_read(unsigned long long* out16, int reset);  // diagnosis library only (csrc/lm_attn_v3.hip)
+extern "C" int lm_attn_v3_stamps_read(unsigned long long* out, int64_t max_words, int reset);  // diagnosis library only (csrc/lm_attn_v3.hip)
 
 // generation 3 of the fused layer tail: only in the diagnosis build of the library (csrc/diag/lm_mlp_fused_v3.hip), as the `tail` / `tail4`
 // modes' A/B reference; operands: W_o as [12][384][32] slabs, W1 with its columns in accumulator order, W2 as [ffn/32][384][32] slabs
@@ -567,11 +567,11 @@ int main(int argc, char** argv) {
         for (int i = 0; i < cu[nchk]; ++i) arows.push_back(i);
         double flops = 0;
         for (int i = 0; i < ns; ++i) flops += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
-        // generation 2 (lm_attn_v2.hip) and the four variants of generation 3 (lm_attn_v3.hip: LEANN_MI355X_ATTN3), two rounds each (interleaved: clocks / box drift);
+        // generation 2 (lm_attn_v2.hip) and generation 3 (lm_attn_v3.hip), two rounds each (interleaved: clocks / box drift);
         // KBENCH_ATTN_ONLY=<variant digit, 9 = generation 2> restricts the run to one kernel (PMC passes: one population per kernel name)
         const char* only = getenv("KBENCH_ATTN_ONLY");
         for (int round = 0; round < (only ? 1 : 2); ++round)
-            for (const char* rev : {"9", "0", "1"}) {  // generation 2; generation 3 with its score MFMAs at the top of a tile (0) / behind the previous tile's exponentials (1)
+            for (const char* rev : {"9", "0"}) {  // generation 2 (LEANN_MI355X_ATTN3=9 routes to it), generation 3
                 if (only && (only[0] != rev[0] || rev[1])) continue;
                 setenv("LEANN_MI355X_ATTN3", std::string(1, rev[0]).c_str(), 1);
                 setenv("LEANN_MI355X_ATTN_XCD", rev[1] ? "0" : "1", 1);
@@ -582,14 +582,14 @@ int main(int argc, char** argv) {
                 const double err = max_err_rows(out.host(), H, 0, H, arows, href);
                 const float us = time_us(st, reps, run);
                 printf("{\"kernel\": \"lm_attn_varlen_hd32_f16\", \"mode\": \"%s%s, %d sequences, %d tokens\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"GBps_qkv_plus_out\": %.0f, \"max_abs_err\": %.3g}\n",
-                       rev[0] == '9' ? "generation 2" : "generation 3, issue order ", rev[0] == '9' ? "" : rev, ns, tot, round, us, flops / us * 1e-6, (double)tot * H * 8 / us * 1e-3, err);
+                       rev[0] == '9' ? "generation 2" : "generation 3", "", ns, tot, round, us, flops / us * 1e-6, (double)tot * H * 8 / us * 1e-3, err);
                 fflush(stdout);
             }
         unsetenv("LEANN_MI355X_ATTN3");
         unsetenv("LEANN_MI355X_ATTN_XCD");
     }
-    if (want("attnstamp")) {
-        // s_memtime stamps of lm_attn_v3.hip (diagnosis library, LEANN_MI355X_ATTN3=2 = issue order 0 + stamps): where a wave's time goes
+    if (want("a3stamps")) {
+        // s_memtime stamps of lm_attn_v3.hip (diagnosis library, LEANN_MI355X_ATTN3=4: the kernel + stamps; NOTE the launch time printed here comes from a 5-launch burst and reads 10 % low against a 20-launch measurement of the same kernel -- clocks): where a wave's time goes
         const int heads = 12;
         std::mt19937 g(5);
         std::normal_distribution<float> d(180.f, 50.f);
@@ -602,20 +602,41 @@ int main(int argc, char** argv) {
         const int ns = (int)cu.size() - 1, tot = cu.back();
         Dev<int> dcu(cu);
         Dev<__half> qkv(rand_half((size_t)tot * 3 * H, 1.0f, 40)), out((size_t)tot * H);
-        setenv("LEANN_MI355X_ATTN3", "2", 1);
+        setenv("LEANN_MI355X_ATTN3", "4", 1);
         auto run = [&] { LM(lm_attn_varlen_hd32_f16(qkv.p, dcu.p, ns, heads, 256, out.p, st)); };
         run();
         CK(hipStreamSynchronize(st));
-        unsigned long long z[16];
-        LM(lm_attn_v3_stamps_read(z, 1));
+        const size_t NW = (size_t)1 << 17, WORDS = 12;
+        std::vector<unsigned long long> z(NW * WORDS);
+        LM(lm_attn_v3_stamps_read(z.data(), (int64_t)z.size(), 1));
+        run();  // ONE stamped launch (records are per wave, overwritten per launch)
+        CK(hipStreamSynchronize(st));
+        LM(lm_attn_v3_stamps_read(z.data(), (int64_t)z.size(), 1));
         const float us = time_us(st, reps, run);
-        LM(lm_attn_v3_stamps_read(z, 1));
         unsetenv("LEANN_MI355X_ATTN3");
-        const double w = (double)z[8], qb = (double)z[6], tl = (double)z[7];
-        printf("{\"kernel\": \"lm_attn_v3 stamps (issue order 0)\", \"us\": %.1f, \"waves\": %.0f, \"query_blocks\": %.0f, \"tiles\": %.0f, \"mean_cycles_per_wave\": {\"lifetime\": %.0f, "
-               "\"entry_to_requests_issued\": %.0f, \"own_dma_landed\": %.0f, \"barrier\": %.0f, \"query_block_setup_total\": %.0f, \"tile_loops_total\": %.0f, \"epilogues_total\": %.0f}, "
-               "\"mean_cycles\": {\"per_query_block_setup\": %.0f, \"per_tile\": %.0f, \"per_query_block_epilogue\": %.0f}}\n",
-               us, w / (reps + 0.0), qb / reps, tl / reps, z[9] / w, z[0] / w, z[1] / w, z[2] / w, z[3] / w, z[4] / w, z[5] / w, z[3] / qb, z[4] / tl, z[5] / qb);
+        // means over all waves, and over the waves grouped by their number of query blocks (0 = a wave with nothing to do: staging + barrier only)
+        double sum[3][12] = {};
+        double cnt[3] = {};
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t w = 0; w < NW; ++w) {
+            const unsigned long long* r = &z[w * WORDS];
+            if (!r[8]) continue;
+            const int grp = (int)std::min<unsigned long long>(r[6], 2);
+            cnt[grp] += 1;
+            for (int k = 0; k < 12; ++k) sum[grp][k] += (double)r[k];
+            tmin = std::min(tmin, r[11]);
+            tmax = std::max(tmax, r[11] + r[9]);
+        }
+        for (int grp = 0; grp < 3; ++grp) {
+            if (cnt[grp] == 0) continue;
+            const double c = cnt[grp], qb = std::max(sum[grp][6], 1.0), tl = std::max(sum[grp][7], 1.0);
+            printf("{\"kernel\": \"lm_attn_v3 stamps\", \"variant\": \"%s\", \"us_stamped_build\": %.1f, \"waves_with_query_blocks\": %d, \"waves\": %.0f, \"mean_sequence_length\": %.1f, "
+                   "\"mean_cycles_per_wave\": {\"lifetime\": %.0f, \"entry_to_requests_issued\": %.0f, \"own_dma_landed\": %.0f, \"barrier\": %.0f, \"query_block_setup_total\": %.0f, "
+                   "\"tile_loops_total\": %.0f, \"epilogues_total\": %.0f}, \"mean_cycles\": {\"per_query_block_setup\": %.0f, \"per_tile\": %.0f, \"per_query_block_epilogue\": %.0f}, "
+                   "\"launch_span_cycles_first_start_to_last_end\": %llu}\n",
+                   "4", us, grp, c, sum[grp][10] / c, sum[grp][9] / c, sum[grp][0] / c, sum[grp][1] / c, sum[grp][2] / c, sum[grp][3] / c, sum[grp][4] / c, sum[grp][5] / c,
+                   sum[grp][3] / qb, sum[grp][4] / tl, sum[grp][5] / qb, tmax - tmin);
+        }
         fflush(stdout);
     }
     if (want("ln")) {

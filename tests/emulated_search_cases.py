@@ -597,7 +597,7 @@ def case_encoder_abi():
 
 def case_attention_v3():
     """Generation 3 of the head_dim-32 attention kernel (csrc/lm_attn_v3.hip: K / V by LDS-DMA, transposing V reads, the running maximum
-    as the score MFMA's C operand, deferred rescaling) against float64 numpy, both issue orders (LEANN_MI355X_ATTN3), and against
+    as the score MFMA's C operand, deferred rescaling) against float64 numpy and against
     generation 2 (LEANN_MI355X_ATTN=2).  Inputs that FORCE the rescale branch (cdna_hip_programming.md T13: the branch is rare and data
     dependent -- a passing check on bounded random data says nothing): a key in a LATER tile whose score exceeds every earlier one by far
     (threshold 8 in log2 units), per head and only for some query rows; rows whose maximum sits in the masked last tile; lengths 1, 31,
@@ -639,21 +639,18 @@ def case_attention_v3():
                     grew += int(((s2[:, 32:].max(1) - s2[:, :32].max(1)) > 8.0).sum())
         assert grew > 0, "the test data does not reach the rescale branch"
         outs = {}
-        for var in ("0", "1"):  # (where a tile's score MFMAs are issued: 1 = the default)
-            os.environ["LEANN_MI355X_ATTN3"] = var
+        for var in ("0",):
             o = np.zeros((tot, Hh), np.float16)
             _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv), vp(cu), n, heads, int(lens.max()), vp(o), None), "attn v3")
             err = np.abs(o.astype(np.float64) - ref).max()
             assert err < 4e-3, (var, lens.tolist(), err)
             outs[var] = o
-        os.environ.pop("LEANN_MI355X_ATTN3")
-        assert np.array_equal(outs["0"], outs["1"])  # (the same arithmetic in another issue order)
         os.environ["LEANN_MI355X_ATTN"] = "2"
         o2 = np.zeros((tot, Hh), np.float16)
         _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv), vp(cu), n, heads, int(lens.max()), vp(o2), None), "attn v2")
         os.environ.pop("LEANN_MI355X_ATTN")
         assert np.abs(o2.astype(np.float64) - ref).max() < 4e-3
-        assert np.abs(o2.astype(np.float32) - outs["1"].astype(np.float32)).max() < 4e-3
+        assert np.abs(o2.astype(np.float32) - outs["0"].astype(np.float32)).max() < 4e-3
         print(f"attention generation 3, lengths {lens.tolist()}: max |err| vs float64 {max(np.abs(v.astype(np.float64) - ref).max() for v in outs.values()):.2e}, {grew} rows through the rescale branch: ok", flush=True)
 
 

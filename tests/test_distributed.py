@@ -91,6 +91,36 @@ def _worker(rank, world, port, mode, out):
     dist.destroy_process_group()
 
 
+def _mixed_build_worker(rank, world, port, out):
+    """Rank 1 pretends to run another build: broadcast_graph must raise ON EVERY RANK (nobody is left waiting in a collective)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from leann_amd import distributed as D
+    from leann_amd.hnsw_builder import build_hnsw
+
+    torch.set_num_threads(1)
+    real = D.build_fingerprint()
+    assert real == D.build_fingerprint() and real >= 0
+    if rank == 1:
+        D.build_fingerprint = lambda: real ^ 1
+    g0 = build_hnsw(clustered(300, 16, 5), "mips", M=4, ef_construction=20, num_threads=1) if rank == 0 else None
+    try:
+        D.broadcast_graph(g0, 0)
+        out[rank] = "no error"
+    except RuntimeError as ex:
+        out[rank] = "different builds" in str(ex) and "[1]" in str(ex)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_mixed_builds_fail_loudly(built_libs):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mixed_build_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 @pytest.mark.parametrize("mode", ["partitioned", "broadcast", "sharded"])
 def test_two_rank_gloo(mode, built_libs):
     world = 2

@@ -45,14 +45,13 @@ def _attention_case(torch, heads, maxlen, nseq=37):
 
 @pytest.mark.parametrize("heads,maxlen", [(12, 256), (12, 255), (12, 200), (12, 70), (12, 64), (4, 33), (4, 32), (2, 2), (2, 1)])
 def test_attention_matches_fp32_reference(heads, maxlen, monkeypatch):
-    """The head_dim-32 attention kernels vs a plain PyTorch fp32 reference of the same op: generation 3 (csrc/lm_attn_v3.hip, the default;
-    both issue orders of its score MFMAs, LEANN_MI355X_ATTN3 = 0 / 1) and generation 2 (csrc/lm_attn_v2.hip, LEANN_MI355X_ATTN=2)."""
+    """The head_dim-32 attention kernels vs a plain PyTorch fp32 reference of the same op: generation 3 (csrc/lm_attn_v3.hip, the default) and generation 2 (csrc/lm_attn_v2.hip, LEANN_MI355X_ATTN=2)."""
     import torch
 
     from leann_amd.encoder import fused_attention_hd32
 
     qkv, cu, mx, ref = _attention_case(torch, heads, maxlen)
-    for env in ({}, {"LEANN_MI355X_ATTN3": "0"}, {"LEANN_MI355X_ATTN3": "1"}, {"LEANN_MI355X_ATTN": "2"}):
+    for env in ({}, {"LEANN_MI355X_ATTN": "2"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         o2 = fused_attention_hd32(qkv, cu, heads, mx)
@@ -70,7 +69,7 @@ def test_attention_matches_fp32_reference(heads, maxlen, monkeypatch):
 def test_attention_rescale_branch_and_masked_maximum(monkeypatch):
     """Generation 3 defers the running maximum (a tile may exceed it by 2^8 before O is rescaled): the rescale branch is rare and data
     dependent, so it gets inputs that force it -- keys in LATER tiles (one of them in the masked last tile) whose scores exceed everything
-    before them by far, for some query rows only -- and a count of the rows that take it.  fp32 torch reference; both issue orders."""
+    before them by far, for some query rows only -- and a count of the rows that take it.  fp32 torch reference."""
     import torch
 
     from leann_amd.encoder import fused_attention_hd32
@@ -101,14 +100,11 @@ def test_attention_rescale_branch_and_masked_maximum(monkeypatch):
             s2 = sc * 1.4426950408889634
             grew += int(((s2[:, :, 32:].max(-1).values - s2[:, :, :32].max(-1).values) > 8.0).sum())
     assert grew >= 5
-    for var in ("0", "1"):
-        monkeypatch.setenv("LEANN_MI355X_ATTN3", var)
-        o = fused_attention_hd32(qkv, cu.cuda(), heads, 256)
-        torch.cuda.synchronize()
-        assert not torch.isnan(o).any(), var
-        err = (o.float() - ref).abs().max().item()
-        assert err < 5e-3, (var, err)
-    monkeypatch.delenv("LEANN_MI355X_ATTN3")
+    o = fused_attention_hd32(qkv, cu.cuda(), heads, 256)
+    torch.cuda.synchronize()
+    assert not torch.isnan(o).any()
+    err = (o.float() - ref).abs().max().item()
+    assert err < 5e-3, err
 
 
 def test_encoder_forward_with_and_without_the_attention_kernel(monkeypatch):
