@@ -233,7 +233,7 @@ static int attn_v2_launch_hd(const void* d_qkv, const int32_t* d_cu_seqlens, int
     if constexpr (HD == 32) {  // generation 3 (lm_attn_v3.hip) is the default at head_dim 32 since round 5; LEANN_MI355X_ATTN=2 = this file's kernel (A/B)
         const char* gen = getenv("LEANN_MI355X_ATTN");
         const char* var = getenv("LEANN_MI355X_ATTN3");  // (9 = generation 2 as well: a switch that leaves the one-call forwards on, for A/B runs of bench.py)
-        if (!(gen && gen[0] == '2') && !(var && var[0] == '9')) return lm_attn_v3_launch_hd32(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, stream);
+        if (!(gen && gen[0] == '2') && !(var && var[0] == '9')) return lm_attn_v3_launch_hd32(d_qkv, d_cu_seqlens, n_seqs, heads, max_len, d_out, 0, stream);
     }
     const int nt = (max_len + 31) / 32;
     const size_t shmem = ((size_t)32 * nt * (HD + 8) + (size_t)HD * (32 * nt + 4)) * 2;

@@ -67,7 +67,7 @@ constexpr float A3_THR = 8.0f;  // a tile may exceed the running maximum by 2^8 
 // (diagnosis library only: kbench a3stamps)
 template <int NT, int VAR>
 __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                                __half* __restrict__ out, int heads, float scale_log2e, int n_units) {
+                                                                __half* __restrict__ out, int heads, float scale_log2e, int n_units, int64_t hm_tokens) {
     extern __shared__ __align__(16) unsigned char smem[];
     // XCD-aware unit order (as generation 2): the twelve heads of a sequence run on one XCD at about the same time, so the two 64-byte
     // halves of a 128-byte line of the [T][3H] activations (neighbouring heads) meet in one L2.  n_units < 0: plain order (A/B).
@@ -80,22 +80,25 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
     if (len <= 0) return;
     [[maybe_unused]] const unsigned long long ts0 = A3_NOW();
     const int H = heads * 32;
-    const int rsb = 6 * H;  // bytes per token row of qkv
+    // qkv layout: hm_tokens == 0: [tokens][3 H] (a head's Q / K / V row = 64 B out of every 6 H); hm_tokens > 0: head major
+    // [3 x heads][hm_tokens][32] (lm_qkv_h384_launch): a (sequence, head)'s rows are one contiguous block per operand
+    const int rsb = hm_tokens ? 64 : 6 * H;  // bytes from one token's row to the next
     constexpr int Tp = 32 * NT;
     unsigned char* Ks = smem;            // [Tp][64 B], 16-byte chunks swizzled
     unsigned char* Vs = smem + Tp * 64;  // [Tp][64 B], row major
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r31 = lane & 31, g = lane >> 5;
     const int nt = (len + 31) >> 5;  // key tiles = query blocks of this sequence
-    const unsigned char* base = (const unsigned char*)qkv + (int64_t)tok0 * rsb + h * 64;
+    const int64_t plane = hm_tokens ? (int64_t)heads * hm_tokens * 64 : (int64_t)2 * H;  // bytes from Q to K to V of the same token and head
+    const unsigned char* base = (const unsigned char*)qkv + (hm_tokens ? ((int64_t)h * hm_tokens + tok0) * 64 : (int64_t)tok0 * rsb + h * 64);
 
     // ---- K and V rows -> LDS by DMA: instruction j covers rows 16 j .. 16 j + 15 (lane l: row 16 j + l / 4, chunk position l % 4);
     //      rows past the sequence end repeat the last row (finite values; their scores are masked, their P is exactly 0).
     //      (Measured equal and dropped: staging through registers -- global_load_dwordx4 x NT per thread, then ds_write_b128; the stamps
     //      show requests issued in 2.5 k instead of 4.9 k cycles and landed 1.9 k later: the same ~7.3 k from entry to the barrier.)
     {
-        const unsigned char* kbase = base + 2 * H;  // K of this head
-        const unsigned char* vbase = base + 4 * H;  // V of this head
+        const unsigned char* kbase = base + plane;      // K of this head
+        const unsigned char* vbase = base + 2 * plane;  // V of this head
         const int rl = lane >> 2, pos = lane & 3;
 #pragma unroll
         for (int i = 0; i < (NT + 1) / 2; ++i) {
@@ -296,7 +299,8 @@ extern "C" int lm_attn_v3_stamps_read(unsigned long long* out, int64_t max_words
 
 #ifndef LM_HOST_EMULATION
 // launched by lm_attn_v2.hip's attn_v2_launch_hd<32> (the default of head_dim 32 since round 5; LEANN_MI355X_ATTN=2 = generation 2)
-int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out, void* stream) {
+int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out, int64_t total_tokens,
+                           void* stream) {
     using namespace lm;
     const int nt = (max_len + 31) / 32;
     const size_t shmem = (size_t)32 * nt * 128;
@@ -319,7 +323,7 @@ int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32
 #endif
     switch (nt * 8 + var) {
 #define CASEV(n, v) \
-    case n * 8 + v: hipLaunchKernelGGL((k_attn_varlen_hd32_v3<n, v>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units); break
+    case n * 8 + v: hipLaunchKernelGGL((k_attn_varlen_hd32_v3<n, v>), grid, block, shmem, st, q, d_cu_seqlens, o, heads, scale_log2e, n_units, total_tokens); break
 #define CASEA(n) CASEV(n, 0); A3_CASE4(n)
         CASEA(1); CASEA(2); CASEA(3); CASEA(4); CASEA(5); CASEA(6); CASEA(7); CASEA(8);
 #undef CASEA

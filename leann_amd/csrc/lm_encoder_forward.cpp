@@ -48,6 +48,11 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     bool small = total_tokens <= small_tokens_limit() && m->ffn % 128 == 0;  // (every multiple of 192 in the envelope that is one of 128: 384, 768, 1152, 1536, ...)
     for (int l = 0; small && l < m->n_layers; ++l) small = m->layers[l].wo && m->layers[l].w1 && m->layers[l].w2;
     void* hid = ws + 3 * row + (size_t)total_tokens * 1152 * 2;  // [T][ffn], small forwards only (lm_bert_h384_workspace_bytes)
+    // LEANN_MI355X_QKV_LAYOUT=0: large forwards keep the [tokens][1152] projection layout (A/B); default: head major (the buffer is private to the forward)
+    const char* lay_env = getenv("LEANN_MI355X_QKV_LAYOUT");
+    const char* a3_env = getenv("LEANN_MI355X_ATTN3");
+    const char* a2_env = getenv("LEANN_MI355X_ATTN");
+    const bool head_major = !(lay_env && lay_env[0] == '0') && !(a3_env && a3_env[0] == '9') && !(a2_env && a2_env[0] == '2') && m->heads == 12;
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
         if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x
@@ -60,10 +65,15 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
             if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln2_gamma, L.ln2_beta, x, total_tokens, 384, m->ln_eps, stream))) return rc;
             continue;
         }
-        if ((rc = L.wqkv_img ? lm_qkv_h384_f16(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, stream)
-                             : lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream)))
-            return rc;
-        if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
+        if (L.wqkv_img && head_major) {  // the projection writes Q / K / V head major; generation 3 of the attention kernel reads contiguous blocks
+            if ((rc = lm_qkv_h384_launch(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, 1, stream))) return rc;
+            if ((rc = lm_attn_v3_launch_hd32(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, total_tokens, stream))) return rc;
+        } else {
+            if ((rc = L.wqkv_img ? lm_qkv_h384_f16(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, stream)
+                                 : lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream)))
+                return rc;
+            if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
+        }
         if ((rc = lm_layer_tail_h384_f16(a, x, L.wo_img, L.bo, L.ln1_gamma, L.ln1_beta, m->ln_eps, L.w1_img, L.b1, L.w2_img, L.b2, L.ln2_gamma,
                                          L.ln2_beta, y, total_tokens, m->ffn, m->ln_eps, stream)))
             return rc;

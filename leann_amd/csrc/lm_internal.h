@@ -147,8 +147,13 @@ inline bool bert_h384_envelope_ok(int n_layers, int heads, int ffn) { return n_l
 
 }  // namespace lm
 
-// lm_attn_v3.hip: generation 3 of the head_dim-32 attention kernel (arguments as lm_attn_varlen_hd32_f16; max_len 1..256 checked by the caller)
-int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out, void* stream);
+// lm_qkv_h384.hip: lm_qkv_h384_f16 with the output layout as a parameter: 0 = [tokens][n_out] (the C ABI's), 1 = head major [n_out / 32][tokens][32]
+int lm_qkv_h384_launch(const void* d_x, const void* d_w_img, const float* d_bias, int32_t n_out, void* d_out, int64_t tokens, int32_t head_major, void* stream);
+
+// lm_attn_v3.hip: generation 3 of the head_dim-32 attention kernel (arguments as lm_attn_varlen_hd32_f16; max_len 1..256 checked by the caller).
+// total_tokens > 0: qkv is lm_qkv_h384_launch's HEAD-MAJOR layout over that many tokens ([3 x heads][total_tokens][32]); 0 = [tokens][3 x heads x 32]
+int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out, int64_t total_tokens,
+                           void* stream);
 
 // lm_encoder_ops2.hip: 16-lanes-per-row LayerNorm (opt-in, LEANN_MI355X_LN=2, hidden <= 768); arguments as lm_add_layernorm_f16
 int lm_add_layernorm_r16_launch(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, void* d_out,

@@ -72,7 +72,12 @@ __device__ __forceinline__ void qk_epilogue_step(const float16v& a, const float1
                 const int id = 64 * (2 * (STEP - 5) + jj) + lane, c16 = id & 7;
                 const int row = (id >> 3) < rows_valid ? (id >> 3) : rows_valid - 1;  // past the end: the last valid row once more (same bytes): the
                 const u32x4 v = *(const u32x4*)(tile + row * 128 + ((c16 ^ (row & 7)) << 4));  // number of stores is what the counted waits assume
-                *(u32x4*)((unsigned char*)out + ((tok0 + row) * N + feat0) * 2 + 16 * c16) = v;
+                // N > 0: row major [T][N].  N < 0 (= -T): HEAD major [N / 32 heads][T][32] -- the 64 features of this tile are two heads, a head's
+                // 32 token rows x 64 B are one contiguous 2 KB run (the attention kernel then reads a (sequence, head)'s K, V, Q rows as contiguous
+                // blocks instead of 64 B out of every 2 N)
+                const int64_t off = N > 0 ? ((tok0 + row) * N + feat0) * 2 + 16 * c16
+                                          : (((int64_t)(feat0 >> 5) + (c16 >> 2)) * (int64_t)(-N) + tok0 + row) * 64 + 16 * (c16 & 3);
+                *(u32x4*)((unsigned char*)out + off) = v;
             }
         }
     }
@@ -127,9 +132,12 @@ __device__ __forceinline__ void qk_slots(std::integer_sequence<int, I...>, const
 // grid: ceil(T / 256) workgroups of 512 threads.  w_img: lm_layer_tail_pack_h384's KIND 0 image of W [N][384] (lm_qkv_pack_h384).
 template <int RD>
 __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_h384(const __half* __restrict__ x, const __half* __restrict__ w_img,
-                                                                         const float* __restrict__ bias, __half* __restrict__ out, int T, int N) {
+                                                                         const float* __restrict__ bias, __half* __restrict__ out, int T, int Nfeat,
+                                                                         int head_major) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* bss = (float*)(smem + QK_BIAS_OFF);
+    const int N = Nfeat;                       // output features (slabs, bias)
+    const int Nst = head_major ? -T : Nfeat;   // what the epilogue's stores take: the row stride, or minus the token count for the head-major layout
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef LM_EMULATED_DEVICE
     const int wv = tid >> 6;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_h384(const __
     for (int i = 0; i < RD; ++i) cy.ring[i] = *(const half8*)(ad.a1[0][i & 7] + 256 * (i >> 3));  // slab 0 = stage 0, k-steps 0 .. RD - 1
     // slab s: stage s % 4, parity s & 1; its DMA is slab s + 3 -> stage (s + 3) % 4 (last read during slab s - 1)
 #define QK_SLAB(ST, P, NEXT, PREV, S)                                                                                                          \
-    qk_slots<ST, P, NEXT, PREV, NEXT, RD>(std::make_integer_sequence<int, 24>{}, ad, bl + 32 * ((S) + 1), xf, acc, cy, tile, out, tok0, rows_valid, N, \
+    qk_slots<ST, P, NEXT, PREV, NEXT, RD>(std::make_integer_sequence<int, 24>{}, ad, bl + 32 * ((S) + 1), xf, acc, cy, tile, out, tok0, rows_valid, Nst, \
                                           32 * ((S) - 2), r31, g, lane, gw + (int64_t)((S) + 3 < nslab ? (S) + 3 : nslab - 1) * T4_SLAB + 3072 * wv, voff0, \
                                           smem + (((ST) + 3) % QK_STAGES) * T4_SLAB + 3072 * wv)
     // (the epilogue of an ODD previous slab stores features [32 (S - 2), 32 S): feat0_prev = 32 (S - 2) of the pair it completes)
@@ -202,20 +210,20 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_h384(const __
         QK_SLAB(1, 1, true, true, s);
         QK_SLAB(2, 0, true, true, s + 1);
         // the last slab: nothing follows it in the ring; its barrier-free
-        qk_slots<3, 1, false, true, false, RD>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, tile, out, tok0, rows_valid, N, 32 * (s + 2 - 2),
+        qk_slots<3, 1, false, true, false, RD>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, tile, out, tok0, rows_valid, Nst, 32 * (s + 2 - 2),
                                                r31, g, lane, nullptr, voff0, nullptr);
     }
 #undef QK_SLAB
     // epilogue of the last slab (odd: completes the last 64-feature tile)
     {
         const int f0 = 32 * (nslab - 2);
-        qk_epilogue_step<0, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
-        qk_epilogue_step<1, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
-        qk_epilogue_step<2, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
-        qk_epilogue_step<3, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
-        qk_epilogue_step<4, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
-        qk_epilogue_step<5, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
-        qk_epilogue_step<6, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, N, f0, r31, g, lane);
+        qk_epilogue_step<0, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
+        qk_epilogue_step<1, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
+        qk_epilogue_step<2, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
+        qk_epilogue_step<3, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
+        qk_epilogue_step<4, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
+        qk_epilogue_step<5, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
+        qk_epilogue_step<6, true>(acc[1][0], acc[1][1], tile, out, tok0, rows_valid, Nst, f0, r31, g, lane);
     }
     T4_WAIT_VM(0);  // the requests past the end (re-reads of the last slab) land before the workgroup's LDS is handed on
 }
@@ -224,7 +232,8 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_h384(const __
 
 // (lm_qkv_pack_h384 -- W [n_out][384] -> the image this kernel streams -- lives next to the image kernel: lm_layer_tail_h384.hip)
 
-extern "C" int lm_qkv_h384_f16(const void* d_x, const void* d_w_img, const float* d_bias, int32_t n_out, void* d_out, int64_t tokens, void* stream) {
+// head_major != 0: the output as [n_out / 32 heads][tokens][32] (see the kernel's epilogue) -- the one-call forward's layout for the attention kernel
+int lm_qkv_h384_launch(const void* d_x, const void* d_w_img, const float* d_bias, int32_t n_out, void* d_out, int64_t tokens, int32_t head_major, void* stream) {
     using namespace lm;
     if (tokens == 0) return LM_OK;
     if (!d_x || !d_w_img || !d_bias || !d_out || tokens < 0 || tokens > 0x7fffffff) LM_FAIL(LM_EINVAL, "bad linear arguments");
@@ -234,7 +243,11 @@ extern "C" int lm_qkv_h384_f16(const void* d_x, const void* d_w_img, const float
     static DynLdsAttr attr;
     LM_HIP(ensure_dyn_lds(attr, (const void*)k_qkv_h384<4>, shmem));
     hipLaunchKernelGGL(k_qkv_h384<4>, dim3((unsigned)((tokens + 255) / 256)), dim3(512), shmem, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_w_img,
-                       d_bias, (__half*)d_out, (int)tokens, n_out);
+                       d_bias, (__half*)d_out, (int)tokens, n_out, (int)(head_major != 0));
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+extern "C" int lm_qkv_h384_f16(const void* d_x, const void* d_w_img, const float* d_bias, int32_t n_out, void* d_out, int64_t tokens, void* stream) {
+    return lm_qkv_h384_launch(d_x, d_w_img, d_bias, n_out, d_out, tokens, 0, stream);
 }
