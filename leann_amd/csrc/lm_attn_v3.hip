@@ -61,6 +61,27 @@ __device__ unsigned long long g_a3_stamps[A3_STAMP_WAVES * A3_STAMP_WORDS];  // 
 #define A3_NOW() 0ull
 #endif
 
+// v_max3_f32 / v_max_f32 as they are: fmaxf on MFMA results makes the compiler quiet possible signalling NaNs first (v_max_f32 x, x, x per operand:
+// four extra instructions per tile); the scores are finite by construction
+__device__ __forceinline__ float a3_max3(float a, float b, float c) {
+#ifdef LM_EMULATED_DEVICE
+    return fmaxf(fmaxf(a, b), c);
+#else
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#endif
+}
+__device__ __forceinline__ float a3_max(float a, float b) {
+#ifdef LM_EMULATED_DEVICE
+    return fmaxf(a, b);
+#else
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+
 constexpr float A3_THR = 8.0f;  // a tile may exceed the running maximum by 2^8 before O is rescaled (P <= 256: exact in fp16's range)
 
 // NT = number of 32-key tiles the launch's longest sequence needs (max_len <= 32 NT), 1..8.  VAR: 0 = the kernel; 4 = the same with phase stamps
@@ -146,6 +167,9 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
         if (qb >= nt) break;
         const int qrow = 32 * qb + r31;
         [[maybe_unused]] const unsigned long long tq0 = A3_NOW();
+        // Q x (softmax scale x log2 e), ONE rounding: f16(float(q) x c).  (Measured in round 5's last session: the same in packed fp16 with the constant
+        // split into two halfs -- fl(q c_hi), then fma(q, c_lo, .): 16 packed instructions instead of ~45 -- makes the kernel 3 % faster and its error
+        // 1.7 x larger (two roundings of the score MFMA's operand: 1.0e-3 instead of 5.8e-4 against fp64 on kbench's data); not taken.)
         half8 qf0, qf1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -192,14 +216,12 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
             // independent and waits ~12 per link of a dependent chain -- the stamps put a tile at 733 cycles for ~62 instructions
             float tm;
             {
-                const float m0 = fmaxf(fmaxf(s[0], s[1]), s[2]), m1 = fmaxf(fmaxf(s[3], s[4]), s[5]), m2 = fmaxf(fmaxf(s[6], s[7]), s[8]);
-                const float m3 = fmaxf(fmaxf(s[9], s[10]), s[11]), m4 = fmaxf(fmaxf(s[12], s[13]), s[14]);
-                tm = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), s[15]));
-            }
-            {
+                const float m0 = a3_max3(s[0], s[1], s[2]), m1 = a3_max3(s[3], s[4], s[5]), m2 = a3_max3(s[6], s[7], s[8]);
+                const float m3 = a3_max3(s[9], s[10], s[11]), m4 = a3_max3(s[12], s[13], s[14]);
+                tm = a3_max(a3_max3(m0, m1, m2), a3_max3(m3, m4, s[15]));
                 uint32_t a = __builtin_bit_cast(uint32_t, tm), b = a;
                 lane32_swap(a, b);
-                tm = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));  // both lanes of the row: its maximum over the tile's 32 keys
+                tm = a3_max(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));  // both lanes of the row: its maximum over the tile's 32 keys
             }
             const bool first = t == 0;
             if (first || __ballot(tm > A3_THR) != 0) {  // wave uniform
@@ -211,10 +233,14 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
                     l2 *= (float2v){alpha, alpha};
                     l2b *= (float2v){alpha, alpha};
                 }
+                const float2v d2 = {delta, delta};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] -= delta;
-                    cm[r] -= delta;
+                for (int r = 0; r < 16; r += 2) {  // (v_pk_add_f32)
+                    const float2v a = (float2v){s[r], s[r + 1]} - d2, b = (float2v){cm[r], cm[r + 1]} - d2;
+                    s[r] = a[0];
+                    s[r + 1] = a[1];
+                    cm[r] = b[0];
+                    cm[r + 1] = b[1];
                 }
             }
             half8 p0, p1;
@@ -248,7 +274,9 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
             _Float16* orow = (_Float16*)out + (int64_t)(tok0 + qrow) * H + h * 32;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const half4 w = {(_Float16)(o[4 * r4] * inv), (_Float16)(o[4 * r4 + 1] * inv), (_Float16)(o[4 * r4 + 2] * inv), (_Float16)(o[4 * r4 + 3] * inv)};
+                const float2v i2 = {inv, inv};
+                const float2v a = (float2v){o[4 * r4], o[4 * r4 + 1]} * i2, b = (float2v){o[4 * r4 + 2], o[4 * r4 + 3]} * i2;  // (v_pk_mul_f32)
+                const half4 w = {(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
                 *(half4*)(orow + 8 * r4 + 4 * g) = w;
             }
         }
@@ -281,6 +309,14 @@ __global__ __launch_bounds__(256, 4) void k_attn_varlen_hd32_v3(const __half* __
     }
 #endif
 }
+
+// (Measured equal and deleted in round 5's last session: the RING form -- flash-attention's loop order at workgroup level: the 32-key K / V tiles
+// stream ONCE per (sequence, head) through a four-stage LDS ring (16 KB), one DMA piece per wave and tile requested three tiles ahead, one counted
+// vmcnt + one barrier per tile, each wave holding BOTH of its query blocks at once, the running reference entering the scores through a third MFMA
+// k-step (v_mfma_f32_32x32x8_f16 with a ones column) instead of a 16-register C tuple: 271-285 us against 272-281 us, whole encoder 107.5 vs 107.1 ms
+// (profiles/r5_kbench_attention_v3_ring_form_equal.jsonl).  With it every structural variant of this kernel -- staging by DMA or through registers,
+// one or two score tuples, 4 or 5 waves per SIMD, row sums on either pipe, K / V per unit or per tile ring -- lands within box noise of 0.31 ns x
+// the VALU instructions a wave executes (generation 2: 969, 300 us; generation 3: 889, 275 us): what is left to gain is instruction COUNT.)
 
 }  // namespace lm
 

@@ -154,6 +154,27 @@ inline H4 ds_read_tr16_b64(const void* p) {
     w.bar.arrive_and_wait();
     return r;
 }
+// v_mfma_f32_32x32x8_f16: A lane l, e (0..3) -> A[m = l % 32][k = 4 (l / 32) + e]; B likewise -> B[k][n = l % 32]; D as the 32x32x16 form
+template <class AB, class C>
+inline C mfma_32x32x8(AB a, AB b, C c) {
+    Wave& w = my_wave();
+    const int lane = my_lane();
+    for (int e = 0; e < 4; ++e) {
+        w.ma[lane][e] = a[e];
+        w.mb[lane][e] = b[e];
+    }
+    w.bar.arrive_and_wait();
+    const int n = lane & 31, g = lane >> 5;
+    C d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * g;
+        float acc = 0.f;
+        for (int k = 0; k < 8; ++k) acc += (float)w.ma[m + 32 * (k >> 2)][k & 3] * (float)w.mb[n + 32 * (k >> 2)][k & 3];
+        d[r] = c[r] + acc;
+    }
+    w.bar.arrive_and_wait();
+    return d;
+}
 inline float med3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 
 inline unsigned long long ballot(bool p) {

@@ -96,6 +96,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emul::launch(dim3(grid), dim3(block), (size_t)(shmem), [&] { (kernel)(__VA_ARGS__); })
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emul::mfma_32x32x16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, x, y, z) emul::mfma_32x32x8((a), (b), (c))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_fmed3f(a, b, c) emul::med3((a), (b), (c))
