@@ -20,14 +20,17 @@
 //   * the maximum is DEFERRED (cdna_hip_programming.md T13): a tile whose scores stay below m + 8 (in log2 units) keeps m, so the
 //     common path never rescales O; the rescale path (first tile of a query block, and tiles that exceed the threshold -- a
 //     wave-uniform branch) scales O and the row sum, and shifts the tile's scores, the NEXT tile's scores and the -m tuple;
-//   * scores of tile t + 1 are requested from the matrix pipe BEFORE tile t's softmax (two score tuples alive, the tile loop unrolled
-//     by two so that they trade roles without copies): MFMA and LDS latency hide under the previous tile's exponentials;
-//   * keys past the sequence end exist in the last tile only; they are pushed to -1e30 with one v_fmaak + one v_med3 per score (a
-//     per-lane limit computed arithmetically: no compare / select pairs);
+//   * keys past the sequence end exist in the last tile only; they are pushed to -1e30 with one v_med3 per score against a per-lane
+//     limit computed arithmetically (no compare / select pairs: v_cndmask on VCC is the most expensive instruction of the set);
+//   * the row maximum is a TREE of v_max3 (asm: fmaxf would canonicalise every MFMA result first), the row sum runs in two
+//     independent packed chains, the rescale and the epilogue are packed-f32;
 //   * both query blocks of a wave are requested from global memory before the first is used; lane halves are exchanged by
 //     v_permlane32_swap instead of ds_bpermute.
-// Per 32 x 32 score tile and wave: 4 MFMAs and ~45 VALU instructions (16 v_exp_f32, 8 v_max3, 8 v_cvt_pk, 8 v_pk_add_f32, ...)
-// against ~110 in generation 2.  LDS per workgroup 64 B x 2 x padded length = 32 KB at 256 tokens: four workgroups per CU.
+// ONE score tuple: issuing tile t + 1's score MFMAs ahead of tile t's softmax (same registers: 278 vs 271 us; a second tuple: 288 us
+// and a wave per SIMD less) did not pay -- the variants measured and dropped are recorded where they would have lived, below.
+// Per 32 x 32 score tile and wave: 4 MFMAs and ~55 VALU instructions (16 v_exp_f32, 6 v_max3, 8 v_cvt_pk, 8 v_pk_add_f32, ...)
+// against ~110 in generation 2; a wave executes 889 VALU instructions against 969 (the per-block prologue / epilogue does not shrink).
+// LDS per workgroup 64 B x 2 x padded length = 32 KB at 256 tokens: four workgroups per CU.  DESIGN.md 6.1a has the measurement record.
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
@@ -61,26 +64,14 @@ __device__ unsigned long long g_a3_stamps[A3_STAMP_WAVES * A3_STAMP_WORDS];  // 
 #define A3_NOW() 0ull
 #endif
 
-// v_max3_f32 / v_max_f32 as they are: fmaxf on MFMA results makes the compiler quiet possible signalling NaNs first (v_max_f32 x, x, x per operand:
-// four extra instructions per tile); the scores are finite by construction
-__device__ __forceinline__ float a3_max3(float a, float b, float c) {
-#ifdef LM_EMULATED_DEVICE
-    return fmaxf(fmaxf(a, b), c);
-#else
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-#endif
-}
-__device__ __forceinline__ float a3_max(float a, float b) {
-#ifdef LM_EMULATED_DEVICE
-    return fmaxf(a, b);
-#else
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#endif
-}
+// Row maximum helpers.  NOT inline asm: an `asm("v_max3_f32 ...")` on the score MFMA's result registers is invisible to the compiler's hazard
+// recogniser -- a VALU read of an 8-pass MFMA's destination needs 11 wait states, the compiler inserts the s_nop for instructions it knows and
+// none for an asm block -- and the tree then reads registers the matrix pipe has not written yet.  Round 5's last-but-one build did exactly
+// that (to save the four v_max_f32 x, x, x canonicalisations per tile that fmaxf costs): the kernel passed every tolerance test (a stale
+// maximum only moves the deferred-rescale reference) but was not bit-reproducible from launch to launch; the full GPU suite's
+// "same bits from both launch paths" tests caught it (profiles/r5_session17_pytest_gpu_9_failed_asm_max_hazard.log).
+__device__ __forceinline__ float a3_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float a3_max(float a, float b) { return __builtin_fmaxf(a, b); }
 
 constexpr float A3_THR = 8.0f;  // a tile may exceed the running maximum by 2^8 before O is rescaled (P <= 256: exact in fp16's range)
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, GPU session 15 (~3 GPU-minutes): attention generation 3 on an instruction diet (packed-fp16 Q prescale, un-canonicalised max tree, packed rescale / epilogue;
+# Round 5, GPU session 16 (~3 GPU-minutes): attention generation 3 on an instruction diet (packed-fp16 Q prescale, un-canonicalised max tree, packed rescale / epilogue;
 # LEANN_MI355X_ATTN3=1) on hardware: tests, kbench, whole encoder.
 set -u
 cd "$(dirname "$0")/.."

@@ -78,3 +78,62 @@ def test_gpu_recompute_search_matches_golden_c1():
             if v in gd:
                 assert abs(dist[i, j] - gd[v]) <= 1e-4
     assert np.all(np.diff(dist, axis=1) <= 1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_fp16_product_path_on_golden_c1():
+    """GPU, the PRODUCT default on C1's own data (the test above runs the encoder in fp32, i.e. torch's forward): the fp16 encoder behind the
+    library-side provider -- one forward over all 1018 chunks takes the hidden-384 kernels (k_qkv_h384, attention generation 3,
+    k_layer_tail_h384), a search round's few chunks the small-forward form.
+      (1) embeddings: fp16 kernels against the fp32 forward of the same weights on the same tokens, bounds below;
+      (2) search on the committed graph from the committed queries: labels, distance bits and counts equal the oracle's replay of the
+          per-round embeddings (the random-init encoder puts all chunks within 1e-4 .. 1e-3 of each other in similarity -- gaps of the
+          size of fp16's error -- so the fp32 golden LABELS are not a meaningful target for the fp16 path; exact traversal parity on the
+          path's own embeddings is, plus (3));
+      (3) every returned distance against the fp32 similarity of that (query, chunk) pair: within the fp16 encoder's bound of (1)."""
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.recompute import RecomputeProvider
+    from leann_amd.synth import pad_batch
+    from leann_amd.token_store import TokenStore
+    from tests.test_gpu_native_provider import _search_native_vs_python_vs_oracle
+
+    _lib.require_gpu()
+    z, g = _load()
+    dev = torch.device("cuda")
+    enc32 = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), seed=0).to("cuda")
+    ids, lens = pad_batch(z["chunk_tok"], z["chunk_off"], 256)
+    with torch.no_grad():
+        X32 = enc32.encode_tokens(torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda(), batch_size=64)
+    enc16 = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), seed=0).to("cuda", dtype=torch.float16).eval()
+    ts = TokenStore(z["chunk_tok"], z["chunk_off"])
+    nat = RecomputeProvider(enc16, ts, 384, dev)
+    py = RecomputeProvider(enc16, ts, 384, dev)
+    assert nat.native() is not None, "the library-side provider must serve the MiniLM-L6 shape"
+    X16 = nat.embed_ids(torch.arange(g.ntotal, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    err = float((X16 - X32).abs().max())
+    Q = torch.from_numpy(np.ascontiguousarray(z["query_emb"])).cuda()
+    sim_err = float((Q @ X16.T - Q @ X32.T).abs().max())
+    print(f"C1 fp16 product path: max |x16 - x32| = {err:.3e}, max |q.x16 - q.x32| = {sim_err:.3e}")
+    assert err < 2e-3, err          # components are ~0.05 (unit vectors, D = 384)
+    assert sim_err < 4e-3, sim_err  # similarities are ~0.93
+    oi, nunique, _, _ = _search_native_vs_python_vs_oracle(torch, nat, py, g, Q, 384, 64, 1, True)
+    assert nunique > 0
+    # (3) the distances the search returned, against fp32 similarities of the same pairs (metric "mips": distance = -<q, x>; the sign
+    # convention is the oracle's, whatever it is the magnitudes must agree)
+    from leann_amd.index import Mi355xIndex
+
+    idx = Mi355xIndex.from_csr(g)
+    idx.set_stream(torch.cuda.current_stream().cuda_stream)
+    idx.set_provider(nat)
+    gd, gi = idx.search_device(Q, 10, idx.make_params(ef=64, beam=1, recompute=True))
+    torch.cuda.synchronize()
+    assert np.array_equal(gi.cpu().numpy(), oi)
+    ref = torch.gather(Q @ X32.T, 1, gi.long())
+    assert float((gd.abs() - ref.abs()).abs().max()) < 4e-3
+    idx.close()
+    nat.close()
+
