@@ -22,8 +22,8 @@
 //     wave-uniform branch) scales O and the row sum, and shifts the tile's scores, the NEXT tile's scores and the -m tuple;
 //   * keys past the sequence end exist in the last tile only; they are pushed to -1e30 with one v_med3 per score against a per-lane
 //     limit computed arithmetically (no compare / select pairs: v_cndmask on VCC is the most expensive instruction of the set);
-//   * the row maximum is a TREE of v_max3 (asm: fmaxf would canonicalise every MFMA result first), the row sum runs in two
-//     independent packed chains, the rescale and the epilogue are packed-f32;
+//   * the row maximum is a TREE of v_max3 (fmaxf: see a3_max3 below for why not asm), the row sum runs in two independent packed
+//     chains, the rescale and the epilogue are packed-f32;
 //   * both query blocks of a wave are requested from global memory before the first is used; lane halves are exchanged by
 //     v_permlane32_swap instead of ds_bpermute.
 // ONE score tuple: issuing tile t + 1's score MFMAs ahead of tile t's softmax (same registers: 278 vs 271 us; a second tuple: 288 us
@@ -69,7 +69,7 @@ __device__ unsigned long long g_a3_stamps[A3_STAMP_WAVES * A3_STAMP_WORDS];  // 
 // none for an asm block -- and the tree then reads registers the matrix pipe has not written yet.  Round 5's last-but-one build did exactly
 // that (to save the four v_max_f32 x, x, x canonicalisations per tile that fmaxf costs): the kernel passed every tolerance test (a stale
 // maximum only moves the deferred-rescale reference) but was not bit-reproducible from launch to launch; the full GPU suite's
-// "same bits from both launch paths" tests caught it (profiles/r5_session17_pytest_gpu_9_failed_asm_max_hazard.log).
+// "same bits from both launch paths" tests caught it (profiles/r5_session17_pytest_gpu_9_failed_asm_max_hazard.log).  Final: 262-274 us (session 19).
 __device__ __forceinline__ float a3_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float a3_max(float a, float b) { return __builtin_fmaxf(a, b); }
 
