@@ -51,14 +51,19 @@ __device__ __forceinline__ void lm_dma16(const void* gsrc, unsigned char* lds_wa
 }
 // The same piece with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): no 64-bit VALU add per
 // piece; with a wave-uniform lds_wave_base the M0 value is SALU arithmetic as well (the readfirstlane folds away).
+// s_nop 3, not 0: the compiler may hand over `sbase` in SGPRs it has just written with a VALU instruction (v_readfirstlane, or v_readlane when it
+// reloads a spilled SGPR -- k_gemm_f16 does), and a VMEM instruction that reads a VALU-written SGPR needs 5 wait states.  The compiler inserts them
+// for memory instructions it knows (s_nop 4 in front of a global_load with an SGPR base) and cannot for the inside of an asm block: s_mov + s_nop 3
+// are the five.  (No wrong result was ever seen with s_nop 0 -- every GEMM test compares bits -- but the ISA does not promise it;
+// tests/test_asm_hazards.py now checks the assembly of every kernel for this pattern.)
 __device__ __forceinline__ void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
 }
 // ... with the non-temporal hint (streamed activations: read once; A/B switch LM_T4_NT of the layer tail)
 __device__ __forceinline__ void lm_dma16_sv_nt(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
 }
 #endif
 

@@ -1,4 +1,5 @@
-"""Static guard (CPU box: hipcc cross-compiles gfx950) for one class of bug that tolerance tests do not see.
+"""Static guard (CPU box: hipcc cross-compiles gfx950) for a class of bug that tolerance tests do not see: hardware hazards inside inline-asm
+blocks.  Two rules: `violations` (VALU reads of MFMA destinations, below) and `sgpr_violations` (VMEM reads of VALU-written SGPRs).
 
 A VALU read of an MFMA's destination registers needs wait states after the MFMA (11 for the 8-pass 32x32x16 fp16 MFMA on gfx950).  The compiler's
 hazard recogniser inserts the s_nop for instructions it knows -- and nothing for the contents of an inline-asm block.  Round 5 shipped (for one
@@ -62,6 +63,45 @@ def violations(asm_text):
     return out
 
 
+def sgpr_violations(asm_text, need=5):
+    """Second rule: a VMEM instruction inside an inline-asm block (the LDS-DMA pieces: global_load_lds_dwordx4 vOFF, s[BASE:BASE+1]) whose SGPR
+    base was written by a VALU instruction (v_readfirstlane / v_readlane -- the latter is how the compiler reloads a spilled SGPR) fewer than
+    `need` wait states earlier.  The compiler inserts `s_nop 4` for VMEM instructions it knows; the asm block has to carry its own (s_mov m0 +
+    s_nop 3 in lm_dma16_sv).  Wait states are counted along the layout order inside a basic block (a label resets the window: conservative
+    towards NOT reporting across a branch target, where the distance is unknown)."""
+    out = []
+    recent = []  # [(sgpr number, wait states since its VALU definition)]
+    inside = False
+    for line in asm_text.splitlines():
+        t = line.strip()
+        if "#ASMSTART" in t:
+            inside = True
+            continue
+        if "#ASMEND" in t:
+            inside = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            if re.match(r"^\.LBB\d+_\d+:", t):
+                recent = []
+            continue
+        if re.match(r"^[\w$.]+:", t):
+            recent = []
+            continue
+        ws = int(t.split()[1]) + 1 if t.startswith("s_nop") else 1
+        if inside and t.startswith(("global_load", "buffer_load", "global_store", "buffer_store")):
+            m = re.search(r"\bs\[(\d+):(\d+)\]", t)
+            if m:
+                used = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                for sg, c in recent:
+                    if sg in used and c < need:
+                        out.append((t, f"s{sg} written by a VALU instruction {c} wait states earlier"))
+        recent = [(sg, c + ws) for sg, c in recent if c + ws < 16]
+        m = re.match(r"(?:v_readfirstlane_b32|v_readlane_b32)\s+s(\d+)\b", t)
+        if m:
+            recent.append((int(m.group(1)), 0))
+    return out
+
+
 def test_the_rule_flags_the_round_5_bug():
     bad = """
 _ZN2lm1kEv:
@@ -74,6 +114,16 @@ _ZN2lm1kEv:
 """
     good = bad.replace("v_max3_f32 v95, v32, v33, v34", "v_max_f32 v95, 0, v96").replace("v[32:47], v[64:67]", "a[0:15], v[64:67]")
     assert violations(bad) and not violations(good)
+    spill = """
+\tv_readlane_b32 s12, v247, 3
+\tv_readlane_b32 s13, v247, 4
+\t;;#ASMSTART
+\ts_mov_b32 m0, s71
+\ts_nop 0
+\tglobal_load_lds_dwordx4 v184, s[12:13]
+\t;;#ASMEND
+"""
+    assert sgpr_violations(spill) and not sgpr_violations(spill.replace("s_nop 0", "s_nop 3"))
 
 
 @pytest.mark.parametrize("src,flags", _sources_and_flags(), ids=lambda v: v if isinstance(v, str) else "")
@@ -86,5 +136,5 @@ def test_no_inline_asm_valu_reads_an_mfma_destination(src, flags, tmp_path):
     out = tmp_path / "k.s"
     r = subprocess.run([HIPCC, *flags, "-I", str(CSRC), "--cuda-device-only", "-S", "-o", str(out), str(CSRC / src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    v = violations(out.read_text())
-    assert not v, f"{src}: inline-asm VALU instructions read MFMA destination registers (no hazard wait states are inserted for them): {v[:5]}"
+    v = violations(out.read_text()) + sgpr_violations(out.read_text())
+    assert not v, f"{src}: hazards inside inline-asm blocks, which the compiler's hazard recogniser does not look into: {v[:5]}"
