@@ -1,5 +1,6 @@
 """Static guard (CPU box: hipcc cross-compiles gfx950) for a class of bug that tolerance tests do not see: hardware hazards inside inline-asm
-blocks.  Two rules: `violations` (VALU reads of MFMA destinations, below) and `sgpr_violations` (VMEM reads of VALU-written SGPRs).
+blocks.  Three rules: `violations` (VALU reads of MFMA destinations, below), `sgpr_violations` (VMEM reads of VALU-written SGPRs) and
+`scratch_violations` (no scratch traffic in kernels whose asm blocks count their vector-memory operations).
 
 A VALU read of an MFMA's destination registers needs wait states after the MFMA (11 for the 8-pass 32x32x16 fp16 MFMA on gfx950).  The compiler's
 hazard recogniser inserts the s_nop for instructions it knows -- and nothing for the contents of an inline-asm block.  Round 5 shipped (for one
@@ -102,6 +103,35 @@ def sgpr_violations(asm_text, need=5):
     return out
 
 
+def scratch_violations(asm_text):
+    """Third rule: a kernel whose asm blocks carry COUNTED vector-memory waits (`s_waitcnt vmcnt(n)`, n > 0: "my older requests have landed, the n
+    younger ones may be in flight") must not touch scratch memory -- a spill store or reload is one more vector-memory operation in the wave's in-order
+    counter, which the count in the source knows nothing about.  (Spills to AGPRs or to VGPR lanes are register traffic and fine.)"""
+    counted = set()
+    name, inside = None, False
+    for line in asm_text.splitlines():
+        t = line.strip()
+        m = re.match(r"^(_Z\w+):", t)
+        if m:
+            name = m.group(1)
+        if "#ASMSTART" in t:
+            inside = True
+        elif "#ASMEND" in t:
+            inside = False
+        elif inside and name:
+            m = re.match(r"s_waitcnt\s+vmcnt\((\d+)\)", t)
+            if m and int(m.group(1)) > 0:
+                counted.add(name)
+    out = []
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", asm_text, re.S):
+        b = m.group(0)
+        kn = re.search(r"\.name:\s+(\S+)", b).group(1)
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1))
+        if kn in counted and scratch:
+            out.append((kn, f"{scratch} B of scratch per lane in a kernel with counted vmcnt waits"))
+    return out
+
+
 def test_the_rule_flags_the_round_5_bug():
     bad = """
 _ZN2lm1kEv:
@@ -136,5 +166,5 @@ def test_no_inline_asm_valu_reads_an_mfma_destination(src, flags, tmp_path):
     out = tmp_path / "k.s"
     r = subprocess.run([HIPCC, *flags, "-I", str(CSRC), "--cuda-device-only", "-S", "-o", str(out), str(CSRC / src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    v = violations(out.read_text()) + sgpr_violations(out.read_text())
+    v = violations(out.read_text()) + sgpr_violations(out.read_text()) + scratch_violations(out.read_text())
     assert not v, f"{src}: hazards inside inline-asm blocks, which the compiler's hazard recogniser does not look into: {v[:5]}"
