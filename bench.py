@@ -77,10 +77,15 @@ def main():
     ap.add_argument("--extra-batches", default="", help="comma-separated batch sizes: one extra search call each on fresh queries after the timed steps (library defaults), "
                     "reported as extra_batch_rows -- e.g. 128 = the per-rank batch of C5 (query batch 1024) on 8 GPUs")
     ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
+    ap.add_argument("--box-probe-only", action="store_true",
+                    help="run only the box probe's kernel launches (the 262,107-token layer tail x 13) and print its line: what the probe's rocprofv3 --pmc child runs")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the box probe (clock / power sampling, reference launches of the dominant kernel, copy rate)")
     ap.add_argument("--dry-run-emulated", default=None, metavar="LIB",
                     help="TEST ONLY (tests/test_bench_dry_run.py): run this script's control flow -- incl. every world > 1 branch, over gloo -- on the CPU against "
                          "the thread-per-lane build of the library (tests/hip_emul), with a tiny model and corpus; the line says data = dry-run and measures nothing")
     args = ap.parse_args()
+    if args.box_probe_only:
+        return _box_probe_only()
     if args.dry_run_emulated:
         import contextlib
 
@@ -265,9 +270,21 @@ def _main(args, ap):
     if args.table_roofline and world == 1:
         try:
             idx.set_profiling(True)
-            Qbig = Q_all.repeat((max(1, 8192 // Q_all.shape[0]) + 1, 1))[:8192].contiguous()
+            # 8192 DISTINCT queries of their own (held-out chunks, another seed than the timed queries'): no row gather of this measurement is a
+            # guaranteed re-read of the same query's twin
+            nbig = 8192 if not dry else 16
+            bt, bo, _ = corpus.queries(nbig, seed=97531)
+            Qbig = RecomputeProvider(enc, TokenStore(bt, bo, device=lib_dev), provider.dp, dev).embed_ids(torch.arange(nbig, dtype=torch.int32, device=dev)).contiguous()
             bytes_eval = D * 4 + 4
-            table_roof = {}
+            table_roof = {"queries_in_flight": nbig, "distinct_queries": int(torch.unique(Qbig, dim=0).shape[0])}
+            try:  # L2-miss-side bytes of this kernel from its own FETCH_SIZE pass (scripts/pmc_table_mode.sh), as a ratio to the algorithmic bytes
+                pm = json.loads((ROOT / "profiles" / "r6_pmc_table_mode.json").read_text())
+                table_roof["traffic"] = {f"beam{c['beam']}": {"l2_miss_side_over_algorithmic": c["l2_miss_side_over_algorithmic"], "l2_miss_side_bytes_per_launch": c["l2_miss_side_bytes"],
+                                                              "algorithmic_bytes_per_launch": c["algorithmic_bytes"]} for c in pm["run"]["calls"][-2:]}
+                table_roof["traffic_source"] = ("profiles/r6_pmc_table_mode.json: rocprofv3 --pmc FETCH_SIZE over scripts/pmc_table_mode.py (same index, 8192 distinct queries), calibrated "
+                                                "in-pass on a read of every table row once in the kernel's own access pattern; FETCH_SIZE counts L2 misses (Infinity-Cache hits included)")
+            except Exception:  # noqa: BLE001
+                pass
             # interleaved A/B: persistent one-launch kernel (wave / workgroup per query; -1 = the library's own choice) vs lock-step rounds
             for persistent, wave in ((1, -1), (1, 1), (1, 0), (0, 0)) * 2:
                 for beam_t, ef_t in ((4, ef), (1, ef)):
@@ -283,6 +300,11 @@ def _main(args, ap):
                          "us_per_launch": round(1e3 * net_ms / max(st["update_launches"], 1), 2),
                          "us_per_launch_event_pair": round(1e3 * st["update_ms"] / max(st["update_launches"], 1), 2),
                          "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
+                    tr_ = (table_roof.get("traffic") or {}).get(f"beam{beam_t}")
+                    if tr_ and persistent:
+                        r["GBps_l2_miss_side"] = round(r["GBps"] * tr_["l2_miss_side_over_algorithmic"], 1)
+                        r["frac_of_8TBps_algorithmic"] = round(r["GBps"] / 8000.0, 4)
+                        r["frac_of_8TBps_l2_miss_side"] = round(r["GBps_l2_miss_side"] / 8000.0, 4)
                     table_roof.setdefault(key, []).append(r)
             idx.set_option("persistent_table", 1)
             idx.set_option("persistent_wave", -1)
@@ -322,6 +344,11 @@ def _main(args, ap):
 
     batches = [global_batch(w) for w in range(W + K)]
     out_labels = []
+    # what box is this?  (reference launches of the dominant kernel + a copy rate on the idle chip, before anything is timed)
+    probe = None
+    if cfg.hidden == 384 and not dry and not args.no_box_probe:
+        probe = box_probe(enc, dev, local_rank)
+        log("box probe:", json.dumps(probe)[:600])
     kt_close("setup")
     for w in range(W):
         ps.search(batches[w], 10)
@@ -329,6 +356,7 @@ def _main(args, ap):
     provider.chunks = 0
     barrier()
     kt_close("warmup")
+    sampler = BoxSampler(local_rank).start() if (probe is not None and rank == 0) else None  # a thread reading sysfs once a second (rocm-smi every 5 s where sysfs has no clocks)
     t0 = time.perf_counter()
     for s in range(K):
         _, l = ps.search(batches[W + s], 10)
@@ -338,6 +366,8 @@ def _main(args, ap):
             agg[k_] += st[k_]
     barrier()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        probe["clocks_during_the_timed_steps"] = sampler.stop()
     ktimes = kt_close("timed")  # (reading waits for the last pairs: after the clock has stopped)
     # ---- the same steps WITHOUT the per-call memo (dedup per lock-step round only: rounds 1 / 2's `value`), on the same queries:
     #      K2 = min(K, 3) steps (one, when a step takes more than 20 s) after one warm-up step, same bracketing; labels must be identical to
@@ -470,6 +500,12 @@ def _main(args, ap):
                     idx.set_provider(provider)
         except Exception as ex:  # noqa: BLE001
             extras_errors["small_batch_latency"] = repr(ex)[:300]
+    frontier = None
+    if world == 1 and not args.no_latency_rows:
+        try:
+            frontier = latency_frontier(idx, Q, recall, next_row)
+        except Exception as ex:  # noqa: BLE001
+            extras_errors["small_batch_latency_frontier"] = repr(ex)[:300]
     if world == 1 and idx.native_provider and K and not args.no_provider_ab:  # one full-size step over the PYTHON provider, on a timed step's own queries: same labels
         os.environ["LEANN_MI355X_NATIVE_PROVIDER"] = "0"
         try:
@@ -569,11 +605,15 @@ def _main(args, ap):
     try:  # HBM bytes per launch from the separate PMC pass (profiles/r1_pmc_k_update.json), scaled to this run's launch size
         pmc_file = next(f for f in ("r4_pmc_k_update.json", "r1_pmc_k_update.json") if (ROOT / "profiles" / f).exists())
         pmc = json.loads((ROOT / "profiles" / pmc_file).read_text())
-        traffic = round(pmc.get("hbm_bytes_per_eval", pmc["hbm_bytes_per_eval_corrected_x1.36"]) * prof["ndis"] / max(prof["update_launches"], 1))
-        traffic_src = (f"rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/{pmc_file}), calibrated x1.36 on a known byte count measured "
-                       "in the same pass, scaled by evals/launch")
-    except Exception:  # noqa: BLE001
-        pass
+        per_eval = pmc.get("hbm_bytes_per_eval") or pmc.get("hbm_bytes_per_eval_corrected_x1.36") or pmc.get("hbm_bytes_per_eval_corrected_x1.08")
+        if per_eval:
+            traffic = round(per_eval * prof["ndis"] / max(prof["update_launches"], 1))
+            traffic_src = (f"rocprofv3 --pmc FETCH_SIZE pass on scripts/kernel_bench.py --provider (profiles/{pmc_file}), calibrated on a known byte count measured "
+                           "in the same pass, scaled by evals/launch")
+        else:
+            traffic_src = f"profiles/{pmc_file} carries no hbm_bytes_per_eval key: traffic not reported"
+    except Exception as ex:  # noqa: BLE001
+        traffic_src = "no PMC file of the distance kernel could be read: " + repr(ex)[:120]
     roofline_dist = {"bound": "hbm", "kernel": "lm::k_update<6,false,false,1,256> (fused gather + distance + beam update, recompute mode)", "achieved": round(achieved, 2),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(bytes_eval * prof["ndis"] / max(prof["update_launches"], 1)),
@@ -673,6 +713,19 @@ def _main(args, ap):
     if isinstance(result["roofline"], dict):
         result["roofline"]["value_without_call_memo_queries_per_s"] = result["without_call_memo"]["value"]
         result["roofline"]["whole_encoder_TFLOPs"] = roofline_encoder["achieved"]
+        if probe is not None:
+            try:  # the three kernels of a hidden-384 layer in the profiled step, scaled to kbench's 262,144-token reference size (every layer's
+                # launches process the same tokens: the tail's flop count gives tokens x layers)
+                tl = kprof.get("lm::k_layer_tail_h384", {})
+                tok_layers = tl.get("work", 0.0) / fpt if fpt else 0.0
+                if tok_layers > 0:
+                    probe["profiled_step_us_per_262144_tokens"] = {
+                        k_.replace("lm::", ""): round(1e3 * v_["ms"] / (tok_layers / 262144.0), 1)
+                        for k_, v_ in kprof.items() if v_["launches"] and k_ in ("lm::k_layer_tail_h384", "lm::k_qkv_h384", "lm::k_attn_varlen", "lm::k_qkv_attn_h384")}
+                    probe["profiled_step_tokens_x_layers"] = round(tok_layers)
+            except Exception as ex:  # noqa: BLE001
+                probe["profiled_step_error"] = repr(ex)[:200]
+            result["roofline"]["box_probe"] = probe
     if min_ef:
         result["at_min_ef"] = min_ef
     if with_hub:
@@ -683,6 +736,10 @@ def _main(args, ap):
         result["small_batch_latency"] = latency_rows
         result["small_batch_latency_provider"] = ("library-side provider (csrc/lm_recompute.hip): no interpreter in the search loop, one host "
                                                   "synchronisation per round" if latency_python_provider is not None else "Python provider")
+    if frontier:
+        result["small_batch_latency_frontier"] = frontier
+        if isinstance(result["roofline"], dict) and frontier.get("best_at_recall_0.9"):  # (the driver's record keeps `roofline` whole)
+            result["roofline"]["b1_best_at_recall_0.9"] = frontier["best_at_recall_0.9"]
     if latency_python_provider:
         result["small_batch_latency_python_provider"] = latency_python_provider
     if latency_speculate and any(latency_speculate.values()):
@@ -722,6 +779,229 @@ def _main(args, ap):
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# ---- box probe: what box did this line run on? --------------------------------------------------------------------
+# Two rounds of driver lines swung by +-8 % with nothing in them to tell a slow box from a slow build.  Three things go into
+# roofline.box_probe: (i) sclk / mclk / socket power sampled WHILE the timed steps run (a thread reading sysfs, or rocm-smi where sysfs has
+# no such file); (ii) before the timed steps, on an idle chip: 10 launches of the dominant kernel at kbench's reference size (262,107 tokens:
+# 675-690 us on the boxes DESIGN 6.1 calls fast, 730+ on the slow ones) and the rate of a 1 GiB device-to-device copy; (iii) when (ii) reads
+# slow, an L2 / fabric counter pass (rocprofv3 --pmc, kernel trace only) over the same launches in a child process, next to the fast-box
+# reference kept under profiles/.
+TAIL_PROBE_TOKENS = 262107
+TAIL_PROBE_SLOW_US = 750.0
+
+
+def _sysfs_cards():
+    import glob
+
+    return sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+
+
+def _sysfs_sample(card):
+    """{"sclk_mhz", "mclk_mhz", "power_w"} of one card from sysfs (None where a file is missing)"""
+    import glob
+    import re
+
+    def cur(name):
+        try:
+            for ln in open(os.path.join(card, name)):
+                if "*" in ln:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
+                    return int(m.group(1)) if m else None
+        except OSError:
+            pass
+        return None
+
+    pw = None
+    for f in glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_input")):
+        try:
+            pw = int(open(f).read().strip()) / 1e6
+            break
+        except (OSError, ValueError):
+            continue
+    return {"sclk_mhz": cur("pp_dpm_sclk"), "mclk_mhz": cur("pp_dpm_mclk"), "power_w": pw}
+
+
+def _rocm_smi_sample():
+    import re
+    import subprocess
+
+    try:
+        txt = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:  # noqa: BLE001
+        return None
+    g = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, txt))  # noqa: E731
+    return {"sclk_mhz": g(r"GPU\[0\]\s*:\s*sclk clock level:[^(]*\((\d+)Mhz\)"), "mclk_mhz": g(r"GPU\[0\]\s*:\s*mclk clock level:[^(]*\((\d+)Mhz\)"),
+            "power_w": g(r"GPU\[0\]\s*:\s*Current Socket Graphics Package Power \(W\):\s*([\d.]+)")}
+
+
+class BoxSampler:
+    """Samples clocks and power of GPU `index` in a thread between start() and stop().  sysfs first (no process per sample); rocm-smi (one
+    process per sample, every 5 s) where sysfs gives no clock."""
+
+    def __init__(self, index=0, period_s=1.0):
+        import threading
+
+        cards = _sysfs_cards()
+        self.card = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.source = "sysfs" if self.card and _sysfs_sample(self.card)["sclk_mhz"] is not None else "rocm-smi"
+        self.period = period_s if self.source == "sysfs" else 5.0
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _one(self):
+        return _sysfs_sample(self.card) if self.source == "sysfs" else _rocm_smi_sample()
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                v = self._one()
+                if v:
+                    self.samples.append(v)
+            except Exception:  # noqa: BLE001
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(timeout=30)
+        out = {"source": self.source, "n_samples": len(self.samples)}
+        for k in ("sclk_mhz", "mclk_mhz", "power_w"):
+            v = [x[k] for x in self.samples if x.get(k) is not None]
+            if v:
+                out[k] = {"min": round(min(v), 1), "median": round(float(np.median(v)), 1), "max": round(max(v), 1)}
+        return out
+
+
+def _tail_probe_launches(enc, dev, tokens=TAIL_PROBE_TOKENS, launches=10, warm=3):
+    """`launches` timed launches of the fused layer tail (layer 0 of `enc`, random activations) at kbench's reference size; HIP events on the
+    launch stream.  Returns the per-launch times in us."""
+    import torch
+
+    from leann_amd.encoder import fused_attn_out_mlp
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    a = (torch.randn((tokens, 384), generator=g) * 0.5).to(dev, torch.float16)
+    r = (torch.randn((tokens, 384), generator=g) * 0.5).to(dev, torch.float16)
+    layer = enc.layers[0]
+    for _ in range(warm):
+        if fused_attn_out_mlp(a, r, layer) is None:
+            return None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for e0, e1 in ev:
+        e0.record()
+        fused_attn_out_mlp(a, r, layer)
+        e1.record()
+    torch.cuda.synchronize()
+    return [1e3 * e0.elapsed_time(e1) for e0, e1 in ev]
+
+
+def _copy_rate(dev, gib=1, reps=5):
+    import torch
+
+    n = gib << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).fill_(3)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + written bytes per second, GB/s
+
+
+def _box_probe_only():
+    """What the probe's rocprofv3 child runs: the reference launches of the dominant kernel and nothing else."""
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder
+
+    _lib.require_gpu()
+    dev = torch.device("cuda", 0)
+    enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2", allow_random=True).to(dev, dtype=torch.float16).eval()
+    us = _tail_probe_launches(enc, dev)
+    print(json.dumps({"tail_probe_us": [round(x, 1) for x in (us or [])]}), flush=True)
+
+
+TCC_PASS_COUNTERS = ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_LEVEL_sum", "GRBM_GUI_ACTIVE"]
+
+
+def _tcc_pass(timeout_s=240):
+    """L2 hit / miss, fabric read requests and their summed occupancy (LEVEL / RDREQ = mean read latency in L2 cycles) of the probe's launches:
+    rocprofv3 --pmc with the kernel trace only, over `bench.py --box-probe-only` in a child process.  Per-launch means of k_layer_tail_h384."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    out = tempfile.mkdtemp(prefix="lm_tcc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = ["rocprofv3", "--pmc", *TCC_PASS_COUNTERS, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "tcc", "--",
+               sys.executable, os.path.abspath(__file__), "--box-probe-only"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+        f = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+        if not f:
+            return {"error": f"no counter file (rc {r.returncode}): {r.stderr[-300:]}"}
+        acc, n = {}, {}
+        for row in csv.DictReader(open(f[0])):
+            if "k_layer_tail_h384" not in row["Kernel_Name"]:
+                continue
+            c = row["Counter_Name"]
+            acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+            n[c] = n.get(c, 0) + 1
+        res = {c: round(acc[c] / n[c]) for c in acc}
+        res["launches"] = max(n.values()) if n else 0
+        if res.get("TCC_HIT_sum") is not None and res.get("TCC_MISS_sum") is not None:
+            res["l2_hit_rate"] = round(res["TCC_HIT_sum"] / max(res["TCC_HIT_sum"] + res["TCC_MISS_sum"], 1), 4)
+        if res.get("TCC_EA0_RDREQ_sum"):
+            res["mean_fabric_read_latency_l2_cycles"] = round(res.get("TCC_EA0_RDREQ_LEVEL_sum", 0) / res["TCC_EA0_RDREQ_sum"], 1)
+        m = None
+        for ln in r.stdout.splitlines():
+            if ln.startswith('{"tail_probe_us"'):
+                m = json.loads(ln)["tail_probe_us"]
+        res["tail_probe_us_under_the_counters"] = m
+        return res
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)[:300]}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def box_probe(enc, dev, local_rank=0):
+    """(ii) and (iii) above.  Never raises."""
+    out = {"what": f"before the timed steps, idle chip: 10 launches of lm_layer_tail_h384_f16 at {TAIL_PROBE_TOKENS} tokens (kbench tail4's size: 675-690 us on the "
+                   f"boxes DESIGN 6.1 calls fast, 730+ on the slow ones) and a 1 GiB device-to-device copy; clocks / power sampled during the timed steps"}
+    try:
+        smp = BoxSampler(local_rank, period_s=0.2).start()
+        us = _tail_probe_launches(enc, dev)
+        out["clocks_during_the_probe_launches"] = smp.stop()
+        if us:
+            out["layer_tail_262107_tokens_us"] = {"median": round(float(np.median(us)), 1), "min": round(min(us), 1), "max": round(max(us), 1), "launches": len(us)}
+            out["layer_tail_TFLOPs"] = round(TAIL_PROBE_TOKENS * (4 * 1536 * 384 + 2 * 384 * 384) / (float(np.median(us)) * 1e-6) / 1e12, 1)
+            out["box_class"] = "slow" if float(np.median(us)) > TAIL_PROBE_SLOW_US else "fast"
+        out["copy_1GiB_GBps_read_plus_written"] = round(_copy_rate(dev), 1)
+        ref = ROOT / "profiles" / "r6_box_probe_tcc_pass_fast_box.json"
+        if ref.exists():
+            out["tcc_pass_fast_box_reference"] = json.loads(ref.read_text()).get("tcc_pass")
+        if os.environ.get("BENCH_FORCE_TCC_PASS") == "1" or (us and float(np.median(us)) > TAIL_PROBE_SLOW_US and os.environ.get("BENCH_NO_TCC_PASS") != "1"):
+            out["tcc_pass"] = _tcc_pass()
+            out["tcc_pass_counters"] = ("rocprofv3 --pmc " + " ".join(TCC_PASS_COUNTERS) + " --kernel-trace -- python bench.py --box-probe-only (child process, "
+                                        "per-launch means of k_layer_tail_h384; LEVEL / RDREQ = mean fabric read latency in L2 cycles)")
+    except Exception as ex:  # noqa: BLE001
+        out["error"] = repr(ex)[:300]
+    return out
 
 
 def parity_check(idx, g, X, Q, provider, ef, beam, dim, n_table=256, n_recompute=16):
@@ -829,6 +1109,66 @@ def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 2
                      "recall_at_10": round(rec, 4), "recomputed_chunks_per_query": round(chunks / (len(lat) * b), 1),
                      "rounds_per_call": round(rounds / len(lat), 1)})
     return rows, lo
+
+
+def latency_frontier(idx, Q, recall, first_row, efs=(16, 32, 64), beams=(1, 4), batch_sizes=(0, 32, 64, 128), reps=10, b256=True, budget_s=60.0):
+    """Latency vs recall at B = 1 over the three knobs the reference's search call carries (hnsw_backend.py:203-234): complexity (efSearch),
+    beam_width (pops per round) and batch_size (dynamic batching, paper section 4.2: k_expand keeps popping while a round's new-list is
+    shorter).  Every cell: `reps` one-query calls on fresh queries (the SAME queries in every cell), p50 latency, recall@10 against the exact
+    top-10, rounds and recomputed chunks per call.  `best_at_recall_0.9` = the fastest cell with recall >= 0.9.  B = 256 (one call per
+    setting) for the throughput side of the same knob."""
+    import torch
+
+    cells, t_all = [], time.perf_counter()
+    lo = first_row
+    if lo + reps + 1 + 512 > Q.shape[0]:
+        lo = max(0, Q.shape[0] - (reps + 1 + 512))
+    qs = [Q[lo + 1 + i : lo + 2 + i].contiguous() for i in range(reps)]
+    rows = [range(lo + 1 + i, lo + 2 + i) for i in range(reps)]
+    for ef in efs:
+        for beam in beams:
+            for bs in batch_sizes:
+                if time.perf_counter() - t_all > budget_s:
+                    break
+                prm = idx.make_params(ef=ef, beam=beam, recompute=True, max_batch=1, batch_size=bs)
+                idx.search_device(Q[lo : lo + 1].contiguous(), 10, prm)  # warm-up of this setting (workspace sizing)
+                lat, rec, rounds, chunks, ndis = [], [], 0, 0, 0
+                for q1, r1 in zip(qs, rows):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    _, l = idx.search_device(q1, 10, prm)
+                    torch.cuda.synchronize()
+                    lat.append((time.perf_counter() - t0) * 1e3)
+                    st_ = idx.stats()
+                    rounds += int(st_["nrounds"])
+                    chunks += int(st_["nunique"])
+                    ndis += int(st_["ndis"])
+                    rec.append(recall(l.cpu().numpy(), r1))
+                cells.append({"ef": ef, "beam": beam, "batch_size": bs, "p50_ms": round(float(np.median(lat)), 2), "mean_ms": round(float(np.mean(lat)), 2),
+                              "recall_at_10": round(float(np.mean(rec)), 4), "rounds_per_call": round(rounds / reps, 1), "recomputed_chunks_per_call": round(chunks / reps, 1),
+                              "distance_evals_per_call": round(ndis / reps, 1)})
+    ok = [c for c in cells if c["recall_at_10"] >= 0.9]
+    out = {"batch": 1, "reps_per_cell": reps, "cells": cells, "best_at_recall_0.9": min(ok, key=lambda c: c["p50_ms"]) if ok else None,
+           "what": "one-query calls (the real caller's batch, api.py:644-796) over efSearch x beam_width x batch_size; the same queries in every cell; recall against the exact top-10"}
+    if b256:
+        out["batch_256"] = []
+        qb = Q[lo + reps + 1 : lo + reps + 1 + 256].contiguous()
+        rb = range(lo + reps + 1, lo + reps + 1 + 256)
+        for ef, beam, bs in ((64, 1, 0), (64, 1, 64), (64, 4, 0), (32, 1, 64)):
+            if time.perf_counter() - t_all > 1.5 * budget_s:
+                break
+            prm = idx.make_params(ef=ef, beam=beam, recompute=True, max_batch=256, batch_size=bs)
+            idx.search_device(Q[lo + reps + 257 : lo + reps + 513].contiguous(), 10, prm)  # warm-up on other queries
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, l = idx.search_device(qb, 10, prm)
+            torch.cuda.synchronize()
+            e_ = time.perf_counter() - t0
+            st_ = idx.stats()
+            out["batch_256"].append({"ef": ef, "beam": beam, "batch_size": bs, "ms": round(1e3 * e_, 1), "queries_per_s": round(256 / e_, 1),
+                                     "recall_at_10": round(recall(l.cpu().numpy(), rb), 4), "rounds": int(st_["nrounds"]),
+                                     "recomputed_chunks_per_query": round(st_["nunique"] / 256, 1)})
+    return out
 
 
 def cpu_traversal_only(orc, og, Q, X, ef, beam, ncores):

@@ -41,6 +41,11 @@ typedef struct lm_tokens lm_tokens;   /* HBM-resident pre-tokenised passage stor
 const char *lm_last_error(void);
 int lm_device_count(void);           /* 0 when no HIP device is visible */
 const char *lm_version(void);
+/* Revision of THIS interface: bumped whenever an entry point, a struct layout or an enum of this header changes incompatibly (6: round 6 --
+ * lm_kernel_timing_read takes the caller's capacity; lm_search_params.batch_size has a meaning; LM_KT_COUNT grew in round 5).  A binding
+ * compares lm_abi_revision() with the LM_ABI_REVISION it was written against before it calls anything else. */
+#define LM_ABI_REVISION 6
+int lm_abi_revision(void);
 
 /* ---- index lifetime ---------------------------------------------------------------------
  * Replaces faiss.read_index(str(index_file), faiss.IO_FLAG_MMAP, HNSWIndexConfig{is_compact,
@@ -116,7 +121,14 @@ typedef struct {
     float send_neigh_times_ratio;    /* > 1e-6: "proportional": quota from this hop's count, taken from the
                                         per-query approximate queue; else "global": everything unconsumed in
                                         the top (1-ratio) fraction of the approximate queue            :226-231 */
-    int32_t batch_size;              /* accepted, unused: rounds batch across queries :234 */
+    int32_t batch_size;              /* "Neighbor processing batch size" :163,181,234 -- the paper's dynamic batching (section 4.2):
+                                        > 0: after its beam_size pops a query keeps popping its best unexpanded candidate, one at a
+                                        time and under the same stop rules, while the round's new-list (unvisited neighbours gathered
+                                        so far) is shorter than batch_size -- fewer, fuller recompute forwards per search (a one-query
+                                        search at efSearch 64: ~75 rounds of ~10 chunks -> ~20 rounds of ~64 at batch_size 64) for a
+                                        few per cent more distance evaluations; the pops are chosen on the pool as it stood at the
+                                        start of the round.  0 (the reference's default): off, results unchanged bit for bit.
+                                        Rounds batch ACROSS queries as well, whatever this says.  oracle/lm_oracle.c restates it. */
     int32_t zmq_port;                /* accepted, unused: the encoder is in-process   :205 */
     int32_t recompute;               /* 1: use the provider, 0: use the attached table */
     int32_t max_batch;               /* queries in flight per pass (0 = default 4096) */
@@ -461,7 +473,8 @@ typedef struct lm_kernel_time {
     double ms, work;
 } lm_kernel_time;
 int lm_kernel_timing_enable(uint32_t mask);
-int lm_kernel_timing_read(lm_kernel_time *out /* [LM_KT_COUNT] */, int32_t reset);
+/* out[0 .. min(capacity, LM_KT_COUNT)) are written (a caller built against an older, shorter LM_KT_COUNT is never overrun). */
+int lm_kernel_timing_read(lm_kernel_time *out, int32_t capacity, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -14,5 +14,5 @@ from .backend import (  # noqa: F401  (registers the backends)
     Mi355xSearcher,
 )
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 __all__ = ["Mi355xBackend", "Mi355xBuilder", "Mi355xSearcher", "Mi355xDiskannBackend", "Mi355xDiskannBuilder", "Mi355xDiskannSearcher"]

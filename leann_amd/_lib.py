@@ -95,11 +95,13 @@ class RecomputeStats(C.Structure):  # include/leann_mi355x.h: lm_recompute_stats
     _fields_ = [(n, C.c_int64) for n in ("calls", "chunks", "tokens", "forwards", "host_syncs")]
 
 
+ABI_REVISION = 6  # include/leann_mi355x.h: LM_ABI_REVISION
+
 PROVIDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p)
 
 # every symbol include/leann_mi355x.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "lm_last_error", "lm_device_count", "lm_version",
+    "lm_last_error", "lm_device_count", "lm_version", "lm_abi_revision",
     "lm_index_read", "lm_index_create_from_csr", "lm_index_free", "lm_index_info",
     "lm_index_attach_table", "lm_index_set_provider", "lm_index_set_hub_cache", "lm_index_set_stream",
     "lm_search_params_default", "lm_index_search", "lm_index_search_device",
@@ -132,6 +134,9 @@ def load() -> C.CDLL:
     vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
     lib.lm_last_error.restype = C.c_char_p
     lib.lm_version.restype = C.c_char_p
+    if lib.lm_abi_revision() != ABI_REVISION:  # a stale build of the library beside a newer package (or the reverse): struct layouts may differ
+        raise LeannMi355xError(f"{LIB_PATH} speaks ABI revision {lib.lm_abi_revision()}, this package was written against {ABI_REVISION}: rebuild it "
+                               "(`make -C leann_amd/csrc`)")
     lib.lm_device_count.restype = C.c_int
     lib.lm_index_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.lm_index_create_from_csr.argtypes = [i64, i32, i32, vp, vp, i64, vp, i64, vp, i32, i32, C.c_int, C.POINTER(vp)]
@@ -193,7 +198,7 @@ def load() -> C.CDLL:
     lib.lm_recompute_get_stats.argtypes = [vp, C.POINTER(RecomputeStats)]
     lib.lm_index_set_recompute.argtypes = [vp, vp]
     lib.lm_kernel_timing_enable.argtypes = [C.c_uint32]
-    lib.lm_kernel_timing_read.argtypes = [C.POINTER(KernelTime), i32]
+    lib.lm_kernel_timing_read.argtypes = [C.POINTER(KernelTime), i32, i32]
     _lib = lib
     return lib
 
@@ -223,7 +228,7 @@ def kernel_timing_enable(mask: int) -> None:
 def kernel_timing_read(reset: bool = False) -> dict:
     """{kernel name: {"launches", "ms", "work"}} accumulated since the last reset (waits for the pairs recorded so far)."""
     arr = (KernelTime * KT_COUNT)()
-    check(load().lm_kernel_timing_read(arr, 1 if reset else 0), "lm_kernel_timing_read")
+    check(load().lm_kernel_timing_read(arr, KT_COUNT, 1 if reset else 0), "lm_kernel_timing_read")
     return {a.name.decode(): {"launches": int(a.launches), "ms": float(a.ms), "work": float(a.work)} for a in arr}
 
 

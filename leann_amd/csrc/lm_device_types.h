@@ -25,6 +25,8 @@ struct GraphDev {
 struct WsDev {
     int32_t B, ef, W, maxnew;  // ef = pool capacity max(efSearch, k)
     int32_t efs;               // the caller's efSearch: what both faiss stop rules count against (lm_beam_common.h: select_pops)
+    int32_t batch;             // dynamic batching (lm_search_params.batch_size): k_expand goes on popping while a query's new-list is shorter; 0 = off
+    int32_t check_rel;         // lm_search_params.check_relative_distance (k_expand's extra pops obey the same stop rules as select_pops)
     int64_t nw;  // visited words per query
     int32_t* phase;
     int32_t* level;

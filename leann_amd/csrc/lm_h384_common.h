@@ -45,26 +45,44 @@ __device__ inline void lm_dma16(const void* gsrc, unsigned char* lds_wave_base) 
 __device__ inline void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) { lm_dma16((const unsigned char*)sbase + voff, lds_wave_base); }
 __device__ inline void lm_dma16_sv_nt(const void* sbase, unsigned voff, unsigned char* lds_wave_base) { lm_dma16((const unsigned char*)sbase + voff, lds_wave_base); }
 #else
+// Wait states between the M0 write and the first LDS-DMA instruction of an asm block, as the s_nop operand (s_nop N = N + 1 wait states).
+// TWO rules of the gfx9 ISA meet here: (a) SALU writes M0 -> an instruction that uses M0 as its LDS address: 1 wait state (s_nop 0 would do);
+// (b) a VALU instruction wrote an SGPR (v_readfirstlane / v_readlane: how the compiler makes a wave-uniform base or reloads a spilled one)
+// -> a VMEM instruction reads that SGPR: 5 wait states.  The compiler inserts (b) for memory instructions it knows and cannot for the inside
+// of an asm block, so EVERY block whose VMEM instruction takes an "s" operand carries s_mov (1) + s_nop 3 (4) = 5 -- decided by the rule, not
+// by what a build happens to emit (round 5 had s_nop 3 in lm_dma16_sv only).  Cost, measured in round 6's first GPU session with the diagnosis
+// build at LM_DMA_NOP=0 against 3, interleaved: within run-to-run noise on the layer tail and the QKV kernel.
+// Every block that writes M0 says so in its clobber list ("m0" is a reserved register to this compiler, which re-materialises M0 in front of each of
+// its own uses but may MERGE equal initialisations across a region -- an undeclared write in between would go unnoticed; the clobber costs a
+// -Winline-asm note, silenced here; tests/test_asm_hazards.py::test_m0_writes_are_declared keeps the lists honest).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#ifndef LM_DMA_NOP
+#define LM_DMA_NOP 3
+#endif
+#define LM_STR2(x) #x
+#define LM_STR(x) LM_STR2(x)
+#define LM_DMA_NOPS "s_nop " LM_STR(LM_DMA_NOP) "\n\t"
 __device__ __forceinline__ void lm_dma16(const void* gsrc, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);  // low half of the flat address = LDS offset
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
+    // (the address is a VGPR pair: only rule (a) applies)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
 }
 // The same piece with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): no 64-bit VALU add per
 // piece; with a wave-uniform lds_wave_base the M0 value is SALU arithmetic as well (the readfirstlane folds away).
-// s_nop 3, not 0: the compiler may hand over `sbase` in SGPRs it has just written with a VALU instruction (v_readfirstlane, or v_readlane when it
-// reloads a spilled SGPR -- k_gemm_f16 does), and a VMEM instruction that reads a VALU-written SGPR needs 5 wait states.  The compiler inserts them
-// for memory instructions it knows (s_nop 4 in front of a global_load with an SGPR base) and cannot for the inside of an asm block: s_mov + s_nop 3
-// are the five.  (No wrong result was ever seen with s_nop 0 -- every GEMM test compares bits -- but the ISA does not promise it;
-// tests/test_asm_hazards.py now checks the assembly of every kernel for this pattern.)
+// LM_DMA_NOPS (s_nop 3), not s_nop 0: rule (b) above -- the compiler may hand over `sbase` in SGPRs it has just written with a VALU instruction
+// (k_gemm_f16 reloads spilled SGPRs with v_readlane right in front of its pieces).  No wrong result was ever seen with s_nop 0 -- every GEMM
+// test compares bits -- but the ISA does not promise it; tests/test_asm_hazards.py checks the assembly of every kernel for the pattern.
 __device__ __forceinline__ void lm_dma16_sv(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
 }
 // ... with the non-temporal hint (streamed activations: read once; A/B switch LM_T4_NT of the layer tail)
 __device__ __forceinline__ void lm_dma16_sv_nt(const void* sbase, unsigned voff, unsigned char* lds_wave_base) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 #endif
 
 constexpr int ML_H = 384;                 // hidden size

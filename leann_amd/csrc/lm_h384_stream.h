@@ -22,6 +22,8 @@ constexpr int T4_SLAB = 24576;  // bytes of a weight slab image: 32 rows x 384 k
 // NP consecutive 1 KB pieces: LDS [dst + 1024 p + 16 lane, +16) <- global [sbase + voff + 1024 p, +16), p = 0 .. NP-1.  dst and sbase
 // are wave uniform.  ONE M0 write serves the group: the instruction offset is added to the global AND to the LDS address.
 // Inline assembly for the reason given in lm_h384_common.h (lm_dma16); M0 is written in the statement that uses it.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // the "m0" clobbers (lm_h384_common.h says why they are there)
 template <int NP>
 __device__ __forceinline__ void t4_dma_group(const void* sbase, unsigned voff, unsigned char* dst) {
     static_assert(NP >= 1 && NP <= 4, "instruction offsets reach 3072");
@@ -30,15 +32,15 @@ __device__ __forceinline__ void t4_dma_group(const void* sbase, unsigned voff, u
 #else
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);  // low half of the flat address = LDS offset
     if constexpr (NP == 4)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
     else if constexpr (NP == 2)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
     else if constexpr (NP == 1)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
     else
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
 #endif
 }
 // piece Q (0 .. 3) of a group ALONE: the variants that spread the pieces over the MFMA gaps issue Q = 0 with the M0 write and
@@ -50,12 +52,13 @@ __device__ __forceinline__ void t4_dma_piece(const void* sbase, unsigned voff, u
 #else
     if constexpr (Q == 0) {
         const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\t" LM_DMA_NOPS "global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
     } else if constexpr (Q == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase) : "memory");
     else if constexpr (Q == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(sbase) : "memory");
     else asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase) : "memory");
 #endif
 }
+#pragma clang diagnostic pop
 // a wave's quarter (6 KB: pieces 6 wv .. 6 wv + 5) of a 24 KB image -> the same place of a stage: prologue fills and the W_o ring
 __device__ __forceinline__ void t4_copy_quarter(const unsigned char* img, unsigned char* stage, int wv, unsigned voff) {
     t4_dma_group<4>(img + 6144 * wv, voff, stage + 6144 * wv);

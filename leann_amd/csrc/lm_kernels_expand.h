@@ -104,6 +104,52 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
             }
             __syncthreads();
         }
+        // ---- dynamic batching (SearchParametersHNSW.batch_size, hnsw_backend.py:163,181,234; LEANN paper section 4.2: "collect the closest
+        //      candidates from the queue until a target batch size is reached"): while this round's new-list is shorter than ws.batch, pop the
+        //      best unexpanded pool entry -- one at a time, under select_pops' stop rules, on the pool as k_update left it -- and gather its
+        //      unvisited neighbours behind the others.  Word for word oracle/lm_oracle.c ("batching"); ws.batch == 0: nothing happens here.
+        //      A one-query search is a chain of ~75 rounds of ~10 chunks each on a 256-CU chip; with batch 64 it is ~20 rounds of ~64. ----
+        if (ws.batch > 0 && total < ws.batch) {
+            uint64_t* pool = ws.pool + (size_t)q * ws.ef;
+            const int npool = ws.npool[q];
+            const int scan_n = ws.check_rel ? min(npool, ws.efs) : npool;
+            int nsteps = ws.nsteps[q];
+            int cursor = 0;  // entries below it are expanded (the pool is scanned in order, and what this loop pops it never looks at again)
+            while (total < ws.batch) {
+                if (!ws.check_rel && nsteps > ws.efs) break;
+                int idx = -1;
+                for (int base = cursor & ~63; base < scan_n; base += 64) {
+                    const int i = base + lane;
+                    const bool un = i >= cursor && i < scan_n && !(pool[i] & KEY_EXPANDED);
+                    const unsigned long long m = __ballot(un);
+                    if (m) {
+                        idx = base + __ffsll((long long)m) - 1;
+                        break;
+                    }
+                }
+                if (idx < 0) break;
+                const uint64_t key = pool[idx];
+                if (lane == 0) pool[idx] = key | KEY_EXPANDED;
+                cursor = idx + 1;
+                ++nsteps;
+                const L0Range r = g.l0[key_id(key)];
+                for (uint32_t j0 = 0; j0 < r.count; j0 += 64) {
+                    const uint32_t j = j0 + lane;
+                    bool fresh = false;
+                    int32_t v = -1;
+                    if (j < r.count) {
+                        v = g.neighbors[r.begin + j];
+                        const uint32_t bit = 1u << (v & 31);
+                        const uint32_t old = atomicOr(&vis[v >> 5], bit);
+                        fresh = !(old & bit);
+                    }
+                    const unsigned long long m = __ballot(fresh);
+                    if (fresh) s_new[total + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                    total += __popcll(m);
+                }
+            }
+            if (lane == 0) ws.nsteps[q] = nsteps;
+        }
     }
     __syncthreads();
     int32_t* newid = ws.newid + (size_t)q * ws.maxnew;

@@ -83,7 +83,7 @@ struct lm_index {
     hipStream_t stream = nullptr;
     // workspace
     WsDev ws{};
-    int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0, ws_spec = 0;
+    int32_t ws_B = 0, ws_ef = 0, ws_W = 0, ws_maxnew = 0, ws_spec = 0;  // (ws_maxnew covers the dynamic-batching target: ensure_ws)
     int64_t ws_ucap = 0;
     int single_query_direct = 0;  // option "single_query_direct": a one-query recompute pass hands its new-list to the provider as it is (no k_uniq_*)
     int speculate = 0;            // option "speculate": candidates whose neighbours a small-batch round embeds ahead of time (k_speculate); 0 = off
@@ -132,8 +132,9 @@ static int ws_alloc(lm_index* ix, T** p, size_t count) {
     return LM_OK;
 }
 
-static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune = false, int32_t spec = 0) {
+static int ensure_ws(lm_index* ix, int32_t B, int32_t ef, int32_t W, bool prune = false, int32_t spec = 0, int32_t batch = 0) {
     int32_t maxnew = std::max({W * ix->maxdeg0, ix->maxdeg_up, 1});
+    if (batch > 0) maxnew = std::max(maxnew, batch - 1 + ix->maxdeg0);  // dynamic batching: the last extra pop starts below `batch` and adds one list at most
     if (prune) maxnew = std::max(maxnew, (int32_t)AQ_CAP);
     if (B <= ix->ws_B && ef == ix->ws_ef && W == ix->ws_W && maxnew == ix->ws_maxnew && spec == ix->ws_spec) {
         ix->ws.B = B;
@@ -305,6 +306,8 @@ static int search_pass_persistent(lm_index* ix, int32_t B, const float* d_q, int
     if (rc) return rc;
     WsDev& ws = ix->ws;
     ws.efs = prm.efSearch;
+    ws.batch = 0;
+    ws.check_rel = prm.check_relative_distance;
     hipStream_t st = ix->stream;
     if ((int64_t)B > ix->pq_cap) {
         if (ix->d_pq_nadc) (void)hipFree(ix->d_pq_nadc);
@@ -358,10 +361,12 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
     // speculative prefetch (k_speculate): small recompute batches with the per-call memo; not with the two-level search (its new-lists are
     // finished by k_prune)
     const int spec = (recompute && prm.recompute_memo != 0 && !prune && B <= ix->speculate_max_batch) ? ix->speculate : 0;
-    int rc = ensure_ws(ix, B, ef, W, prune, spec);
+    int rc = ensure_ws(ix, B, ef, W, prune, spec, prm.batch_size);
     if (rc) return rc;
     WsDev& ws = ix->ws;
     ws.efs = prm.efSearch;
+    ws.batch = prm.batch_size;
+    ws.check_rel = prm.check_relative_distance;
     hipStream_t st = ix->stream;
     PruneArgs pa{};
     size_t prune_shmem = 0;
@@ -433,7 +438,7 @@ static int search_pass(lm_index* ix, int32_t B, const float* d_q, int32_t k, con
         // dynamic LDS of the update kernel (default launch limit 64 KiB): pool | merged pool | new keys
         const size_t need = ((size_t)2 * ef + next_pow2(ws.maxnew)) * 8;
         if (need > 64 * 1024)
-            LM_FAIL(LM_EINVAL, "efSearch / beam_size too large for the LDS-resident pool (2*max(efSearch,k) + beam*max_degree keys must fit 64 KiB)");
+            LM_FAIL(LM_EINVAL, "efSearch / beam_size / batch_size too large for the LDS-resident pool (2*max(efSearch,k) + max(beam*max_degree, batch_size + max_degree) keys must fit 64 KiB)");
     }
     const int ntiles = (int)((ws.nw + UNIQ_TILE - 1) / UNIQ_TILE);
     const int sync_every = recompute ? 1 : 4;
@@ -552,6 +557,7 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     if (!ix || !params || n < 0 || k <= 0) LM_FAIL(LM_EINVAL, "bad search arguments");
     lm_search_params prm = *params;
     if (prm.efSearch <= 0) LM_FAIL(LM_EINVAL, "efSearch must be positive");
+    if (prm.batch_size < 0) LM_FAIL(LM_EINVAL, "batch_size must not be negative (0 = no dynamic batching)");
     LM_HIP(hipSetDevice(ix->device));
     ix->stats = lm_search_stats{};
     ix->span_ms = 0;
@@ -593,7 +599,8 @@ static int do_search_device(lm_index* ix, int64_t n, const float* d_x, int32_t k
     for (int64_t off = 0; off < n; off += maxb) {
         int32_t B = (int32_t)std::min<int64_t>(maxb, n - off);
         int rc = 1;
-        if (!prm.recompute && prm.pq_pruning_ratio <= 0.0f && ix->persistent_table && ix->update_variant == 0 && std::max(prm.beam_size, 1) <= 64)
+        // (dynamic batching exists to fill the recompute forward: a stored-embedding search that asks for it runs the lock-step kernels, which implement it)
+        if (!prm.recompute && prm.pq_pruning_ratio <= 0.0f && prm.batch_size == 0 && ix->persistent_table && ix->update_variant == 0 && std::max(prm.beam_size, 1) <= 64)
             rc = search_pass_persistent(ix, B, d_q + (size_t)off * ix->Dp, k, prm, d_dist + (size_t)off * k, d_labels + (size_t)off * k);
         if (rc == 1)  // not applicable (or LDS budget exceeded): lock-step rounds
             rc = search_pass(ix, B, d_q + (size_t)off * ix->Dp, k, prm, d_dist + (size_t)off * k, d_labels + (size_t)off * k);
@@ -636,7 +643,8 @@ static void compute_degrees(lm_index* ix, const uint64_t* node_offsets, const ui
 extern "C" {
 
 const char* lm_last_error(void) { return g_err.c_str(); }
-const char* lm_version(void) { return "leann-mi355x 0.1 (gfx950)"; }
+const char* lm_version(void) { return "leann-mi355x 0.2 (gfx950)"; }
+int lm_abi_revision(void) { return LM_ABI_REVISION; }
 
 int lm_device_count(void) {
     int n = 0;

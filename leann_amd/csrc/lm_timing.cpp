@@ -153,9 +153,9 @@ extern "C" int lm_kernel_timing_enable(uint32_t mask) {
     return LM_OK;
 }
 
-extern "C" int lm_kernel_timing_read(lm_kernel_time* out, int32_t reset) {
+extern "C" int lm_kernel_timing_read(lm_kernel_time* out, int32_t capacity, int32_t reset) {
     using namespace lm;
-    if (!out) LM_FAIL(LM_EINVAL, "lm_kernel_timing_read: NULL argument");
+    if (!out || capacity < 0) LM_FAIL(LM_EINVAL, "lm_kernel_timing_read: NULL argument / negative capacity");
     std::lock_guard<std::mutex> lk(g_mu);
     while (!g_pending.empty()) {  // waits for what has been recorded so far
         (void)hipEventSynchronize(g_pending.front().b);
@@ -175,10 +175,12 @@ extern "C" int lm_kernel_timing_read(lm_kernel_time* out, int32_t reset) {
     }
     (void)hipSetDevice(before);
     for (int i = 0; i < LM_KT_COUNT; ++i) {
-        out[i].name = g_names[i];
-        out[i].launches = g_acc[i].launches;
-        out[i].ms = g_acc[i].ms;
-        out[i].work = g_acc[i].work;
+        if (i < capacity) {
+            out[i].name = g_names[i];
+            out[i].launches = g_acc[i].launches;
+            out[i].ms = g_acc[i].ms;
+            out[i].work = g_acc[i].work;
+        }
         if (reset) g_acc[i] = Acc{};
     }
     return LM_OK;

@@ -130,9 +130,11 @@ def shard_bounds(n: int, world: int):
 
 
 def build_fingerprint() -> int:
-    """63-bit fingerprint of what a rank runs: package version, the library's own version string, its exported-symbol list and the byte
-    size of the shared object.  Ranks of one job must agree (same checkout, same build): a rank whose library differs would otherwise
-    interpret broadcast bytes or packed results differently -- or hang in a collective the others never enter."""
+    """63-bit fingerprint of what a rank runs: package version, the library's own version string, its ABI revision (lm_abi_revision) and the
+    exported-symbol list.  Ranks of one job must agree (same checkout, same interface): a rank whose library differs would otherwise
+    interpret broadcast bytes or packed results differently -- or hang in a collective the others never enter.  NOT the byte size of the
+    shared object (round 5 hashed it): nodes that build the same checkout with different compiler paths get different sizes and the
+    job would fail for nothing."""
     import hashlib
 
     from . import __version__
@@ -142,7 +144,7 @@ def build_fingerprint() -> int:
         lib = _lib.load()
         h.update(bytes(lib.lm_version() or b""))
         h.update(",".join(_lib.EXPORTED_SYMBOLS).encode())
-        h.update(str(_lib.LIB_PATH.stat().st_size).encode())
+        h.update(str(int(lib.lm_abi_revision())).encode())
     except Exception as ex:  # noqa: BLE001 - a rank without the library is a different build by definition
         h.update(("no library: " + type(ex).__name__).encode())
     return int.from_bytes(h.digest()[:8], "little") >> 1
@@ -152,6 +154,10 @@ def check_same_build(device: Optional[torch.device] = None, group: Optional[dist
     """Every rank contributes its build_fingerprint() to ONE all_gather; if they differ, EVERY rank raises the same RuntimeError (they all
     see the same list), so a mixed job fails loudly at start-up instead of hanging in its first data-path collective."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    import os
+
+    if os.environ.get("LEANN_MI355X_SKIP_BUILD_CHECK") == "1":  # the operator's override (set it on EVERY rank: the check is a collective)
         return
     dev = device if device is not None else torch.device("cpu")
     mine = torch.tensor([build_fingerprint()], dtype=torch.int64, device=dev)
@@ -187,7 +193,9 @@ def broadcast_graph(g, src: int = 0, device: Optional[torch.device] = None, grou
         hdr = torch.zeros(6 + len(names), dtype=torch.int64, device=dev)
     dist.broadcast(hdr, src, group=group)
     h = [int(v) for v in hdr.cpu().tolist()]
-    # the header every rank now holds must describe a graph (the same check on every rank: a bad header raises everywhere, nobody waits)
+    # the header every rank now holds must describe a graph (the same check on every rank: a bad header raises everywhere, nobody waits);
+    # metric_type is 0 (inner product) or 1 (L2): the only two lm_index_create_from_csr accepts (faiss metrics > 1 carry a metric_arg
+    # this library has no kernel for)
     if not (h[0] > 0 and h[1] > 0 and h[2] in (0, 1) and 0 <= h[3] < h[1] and h[4] >= 0 and h[6] == h[1] and h[8] == h[1] + 1 and h[7] >= h[1] and h[9] >= 0):
         raise RuntimeError(f"broadcast_graph: implausible header from rank {src}: {h}")
     out = []

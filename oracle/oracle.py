@@ -45,7 +45,7 @@ class _Graph(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("ef", C.c_int32), ("beam", C.c_int32), ("k", C.c_int32), ("check_relative_distance", C.c_int32),
-                ("prune_ratio", C.c_float), ("prune_strategy", C.c_int32)]
+                ("prune_ratio", C.c_float), ("prune_strategy", C.c_int32), ("batch_size", C.c_int32)]
 
 
 class _Stats(C.Structure):
@@ -171,12 +171,13 @@ class OracleGraph:
 def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: int = 1,
            check_relative_distance: bool = True, table: Optional[np.ndarray] = None,
            provider: Optional[Callable[[np.ndarray], np.ndarray]] = None, prune_ratio: float = 0.0,
-           pruning_strategy: str = "global", pq=None, memo: bool = False):
+           pruning_strategy: str = "global", pq=None, memo: bool = False, batch_size: int = 0):
     """Run the oracle search.  Exactly one of ``table`` (N x D, stored embeddings) or
     ``provider`` (callable: sorted unique int32 ids -> (n, D) float32) must be given.
     ``memo`` restates the product's per-call recompute memo (lm_search_params.recompute_memo, the library default for a call of
     more than one query): a node's embedding is requested from ``provider`` at most once per call and kept until the call returns;
     ids, distances and ndis are unchanged by construction, ``stats["nunique"]`` becomes the number of rows actually requested.
+    ``batch_size`` > 0: dynamic batching (lm_oracle.c header, "batching": a query keeps popping while its round's new-list is shorter).
     Returns (ids int64 (B,k), dist float32 (B,k), stats dict)."""
     assert (table is None) != (provider is None)
     q = pad64(np.atleast_2d(queries))
@@ -185,7 +186,7 @@ def search(graph: OracleGraph, queries: np.ndarray, k: int, ef: int = 64, beam: 
     ids = np.empty((B, k), dtype=np.int64)
     dd = np.empty((B, k), dtype=np.float32)
     st = _Stats()
-    prm = _Params(ef, beam, k, 1 if check_relative_distance else 0, float(prune_ratio), PRUNE_STRATEGY[pruning_strategy])
+    prm = _Params(ef, beam, k, 1 if check_relative_distance else 0, float(prune_ratio), PRUNE_STRATEGY[pruning_strategy], int(batch_size))
     g = graph.cstruct()
     pqs = None
     if pq is not None:  # (codebooks [m,256,dsub], codes [N,m]) for the two-level search

@@ -137,5 +137,17 @@ if os.environ.get("LAT_VARIANTS"):
         for k_ in set_here:
             os.environ.pop(k_, None)
     idx.set_option("single_query_direct", 0)
-print(json.dumps({"chunks": n, "small_forward_variants": variant_rows, "b1_speculative_prefetch": spec_rows, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
+# --frontier: B = 1 latency vs recall over efSearch x beam_width x batch_size (bench.py: latency_frontier), exact ground truth on this index
+frontier = None
+if "--frontier" in sys.argv:
+    from bench import latency_frontier
+    from leann_amd.exact import exact_topk_ip
+
+    gt = exact_topk_ip(Q, X, 10)[1].cpu().numpy()
+
+    def recall(labels_np, rws):
+        return sum(len(set(labels_np[i].tolist()) & set(gt[r].tolist())) for i, r in enumerate(rws)) / (10 * len(rws))
+
+    frontier = latency_frontier(idx, Q, recall, 64, efs=(16, 32, 64), beams=(1, 2, 4, 8), batch_sizes=(0, 32, 64, 128), reps=16, budget_s=240.0)
+print(json.dumps({"chunks": n, "small_batch_latency_frontier": frontier, "small_forward_variants": variant_rows, "b1_speculative_prefetch": spec_rows, "switches": {k: v for k, v in os.environ.items() if k.startswith("LEANN_MI355X_")}, "latency": rows,
                   "identical_results_between_the_providers": same, "library_side_provider_stats": provider.native_stats()}))

@@ -224,6 +224,74 @@ def case_single_query_direct():
     print("single_query_direct: ok", flush=True)
 
 
+def case_dynamic_batching():
+    """lm_search_params.batch_size (SearchParametersHNSW.batch_size, hnsw_backend.py:234): the paper's dynamic batching, k_expand's extra pops.
+    Against the oracle's restatement: labels, distances, distance evaluations, expansions AND rounds, for batch_size 0 / small / larger than any
+    list, both stop rules, beam 1 and 3, stored table (lock-step rounds: the persistent kernel declines a batching call) and provider with /
+    without the per-call memo, single_query_direct, two-level search; the provider sees the oracle's id lists round by round.  batch_size = 0
+    equals the answers every other case pins; a batching search must need FEWER rounds than batch_size 0 (else the case proves nothing)."""
+    from leann_amd.hnsw_builder import build_hnsw
+    from leann_amd.index import Mi355xIndex
+    from oracle import oracle as orc
+
+    x, q = _data(500, 48, 41, nq=4)
+    for metric, M in (("mips", 6), ("l2", 10)):
+        g = build_hnsw(x, metric, M=M, ef_construction=40)
+        og = orc.OracleGraph(g.node_offsets, g.level_ptr, g.neighbors, g.levels, g.entry_point, g.max_level, g.metric_type, 48)
+        idx = Mi355xIndex.from_csr(g)
+        idx.attach_table(x)
+        rounds_at = {}
+        for bs in ((0, 1, 7, 24, 400) if metric == "mips" else (0, 24)):
+            for beam, ef, k, check in (((1, 24, 5, True), (3, 16, 5, True), (1, 9, 5, False), (2, 4, 9, True)) if bs in (0, 7, 24) else ((1, 24, 5, True),)):
+                tag = f"dynamic batching {metric} bs={bs} beam={beam} ef={ef} k={k} check={check}"
+                exp = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check, table=x, batch_size=bs)
+                rounds_at[(bs, beam, ef, k, check)] = exp[2]["nrounds"]
+                # stored table: a batching call runs the lock-step kernels whatever "persistent_table" says
+                for persistent in (1, 0):
+                    idx.set_option("persistent_table", persistent)
+                    got = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=False, check_relative_distance=check, batch_size=bs))
+                    st = idx.stats()
+                    _check(tag + f" table persistent={persistent}", got, exp[:2], st, exp[2])
+                    assert int(st["nexpand"]) == exp[2]["nexpand"] and int(st["nrounds"]) == exp[2]["nrounds"], (tag, dict(st), exp[2])
+                # provider, with and without the per-call memo: the oracle's request lists, round by round
+                for memo in (True, False):
+                    want = []
+                    orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check, batch_size=bs, memo=memo,
+                               provider=lambda idv, want=want: (want.append(idv.copy()), x[idv])[1])
+                    prov = NumpyProvider(x, idx.info.d_padded)
+                    seen = []
+
+                    def logging_provider(d_ids_ptr, n, stream_ptr, seen=seen, inner=prov.__call__):
+                        seen.append(np.ctypeslib.as_array(C.cast(d_ids_ptr, C.POINTER(C.c_int32)), shape=(n,)).copy())
+                        return inner(d_ids_ptr, n, stream_ptr)
+
+                    idx.set_provider(logging_provider)
+                    got = idx.search(q, k, idx.make_params(ef=ef, beam=beam, recompute=True, check_relative_distance=check, batch_size=bs, recompute_memo=memo))
+                    st = idx.stats()
+                    _check(tag + f" provider memo={memo}", got, exp[:2], st, exp[2])
+                    assert int(st["nexpand"]) == exp[2]["nexpand"] and int(st["nrounds"]) == exp[2]["nrounds"]
+                    assert len(seen) == len(want) and all(np.array_equal(a, b) for a, b in zip(seen, want)), tag + " request lists"
+        # one query, handed over directly (k_expand writes the list length itself)
+        idx.set_option("single_query_direct", 1)
+        prov = NumpyProvider(x, idx.info.d_padded, sorted_ids=False)
+        idx.set_provider(prov)
+        for bs in (0, 24):
+            exp = orc.search(og, q[:1], 5, ef=24, table=x, batch_size=bs)
+            got = idx.search(q[:1], 5, idx.make_params(ef=24, recompute=True, batch_size=bs))
+            _check(f"dynamic batching {metric} single_query_direct bs={bs}", got, exp[:2], idx.stats(), exp[2])
+            assert int(idx.stats()["nrounds"]) == exp[2]["nrounds"]
+        idx.set_option("single_query_direct", 0)
+        assert rounds_at[(24, 1, 24, 5, True)] < rounds_at[(0, 1, 24, 5, True)], rounds_at
+        assert metric != "mips" or rounds_at[(400, 1, 24, 5, True)] <= rounds_at[(24, 1, 24, 5, True)]
+        try:
+            idx.search(q, 5, idx.make_params(ef=8, recompute=False, batch_size=-1))
+            raise AssertionError("negative batch_size accepted")
+        except ValueError:
+            pass
+        idx.close()
+    print("dynamic batching: ok", flush=True)
+
+
 def case_stop_rules():
     """Both faiss stop rules against the oracle (itself pinned by the literal transcription, tests/test_oracle_faiss.py):
     k > efSearch (count_below(d0) >= efSearch ends the search although the pool holds k entries) and
@@ -359,6 +427,11 @@ def case_two_level():
         got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True, prune_ratio=0.5, local_prune=(strategy == "local")))
         exp = orc.search(og, q, 5, ef=14, beam=2, table=x, pq=(cb.numpy(), codes.numpy()), prune_ratio=0.5, pruning_strategy=strategy)
         _check(f"two-level search {strategy}", got, exp[:2], idx.stats(), exp[2])
+        # ... and with dynamic batching on top (the extra pops count the fresh neighbours BEFORE pruning; k_prune finishes the longer list)
+        got = idx.search(q, 5, idx.make_params(ef=14, beam=2, recompute=True, prune_ratio=0.5, local_prune=(strategy == "local"), batch_size=20))
+        exp = orc.search(og, q, 5, ef=14, beam=2, table=x, pq=(cb.numpy(), codes.numpy()), prune_ratio=0.5, pruning_strategy=strategy, batch_size=20)
+        _check(f"two-level search {strategy} + batch_size 20", got, exp[:2], idx.stats(), exp[2])
+        assert int(idx.stats()["nadc"]) == exp[2]["nadc"] and int(idx.stats()["nrounds"]) == exp[2]["nrounds"]
     idx.close()
 
 
@@ -710,6 +783,7 @@ CASES = {
     "recompute_one_query_skips_memo": lambda: case_recompute(0, memo=True, nq=1),
     "recompute_wave_variant": lambda: case_recompute(3),
     "stop_rules": case_stop_rules,
+    "dynamic_batching": case_dynamic_batching,
     "speculative_prefetch": case_speculative_prefetch,
     "single_query_direct": case_single_query_direct,
     "pq_deferred": lambda: case_pq(True),

@@ -157,6 +157,29 @@ _ZN2lm1kEv:
     assert sgpr_violations(spill) and not sgpr_violations(spill.replace("s_nop 0", "s_nop 3"))
 
 
+def undeclared_m0_writes(source_text):
+    """Fourth rule, on the SOURCE (a clobber list leaves no trace in the assembly): an asm statement that writes M0 names "m0" among its clobbers.
+    The compiler re-materialises M0 in front of its own uses but may merge equal initialisations over a region; an asm block that changes M0 behind
+    its back must say so."""
+    out = []
+    for m in re.finditer(r"asm\s+volatile\s*\((.*?)\)\s*;", source_text, re.S):
+        stmt = m.group(1)
+        if re.search(r"s_mov_b32\s+m0\b|s_add_u32\s+m0\b|s_movk_i32\s+m0\b", stmt) and not re.search(r':[^:]*"m0"[^:]*$', stmt):
+            out.append(" ".join(stmt.split())[:160])
+    return out
+
+
+def test_m0_writes_are_declared():
+    assert undeclared_m0_writes('asm volatile("s_mov_b32 m0, %1\\n\\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(m) : "memory");')
+    assert not undeclared_m0_writes('asm volatile("s_mov_b32 m0, %1\\n\\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(m) : "memory", "m0");')
+    bad = {}
+    for f in sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list(CSRC.glob("diag/*.hip"))):
+        v = undeclared_m0_writes(f.read_text())
+        if v:
+            bad[f.name] = v
+    assert not bad, bad
+
+
 _ASM_CACHE = {}
 
 

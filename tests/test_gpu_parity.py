@@ -37,7 +37,7 @@ def _build(n, d, metric, seed, M=16, efc=60, normalize=True):
     return x.copy(), g
 
 
-def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32, variant=0, wave=None):
+def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.float32, variant=0, wave=None, batch_size=0):
     from leann_amd.devmem import as_tensor
     from leann_amd.index import Mi355xIndex
     from oracle import oracle as orc
@@ -45,7 +45,7 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
     d = x.shape[1]
     og = oracle_graph(g, d)
     xt = x.astype(table_dtype)
-    oi, od, ost = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, table=xt.astype(np.float32))
+    oi, od, ost = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, table=xt.astype(np.float32), batch_size=batch_size)
     idx = Mi355xIndex.from_csr(g, device=0)
     idx.set_stream(torch.cuda.current_stream().cuda_stream)
     idx.set_option("update_variant", variant)
@@ -53,7 +53,7 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
         idx.set_option("persistent_wave", wave)
     if mode == "table":
         idx.attach_table(xt)
-        prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=False)
+        prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=False, batch_size=batch_size)
         gd, gi = idx.search(q, k, prm)
     else:
         dp = idx.info.d_padded
@@ -69,7 +69,7 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
             return keep["e"].data_ptr()
 
         idx.set_provider(provider)
-        prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=True)
+        prm = idx.make_params(ef=ef, beam=beam, check_relative_distance=check_rel, recompute=True, batch_size=batch_size)
         gdt, git = idx.search_device(torch.from_numpy(q).cuda(), k, prm)
         torch.cuda.synchronize()
         gd, gi = gdt.cpu().numpy(), git.cpu().numpy()
@@ -77,9 +77,11 @@ def _check(torch, x, g, q, k, ef, beam, mode, check_rel=True, table_dtype=np.flo
         for s in seen:
             assert np.all(np.diff(s) > 0)
         # the library default keeps a per-call memo for a call of more than one query: the oracle restates it (oracle.py: memo=)
-        _, _, pst = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, provider=lambda idv: xt.astype(np.float32)[idv],
-                               memo=q.shape[0] > 1)
+        want = []
+        _, _, pst = orc.search(og, q, k, ef=ef, beam=beam, check_relative_distance=check_rel, memo=q.shape[0] > 1, batch_size=batch_size,
+                               provider=lambda idv: (want.append(idv.copy()), xt.astype(np.float32)[idv])[1])
         assert idx.stats()["nunique"] == pst["nunique"]
+        assert len(seen) == len(want) and all(np.array_equal(a, b) for a, b in zip(seen, want)), "the provider was not asked for the oracle's ids, round by round"
         if q.shape[0] > 1:
             allids = np.concatenate(seen)
             assert np.unique(allids).shape[0] == allids.shape[0], "a node reached the provider twice in one call"
@@ -98,6 +100,43 @@ def test_table_mode_parity(env, metric, ef, beam):
     x, g = _build(3000, 384, metric, seed=1)
     q = queries_near(x, 32, seed=2)
     _check(env, x, g, q, 10, ef, beam, "table")
+
+
+@pytest.mark.parametrize("mode", ["table", "provider"])
+@pytest.mark.parametrize("batch_size,ef,beam,check_rel,nq", [(0, 64, 1, True, 24), (16, 64, 1, True, 24), (64, 64, 1, True, 24), (64, 32, 4, True, 24),
+                                                            (32, 40, 1, False, 24), (64, 64, 1, True, 1), (500, 24, 2, True, 3)])
+def test_dynamic_batching_parity(env, mode, batch_size, ef, beam, check_rel, nq):
+    """lm_search_params.batch_size = SearchParametersHNSW.batch_size (hnsw_backend.py:163,181,234): the paper's dynamic batching (section 4.2),
+    k_expand's extra pops, against the oracle's restatement -- ids, distance bits, evaluations, expansions, ROUNDS and (provider mode) the
+    request list of every round; batch_size 0 is the plain search.  A one-query call (the real caller's batch, api.py:644-796) included."""
+    x, g = _build(4000, 384, "mips", seed=5, M=12)
+    q = queries_near(x, nq, seed=31)
+    _check(env, x, g, q, 10, ef, beam, mode, check_rel=check_rel, batch_size=batch_size)
+
+
+def test_dynamic_batching_needs_fewer_rounds(env):
+    """What the knob is for: a one-query recompute search at efSearch 64 in a third of the rounds or fewer, recall intact."""
+    from leann_amd.index import Mi355xIndex
+
+    torch = env
+    x, g = _build(20000, 128, "mips", seed=9, M=16)
+    q = queries_near(x, 16, seed=33, noise=0.2)
+    idx = Mi355xIndex.from_csr(g, device=0)
+    idx.attach_table(x)
+    from oracle import oracle as orc
+
+    gt, _ = orc.bruteforce_topk(x, q, 10, 0)
+    res = {}
+    for bs in (0, 64):
+        rounds, labels = 0, []
+        for i in range(q.shape[0]):
+            _, l = idx.search(q[i : i + 1], 10, idx.make_params(ef=64, recompute=False, batch_size=bs))
+            rounds += idx.stats()["nrounds"]
+            labels.append(l[0])
+        res[bs] = (rounds / q.shape[0], recall_at_k(np.stack(labels), gt))
+    assert res[64][0] <= 0.5 * res[0][0], res
+    assert res[64][1] >= res[0][1] - 0.02, res
+    idx.close()
 
 
 @pytest.mark.parametrize("metric", ["mips", "l2"])

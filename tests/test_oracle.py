@@ -54,6 +54,44 @@ def test_hand_traced_line_graph():
     assert ids2.tolist() == [[6, 7, 5, 4]]
 
 
+def test_hand_traced_dynamic_batching():
+    """batch_size (hnsw_backend.py:163,181,234; paper section 4.2) on the line graph, traced by hand.  q = 6.4, ef = k = 4, W = 1, batch_size = 2:
+    rounds 1-3 as above (seed 3, move to 6, level down); pool = {6}, pop 6.
+    round 4: list of 6 -> new [5, 7]: 2 >= batch, no extra pop; pool {6*, 7 (0.36), 5 (1.96)}; pop 7.
+    round 5: list of 7 = {6}: visited -> new []: 0 < 2 -> extra pop 5 (the pool as the round found it) -> list {4, 6} -> new [4]: 1 < 2 -> nothing
+             unexpanded left; pool {6*, 7*, 5*, 4 (5.76)}; pop 4.
+    round 6: list of 4 = {3, 5}: 3 was only evaluated on the way down (faiss marks level-0 visits only) -> new [3]; no candidate left;
+             d(3) = 11.56 does not enter the full pool; nothing unexpanded -> done.
+    6 rounds instead of 7, the same 7 evaluations and 4 expansions, the same answer."""
+    x, g = _line_graph()
+    og = oracle_graph(g, 64)
+    q = np.zeros((1, 64), np.float32)
+    q[0, 0] = 6.4
+    ids0, d0, st0 = orc.search(og, q, 4, ef=4, beam=1, table=x)
+    ids2, d2, st2 = orc.search(og, q, 4, ef=4, beam=1, table=x, batch_size=2)
+    assert ids0.tolist() == ids2.tolist() == [[6, 7, 5, 4]] and np.array_equal(d0, d2)
+    assert (st0["nrounds"], st0["ndis"], st0["nexpand"]) == (7, 7, 4)
+    assert (st2["nrounds"], st2["ndis"], st2["nexpand"]) == (6, 7, 4)
+    asked = []
+    orc.search(og, q, 4, ef=4, beam=1, provider=lambda idv: (asked.append(idv.tolist()), x[idv])[1], batch_size=2)
+    assert asked == [[3], [6], [3], [5, 7], [4], [3]]
+    # a batch larger than anything reachable: everything the pool offers is popped in one round per frontier
+    _, _, st9 = orc.search(og, q, 4, ef=4, beam=1, table=x, batch_size=99)
+    assert st9["nrounds"] <= 6 and st9["ndis"] == 7
+    # batch_size = 0 is the plain search, bit for bit, on a real graph; a batching search evaluates a few more nodes in far fewer rounds
+    from leann_amd.hnsw_builder import build_hnsw
+
+    xs = clustered(3000, 64, 6)
+    qs = queries_near(xs, 1, 7)
+    gs = build_hnsw(xs, "mips", M=12, ef_construction=60)
+    ogs = oracle_graph(gs, 64)
+    a = orc.search(ogs, qs, 10, ef=48, table=xs)
+    b = orc.search(ogs, qs, 10, ef=48, table=xs, batch_size=0)
+    c = orc.search(ogs, qs, 10, ef=48, table=xs, batch_size=48)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert c[2]["nrounds"] * 2 <= a[2]["nrounds"] and c[2]["ndis"] <= 1.25 * a[2]["ndis"]
+
+
 def test_distance_formulas_match_reference_server():
     rng = np.random.default_rng(0)
     for d in (64, 100, 384, 768):

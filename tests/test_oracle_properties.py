@@ -41,15 +41,16 @@ def _reachable(g, start_nodes):
 
 @settings(max_examples=60, deadline=None)
 @given(seed=st.integers(0, 10**6), n=st.integers(1, 24), metric=st.sampled_from([METRIC_INNER_PRODUCT, METRIC_L2]),
-       beam=st.integers(1, 5), k=st.integers(1, 6))
-def test_exhaustive_pool_gives_exact_topk_of_reachable_set(seed, n, metric, beam, k):
+       beam=st.integers(1, 5), k=st.integers(1, 6), batch=st.sampled_from([0, 0, 1, 3, 8, 40]))
+def test_exhaustive_pool_gives_exact_topk_of_reachable_set(seed, n, metric, beam, k, batch):
     rng = np.random.default_rng(seed)
     x, g, ep = _random_graph(rng, n, 64, metric)
     g.validate()
     og = oracle_graph(g, 64)
     q = rng.standard_normal((3, 64)).astype(np.float32)
-    ids, dist, stats = orc.search(og, q, k, ef=n + 4, beam=beam, table=x)
-    ids_p, dist_p, _ = orc.search(og, q, k, ef=n + 4, beam=beam, provider=lambda idv: x[idv])
+    # (any dynamic-batching target: it changes the ORDER nodes are expanded in, never the set a pool >= N ends with)
+    ids, dist, stats = orc.search(og, q, k, ef=n + 4, beam=beam, table=x, batch_size=batch)
+    ids_p, dist_p, _ = orc.search(og, q, k, ef=n + 4, beam=beam, provider=lambda idv: x[idv], batch_size=batch)
     assert np.array_equal(ids, ids_p) and np.array_equal(dist, dist_p)
     for qi in range(3):
         # where the greedy descent lands on level 0: emulate it with exact distances
