@@ -174,7 +174,7 @@ def _main(args, ap):
     # --kernel-trace --stats table of this same command reports for the kernel.
     kt_dominant = _lib.KT_LAYER_TAIL if config_for(args.model).hidden == 384 and config_for(args.model).ffn % 192 == 0 else _lib.KT_GEMM_F16
     KT_NAMES = {_lib.KT_LAYER_TAIL: "lm::k_layer_tail_h384", _lib.KT_GEMM_WS: "lm::k_gemm_ws_h384", _lib.KT_ATTN: "lm::k_attn_varlen", _lib.KT_GEMM_F16: "lm::k_gemm_f16",
-                _lib.KT_QKV: "lm::k_qkv_h384"}
+                _lib.KT_QKV: "lm::k_qkv_h384", _lib.KT_QKV_ATTN: "lm::k_qkv_attn_h384"}
     _lib.kernel_timing_enable(1 << kt_dominant)
     kt_phase = {}  # phase -> {kernel: {"launches", "ms", "work"}}
 

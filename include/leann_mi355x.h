@@ -306,6 +306,20 @@ int lm_layer_tail_h384_f16(const void *d_attn, const void *d_resid, const void *
 int lm_layer_tail_pack_h384(const void *d_wo_slabs, const void *d_w1_acc, const void *d_w2_slabs, int32_t ffn, void *d_wo_img,
                             void *d_w1_img, void *d_w2_img, void *stream);
 
+/* The FIRST half of a BERT layer with hidden size 384 = 12 heads x 32 in ONE kernel (csrc/lm_qkv_attn_h384.hip, round 6): QKV projection fused into
+ * self-attention -- d_out[tokens][384] = concat_h softmax(Q_h K_h^T / sqrt(32)) V_h with [Q | K | V] = x W_qkv^T + b_qkv computed per (sequence, head)
+ * on chip: Q, K, V never go to HBM (as two kernels they were a 604 MB write + 604 MB read per 262 k tokens around 201 MB of x and 201 MB of output).
+ * d_x [tokens][384] fp16 packed sequences, d_cu_seqlens int32[n_seqs + 1], lengths 1..256; d_wqkv_img = lm_qkv_pack_h384's image of the nn.Linear
+ * weight [1152][384] (rows W_q | W_k | W_v), d_bqkv fp32[1152].  Replaces the model.encode() call's per-layer QKV GEMM + attention
+ * (leann/embedding_compute.py:229-239) on the large hidden-384 forwards; the stand-alone pair below stays for A/B (LEANN_MI355X_FUSED_QKV_ATTN=0). */
+int lm_qkv_attn_h384_f16(const void *d_x, const void *d_wqkv_img, const float *d_bqkv, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t max_len,
+                         int64_t total_tokens, void *d_out, void *stream);
+/* Which kernels the first half (QKV projection + attention) of a LARGE hidden-384 layer runs on, for a model with `heads` heads and a forward whose
+ * longest sequence is max_len -- the one decision lm_bert_h384_forward_packed and a host that launches kernel by kernel share: 0 = lm_qkv_attn_h384_f16
+ * (the default), 1 = lm_qkv_h384_f16 (head-major output) + attention generation 3 (LEANN_MI355X_FUSED_QKV_ATTN=0), 2 = the pair over the
+ * [tokens][1152] layout (other head counts / lengths, LEANN_MI355X_QKV_LAYOUT=0, the older attention generations' switches). */
+int lm_h384_first_half_form(int32_t heads, int32_t max_len);
+
 /* Weight-STREAMING form of the 384-input linear layer (csrc/lm_qkv_h384.hip): d_out[tokens][n_out] = x W^T + b, n_out a multiple of
  * 128 in [256, 6144], d_w_img = lm_qkv_pack_h384's image of the nn.Linear weight [n_out][384] (same size).  x is read once (a wave holds
  * its 32 token rows as MFMA B fragments for the whole kernel), W streams through a four-stage LDS ring shared by eight waves -- two per
@@ -466,7 +480,8 @@ int lm_index_set_recompute(lm_index *idx, lm_recompute *rc);
 #define LM_KT_ATTN 2       /* lm_attn_varlen_hd32_f16 / lm_attn_varlen_f16 */
 #define LM_KT_GEMM_F16 3   /* lm_gemm_f16 */
 #define LM_KT_QKV 4        /* lm_qkv_h384_f16 (the weight-streaming QKV projection of the large hidden-384 forwards) */
-#define LM_KT_COUNT 5
+#define LM_KT_QKV_ATTN 5   /* lm_qkv_attn_h384_f16 (QKV projection fused into attention: the first half of a hidden-384 layer of the large forwards) */
+#define LM_KT_COUNT 6
 typedef struct lm_kernel_time {
     const char *name;
     int64_t launches;

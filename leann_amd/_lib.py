@@ -88,7 +88,7 @@ class KernelTime(C.Structure):  # include/leann_mi355x.h: lm_kernel_time
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("ms", C.c_double), ("work", C.c_double)]
 
 
-KT_LAYER_TAIL, KT_GEMM_WS, KT_ATTN, KT_GEMM_F16, KT_QKV, KT_COUNT = 0, 1, 2, 3, 4, 5
+KT_LAYER_TAIL, KT_GEMM_WS, KT_ATTN, KT_GEMM_F16, KT_QKV, KT_QKV_ATTN, KT_COUNT = 0, 1, 2, 3, 4, 5, 6
 
 
 class RecomputeStats(C.Structure):  # include/leann_mi355x.h: lm_recompute_stats
@@ -109,7 +109,7 @@ EXPORTED_SYMBOLS = [
     "lm_dist_gather", "lm_topk_merge",
     "lm_pq_attach", "lm_pq_attach_chunked", "lm_pq_search_params_default", "lm_pq_batch_search", "lm_pq_batch_search_device",
     "lm_add_layernorm_f16", "lm_attn_varlen_hd32_f16", "lm_attn_varlen_f16", "lm_embed_layernorm_f16", "lm_meanpool_varlen_f16",
-    "lm_layer_tail_h384_f16", "lm_layer_tail_pack_h384", "lm_qkv_h384_f16", "lm_qkv_pack_h384", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
+    "lm_layer_tail_h384_f16", "lm_layer_tail_pack_h384", "lm_qkv_h384_f16", "lm_qkv_attn_h384_f16", "lm_h384_first_half_form", "lm_qkv_pack_h384", "lm_gemm_ws_h384_f16", "lm_gemm_f16", "lm_pack_tokens",
     "lm_tokens_create", "lm_tokens_free", "lm_tokens_gather", "lm_tokens_count",
     "lm_bert_h384_workspace_bytes", "lm_bert_h384_forward_packed",
     "lm_bert_workspace_bytes", "lm_bert_forward_packed", "lm_clspool_varlen_f16",
@@ -172,6 +172,8 @@ def load() -> C.CDLL:
     lib.lm_layer_tail_h384_f16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, i64, i32, C.c_float, vp]
     lib.lm_layer_tail_pack_h384.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     lib.lm_qkv_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
+    lib.lm_qkv_attn_h384_f16.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp, vp]
+    lib.lm_h384_first_half_form.argtypes = [i32, i32]
     lib.lm_qkv_pack_h384.argtypes = [vp, i32, vp, vp]
     lib.lm_gemm_ws_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
     lib.lm_gemm_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]

@@ -19,6 +19,24 @@ static int64_t small_tokens_limit() {  // read per call (one getenv per forward)
     return e ? (int64_t)atoll(e) : (int64_t)LM_BERT_SMALL_TOKENS;
 }
 
+// Which form the first half of a LARGE hidden-384 layer takes -- decided in ONE place (round-5 advisor: three environment variables were parsed
+// inline and the QKV layout depended implicitly on the attention generation):
+//   H384_FUSED            lm_qkv_attn_h384_f16: projection fused into attention (the default: 12 heads, lengths <= 256)
+//   H384_PAIR_HEAD_MAJOR  lm_qkv_h384 (head-major output) -> lm_attn_v3 (LEANN_MI355X_FUSED_QKV_ATTN=0: the round-5 path, A/B)
+//   H384_PAIR_ROW_MAJOR   lm_qkv_h384_f16 / lm_gemm_ws_h384_f16 -> lm_attn_varlen_hd32_f16, [tokens][1152] in between (LEANN_MI355X_QKV_LAYOUT=0, or an
+//                         attention generation that reads that layout: LEANN_MI355X_ATTN=2, LEANN_MI355X_ATTN3=9)
+lm::H384FirstHalf lm::h384_first_half_form(int32_t heads, int32_t max_len) {
+    auto is = [](const char* name, char c) {
+        const char* e = getenv(name);
+        return e && e[0] == c;
+    };
+    if (heads != 12 || max_len > 256) return H384_PAIR_ROW_MAJOR;
+    if (is("LEANN_MI355X_QKV_LAYOUT", '0') || is("LEANN_MI355X_ATTN3", '9') || is("LEANN_MI355X_ATTN", '2')) return H384_PAIR_ROW_MAJOR;
+    if (is("LEANN_MI355X_FUSED_QKV_ATTN", '0')) return H384_PAIR_HEAD_MAJOR;
+    return H384_FUSED;
+}
+extern "C" int lm_h384_first_half_form(int32_t heads, int32_t max_len) { return (int)lm::h384_first_half_form(heads, max_len); }
+
 extern "C" size_t lm_bert_h384_workspace_bytes(int64_t total_tokens) {
     if (total_tokens <= 0) return 0;
     // x, attention output, y: [T][384]; qkv: [T][1152]; small forwards additionally the feed-forward intermediate [T][ffn <= 2560]; fp16
@@ -48,11 +66,7 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     bool small = total_tokens <= small_tokens_limit() && m->ffn % 128 == 0;  // (every multiple of 192 in the envelope that is one of 128: 384, 768, 1152, 1536, ...)
     for (int l = 0; small && l < m->n_layers; ++l) small = m->layers[l].wo && m->layers[l].w1 && m->layers[l].w2;
     void* hid = ws + 3 * row + (size_t)total_tokens * 1152 * 2;  // [T][ffn], small forwards only (lm_bert_h384_workspace_bytes)
-    // LEANN_MI355X_QKV_LAYOUT=0: large forwards keep the [tokens][1152] projection layout (A/B); default: head major (the buffer is private to the forward)
-    const char* lay_env = getenv("LEANN_MI355X_QKV_LAYOUT");
-    const char* a3_env = getenv("LEANN_MI355X_ATTN3");
-    const char* a2_env = getenv("LEANN_MI355X_ATTN");
-    const bool head_major = !(lay_env && lay_env[0] == '0') && !(a3_env && a3_env[0] == '9') && !(a2_env && a2_env[0] == '2') && m->heads == 12;
+    const H384FirstHalf first_half = h384_first_half_form(m->heads, max_len);  // one decision per forward, shared with the Python host's launch path
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
         if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x
@@ -65,7 +79,9 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
             if ((rc = lm_add_layernorm_f16(y, nullptr, L.ln2_gamma, L.ln2_beta, x, total_tokens, 384, m->ln_eps, stream))) return rc;
             continue;
         }
-        if (L.wqkv_img && head_major) {  // the projection writes Q / K / V head major; generation 3 of the attention kernel reads contiguous blocks
+        if (L.wqkv_img && first_half == H384_FUSED) {  // QKV projection fused into attention: Q, K, V never leave the CU (lm_qkv_attn_h384.hip)
+            if ((rc = lm_qkv_attn_h384_launch(x, L.wqkv_img, L.bqkv, d_cu_seqlens, n_seqs, max_len, total_tokens, a, stream))) return rc;
+        } else if (L.wqkv_img && first_half == H384_PAIR_HEAD_MAJOR) {  // the pair: the projection writes Q / K / V head major, generation 3 of the attention kernel reads contiguous blocks
             if ((rc = lm_qkv_h384_launch(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, 1, stream))) return rc;
             if ((rc = lm_attn_v3_launch_hd32(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, total_tokens, stream))) return rc;
         } else {

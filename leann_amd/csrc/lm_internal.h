@@ -84,7 +84,7 @@ struct KtScope {
 
 // attention's algorithmic flops (4 H sum(len^2): the lengths live in device memory) onto the current device's counter; no-op while
 // attention's timing bit is off.  Call it in front of the launch's KtScope.
-void kt_attn_work(const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t hidden, void* stream);
+void kt_attn_work(const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t hidden, void* stream, int kid = LM_KT_ATTN);
 
 // ---- query phases (same state machine as oracle/lm_oracle.c) ----
 enum : int32_t { PH_SEED = 0, PH_UPPER = 1, PH_BEAM = 2, PH_DONE = 3 };
@@ -144,6 +144,9 @@ int32_t rc_width(const lm_recompute* rc);  // floats per embedding row
 // lm_recompute_create, so that a handle it accepts cannot fail on every search round (round-4 advisor finding).
 inline bool bert_h384_envelope_ok(int n_layers, int heads, int ffn) { return n_layers > 0 && heads * 32 == 384 && ffn >= 192 && ffn <= 1728 && ffn % 192 == 0; }
 #define LM_BERT_H384_ENVELOPE_TEXT "hidden 384 = heads x 32 and ffn a multiple of 192 in [192, 1728]"
+// lm_encoder_forward.cpp: the form of the first half (QKV projection + attention) of a large hidden-384 layer
+enum H384FirstHalf : int { H384_FUSED = 0, H384_PAIR_HEAD_MAJOR = 1, H384_PAIR_ROW_MAJOR = 2 };
+H384FirstHalf h384_first_half_form(int32_t heads, int32_t max_len);
 
 }  // namespace lm
 
@@ -154,6 +157,10 @@ int lm_qkv_h384_launch(const void* d_x, const void* d_w_img, const float* d_bias
 // total_tokens > 0: qkv is lm_qkv_h384_launch's HEAD-MAJOR layout over that many tokens ([3 x heads][total_tokens][32]); 0 = [tokens][3 x heads x 32]
 int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out, int64_t total_tokens,
                            void* stream);
+
+// lm_qkv_attn_h384.hip: the QKV projection fused into attention (hidden 384, 12 heads, lengths 1..256): x [T][384] -> attention output [T][384]
+int lm_qkv_attn_h384_launch(const void* d_x, const void* d_wqkv_img, const float* d_bqkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t max_len,
+                            int64_t total_tokens, void* d_out, void* stream);
 
 // lm_encoder_ops2.hip: 16-lanes-per-row LayerNorm (opt-in, LEANN_MI355X_LN=2, hidden <= 768); arguments as lm_add_layernorm_f16
 int lm_add_layernorm_r16_launch(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, void* d_out,

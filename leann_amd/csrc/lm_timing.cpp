@@ -39,14 +39,16 @@ struct DevState {
     // charged from max(its start, the previous pair's end).
     hipEvent_t last_end = nullptr;
     void* last_stream = nullptr;
-    unsigned long long* d_attn_work = nullptr;  // sum over launches of H * sum(len^2) (x 4 = flops), added by k_kt_attn_work
+    unsigned long long* d_attn_work = nullptr;  // [2]: sum over launches of H * sum(len^2) (x 4 = flops), added by k_kt_attn_work -- [0] the stand-alone
+                                                // attention kernels (LM_KT_ATTN), [1] the fused QKV + attention kernel (LM_KT_QKV_ATTN)
 };
 std::atomic<unsigned> g_mask{0};
 std::mutex g_mu;
 std::deque<Pair> g_pending;
 std::map<int, DevState> g_dev;
 Acc g_acc[LM_KT_COUNT];
-const char* const g_names[LM_KT_COUNT] = {"lm::k_layer_tail_h384", "lm::k_gemm_ws_h384", "lm::k_attn_varlen", "lm::k_gemm_f16", "lm::k_qkv_h384"};
+const char* const g_names[LM_KT_COUNT] = {"lm::k_layer_tail_h384", "lm::k_gemm_ws_h384", "lm::k_attn_varlen", "lm::k_gemm_f16", "lm::k_qkv_h384",
+                                         "lm::k_qkv_attn_h384"};
 
 int current_device() {
     int d = 0;
@@ -128,20 +130,20 @@ KtScope::~KtScope() {
 }
 
 // attention launchers, in front of their KtScope: the launch's flops / 4 onto the current device's counter (no-op while the bit is off)
-void kt_attn_work(const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t hidden, void* stream) {
-    if (!(g_mask.load(std::memory_order_relaxed) & (1u << LM_KT_ATTN))) return;
+void kt_attn_work(const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t hidden, void* stream, int kid) {
+    if (!(g_mask.load(std::memory_order_relaxed) & (1u << kid))) return;
     unsigned long long* acc;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         DevState& ds = g_dev[current_device()];
         if (!ds.d_attn_work) {
-            if (hipMalloc((void**)&ds.d_attn_work, 8) != hipSuccess || hipMemset(ds.d_attn_work, 0, 8) != hipSuccess) {
+            if (hipMalloc((void**)&ds.d_attn_work, 16) != hipSuccess || hipMemset(ds.d_attn_work, 0, 16) != hipSuccess) {
                 (void)hipGetLastError();
                 ds.d_attn_work = nullptr;
                 return;
             }
         }
-        acc = ds.d_attn_work;
+        acc = ds.d_attn_work + (kid == LM_KT_QKV_ATTN ? 1 : 0);
     }
     hipLaunchKernelGGL(k_kt_attn_work, dim3(1), dim3(256), 0, (hipStream_t)stream, d_cu_seqlens, n_seqs, (unsigned long long)hidden, acc);
     (void)hipGetLastError();
@@ -165,10 +167,11 @@ extern "C" int lm_kernel_timing_read(lm_kernel_time* out, int32_t capacity, int3
     const int before = current_device();
     for (auto& kv : g_dev) {  // attention's device-side flop counters (the kernels that fed them precede the pairs waited for above)
         if (!kv.second.d_attn_work) continue;
-        unsigned long long h = 0;
-        if (hipSetDevice(kv.first) == hipSuccess && hipMemcpy(&h, kv.second.d_attn_work, 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            g_acc[LM_KT_ATTN].work += 4.0 * (double)h;
-            (void)hipMemset(kv.second.d_attn_work, 0, 8);
+        unsigned long long h[2] = {0, 0};
+        if (hipSetDevice(kv.first) == hipSuccess && hipMemcpy(h, kv.second.d_attn_work, 16, hipMemcpyDeviceToHost) == hipSuccess) {
+            g_acc[LM_KT_ATTN].work += 4.0 * (double)h[0];
+            g_acc[LM_KT_QKV_ATTN].work += 4.0 * (double)h[1];
+            (void)hipMemset(kv.second.d_attn_work, 0, 16);
         } else {
             (void)hipGetLastError();
         }

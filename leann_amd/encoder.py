@@ -435,6 +435,36 @@ def pack_qkv_image(w: torch.Tensor) -> torch.Tensor:
     return img
 
 
+def fused_qkv_attention(x: torch.Tensor, lin: nn.Linear, cu: torch.Tensor, heads: int, max_len: int) -> Optional[torch.Tensor]:
+    """softmax(Q K^T / sqrt(32)) V per (sequence, head) with [Q | K | V] = x W^T + b computed inside the kernel (csrc/lm_qkv_attn_h384.hip, round 6:
+    the projection's 604 MB per 262 k tokens never go to HBM) -- the first half of a LARGE hidden-384 layer.  None = the caller takes the
+    stand-alone pair: another shape, or the library's own decision says so (lm_h384_first_half_form: LEANN_MI355X_FUSED_QKV_ATTN=0 and the
+    switches of the older attention generations; the one-call forward asks the same function, so both launch paths run the same kernels)."""
+    import ctypes as C
+
+    from . import _lib
+
+    n, k = lin.weight.shape
+    if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n == 1152 and heads == 12 and lin.bias is not None
+            and 0 < max_len <= 256 and cu.dtype == torch.int32):
+        return None
+    lib = _lib.load()
+    if lib.lm_h384_first_half_form(int(heads), int(max_len)) != 0:
+        return None
+    pk = _packed(lin, "_qkv_pack", (lin.weight, lin.bias), lambda: (pack_qkv_image(lin.weight), lin.bias.detach().float().contiguous()))
+    out = torch.empty((x.shape[0], 384), dtype=torch.float16, device=x.device)
+    tm = KernelTimers.active
+    ev = tm.span("qkv_attn_h384", x.shape[0] * 2.0 * 384 * 1152) if tm is not None else None
+    if ev:
+        ev[0].record()
+    _lib.check(lib.lm_qkv_attn_h384_f16(C.c_void_p(x.data_ptr()), C.c_void_p(pk[0].data_ptr()), C.c_void_p(pk[1].data_ptr()), C.c_void_p(cu.data_ptr()),
+                                        int(cu.shape[0] - 1), int(max_len), int(x.shape[0]), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "lm_qkv_attn_h384_f16")
+    if ev:
+        ev[1].record()
+    return out
+
+
 def _linear_ws_h384(x: torch.Tensor, lin: nn.Linear, residual: Optional[torch.Tensor], ln: Optional[nn.LayerNorm]) -> Optional[torch.Tensor]:
     n, k = lin.weight.shape
     if not (x.is_cuda and x.dtype == torch.float16 and x.is_contiguous() and k == 384 and n % 192 == 0 and n <= 6144 and lin.bias is not None):
@@ -491,15 +521,19 @@ class _Layer(nn.Module):
             y = self._forward_packed_general(x, cu, max_len)
             if y is not None:
                 return y
-        qkv2 = (fused_gemm(x, self.qkv) if os.environ.get("LEANN_MI355X_GEMM") == "1" else None) if h == 384 else None
-        if qkv2 is None:
-            qkv2 = fused_linear_h384(x, self.qkv)
-        if qkv2 is None:
-            qkv2 = self.qkv(x)
-        a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
+        a = None
+        if h == 384 and os.environ.get("LEANN_MI355X_GEMM") != "1" and os.environ.get("LEANN_MI355X_LINEAR", "1") != "0" and os.environ.get("LEANN_MI355X_QKV", "1") == "1":
+            a = fused_qkv_attention(x, self.qkv, cu, self.heads, max_len)  # projection fused into attention (the default of the large forwards)
         if a is None:
-            qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
-            a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
+            qkv2 = (fused_gemm(x, self.qkv) if os.environ.get("LEANN_MI355X_GEMM") == "1" else None) if h == 384 else None
+            if qkv2 is None:
+                qkv2 = fused_linear_h384(x, self.qkv)
+            if qkv2 is None:
+                qkv2 = self.qkv(x)
+            a = fused_attention_hd32(qkv2, cu, self.heads, max_len)
+            if a is None:
+                qkv = qkv2.view(tot, 3, self.heads, h // self.heads)
+                a = varlen_attn(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, max_len, max_len).reshape(tot, h)
         y = fused_attn_out_mlp(a, x, self)  # output projection + LayerNorm + feed-forward block + LayerNorm in one kernel
         if y is not None:
             return y

@@ -3,7 +3,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/kbench.cpp -Iinclude -Lleann_amd/lib -lleann_mi355x -lrocblas
 //         -Wl,-rpath,$PWD/leann_amd/lib -o gpurun_out/kbench            (scripts/build_kbench.sh)
-//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|wsgemm|tail|tail4|attn|a3stamps|attn64|ln|gemmf16|gemmstamp]
+//   ./kbench [tokens=262144] [reps=20] [what=all|bw|linear|qkv|fusedqa|wsgemm|tail|tail4|attn|a3stamps|attn64|ln|gemmf16|gemmstamp]
 //
 // Every kernel is checked against a plain fp32 GPU reference of the same op on the first and last 192 tokens (incl. the
 // ragged tail: tokens is deliberately not a multiple of 128) and timed with HIP events on the launch stream.  One JSON
@@ -30,6 +30,11 @@ extern "C" int lm_attn_out_mlp_fused_h384_f16(const void* d_attn, const void* d_
                                               const void* d_beta1, float eps1, const void* d_w1acc, const float* d_b1, const void* d_w2p,
                                               const float* d_b2, const void* d_gamma, const void* d_beta, void* d_out, int64_t tokens, int32_t ffn,
                                               float eps, void* stream);
+
+// internal (C++-linkage) entry points of the library: the head-major QKV projection + generation-3 attention pair of round 5's large forwards
+int lm_qkv_h384_launch(const void* d_x, const void* d_w_img, const float* d_bias, int32_t n_out, void* d_out, int64_t tokens, int32_t head_major, void* stream);
+int lm_attn_v3_launch_hd32(const void* d_qkv, const int32_t* d_cu_seqlens, int32_t n_seqs, int32_t heads, int32_t max_len, void* d_out, int64_t total_tokens,
+                           void* stream);
 
 #define CK(e)                                                                                  \
     do {                                                                                       \
@@ -544,6 +549,64 @@ int main(int argc, char** argv) {
             unsetenv("LEANN_MI355X_TAIL4");
         }
         fflush(stdout);
+    }
+    if (want("fusedqa")) {  // round 6: the QKV projection fused into attention (lm_qkv_attn_h384.hip) against the pair it replaces, same operands, interleaved
+        const int heads = 12, N = 3 * H;
+        std::mt19937 g(5);
+        std::normal_distribution<float> d(180.f, 50.f);
+        const char* fl = getenv("KBENCH_FIXED_LEN");  // every sequence this long instead of N(180, 50) clipped to [16, 256]
+        std::vector<int> cu{0};
+        while (true) {
+            int len = fl ? atoi(fl) : std::min(256, std::max(16, (int)lroundf(d(g))));
+            if (cu.back() + len > T) break;
+            cu.push_back(cu.back() + len);
+        }
+        const int ns = (int)cu.size() - 1, tot = cu.back();
+        Dev<int> dcu(cu);
+        auto hw = rand_half((size_t)N * H, 0.05f, 60);
+        Dev<__half> w(hw), wimg((size_t)N * H), qkv((size_t)tot * N), qkvr((size_t)tot * N), outp((size_t)tot * H), outr((size_t)tot * H), outf((size_t)tot * H);
+        Dev<float> b(rand_float(N, 0.2f, 61));
+        LM(lm_qkv_pack_h384(w.p, N, wimg.p, st));
+        auto run_q = [&] { LM(lm_qkv_h384_launch(x.p, wimg.p, b.p, N, qkv.p, tot, 1, st)); };
+        auto run_a = [&] { LM(lm_attn_v3_launch_hd32(qkv.p, dcu.p, ns, heads, 256, outp.p, tot, st)); };
+        auto run_f = [&] { LM(lm_qkv_attn_h384_f16(x.p, wimg.p, b.p, dcu.p, ns, 256, tot, outf.p, st)); };
+        // reference: the public row-major pair, then the fp32 attention reference on ITS fp16 projection (first sequences)
+        LM(lm_qkv_h384_f16(x.p, wimg.p, b.p, N, qkvr.p, tot, st));
+        LM(lm_attn_varlen_hd32_f16(qkvr.p, dcu.p, ns, heads, 256, outr.p, st));
+        const int nchk = std::min(ns, 6);
+        Dev<float> ref((size_t)cu[nchk] * H);
+        hipLaunchKernelGGL(ref_attn, dim3(nchk, heads), dim3(64), 0, st, qkvr.p, dcu.p, heads, ref.p);
+        CK(hipMemsetAsync(outf.p, 0xff, (size_t)tot * H * 2, st));
+        run_q(); run_a(); run_f();
+        CK(hipStreamSynchronize(st));
+        {
+            auto href = ref.host();
+            std::vector<int> arows;
+            for (int i = 0; i < cu[nchk]; ++i) arows.push_back(i);
+            auto hp = outp.host(), hf = outf.host(), hr = outr.host();
+            double dpf = 0, dpr = 0;
+            size_t nan_f = 0;
+            for (size_t i = 0; i < hp.size(); ++i) {
+                const double vf = (double)__half2float(hf[i]);
+                if (!(vf == vf)) ++nan_f;
+                dpf = std::max(dpf, fabs((double)__half2float(hp[i]) - vf));
+                dpr = std::max(dpr, fabs((double)__half2float(hp[i]) - (double)__half2float(hr[i])));
+            }
+            printf("{\"kernel\": \"lm_qkv_attn_h384_f16\", \"sequences\": %d, \"tokens\": %d, \"max_abs_err_fused_vs_fp32_attention_of_fp16_qkv\": %.3g, \"max_abs_err_pair\": %.3g, "
+                   "\"max_abs_diff_fused_vs_pair_all_rows\": %.3g, \"max_abs_diff_head_major_pair_vs_row_major_pair\": %.3g, \"nan_in_fused\": %zu}\n",
+                   ns, tot, max_err_rows(hf, H, 0, H, arows, href), max_err_rows(hp, H, 0, H, arows, href), dpf, dpr, nan_f);
+        }
+        double flops_attn = 0;
+        for (int i = 0; i < ns; ++i) flops_attn += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
+        const double flops = flops_attn + 2.0 * tot * N * H;
+        for (int round = 0; round < 3; ++round) {
+            const float uq = time_us(st, reps, run_q), ua = time_us(st, reps, run_a), uf = time_us(st, reps, run_f);
+            printf("{\"kernel\": \"pair: lm_qkv_h384 (head major) + lm_attn_v3\", \"round\": %d, \"us_qkv\": %.1f, \"us_attn\": %.1f, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, uq, ua, uq + ua,
+                   flops / (uq + ua) * 1e-6);
+            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"us_per_262144_tokens\": %.1f}\n", round, uf, flops / uf * 1e-6,
+                   uf * 262144.0 / tot);
+            fflush(stdout);
+        }
     }
     if (want("attn")) {
         const int heads = 12;

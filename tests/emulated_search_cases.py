@@ -727,6 +727,63 @@ def case_attention_v3():
         print(f"attention generation 3, lengths {lens.tolist()}: max |err| vs float64 {max(np.abs(v.astype(np.float64) - ref).max() for v in outs.values()):.2e}, {grew} rows through the rescale branch: ok", flush=True)
 
 
+def case_qkv_attn_fused(lens_list=((70, 1, 33), (256, 31))):
+    """The QKV projection fused into attention (csrc/lm_qkv_attn_h384.hip, round 6) against float64 numpy: x [T][384] -> attention output
+    [T][384] for 12 heads x 32, with Q, K, V rounded where the kernel rounds them (Q after the softmax scale, once; K and V to fp16).  Weights
+    scaled so that scores spread over many powers of two: later key tiles exceed the running maximum by more than the deferred-rescaling
+    threshold for many rows (counted: the branch must be exercised), and the last tile is masked at lengths that are not multiples of 32.
+    Lengths 1, 31, 33, 70, 256: one to eight active waves, idle waves that only stream weights, a full workgroup.  Also against the
+    stand-alone pair (lm_qkv_h384_f16 -> lm_attn_varlen_hd32_f16) on the same operands."""
+    from leann_amd import _lib
+
+    lib = _lib.load()
+    vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    rng = np.random.default_rng(91)
+    H, heads = 384, 12
+    w = rng.standard_normal((3 * H, H)).astype(np.float32)
+    w[: 2 * H] *= 0.26  # q, k entries ~ N(0, 2.5^2): scores ~ N(0, (6.3 / sqrt 32 x 5.6 ...)) -- wide enough for the rescale branch
+    w[2 * H:] *= 0.1
+    w = w.astype(np.float16)
+    b = (0.3 * rng.standard_normal(3 * H)).astype(np.float32)
+    img = np.zeros_like(w)
+    _lib.check(lib.lm_qkv_pack_h384(vp(w), 3 * H, vp(img), None), "lm_qkv_pack_h384")
+    c = 1.4426950408889634 / np.sqrt(32.0)
+    for lens in lens_list:
+        lens = np.asarray(lens, np.int32)
+        n = lens.shape[0]
+        cu = np.zeros(n + 1, np.int32)
+        cu[1:] = np.cumsum(lens)
+        tot = int(cu[-1])
+        x = (0.5 * rng.standard_normal((tot, H))).astype(np.float16)
+        qkv = x.astype(np.float64) @ w.astype(np.float64).T + b.astype(np.float64)
+        q2 = (qkv[:, :H] * c).astype(np.float16).astype(np.float64)  # (log2 units)
+        k = qkv[:, H: 2 * H].astype(np.float16).astype(np.float64)
+        v = qkv[:, 2 * H:].astype(np.float16).astype(np.float64)
+        ref = np.zeros((tot, H))
+        grew = 0
+        for i in range(n):
+            a_, b_ = cu[i], cu[i + 1]
+            for h in range(heads):
+                s2 = q2[a_:b_, 32 * h: 32 * h + 32] @ k[a_:b_, 32 * h: 32 * h + 32].T
+                pr = np.exp2(s2 - s2.max(1, keepdims=True))
+                ref[a_:b_, 32 * h: 32 * h + 32] = (pr / pr.sum(1, keepdims=True)) @ v[a_:b_, 32 * h: 32 * h + 32]
+                if s2.shape[1] > 32:
+                    grew += int(((s2[:, 32:].max(1) - s2[:, :32].max(1)) > 8.0).sum())
+        assert max(lens) <= 32 or grew > 0, "the test data does not reach the rescale branch"
+        o = np.zeros((tot, H), np.float16)
+        _lib.check(lib.lm_qkv_attn_h384_f16(vp(x), vp(img), vp(b), vp(cu), n, int(lens.max()), tot, vp(o), None), "lm_qkv_attn_h384_f16")
+        err = np.abs(o.astype(np.float64) - ref).max()
+        assert np.isfinite(o.astype(np.float32)).all() and err < 6e-3, (lens.tolist(), err)
+        # the stand-alone pair on the same operands (Q rounded twice there: fp16-close, not bit-equal)
+        qkv16 = np.zeros((tot, 3 * H), np.float16)
+        _lib.check(lib.lm_qkv_h384_f16(vp(x), vp(img), vp(b), 3 * H, vp(qkv16), tot, None), "lm_qkv_h384_f16")
+        o2 = np.zeros((tot, H), np.float16)
+        _lib.check(lib.lm_attn_varlen_hd32_f16(vp(qkv16), vp(cu), n, heads, int(lens.max()), vp(o2), None), "attn v3")
+        pair = np.abs(o2.astype(np.float64) - o.astype(np.float64)).max()
+        assert pair < 3e-2, (lens.tolist(), pair)
+        print(f"fused QKV + attention, lengths {lens.tolist()}: max |err| vs float64 {err:.2e}, vs the stand-alone pair {pair:.2e}, {grew} rows through the rescale branch: ok", flush=True)
+
+
 def case_layer_tail_small():
     """The fused layer tail alone (small enough for the ThreadSanitizer build): every LDS stage hand-over of lm_layer_tail_h384.hip -- the
     six-stage W_o ring with the residual rows behind it, the W1 / W2 rings, the continuous fragment ring, the output tiles -- with real
@@ -795,6 +852,7 @@ CASES = {
     "encoder_abi": case_encoder_abi,
     "dims_and_batches": case_dims_and_batches,
     "attention_v3": case_attention_v3,
+    "qkv_attn_fused": case_qkv_attn_fused,
 }
 
 def case_gemm_f16():
@@ -989,8 +1047,8 @@ def case_encoder_python_wiring():
             mock.patch.object(_lib, "check", new=recording_check):
         with torch.no_grad():
             got = enc16.encode_tokens_packed(ti, tl, 4096)
-    expected = {"lm_pack_tokens": 1, "lm_embed_layernorm_f16": 1, "lm_qkv_h384_f16": cfg.layers, "lm_gemm_ws_h384_f16": cfg.layers,
-                "lm_attn_varlen_hd32_f16": cfg.layers, "lm_gemm_f16": 2 * cfg.layers, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_meanpool_varlen_f16": 1}
+    expected = {"lm_pack_tokens": 1, "lm_embed_layernorm_f16": 1, "lm_qkv_attn_h384_f16": cfg.layers, "lm_qkv_h384_f16": 0, "lm_gemm_ws_h384_f16": cfg.layers,
+                "lm_attn_varlen_hd32_f16": 0, "lm_gemm_f16": 2 * cfg.layers, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_meanpool_varlen_f16": 1}
     counts = {k: used.count(k) for k in expected}
     assert counts == expected, (counts, sorted(set(used)))  # no library GEMM, no torch op left
     # mixed configuration: packing kernel + torch pooling (needs the lazily built token -> sequence map) + torch embedding
@@ -1002,8 +1060,11 @@ def case_encoder_python_wiring():
         with torch.no_grad():
             got2 = enc16.encode_tokens_packed(ti, tl, 4096)
     assert float((got2.float() - ref).abs().max()) < 6e-3
-    # the DEFAULT kernel set (weight-streaming QKV projection, attention, fused layer tail)
-    for ffn, extra, want in ((384, {}, {"lm_qkv_h384_f16": 2, "lm_layer_tail_h384_f16": 2}), (384, {"LEANN_MI355X_QKV": "0"}, {"lm_gemm_ws_h384_f16": 2, "lm_layer_tail_h384_f16": 2})):
+    # the DEFAULT kernel set (QKV projection fused into attention, fused layer tail), then the stand-alone pair behind its switch (weight-streaming
+    # QKV projection, attention), then the weight-stationary projection
+    for ffn, extra, want in ((384, {}, {"lm_qkv_attn_h384_f16": 2, "lm_qkv_h384_f16": 0, "lm_attn_varlen_hd32_f16": 0, "lm_layer_tail_h384_f16": 2}),
+                             (384, {"LEANN_MI355X_FUSED_QKV_ATTN": "0"}, {"lm_qkv_attn_h384_f16": 0, "lm_qkv_h384_f16": 2, "lm_attn_varlen_hd32_f16": 2, "lm_layer_tail_h384_f16": 2}),
+                             (384, {"LEANN_MI355X_QKV": "0"}, {"lm_gemm_ws_h384_f16": 2, "lm_attn_varlen_hd32_f16": 2, "lm_layer_tail_h384_f16": 2})):
         cfg3 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=ffn, max_pos=64, max_seq_length=48)
         e32 = BertEncoder.random_init(cfg3, 5).eval()
         with torch.no_grad():
@@ -1020,7 +1081,7 @@ def case_encoder_python_wiring():
             with torch.no_grad():
                 got3 = e16.encode_tokens_packed(ti, tl, 4096)
         counts3 = {k: used.count(k) for k in want}
-        assert counts3 == want and used.count("lm_attn_varlen_hd32_f16") == 2 and "lm_add_layernorm_f16" not in used, (ffn, counts3, sorted(set(used)))
+        assert counts3 == want and "lm_add_layernorm_f16" not in used, (ffn, extra, counts3, sorted(set(used)))
         err3 = float((got3.float() - ref3).abs().max())
         assert err3 < 6e-3, (ffn, err3)
     # the default launch path: the whole forward as ONE library call (csrc/lm_encoder_forward.cpp) -- same kernels, same result as the default path

@@ -14,7 +14,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent.parent
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SRCS = ["lm_search.hip", "lm_tokens.hip", "lm_recompute.hip", "lm_encoder_ops.hip", "lm_attn_v2.hip", "lm_attn_v3.hip", "lm_encoder_ops2.hip", "lm_layer_tail_h384.hip", "lm_qkv_h384.hip", 
+SRCS = ["lm_search.hip", "lm_tokens.hip", "lm_recompute.hip", "lm_encoder_ops.hip", "lm_attn_v2.hip", "lm_attn_v3.hip", "lm_encoder_ops2.hip", "lm_layer_tail_h384.hip", "lm_qkv_h384.hip", "lm_qkv_attn_h384.hip",
         "lm_gemm_ws_h384.hip", "lm_gemm_f16.hip", "lm_csr_reader.cpp", "lm_encoder_forward.cpp", "lm_timing.cpp"]
 
 

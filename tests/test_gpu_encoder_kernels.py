@@ -116,6 +116,124 @@ def test_attention_rescale_branch_and_masked_maximum(monkeypatch):
     assert err < 5e-3, err
 
 
+def _fused_case(torch, maxlen, nseq, wscale=0.26, seed=0):
+    """x, the QKV nn.Linear and the plain fp32 reference of the FIRST half of a hidden-384 layer: [Q | K | V] = x W^T + b (fp32 matmul), per (sequence,
+    head) softmax(Q K^T / sqrt 32) V.  wscale 0.26: q, k entries of +-2.5 -- scores spread over ~ +-20 log2 units, so that later key tiles exceed the
+    running maximum by more than the deferred-rescaling threshold for many rows."""
+    g = torch.Generator(device="cpu").manual_seed(1000 * maxlen + nseq + seed)
+    lens = torch.randint(1, maxlen + 1, (nseq,), generator=g)
+    lens[0], lens[-1] = maxlen, 1
+    if nseq > 4:
+        lens[1] = max(1, maxlen - 1)
+        lens[2] = max(1, (maxlen // 32) * 32)
+    cu = torch.zeros(nseq + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    tot, H, heads = int(cu[-1]), 384, 12
+    lin = torch.nn.Linear(H, 3 * H)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn((3 * H, H), generator=g) * torch.tensor([wscale] * (2 * H) + [0.1] * H)[:, None])
+        lin.bias.copy_(torch.randn(3 * H, generator=g) * 0.3)
+    lin = lin.half().cuda()
+    x = (torch.randn((tot, H), generator=g) * 0.5).half().cuda()
+    with torch.no_grad():
+        q3 = (x.float() @ lin.weight.float().t() + lin.bias.float()).view(tot, 3, heads, 32)
+    ref = torch.empty((tot, H), device="cuda")
+    grew = 0
+    for i in range(nseq):
+        a, b = int(cu[i]), int(cu[i + 1])
+        q, k, v = (q3[a:b, j].transpose(0, 1) for j in range(3))
+        sc = q @ k.transpose(1, 2) / 32**0.5
+        ref[a:b] = (torch.softmax(sc, dim=-1) @ v).transpose(0, 1).reshape(b - a, H)
+        if b - a > 32:
+            s2 = sc * 1.4426950408889634
+            grew += int(((s2[:, :, 32:].max(-1).values - s2[:, :, :32].max(-1).values) > 8.0).sum())
+    return x, lin, cu.cuda(), int(lens.max()), ref, grew
+
+
+@pytest.mark.parametrize("maxlen,nseq,wscale", [(256, 37, 0.26), (255, 9, 0.26), (200, 37, 0.1), (70, 20, 0.26), (64, 8, 0.1), (33, 8, 0.26), (32, 6, 0.1), (2, 5, 0.26), (1, 3, 0.26)])
+def test_fused_qkv_attention_matches_fp32_reference(maxlen, nseq, wscale):
+    """csrc/lm_qkv_attn_h384.hip (round 6: the QKV projection fused into attention -- the first half of every large hidden-384 layer, what the timed path
+    runs) against a plain PyTorch fp32 reference of the same op (fp32 linear + softmax attention), lengths from 1 to 256 (one to eight active waves,
+    idle waves, a masked last tile or none), scores wide enough for the deferred-rescale branch (counted), and the same bits launch after launch."""
+    import torch
+
+    from leann_amd.encoder import fused_qkv_attention
+
+    x, lin, cu, mx, ref, grew = _fused_case(torch, maxlen, nseq, wscale)
+    assert wscale < 0.2 or maxlen <= 32 or grew > 0, "the test data does not reach the rescale branch"
+    o = fused_qkv_attention(x, lin, cu, 12, mx)
+    torch.cuda.synchronize()
+    assert o is not None and o.shape == ref.shape and not torch.isnan(o).any()
+    err = (o.float() - ref).abs().max().item()
+    # K and V are rounded to fp16 once (as in the two-kernel form), Q once AFTER the softmax scale; at wscale 0.26 the logits reach +-20 log2 units
+    # and a rounding of k moves a probability by up to ~1 %: fp16-level, looser than the pure attention test (whose inputs ARE fp16)
+    assert err < (8e-3 if wscale < 0.2 else 2.5e-2), (maxlen, err)
+    again = [fused_qkv_attention(x, lin, cu, 12, mx) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, a) for a in again)
+
+
+def test_fused_qkv_attention_against_the_pair_it_replaces(monkeypatch):
+    """The same operands through the stand-alone pair (LEANN_MI355X_FUSED_QKV_ATTN=0 -> lm_qkv_h384_f16 + attention generation 3): fp16-close (the pair
+    rounds Q twice), and the fused kernel is at least as close to an fp64 reference built from the kernels' own rounding points."""
+    import torch
+
+    from leann_amd.encoder import fused_attention_hd32, fused_linear_h384, fused_qkv_attention
+
+    x, lin, cu, mx, ref, _ = _fused_case(torch, 256, 24, 0.1, seed=3)
+    of = fused_qkv_attention(x, lin, cu, 12, mx)
+    qkv = fused_linear_h384(x, lin)
+    op = fused_attention_hd32(qkv, cu, 12, mx)
+    torch.cuda.synchronize()
+    assert of is not None and op is not None
+    assert (of.float() - op.float()).abs().max().item() < 6e-3
+    ef, ep = (of.float() - ref).abs().max().item(), (op.float() - ref).abs().max().item()
+    assert ef < 8e-3 and ep < 8e-3 and ef <= 1.5 * ep, (ef, ep)
+    monkeypatch.setenv("LEANN_MI355X_FUSED_QKV_ATTN", "0")
+    assert fused_qkv_attention(x, lin, cu, 12, mx) is None  # the switch hands the layer back to the pair
+
+
+@pytest.mark.parametrize("maxlen", [256, 70, 33])
+def test_head_major_qkv_projection_and_attention_pair(maxlen):
+    """The two launch paths of a LARGE forward, in both forms of its first half, four runs each (same bits every time):
+      * pair (LEANN_MI355X_FUSED_QKV_ATTN=0): the one-call forward runs lm_qkv_h384_launch(head_major = 1) -> lm_attn_v3_launch_hd32 over the
+        head-major layout (round 5's timed path; those two entry points are internal), the per-kernel path lm_qkv_h384_f16 ->
+        lm_attn_varlen_hd32_f16 over [tokens][1152], whose kernels test_attention_matches_fp32_reference and kbench check against fp32 references:
+        the same arithmetic in another layout, so the outputs must be IDENTICAL -- that equality is the head-major pair's kernel-level pin;
+      * fused (the default): both paths run lm_qkv_attn_h384_f16 -> identical; and fp16-close to the pair."""
+    import os
+
+    import torch
+
+    from leann_amd.encoder import BertEncoder, config_for
+    from leann_amd.synth import CorpusSpec, SyntheticCorpus, pad_batch
+
+    enc = BertEncoder.random_init(config_for("all-MiniLM-L6-v2"), 0).to("cuda", dtype=torch.float16).eval()
+    corpus = SyntheticCorpus(CorpusSpec(n_chunks=160, seed=maxlen, len_mean=0.8 * maxlen, len_std=0.2 * maxlen, len_min=1, len_max=maxlen))
+    tok, off = corpus.chunks()
+    ids, lens = pad_batch(tok, off, maxlen)
+    ti, tl = torch.from_numpy(ids).cuda(), torch.from_numpy(lens).cuda()
+    outs = {}
+    for name, env in (("onecall_pair", {"LEANN_MI355X_FUSED_QKV_ATTN": "0", "LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
+                      ("kernels_pair", {"LEANN_MI355X_FUSED_QKV_ATTN": "0", "LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"}),
+                      ("onecall_fused", {"LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
+                      ("kernels_fused", {"LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with torch.no_grad():
+                outs[name] = [enc.encode_tokens_packed(ti, tl, 1 << 20).clone() for _ in range(4)]
+            torch.cuda.synchronize()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for name, o in outs.items():
+        assert all(torch.equal(o[0], z) for z in o[1:]), name + ": not bit-reproducible"
+    assert torch.equal(outs["onecall_pair"][0], outs["kernels_pair"][0])    # head-major pair == row-major pair
+    assert torch.equal(outs["onecall_fused"][0], outs["kernels_fused"][0])  # both launch paths run the fused kernel
+    assert (outs["onecall_fused"][0] - outs["onecall_pair"][0]).abs().max().item() < 5e-3  # unit vectors: fp16-level agreement of the two forms
+
+
 def test_encoder_forward_with_and_without_the_attention_kernel(monkeypatch):
     import torch
 
