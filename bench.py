@@ -879,9 +879,10 @@ class BoxSampler:
         return out
 
 
-def _tail_probe_launches(enc, dev, tokens=TAIL_PROBE_TOKENS, launches=10, warm=3):
+def _tail_probe_launches(enc, dev, tokens=TAIL_PROBE_TOKENS, launches=10, warm=60):
     """`launches` timed launches of the fused layer tail (layer 0 of `enc`, random activations) at kbench's reference size; HIP events on the
-    launch stream.  Returns the per-launch times in us."""
+    launch stream.  Returns the per-launch times in us.  60 warm-up launches (~45 ms) first: the clock of an idle chip (sclk 95 MHz) takes tens
+    of milliseconds to come up -- round 6's first probe warmed up with 3 launches and read 788-950 us on a box where kbench read 700."""
     import torch
 
     from leann_amd.encoder import fused_attn_out_mlp
@@ -984,7 +985,8 @@ def box_probe(enc, dev, local_rank=0):
     out = {"what": f"before the timed steps, idle chip: 10 launches of lm_layer_tail_h384_f16 at {TAIL_PROBE_TOKENS} tokens (kbench tail4's size: 675-690 us on the "
                    f"boxes DESIGN 6.1 calls fast, 730+ on the slow ones) and a 1 GiB device-to-device copy; clocks / power sampled during the timed steps"}
     try:
-        smp = BoxSampler(local_rank, period_s=0.2).start()
+        _tail_probe_launches(enc, dev, launches=2)  # (allocations, weight images, first clock ramp: outside the sampled window)
+        smp = BoxSampler(local_rank, period_s=0.004).start()
         us = _tail_probe_launches(enc, dev)
         out["clocks_during_the_probe_launches"] = smp.stop()
         if us:

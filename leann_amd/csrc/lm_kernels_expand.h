@@ -118,18 +118,21 @@ __global__ __launch_bounds__(64) void k_expand(GraphDev g, WsDev ws, int use_rbm
             while (total < ws.batch) {
                 if (!ws.check_rel && nsteps > ws.efs) break;
                 int idx = -1;
+                uint64_t key = 0;
                 for (int base = cursor & ~63; base < scan_n; base += 64) {
                     const int i = base + lane;
-                    const bool un = i >= cursor && i < scan_n && !(pool[i] & KEY_EXPANDED);
+                    const uint64_t mine = i < scan_n ? pool[i] : KEY_NONE;
+                    const bool un = i >= cursor && i < scan_n && !(mine & KEY_EXPANDED);
                     const unsigned long long m = __ballot(un);
                     if (m) {
-                        idx = base + __ffsll((long long)m) - 1;
+                        const int src = __ffsll((long long)m) - 1;
+                        idx = base + src;
+                        if (lane == src) pool[i] = mine | KEY_EXPANDED;  // the lane that read the entry marks it: no lane reads another lane's write
+                        key = (uint64_t)__shfl((unsigned long long)mine, src);
                         break;
                     }
                 }
                 if (idx < 0) break;
-                const uint64_t key = pool[idx];
-                if (lane == 0) pool[idx] = key | KEY_EXPANDED;
                 cursor = idx + 1;
                 ++nsteps;
                 const L0Range r = g.l0[key_id(key)];

@@ -84,10 +84,12 @@ __device__ __forceinline__ void qa_load_bias(QaCarry& cy, const float* bl) {  //
 //   slot 24 - RD  (NEXT) counted wait + barrier: the next slab's stage has landed for every wave, and every wave has issued its last
 //                 read of this slab's stage (fragment 23 is read in slot 23 - RD); from here on the fragment ring reads the next stage
 //   slots 16..19  (NEXT) the next slab's bias vector
-template <int ST, bool NEXT, bool DMA, int I>
+// ABL (diagnosis library only, kbench fusedqa with LEANN_MI355X_QA_ABLATE: timing runs whose RESULTS ARE GARBAGE -- what each ingredient of the slab loop
+// costs): bit 0 skip the tile loop, bit 1 skip the slab barriers and their counted waits, bit 2 issue no DMA, bit 3 no fragment reads (MFMAs on stale registers)
+template <int ST, bool NEXT, bool DMA, int ABL, int I>
 __device__ __forceinline__ void qa_slot(const QaAddr& c, const float* bl_next, const half8 (&xf)[ML_KS], float16v (&acc)[2], QaCarry& cy,
                                         const unsigned char* dsrc, unsigned voff, unsigned char* ddst) {
-    if constexpr (I == 24 - QA_RD && NEXT) {
+    if constexpr (I == 24 - QA_RD && NEXT && !(ABL & 2)) {
         t4_wait_vm<3>();  // younger than the awaited slab's pieces: at most one other request (3 pieces) -- and stores, which are then older or youngest
         T4_BARRIER();
     }
@@ -96,7 +98,8 @@ __device__ __forceinline__ void qa_slot(const QaAddr& c, const float* bl_next, c
         const float16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cy.ring[1 % QA_RD], xf[1], z, 0, 0, 0);
     } else acc[I & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cy.ring[I % QA_RD], xf[I], acc[I & 1], 0, 0, 0);
-    if constexpr (I + QA_RD < 24) cy.ring[I % QA_RD] = qa_frag<ST, I + QA_RD>(c);
+    if constexpr (ABL & 8) {
+    } else if constexpr (I + QA_RD < 24) cy.ring[I % QA_RD] = qa_frag<ST, I + QA_RD>(c);
     else if constexpr (NEXT) cy.ring[I % QA_RD] = qa_frag<(ST + 1) % 3, I + QA_RD - 24>(c);
     if constexpr (NEXT && I >= 16 && I < 20) {
         constexpr int q = I - 16;
@@ -104,17 +107,18 @@ __device__ __forceinline__ void qa_slot(const QaAddr& c, const float* bl_next, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) cy.biasv[4 * q + i] = bv[i];
     }
-    if constexpr (DMA && I == 1) t4_dma_group<3>(dsrc, voff, ddst);
+    if constexpr (DMA && I == 1 && !(ABL & 4)) t4_dma_group<3>(dsrc, voff, ddst);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int ST, bool NEXT, bool DMA, int... I>
+template <int ST, bool NEXT, bool DMA, int ABL, int... I>
 __device__ __forceinline__ void qa_slab(std::integer_sequence<int, I...>, const QaAddr& c, const float* bl_next, const half8 (&xf)[ML_KS], float16v (&acc)[2],
                                         QaCarry& cy, const unsigned char* dsrc, unsigned voff, unsigned char* ddst) {
-    (qa_slot<ST, NEXT, DMA, I>(c, bl_next, xf, acc, cy, dsrc, voff, ddst), ...);
+    (qa_slot<ST, NEXT, DMA, ABL, I>(c, bl_next, xf, acc, cy, dsrc, voff, ddst), ...);
 }
 
 // grid: one workgroup per sequence.  w_img: lm_qkv_pack_h384's image of the nn.Linear weight [1152][384] (rows: W_q | W_k | W_v, head h = rows
 // 32 h .. 32 h + 31 of each); bias [1152] fp32; out [T][384] fp16.
+template <int ABL>
 __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384(const __half* __restrict__ x, const __half* __restrict__ w_img,
                                                                               const float* __restrict__ bias, const int32_t* __restrict__ cu,
                                                                               __half* __restrict__ out, float scale_log2e) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384(con
         half8 qf0, qf1;
         // ---- Q slab (stage 0) ----
         if (active) {
-            qa_slab<0, true, false>(std::make_integer_sequence<int, 24>{}, ad, bl + 32 * (HEADS + h), xf, acc, cy, nullptr, voff0, nullptr);
+            qa_slab<0, true, false, ABL>(std::make_integer_sequence<int, 24>{}, ad, bl + 32 * (HEADS + h), xf, acc, cy, nullptr, voff0, nullptr);
             // Q x (softmax scale x log2 e): ONE rounding, and the result is the score MFMA's B operand as it stands (k-slot e of k-step ks of lane
             // g <-> head feature 16 ks + 8 (e >> 2) + 4 g + (e & 3); K's chunks below carry the same order)
 #pragma unroll
@@ -206,13 +210,13 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384(con
                 qf0[e] = (_Float16)((acc[0][e] + acc[1][e]) * scale_log2e);
                 qf1[e] = (_Float16)((acc[0][8 + e] + acc[1][8 + e]) * scale_log2e);
             }
-        } else {
+        } else if constexpr (!(ABL & 2)) {
             t4_wait_vm<3>();
             T4_BARRIER();
         }
         // ---- K slab (stage 1); stage 0 fell free at the barrier above: request the next head's Q slab ----
         if (active) {
-            qa_slab<1, true, true>(std::make_integer_sequence<int, 24>{}, ad, bl + 32 * (2 * HEADS + h), xf, acc, cy, gw + (int64_t)hn * T4_SLAB + 3072 * wv, voff0,
+            qa_slab<1, true, true, ABL>(std::make_integer_sequence<int, 24>{}, ad, bl + 32 * (2 * HEADS + h), xf, acc, cy, gw + (int64_t)hn * T4_SLAB + 3072 * wv, voff0,
                                    smem + 3072 * wv);
             half8 k0, k1;
 #pragma unroll
@@ -223,13 +227,15 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384(con
             *(half8*)kw0 = k0;
             *(half8*)kw1 = k1;
         } else {
-            dma_slab(hn, 0);
-            t4_wait_vm<3>();
-            T4_BARRIER();
+            if constexpr (!(ABL & 4)) dma_slab(hn, 0);
+            if constexpr (!(ABL & 2)) {
+                t4_wait_vm<3>();
+                T4_BARRIER();
+            }
         }
         // ---- V slab (stage 2, nothing follows it in the ring); stage 1 fell free: request the next head's K slab ----
         if (active) {
-            qa_slab<2, false, true>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, gw + (int64_t)(HEADS + hn) * T4_SLAB + 3072 * wv, voff0,
+            qa_slab<2, false, true, ABL>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, gw + (int64_t)(HEADS + hn) * T4_SLAB + 3072 * wv, voff0,
                                     smem + T4_SLAB + 3072 * wv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -239,12 +245,16 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384(con
                 *(half4*)(vw + 16 * q) = v;  // head features 8 q + 4 g .. + 3 of this token: row major
             }
         } else {
-            dma_slab(HEADS + hn, 1);
+            if constexpr (!(ABL & 4)) dma_slab(HEADS + hn, 1);
         }
         T4_WAIT_LGKM0();
         T4_BARRIER();  // K and V of every block are in LDS; every wave is done with stage 2
-        dma_slab(2 * HEADS + hn, 2);
+        if constexpr (!(ABL & 4)) dma_slab(2 * HEADS + hn, 2);
         if (!active) continue;
+        if constexpr (ABL & 1) {  // (timing run without the tile loop: the projected Q still has a consumer)
+            if (row < len) *(half8*)((_Float16*)out + (int64_t)(tok0 + row) * H + h * 32 + 8 * g) = qf0 + qf1;
+            continue;
+        }
 
         // ---- generation 3's tile loop (lm_attn_v3.hip) for this wave's 32 query rows against the sequence's nt key tiles ----
         float16v cm, o;  // cm = -m (running reference of the row, log2 units): the C operand of the score MFMAs
@@ -349,9 +359,25 @@ int lm_qkv_attn_h384_launch(const void* d_x, const void* d_wqkv_img, const float
     const float scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
     kt_attn_work(d_cu_seqlens, n_seqs, ML_H, stream, LM_KT_QKV_ATTN);  // attention's flops depend on the lengths (device memory): summed there, onto THIS kernel's slot
     KtScope kt(LM_KT_QKV_ATTN, stream, 2.0 * (double)total_tokens * 3 * ML_H * ML_H);
+#if defined(LM_DIAG)
+    if (const char* ab = getenv("LEANN_MI355X_QA_ABLATE")) {  // diagnosis library only: timing runs, garbage results (see qa_slot)
+        const int v = atoi(ab);
+#define QA_ABL(n)                                                                                                                                          \
+    if (v == n) {                                                                                                                                          \
+        static DynLdsAttr a##n;                                                                                                                            \
+        LM_HIP(ensure_dyn_lds(a##n, (const void*)k_qkv_attn_h384<n>, (size_t)QA_LDS));                                                                     \
+        hipLaunchKernelGGL(k_qkv_attn_h384<n>, dim3((unsigned)n_seqs), dim3(512), (size_t)QA_LDS, (hipStream_t)stream, (const __half*)d_x,                 \
+                           (const __half*)d_wqkv_img, d_bqkv, d_cu_seqlens, (__half*)d_out, scale_log2e);                                                  \
+        LM_HIP(hipGetLastError());                                                                                                                         \
+        return LM_OK;                                                                                                                                      \
+    }
+        QA_ABL(1) QA_ABL(3) QA_ABL(7) QA_ABL(15) QA_ABL(2) QA_ABL(9)
+#undef QA_ABL
+    }
+#endif
     static DynLdsAttr attr;
-    LM_HIP(ensure_dyn_lds(attr, (const void*)k_qkv_attn_h384, (size_t)QA_LDS));
-    hipLaunchKernelGGL(k_qkv_attn_h384, dim3((unsigned)n_seqs), dim3(512), (size_t)QA_LDS, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_wqkv_img,
+    LM_HIP(ensure_dyn_lds(attr, (const void*)k_qkv_attn_h384<0>, (size_t)QA_LDS));
+    hipLaunchKernelGGL(k_qkv_attn_h384<0>, dim3((unsigned)n_seqs), dim3(512), (size_t)QA_LDS, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_wqkv_img,
                        d_bqkv, d_cu_seqlens, (__half*)d_out, scale_log2e);
     LM_HIP(hipGetLastError());
     return LM_OK;

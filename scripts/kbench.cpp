@@ -599,6 +599,19 @@ int main(int argc, char** argv) {
         double flops_attn = 0;
         for (int i = 0; i < ns; ++i) flops_attn += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
         const double flops = flops_attn + 2.0 * tot * N * H;
+        if (const char* abl = getenv("KBENCH_QA_ABLATIONS")) {  // diagnosis library: what each ingredient of the fused kernel costs (timing only, garbage results)
+            for (const char* v : {"0", "1", "3", "7", "15", "2", "9"}) {
+                if (v[0] != '0') setenv("LEANN_MI355X_QA_ABLATE", v, 1);
+                else unsetenv("LEANN_MI355X_QA_ABLATE");
+                run_f();
+                CK(hipStreamSynchronize(st));
+                const float uf = time_us(st, reps, run_f);
+                printf("{\"kernel\": \"lm_qkv_attn_h384_f16 ablation\", \"bits\": \"%s\", \"meaning\": \"1 no tile loop, 2 no slab barriers / waits, 4 no DMA, 8 no fragment reads\", \"us\": %.1f}\n", v, uf);
+                fflush(stdout);
+            }
+            unsetenv("LEANN_MI355X_QA_ABLATE");
+            (void)abl;
+        }
         for (int round = 0; round < 3; ++round) {
             const float uq = time_us(st, reps, run_q), ua = time_us(st, reps, run_a), uf = time_us(st, reps, run_f);
             printf("{\"kernel\": \"pair: lm_qkv_h384 (head major) + lm_attn_v3\", \"round\": %d, \"us_qkv\": %.1f, \"us_attn\": %.1f, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, uq, ua, uq + ua,

@@ -28,7 +28,9 @@ if f:
         elif "k_search_table" in k:
             srch.append((k.split("(")[0][-60:], float(r["Counter_Value"])))
 res = {"run": run, "FETCH_SIZE_KB_calibration_launch": cal, "FETCH_SIZE_KB_search_launches": srch}
-if run and cal and len(srch) == len(run["calls"]):
+if run and cal and len(srch) >= len(run["calls"]):
+    srch = srch[-len(run["calls"]):]  # (the graph builder searches with the same kernel: the script's own four calls are the LAST launches of the pass)
+    res["FETCH_SIZE_KB_search_launches"] = srch
     factor = run["calibration"]["known_bytes"] / (cal[0] * 1024.0)
     res["factor_known_bytes_over_FETCH_SIZE_in_this_access_pattern"] = round(factor, 4)
     for c, (kn, kb) in zip(run["calls"], srch):

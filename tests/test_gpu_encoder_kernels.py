@@ -160,7 +160,7 @@ def test_fused_qkv_attention_matches_fp32_reference(maxlen, nseq, wscale):
     from leann_amd.encoder import fused_qkv_attention
 
     x, lin, cu, mx, ref, grew = _fused_case(torch, maxlen, nseq, wscale)
-    assert wscale < 0.2 or maxlen <= 32 or grew > 0, "the test data does not reach the rescale branch"
+    assert wscale < 0.2 or maxlen < 64 or grew > 0, "the test data does not reach the rescale branch"
     o = fused_qkv_attention(x, lin, cu, 12, mx)
     torch.cuda.synchronize()
     assert o is not None and o.shape == ref.shape and not torch.isnan(o).any()
