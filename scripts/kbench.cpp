@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "leann_mi355x.h"
+extern "C" int lm_qa_stamps_read(unsigned long long* out, int64_t max_words, int reset);       // diagnosis library only (csrc/lm_qkv_attn_h384.hip)
 extern "C" int lm_attn_v3_stamps_read(unsigned long long* out, int64_t max_words, int reset);  // diagnosis library only (csrc/lm_attn_v3.hip)
 
 // generation 3 of the fused layer tail: only in the diagnosis build of the library (csrc/diag/lm_mlp_fused_v3.hip), as the `tail` / `tail4`
@@ -579,6 +580,17 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(outf.p, 0xff, (size_t)tot * H * 2, st));
         run_q(); run_a(); run_f();
         CK(hipStreamSynchronize(st));
+        size_t gen_diff = 0;
+        {
+            Dev<__half> outf1((size_t)tot * H);
+            setenv("LEANN_MI355X_FUSED_QKV_ATTN", "1", 1);
+            LM(lm_qkv_attn_h384_f16(x.p, wimg.p, b.p, dcu.p, ns, 256, tot, outf1.p, st));
+            unsetenv("LEANN_MI355X_FUSED_QKV_ATTN");
+            CK(hipStreamSynchronize(st));
+            auto h1 = outf1.host(), h2 = outf.host();
+            for (size_t i = 0; i < h1.size(); ++i) gen_diff += memcmp(&h1[i], &h2[i], 2) != 0;
+            printf("{\"kernel\": \"lm_qkv_attn_h384_f16\", \"elements_where_generation_1_and_2_differ\": %zu}\n", gen_diff);
+        }
         {
             auto href = ref.host();
             std::vector<int> arows;
@@ -599,6 +611,37 @@ int main(int argc, char** argv) {
         double flops_attn = 0;
         for (int i = 0; i < ns; ++i) flops_attn += 4.0 * (double)(cu[i + 1] - cu[i]) * (cu[i + 1] - cu[i]) * H;
         const double flops = flops_attn + 2.0 * tot * N * H;
+        if (getenv("KBENCH_QA_STAMPS")) {  // where a wave's cycles go (s_memtime stamps, one record per wave of ONE launch)
+            setenv("LEANN_MI355X_QA_ABLATE", "16", 1);
+            run_f();
+            CK(hipStreamSynchronize(st));
+            const size_t NW = (size_t)1 << 15, WORDS = 16;
+            std::vector<unsigned long long> z(NW * WORDS);
+            LM(lm_qa_stamps_read(z.data(), (int64_t)z.size(), 1));
+            run_f();
+            CK(hipStreamSynchronize(st));
+            LM(lm_qa_stamps_read(z.data(), (int64_t)z.size(), 1));
+            const float us = time_us(st, reps, run_f);
+            unsetenv("LEANN_MI355X_QA_ABLATE");
+            const char* names[14] = {"prologue_issue", "prologue_own_landed", "prologue_barrier", "head_start_wait_barrier", "q_slab", "q_epilogue", "k_slab", "k_epilogue", "v_slab",
+                                     "v_epilogue_lds_retired", "barrier_before_tiles", "tile_loop", "normalise_store", "lifetime"};
+            for (int kind = 1; kind <= 2; ++kind) {  // 1 = active waves, 2 = waves past the sequence end
+                double sum[14] = {};
+                double n = 0, lens = 0;
+                for (size_t w = 0; w < NW; ++w) {
+                    const unsigned long long* r = z.data() + w * WORDS;
+                    if (r[15] != (unsigned long long)kind) continue;
+                    for (int i = 0; i < 14; ++i) sum[i] += (double)r[i];
+                    lens += (double)r[14];
+                    n += 1;
+                }
+                if (n == 0) continue;
+                printf("{\"kernel\": \"lm_qkv_attn_h384_f16 stamps\", \"waves\": \"%s\", \"n_waves\": %.0f, \"mean_sequence_length\": %.1f, \"us_stamped_build\": %.1f, \"mean_cycles_per_wave\": {", kind == 1 ? "active" : "past the sequence end",
+                       n, lens / n, us);
+                for (int i = 0; i < 14; ++i) printf("\"%s\": %.0f%s", names[i], sum[i] / n, i < 13 ? ", " : "}}\n");
+            }
+            fflush(stdout);
+        }
         if (const char* abl = getenv("KBENCH_QA_ABLATIONS")) {  // diagnosis library: what each ingredient of the fused kernel costs (timing only, garbage results)
             for (const char* v : {"0", "1", "3", "7", "15", "2", "9"}) {
                 if (v[0] != '0') setenv("LEANN_MI355X_QA_ABLATE", v, 1);
@@ -613,10 +656,15 @@ int main(int argc, char** argv) {
             (void)abl;
         }
         for (int round = 0; round < 3; ++round) {
-            const float uq = time_us(st, reps, run_q), ua = time_us(st, reps, run_a), uf = time_us(st, reps, run_f);
+            const float uq = time_us(st, reps, run_q), ua = time_us(st, reps, run_a);
+            setenv("LEANN_MI355X_FUSED_QKV_ATTN", "1", 1);
+            const float uf1 = time_us(st, reps, run_f);
+            unsetenv("LEANN_MI355X_FUSED_QKV_ATTN");
+            const float uf = time_us(st, reps, run_f);
+            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused, generation 1: all waves in one phase)\", \"round\": %d, \"us\": %.1f}\n", round, uf1);
             printf("{\"kernel\": \"pair: lm_qkv_h384 (head major) + lm_attn_v3\", \"round\": %d, \"us_qkv\": %.1f, \"us_attn\": %.1f, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, uq, ua, uq + ua,
                    flops / (uq + ua) * 1e-6);
-            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"us_per_262144_tokens\": %.1f}\n", round, uf, flops / uf * 1e-6,
+            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused, generation 2)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"us_per_262144_tokens\": %.1f}\n", round, uf, flops / uf * 1e-6,
                    uf * 262144.0 / tot);
             fflush(stdout);
         }

@@ -25,7 +25,7 @@ from leann_amd.synth import CorpusSpec, SyntheticCorpus  # noqa: E402
 from leann_amd.token_store import TokenStore  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-nq = 8192
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 8192  # queries in flight (round 6: 8192 -> 5.1, 16384 -> 6.0, 32768 -> 6.5 TB/s algorithmic at beam 1)
 dev = torch.device("cuda")
 corpus = SyntheticCorpus(CorpusSpec(n_chunks=n, seed=1234))
 tok, off = corpus.chunks()
@@ -59,7 +59,7 @@ idx.set_option("persistent_table", 1)
 idx.set_option("persistent_wave", -1)
 for rnd in range(2):
     for beam in (1, 4):
-        prm = idx.make_params(ef=64, beam=beam, recompute=False, max_batch=16384)
+        prm = idx.make_params(ef=64, beam=beam, recompute=False, max_batch=32768)
         d, l = idx.search_device(Q, 10, prm)
         st = idx.stats()
         ms = max(st["update_span_ms"], 1e-9)

@@ -4,10 +4,11 @@
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-r6}
+NQ=${2:-8192}
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
 rm -rf /tmp/pmc_tm_$TAG
-( cd $ROOT && timeout -k 5 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tm_$TAG -o pmc -- python scripts/pmc_table_mode.py > $OUT/pmc_table_mode_run.json 2> $OUT/pmc_table_mode_run.err )
+( cd $ROOT && timeout -k 5 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tm_$TAG -o pmc -- python scripts/pmc_table_mode.py 1000000 $NQ > $OUT/pmc_table_mode_run.json 2> $OUT/pmc_table_mode_run.err )
 echo "pmc table mode rc=$?"; tail -2 $OUT/pmc_table_mode_run.err | cut -c1-300
 python - "$OUT" /tmp/pmc_tm_$TAG <<'PY'
 import csv, glob, json, sys

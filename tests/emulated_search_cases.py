@@ -727,7 +727,7 @@ def case_attention_v3():
         print(f"attention generation 3, lengths {lens.tolist()}: max |err| vs float64 {max(np.abs(v.astype(np.float64) - ref).max() for v in outs.values()):.2e}, {grew} rows through the rescale branch: ok", flush=True)
 
 
-def case_qkv_attn_fused(lens_list=((70, 1, 33), (256, 31))):
+def case_qkv_attn_fused(lens_list=((70, 1, 33), (256, 31), (150, 200))):
     """The QKV projection fused into attention (csrc/lm_qkv_attn_h384.hip, round 6) against float64 numpy: x [T][384] -> attention output
     [T][384] for 12 heads x 32, with Q, K, V rounded where the kernel rounds them (Q after the softmax scale, once; K and V to fp16).  Weights
     scaled so that scores spread over many powers of two: later key tiles exceed the running maximum by more than the deferred-rescaling
@@ -774,6 +774,16 @@ def case_qkv_attn_fused(lens_list=((70, 1, 33), (256, 31))):
         _lib.check(lib.lm_qkv_attn_h384_f16(vp(x), vp(img), vp(b), vp(cu), n, int(lens.max()), tot, vp(o), None), "lm_qkv_attn_h384_f16")
         err = np.abs(o.astype(np.float64) - ref).max()
         assert np.isfinite(o.astype(np.float32)).all() and err < 6e-3, (lens.tolist(), err)
+        # generation 1 of the kernel (all eight waves in one phase; LEANN_MI355X_FUSED_QKV_ATTN=1) is the same arithmetic in another schedule: same bits
+        import os
+
+        os.environ["LEANN_MI355X_FUSED_QKV_ATTN"] = "1"
+        o1 = np.zeros((tot, H), np.float16)
+        try:
+            _lib.check(lib.lm_qkv_attn_h384_f16(vp(x), vp(img), vp(b), vp(cu), n, int(lens.max()), tot, vp(o1), None), "lm_qkv_attn_h384_f16 generation 1")
+        finally:
+            os.environ.pop("LEANN_MI355X_FUSED_QKV_ATTN")
+        assert np.array_equal(o.view(np.uint16), o1.view(np.uint16)), "generations 1 and 2 of the fused kernel differ"
         # the stand-alone pair on the same operands (Q rounded twice there: fp16-close, not bit-equal)
         qkv16 = np.zeros((tot, 3 * H), np.float16)
         _lib.check(lib.lm_qkv_h384_f16(vp(x), vp(img), vp(b), 3 * H, vp(qkv16), tot, None), "lm_qkv_h384_f16")
