@@ -311,14 +311,17 @@ int lm_layer_tail_pack_h384(const void *d_wo_slabs, const void *d_w1_acc, const 
  * on chip: Q, K, V never go to HBM (as two kernels they were a 604 MB write + 604 MB read per 262 k tokens around 201 MB of x and 201 MB of output).
  * d_x [tokens][384] fp16 packed sequences, d_cu_seqlens int32[n_seqs + 1], lengths 1..256; d_wqkv_img = lm_qkv_pack_h384's image of the nn.Linear
  * weight [1152][384] (rows W_q | W_k | W_v), d_bqkv fp32[1152].  Replaces the model.encode() call's per-layer QKV GEMM + attention
- * (leann/embedding_compute.py:229-239) on the large hidden-384 forwards; the stand-alone pair below stays for A/B (LEANN_MI355X_FUSED_QKV_ATTN=0). */
+ * (leann/embedding_compute.py:229-239) on large hidden-384 forwards of long sequences (lm_h384_first_half_form below says when); the stand-alone pair stays
+ * the default elsewhere. */
 int lm_qkv_attn_h384_f16(const void *d_x, const void *d_wqkv_img, const float *d_bqkv, const int32_t *d_cu_seqlens, int32_t n_seqs, int32_t max_len,
                          int64_t total_tokens, void *d_out, void *stream);
-/* Which kernels the first half (QKV projection + attention) of a LARGE hidden-384 layer runs on, for a model with `heads` heads and a forward whose
- * longest sequence is max_len -- the one decision lm_bert_h384_forward_packed and a host that launches kernel by kernel share: 0 = lm_qkv_attn_h384_f16
- * (the default), 1 = lm_qkv_h384_f16 (head-major output) + attention generation 3 (LEANN_MI355X_FUSED_QKV_ATTN=0), 2 = the pair over the
- * [tokens][1152] layout (other head counts / lengths, LEANN_MI355X_QKV_LAYOUT=0, the older attention generations' switches). */
-int lm_h384_first_half_form(int32_t heads, int32_t max_len);
+/* Which kernels the first half (QKV projection + attention) of a LARGE hidden-384 layer runs on, for a model with `heads` heads and a forward of n_seqs
+ * sequences / total_tokens tokens whose longest sequence is max_len -- the one decision lm_bert_h384_forward_packed and a host that launches kernel by
+ * kernel share: 0 = lm_qkv_attn_h384_f16 (forwards whose MEAN length is >= 216: its cost per sequence is the same from 129 to 256 tokens, it wins on
+ * long sequences and ties on the benchmark corpus' N(180, 50) lengths; LEANN_MI355X_FUSED_QKV_ATTN=1 forces it, =0 forbids it), 1 = lm_qkv_h384_f16
+ * (head-major output) + attention generation 3, 2 = the pair over the [tokens][1152] layout (other head counts / lengths,
+ * LEANN_MI355X_QKV_LAYOUT=0, the older attention generations' switches). */
+int lm_h384_first_half_form(int32_t heads, int32_t max_len, int64_t total_tokens, int32_t n_seqs);
 
 /* Weight-STREAMING form of the 384-input linear layer (csrc/lm_qkv_h384.hip): d_out[tokens][n_out] = x W^T + b, n_out a multiple of
  * 128 in [256, 6144], d_w_img = lm_qkv_pack_h384's image of the nn.Linear weight [n_out][384] (same size).  x is read once (a wave holds

@@ -173,7 +173,7 @@ def load() -> C.CDLL:
     lib.lm_layer_tail_pack_h384.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     lib.lm_qkv_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
     lib.lm_qkv_attn_h384_f16.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp, vp]
-    lib.lm_h384_first_half_form.argtypes = [i32, i32]
+    lib.lm_h384_first_half_form.argtypes = [i32, i32, i64, i32]
     lib.lm_qkv_pack_h384.argtypes = [vp, i32, vp, vp]
     lib.lm_gemm_ws_h384_f16.argtypes = [vp, vp, vp, i32, vp, i64, vp]
     lib.lm_gemm_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]

@@ -21,11 +21,15 @@ static int64_t small_tokens_limit() {  // read per call (one getenv per forward)
 
 // Which form the first half of a LARGE hidden-384 layer takes -- decided in ONE place (round-5 advisor: three environment variables were parsed
 // inline and the QKV layout depended implicitly on the attention generation):
-//   H384_FUSED            lm_qkv_attn_h384_f16: projection fused into attention (the default: 12 heads, lengths <= 256)
-//   H384_PAIR_HEAD_MAJOR  lm_qkv_h384 (head-major output) -> lm_attn_v3 (LEANN_MI355X_FUSED_QKV_ATTN=0: the round-5 path, A/B)
+//   H384_FUSED            lm_qkv_attn_h384_f16: projection fused into attention -- for forwards of LONG sequences (mean length >= 216 of at most 256; 12
+//                         heads).  One workgroup per sequence, a 32-row block per wave: its cost per sequence is that of ceil(blocks / 4) rounds, i.e. the same
+//                         from 129 to 256 tokens.  Measured (profiles/r6_kbench_fused_qkv_attention_*): 425-436 us against 492-515 us for the pair per 262 k
+//                         tokens at length 256, 492-536 against 497-517 at the N(180, 50) lengths of the benchmark corpus -- where the pair stays.
+//                         LEANN_MI355X_FUSED_QKV_ATTN=1 forces it at every length, =0 never
+//   H384_PAIR_HEAD_MAJOR  lm_qkv_h384 (head-major output) -> lm_attn_v3
 //   H384_PAIR_ROW_MAJOR   lm_qkv_h384_f16 / lm_gemm_ws_h384_f16 -> lm_attn_varlen_hd32_f16, [tokens][1152] in between (LEANN_MI355X_QKV_LAYOUT=0, or an
 //                         attention generation that reads that layout: LEANN_MI355X_ATTN=2, LEANN_MI355X_ATTN3=9)
-lm::H384FirstHalf lm::h384_first_half_form(int32_t heads, int32_t max_len) {
+lm::H384FirstHalf lm::h384_first_half_form(int32_t heads, int32_t max_len, int64_t total_tokens, int32_t n_seqs) {
     auto is = [](const char* name, char c) {
         const char* e = getenv(name);
         return e && e[0] == c;
@@ -33,9 +37,12 @@ lm::H384FirstHalf lm::h384_first_half_form(int32_t heads, int32_t max_len) {
     if (heads != 12 || max_len > 256) return H384_PAIR_ROW_MAJOR;
     if (is("LEANN_MI355X_QKV_LAYOUT", '0') || is("LEANN_MI355X_ATTN3", '9') || is("LEANN_MI355X_ATTN", '2')) return H384_PAIR_ROW_MAJOR;
     if (is("LEANN_MI355X_FUSED_QKV_ATTN", '0')) return H384_PAIR_HEAD_MAJOR;
-    return H384_FUSED;
+    if (is("LEANN_MI355X_FUSED_QKV_ATTN", '1')) return H384_FUSED;
+    return n_seqs > 0 && total_tokens >= (int64_t)H384_FUSED_MIN_MEAN_LEN * n_seqs ? H384_FUSED : H384_PAIR_HEAD_MAJOR;
 }
-extern "C" int lm_h384_first_half_form(int32_t heads, int32_t max_len) { return (int)lm::h384_first_half_form(heads, max_len); }
+extern "C" int lm_h384_first_half_form(int32_t heads, int32_t max_len, int64_t total_tokens, int32_t n_seqs) {
+    return (int)lm::h384_first_half_form(heads, max_len, total_tokens, n_seqs);
+}
 
 extern "C" size_t lm_bert_h384_workspace_bytes(int64_t total_tokens) {
     if (total_tokens <= 0) return 0;
@@ -66,7 +73,7 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     bool small = total_tokens <= small_tokens_limit() && m->ffn % 128 == 0;  // (every multiple of 192 in the envelope that is one of 128: 384, 768, 1152, 1536, ...)
     for (int l = 0; small && l < m->n_layers; ++l) small = m->layers[l].wo && m->layers[l].w1 && m->layers[l].w2;
     void* hid = ws + 3 * row + (size_t)total_tokens * 1152 * 2;  // [T][ffn], small forwards only (lm_bert_h384_workspace_bytes)
-    const H384FirstHalf first_half = h384_first_half_form(m->heads, max_len);  // one decision per forward, shared with the Python host's launch path
+    const H384FirstHalf first_half = h384_first_half_form(m->heads, max_len, total_tokens, n_seqs);  // one decision per forward, shared with the Python host's launch path
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
         if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x

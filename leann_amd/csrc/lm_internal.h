@@ -146,7 +146,8 @@ inline bool bert_h384_envelope_ok(int n_layers, int heads, int ffn) { return n_l
 #define LM_BERT_H384_ENVELOPE_TEXT "hidden 384 = heads x 32 and ffn a multiple of 192 in [192, 1728]"
 // lm_encoder_forward.cpp: the form of the first half (QKV projection + attention) of a large hidden-384 layer
 enum H384FirstHalf : int { H384_FUSED = 0, H384_PAIR_HEAD_MAJOR = 1, H384_PAIR_ROW_MAJOR = 2 };
-H384FirstHalf h384_first_half_form(int32_t heads, int32_t max_len);
+constexpr int H384_FUSED_MIN_MEAN_LEN = 216;  // mean sequence length from which the fused kernel is the default (see lm_encoder_forward.cpp)
+H384FirstHalf h384_first_half_form(int32_t heads, int32_t max_len, int64_t total_tokens, int32_t n_seqs);
 
 }  // namespace lm
 

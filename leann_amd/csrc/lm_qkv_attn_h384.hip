@@ -44,7 +44,10 @@ constexpr int QA_K_OFF = 3 * T4_SLAB;          // 73728
 constexpr int QA_V_OFF = QA_K_OFF + 256 * 64;  // 90112
 constexpr int QA_BIAS_OFF = QA_V_OFF + 256 * 64;
 constexpr int QA_LDS = QA_BIAS_OFF + 1152 * 4;  // 111104
-constexpr int QA_RD = 4;                        // fragment reads in flight
+#ifndef LM_QA_RD
+#define LM_QA_RD 8
+#endif
+constexpr int QA_RD = LM_QA_RD;                 // fragment reads in flight (round 6: 4 -> 8: a wave alone in its slabs -- generation 2 -- has nobody to hide the LDS latency behind)
 constexpr float QA_THR = 8.0f;                  // deferred rescaling threshold (lm_attn_v3.hip: A3_THR)
 
 __device__ __forceinline__ half4 qa_lds_read_tr16(const unsigned char* p) {
@@ -392,298 +395,15 @@ __global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384(con
 }
 
 
-// ======================================================================================================================================================
-// Generation 2 of the fused kernel: the two waves of a SIMD HALF A HEAD APART.
-// What the stamps said about generation 1 (profiles/r6_kbench_fused_qkv_attention_v1_phase_stamps.jsonl, length 256: 201 k cycles per wave): the slabs run
-// at ~88 % of the matrix pipe (1.7-1.8 k cycles per 24 MFMAs x two waves), the tile loop takes as long again (765 cycles per tile per wave: VALU issue,
-// 4 MFMAs per tile) -- but never at the same time: the four barriers per head keep all eight waves in the same phase, so a SIMD's matrix pipe idles
-// through the tile loops and its VALU through the slabs.  Here waves 0-3 (group A: blocks 0-3) and waves 4-7 (group B: blocks 4-7; SIMD i hosts waves i
-// and i + 4) alternate phases: while A runs head h's tile loop, B projects head h + 1; then A projects head h + 1 while B runs head h's tile loop.  Every
-// SIMD has one MFMA-bound and one VALU-bound wave at any time.  What it takes:
-//   * K / V double buffered by head parity (2 x 32 KB): a group writes head h + 1's rows while the other still reads head h's;
-//   * B carries two Q fragment sets (it projects head h + 1 before it attends head h);
-//   * a head's three weight slabs are consumed twice, one slot apart (B, then A): stage = kind as before; a stage falls free when A has passed its
-//     slab, so the next head's slabs are requested at the barriers INSIDE A's projection slots (Q after the first, K after the second) and at the
-//     start of the next slot (V) -- every request has two thirds of a slot to land;
-//   * three workgroup barriers per slot (slot start, after the first and the second third), 2 slots per head + 1: the tile loop of the attending
-//     group is cut in three parts so that it meets the projecting group's slab boundaries.
-// Slots: S0 (both groups project head 0), then for h = 0 .. 11: X_h (A: tiles of h | B: slabs of h + 1), Y_h (A: slabs of h + 1 | B: tiles of h).
-// Vector-memory order of a wave and the counted waits (N = operations that may still be outstanding, i.e. everything YOUNGER than the awaited slab):
-//   Y_h: after barrier 1 request Q(h+2), after barrier 2 request K(h+2); B's active waves issue their 4 output stores at the end;
-//        before the slot barrier wait for Q(h+2): younger = K's 3 pieces (+ 4 stores on B's active waves)
-//   X_h: at the start request V(h+1); before barrier 1 wait for K(h+1): younger = V's 3 pieces (+ B's 4 stores of the slot before, if any);
-//        before barrier 2 wait for V(h+1): nothing younger; A's active waves issue their 4 stores at the end.
-// LDS: [0, 72 K) ring, [72 K, 136 K) K | V x 2 parities, then the 1152 biases.
-constexpr int QB_KV_OFF = 3 * T4_SLAB;           // parity p: K at + 32768 p, V at + 32768 p + 16384
-constexpr int QB_BIAS_OFF = QB_KV_OFF + 2 * 32768;
-constexpr int QB_LDS = QB_BIAS_OFF + 1152 * 4;   // 143872
-
-template <int ABL>
-__global__ __launch_bounds__(512) LM_TWO_WAVES_PER_SIMD void k_qkv_attn_h384_v2(const __half* __restrict__ x, const __half* __restrict__ w_img,
-                                                                                 const float* __restrict__ bias, const int32_t* __restrict__ cu,
-                                                                                 __half* __restrict__ out, float scale_log2e) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int H = ML_H, HEADS = 12;
-    const int seq = blockIdx.x;
-    const int tok0 = cu[seq];
-    const int len = cu[seq + 1] - tok0;
-    if (len <= 0) return;  // (workgroup uniform)
-    float* bss = (float*)(smem + QB_BIAS_OFF);
-    unsigned char* kv = smem + QB_KV_OFF;
-    const int tid = threadIdx.x, lane = tid & 63;
-#ifdef LM_EMULATED_DEVICE
-    const int wv = tid >> 6;
-#else
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-    const int r31 = lane & 31, g = lane >> 5;
-    const int nt = (len + 31) >> 5;
-    const bool active = wv < nt;  // wave uniform
-    const bool grpB = wv >= 4;
-    const int row = 32 * wv + r31;
-    const unsigned char* gw = (const unsigned char*)w_img;
-    const unsigned voff0 = (unsigned)lane * 16u;
-    auto dma_slab = [&](int slab, int st) {
-        if constexpr (!(ABL & 4)) t4_dma_group<3>(gw + (int64_t)slab * T4_SLAB + 3072 * wv, voff0, smem + st * T4_SLAB + 3072 * wv);
-    };
-    dma_slab(0, 0);
-    dma_slab(HEADS, 1);
-    dma_slab(2 * HEADS, 2);
-    for (int i = tid; i < 3 * H; i += 512) bss[i] = bias[i];
-    half8 xf[ML_KS];
-    {
-        const bool valid = row < len;
-        const _Float16* xr = (const _Float16*)x + (int64_t)(tok0 + (valid ? row : 0)) * H + 8 * g;
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < ML_KS; ++ks) {
-            const half8 v = *(const half8*)(xr + 16 * ks);
-            xf[ks] = valid ? v : z;
-        }
-    }
-    QaAddr ad;
-#pragma unroll
-    for (int k7 = 0; k7 < 8; ++k7) {
-        const int a = r31 * 768 + ((((2 * k7 + g) ^ r31) & 15) << 4);
-        ad.a[0][k7] = smem + a;
-        ad.a[1][k7] = smem + 2 * T4_SLAB + a;
-    }
-    const int sw = (r31 >> 2) & 3;
-    // offsets inside a K | V parity block (lm_attn_v3.hip's layouts)
-    const int kf0_o = r31 * 64 + ((g ^ sw) << 4), kf1_o = r31 * 64 + (((2 + g) ^ sw) << 4);
-    const int vf_o = 16384 + g * 256 + ((lane >> 2) & 3) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
-    const int kw0_o = row * 64 + ((g ^ sw) << 4), kw1_o = row * 64 + (((2 + g) ^ sw) << 4), vw_o = 16384 + row * 64 + 8 * g;
-    const int tail = len & 31;
-    const float lenv = (float)(tail - 4 * g);
-    const float* bl = bss + 4 * g;
-    float16v acc[2];
-    QaCarry cy;
-    T4_WAIT_VM(0);
-    __syncthreads();
-
-    // ---- one group's projection of head hs: Q slab | mid(1) | K slab | mid(2) | V slab; Q fragments to (q0, q1), K / V rows to the parity block kvb ----
-    auto s_phase = [&](int hs, unsigned char* kvb, half8& q0, half8& q1, auto&& mid) {
-        qa_load_bias(cy, bl + 32 * hs);
-#pragma unroll
-        for (int i = 0; i < QA_RD; ++i) cy.ring[i] = *(const half8*)(ad.a[0][i & 7] + 256 * (i >> 3));
-        qa_slab<0, false, false, ABL>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, nullptr, voff0, nullptr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            q0[e] = (_Float16)((acc[0][e] + acc[1][e]) * scale_log2e);
-            q1[e] = (_Float16)((acc[0][8 + e] + acc[1][8 + e]) * scale_log2e);
-        }
-        mid(1);
-        qa_load_bias(cy, bl + 32 * (HEADS + hs));
-#pragma unroll
-        for (int i = 0; i < QA_RD; ++i) cy.ring[i] = *(const half8*)(ad.a[0][i & 7] + T4_SLAB + 256 * (i >> 3));
-        qa_slab<1, false, false, ABL>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, nullptr, voff0, nullptr);
-        {
-            half8 k0, k1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                k0[e] = (_Float16)(acc[0][e] + acc[1][e]);
-                k1[e] = (_Float16)(acc[0][8 + e] + acc[1][8 + e]);
-            }
-            *(half8*)(kvb + kw0_o) = k0;
-            *(half8*)(kvb + kw1_o) = k1;
-        }
-        mid(2);
-        qa_load_bias(cy, bl + 32 * (2 * HEADS + hs));
-#pragma unroll
-        for (int i = 0; i < QA_RD; ++i) cy.ring[i] = *(const half8*)(ad.a[1][i & 7] + 256 * (i >> 3));
-        qa_slab<2, false, false, ABL>(std::make_integer_sequence<int, 24>{}, ad, nullptr, xf, acc, cy, nullptr, voff0, nullptr);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            half4 v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (_Float16)(acc[0][4 * q + i] + acc[1][4 * q + i]);
-            *(half4*)(kvb + vw_o + 16 * q) = v;
-        }
-    };
-
-    // ---- one group's tile loop of head ht (generation 3's, lm_attn_v3.hip), cut in three parts around mid(1) / mid(2) ----
-    auto t_phase = [&](int ht, const unsigned char* kvb, const half8& qf0, const half8& qf1, auto&& mid) {
-        float16v cm, o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            cm[r] = 0.f;
-            o[r] = 0.f;
-        }
-        float2v l2 = {0.f, 0.f}, l2b = {0.f, 0.f};
-        const unsigned char* kf0 = kvb + kf0_o;
-        const unsigned char* kf1 = kvb + kf1_o;
-        const unsigned char* vf = kvb + vf_o;
-        auto tile = [&](int t) {
-            const bool more = t + 1 < nt;
-            float16v s;
-            {
-                const half8 k0 = *(const half8*)(kf0 + 2048 * t), k1 = *(const half8*)(kf1 + 2048 * t);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf0, cm, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf1, s, 0, 0, 0);
-            }
-            const unsigned char* vt = vf + 2048 * t;
-            const half4 va0 = qa_lds_read_tr16(vt), vb0 = qa_lds_read_tr16(vt + 512), va1 = qa_lds_read_tr16(vt + 1024), vb1 = qa_lds_read_tr16(vt + 1536);
-            if (!more && tail) {
-                float lb = (lenv - 0.5f) * 1.0e30f;
-                LM_KEEP_LOCAL(lb);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_fmed3f(s[r], lb - (float)((r & 3) + 8 * (r >> 2)) * 1.0e30f, -3.0e38f);
-            }
-            float tm;
-            {
-                const float m0 = qa_max3(s[0], s[1], s[2]), m1 = qa_max3(s[3], s[4], s[5]), m2 = qa_max3(s[6], s[7], s[8]);
-                const float m3 = qa_max3(s[9], s[10], s[11]), m4 = qa_max3(s[12], s[13], s[14]);
-                tm = __builtin_fmaxf(qa_max3(m0, m1, m2), qa_max3(m3, m4, s[15]));
-                uint32_t a = __builtin_bit_cast(uint32_t, tm), b = a;
-                lane32_swap(a, b);
-                tm = __builtin_fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
-            }
-            const bool first = t == 0;
-            if (first || __ballot(tm > QA_THR) != 0) {  // wave uniform
-                const float delta = first ? tm : fmaxf(tm, 0.f);
-                if (!first) {
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-                    l2 *= (float2v){alpha, alpha};
-                    l2b *= (float2v){alpha, alpha};
-                }
-                const float2v d2 = {delta, delta};
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float2v a = (float2v){s[r], s[r + 1]} - d2, b = (float2v){cm[r], cm[r + 1]} - d2;
-                    s[r] = a[0];
-                    s[r + 1] = a[1];
-                    cm[r] = b[0];
-                    cm[r + 1] = b[1];
-                }
-            }
-            half8 p0, p1;
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-                const float2v e0 = {__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1])};
-                const float2v e1 = {__builtin_amdgcn_exp2f(s[8 + r]), __builtin_amdgcn_exp2f(s[9 + r])};
-                l2 += e0;
-                l2b += e1;
-                p0[r] = (_Float16)e0[0];
-                p0[r + 1] = (_Float16)e0[1];
-                p1[r] = (_Float16)e1[0];
-                p1[r + 1] = (_Float16)e1[1];
-            }
-            const half8 v0 = {va0[0], va0[1], va0[2], va0[3], vb0[0], vb0[1], vb0[2], vb0[3]};
-            const half8 v1 = {va1[0], va1[1], va1[2], va1[3], vb1[0], vb1[1], vb1[2], vb1[3]};
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, p0, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, p1, o, 0, 0, 0);
-        };
-        const int t1 = (nt + 2) / 3, t2 = (2 * nt + 2) / 3;
-        for (int t = 0; t < t1; ++t) tile(t);
-        mid(1);
-        for (int t = t1; t < t2; ++t) tile(t);
-        mid(2);
-        for (int t = t2; t < nt; ++t) tile(t);
-        float l = (l2[0] + l2[1]) + (l2b[0] + l2b[1]);
-        {
-            uint32_t a = __builtin_bit_cast(uint32_t, l), b = a;
-            lane32_swap(a, b);
-            l = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
-        }
-        const float inv = 1.0f / l;
-        if (row < len) {
-            _Float16* orow = (_Float16*)out + (int64_t)(tok0 + row) * H + ht * 32;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float2v i2 = {inv, inv};
-                const float2v a = (float2v){o[4 * r4], o[4 * r4 + 1]} * i2, b = (float2v){o[4 * r4 + 2], o[4 * r4 + 3]} * i2;
-                const half4 w = {(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]};
-                *(half4*)(orow + 8 * r4 + 4 * g) = w;
-            }
-        }
-    };
-
-    half8 qc0, qc1, qn0, qn1;  // Q fragments of the head this wave attends next / (group B) of the head after it
-    // ---- slot S0: both groups project head 0; the barriers inside are Y-type (stage k - 1 is free after barrier k: request head 1's Q, K) ----
-    auto ymid = [&](int k, int hreq) {
-        T4_BARRIER();
-        dma_slab((k - 1) * HEADS + hreq, k - 1);
-    };
-    {
-        auto mid = [&](int k) { ymid(k, 1); };
-        if (active) s_phase(0, kv, qc0, qc1, mid);
-        else {
-            mid(1);
-            mid(2);
-        }
-        T4_WAIT_LGKM0();
-        t4_wait_vm<3>();  // Q(1) has landed (younger: K(1)'s three pieces)
-        T4_BARRIER();
-    }
-    bool b_stored = false;  // group B: this wave issued output stores in the slot before (they sit between the awaited K pieces and the V request)
-    for (int h = 0; h < HEADS; ++h) {
-        const int h1 = h + 1 < HEADS ? h + 1 : HEADS - 1, h2 = h + 2 < HEADS ? h + 2 : HEADS - 1;
-        unsigned char* kv_h = kv + 32768 * (h & 1);
-        unsigned char* kv_n = kv + 32768 * ((h + 1) & 1);
-        // ---- X_h: A attends head h, B projects head h + 1.  Stage 2 is free (A's V slab of the slot before): request V(h + 1). ----
-        dma_slab(2 * HEADS + h1, 2);
-        {
-            auto mid = [&](int k) {
-                if (k == 1) {  // K(h + 1) has landed: younger = V's pieces (+ B's stores of the slot before)
-                    if (grpB && b_stored) t4_wait_vm<7>();
-                    else t4_wait_vm<3>();
-                } else {
-                    t4_wait_vm<0>();  // V(h + 1) has landed
-                }
-                T4_BARRIER();
-            };
-            if (!grpB && active) t_phase(h, kv_h, qc0, qc1, mid);
-            else if (grpB && active && h + 1 < HEADS) s_phase(h + 1, kv_n, qn0, qn1, mid);
-            else {
-                mid(1);
-                mid(2);
-            }
-            T4_WAIT_LGKM0();
-            T4_BARRIER();
-        }
-        // ---- Y_h: A projects head h + 1, B attends head h.  After barrier 1 / 2 stage 0 / 1 is free: request Q / K of head h + 2. ----
-        {
-            auto mid = [&](int k) { ymid(k, h2); };
-            if (!grpB && active && h + 1 < HEADS) s_phase(h + 1, kv_n, qc0, qc1, mid);
-            else if (grpB && active) {
-                t_phase(h, kv_h, qc0, qc1, mid);
-                qc0 = qn0;
-                qc1 = qn1;
-            } else {
-                mid(1);
-                mid(2);
-            }
-            T4_WAIT_LGKM0();
-            b_stored = grpB && active;
-            if (b_stored) t4_wait_vm<7>();  // Q(h + 2) has landed: younger = K's pieces + this wave's four stores
-            else t4_wait_vm<3>();
-            T4_BARRIER();
-        }
-    }
-    T4_WAIT_VM(0);
-}
+// (Measured and deleted in round 6: GENERATION 2 of this kernel -- the two waves of a SIMD half a head apart: waves 0-3 run head h's tile loop while waves 4-7
+// project head h + 1, then the roles swap; K / V double buffered by head parity, three workgroup barriers per slot, the attending group's tile loop cut in three
+// parts to meet the projecting group's slab boundaries; bit-identical results.  The idea: one MFMA-bound and one VALU-bound wave per SIMD at any time.  On the
+// chip: 439-446 us against 425-436 us for this kernel at length 256, 526-553 against 492-536 at N(180, 50) lengths.  Stamps per wave, slot part and group
+// (profiles/r6_kbench_fused_qkv_attention_gen2_stamps_and_ring_depth.jsonl): beside a projecting partner a tile takes ~990 cycles -- against 590 for a wave
+// alone on its SIMD and 765 beside a partner that is in its tile loop too -- whichever of the two waves is older, and s_setprio 2 / 3 on the attending wave moves it
+// by 7 % at most (r6_kbench_fused_qkv_attention_gen2_priority_ab_lost.jsonl): the projecting group then idles half of every slot at the barriers.  MFMA-dense and
+// VALU-dense streams of two waves do NOT add up on one SIMD of this chip the way the instruction mix suggests; MI355X_MICROARCH.md's "moving work between the two
+// waves of a SIMD is zero- or negative-sum" held.)
 
 }  // namespace lm
 
@@ -726,18 +446,10 @@ int lm_qkv_attn_h384_launch(const void* d_x, const void* d_wqkv_img, const float
 #undef QA_ABL
     }
 #endif
-    const char* gen = getenv("LEANN_MI355X_FUSED_QKV_ATTN");  // 1: generation 1 (all waves in one phase: A/B), else generation 2
-    if (gen && gen[0] == '1') {
-        static DynLdsAttr attr;
-        LM_HIP(ensure_dyn_lds(attr, (const void*)k_qkv_attn_h384<0>, (size_t)QA_LDS));
-        hipLaunchKernelGGL(k_qkv_attn_h384<0>, dim3((unsigned)n_seqs), dim3(512), (size_t)QA_LDS, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_wqkv_img,
-                           d_bqkv, d_cu_seqlens, (__half*)d_out, scale_log2e);
-    } else {
-        static DynLdsAttr attr2;
-        LM_HIP(ensure_dyn_lds(attr2, (const void*)k_qkv_attn_h384_v2<0>, (size_t)QB_LDS));
-        hipLaunchKernelGGL(k_qkv_attn_h384_v2<0>, dim3((unsigned)n_seqs), dim3(512), (size_t)QB_LDS, (hipStream_t)stream, (const __half*)d_x,
-                           (const __half*)d_wqkv_img, d_bqkv, d_cu_seqlens, (__half*)d_out, scale_log2e);
-    }
+    static DynLdsAttr attr;
+    LM_HIP(ensure_dyn_lds(attr, (const void*)k_qkv_attn_h384<0>, (size_t)QA_LDS));
+    hipLaunchKernelGGL(k_qkv_attn_h384<0>, dim3((unsigned)n_seqs), dim3(512), (size_t)QA_LDS, (hipStream_t)stream, (const __half*)d_x, (const __half*)d_wqkv_img,
+                       d_bqkv, d_cu_seqlens, (__half*)d_out, scale_log2e);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -435,11 +435,12 @@ def pack_qkv_image(w: torch.Tensor) -> torch.Tensor:
     return img
 
 
-def fused_qkv_attention(x: torch.Tensor, lin: nn.Linear, cu: torch.Tensor, heads: int, max_len: int) -> Optional[torch.Tensor]:
+def fused_qkv_attention(x: torch.Tensor, lin: nn.Linear, cu: torch.Tensor, heads: int, max_len: int, force: bool = False) -> Optional[torch.Tensor]:
     """softmax(Q K^T / sqrt(32)) V per (sequence, head) with [Q | K | V] = x W^T + b computed inside the kernel (csrc/lm_qkv_attn_h384.hip, round 6:
-    the projection's 604 MB per 262 k tokens never go to HBM) -- the first half of a LARGE hidden-384 layer.  None = the caller takes the
-    stand-alone pair: another shape, or the library's own decision says so (lm_h384_first_half_form: LEANN_MI355X_FUSED_QKV_ATTN=0 and the
-    switches of the older attention generations; the one-call forward asks the same function, so both launch paths run the same kernels)."""
+    the projection's 604 MB per 262 k tokens never go to HBM) -- the first half of a LARGE hidden-384 layer on forwards of long sequences.  None = the
+    caller takes the stand-alone pair: another shape, or the library's own decision says so (lm_h384_first_half_form: mean sequence length below 216,
+    LEANN_MI355X_FUSED_QKV_ATTN=0, the switches of the older attention generations; the one-call forward asks the same function, so both launch
+    paths run the same kernels).  ``force`` (kernel tests): launch it whatever the decision would be."""
     import ctypes as C
 
     from . import _lib
@@ -449,7 +450,7 @@ def fused_qkv_attention(x: torch.Tensor, lin: nn.Linear, cu: torch.Tensor, heads
             and 0 < max_len <= 256 and cu.dtype == torch.int32):
         return None
     lib = _lib.load()
-    if lib.lm_h384_first_half_form(int(heads), int(max_len)) != 0:
+    if not force and lib.lm_h384_first_half_form(int(heads), int(max_len), int(x.shape[0]), int(cu.shape[0] - 1)) != 0:
         return None
     pk = _packed(lin, "_qkv_pack", (lin.weight, lin.bias), lambda: (pack_qkv_image(lin.weight), lin.bias.detach().float().contiguous()))
     out = torch.empty((x.shape[0], 384), dtype=torch.float16, device=x.device)

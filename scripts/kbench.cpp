@@ -580,17 +580,6 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(outf.p, 0xff, (size_t)tot * H * 2, st));
         run_q(); run_a(); run_f();
         CK(hipStreamSynchronize(st));
-        size_t gen_diff = 0;
-        {
-            Dev<__half> outf1((size_t)tot * H);
-            setenv("LEANN_MI355X_FUSED_QKV_ATTN", "1", 1);
-            LM(lm_qkv_attn_h384_f16(x.p, wimg.p, b.p, dcu.p, ns, 256, tot, outf1.p, st));
-            unsetenv("LEANN_MI355X_FUSED_QKV_ATTN");
-            CK(hipStreamSynchronize(st));
-            auto h1 = outf1.host(), h2 = outf.host();
-            for (size_t i = 0; i < h1.size(); ++i) gen_diff += memcmp(&h1[i], &h2[i], 2) != 0;
-            printf("{\"kernel\": \"lm_qkv_attn_h384_f16\", \"elements_where_generation_1_and_2_differ\": %zu}\n", gen_diff);
-        }
         {
             auto href = ref.host();
             std::vector<int> arows;
@@ -656,15 +645,10 @@ int main(int argc, char** argv) {
             (void)abl;
         }
         for (int round = 0; round < 3; ++round) {
-            const float uq = time_us(st, reps, run_q), ua = time_us(st, reps, run_a);
-            setenv("LEANN_MI355X_FUSED_QKV_ATTN", "1", 1);
-            const float uf1 = time_us(st, reps, run_f);
-            unsetenv("LEANN_MI355X_FUSED_QKV_ATTN");
-            const float uf = time_us(st, reps, run_f);
-            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused, generation 1: all waves in one phase)\", \"round\": %d, \"us\": %.1f}\n", round, uf1);
+            const float uq = time_us(st, reps, run_q), ua = time_us(st, reps, run_a), uf = time_us(st, reps, run_f);
             printf("{\"kernel\": \"pair: lm_qkv_h384 (head major) + lm_attn_v3\", \"round\": %d, \"us_qkv\": %.1f, \"us_attn\": %.1f, \"us\": %.1f, \"TFLOPs\": %.1f}\n", round, uq, ua, uq + ua,
                    flops / (uq + ua) * 1e-6);
-            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused, generation 2)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"us_per_262144_tokens\": %.1f}\n", round, uf, flops / uf * 1e-6,
+            printf("{\"kernel\": \"lm_qkv_attn_h384_f16 (fused)\", \"round\": %d, \"us\": %.1f, \"TFLOPs\": %.1f, \"us_per_262144_tokens\": %.1f}\n", round, uf, flops / uf * 1e-6,
                    uf * 262144.0 / tot);
             fflush(stdout);
         }

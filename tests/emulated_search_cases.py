@@ -774,16 +774,6 @@ def case_qkv_attn_fused(lens_list=((70, 1, 33), (256, 31), (150, 200))):
         _lib.check(lib.lm_qkv_attn_h384_f16(vp(x), vp(img), vp(b), vp(cu), n, int(lens.max()), tot, vp(o), None), "lm_qkv_attn_h384_f16")
         err = np.abs(o.astype(np.float64) - ref).max()
         assert np.isfinite(o.astype(np.float32)).all() and err < 6e-3, (lens.tolist(), err)
-        # generation 1 of the kernel (all eight waves in one phase; LEANN_MI355X_FUSED_QKV_ATTN=1) is the same arithmetic in another schedule: same bits
-        import os
-
-        os.environ["LEANN_MI355X_FUSED_QKV_ATTN"] = "1"
-        o1 = np.zeros((tot, H), np.float16)
-        try:
-            _lib.check(lib.lm_qkv_attn_h384_f16(vp(x), vp(img), vp(b), vp(cu), n, int(lens.max()), tot, vp(o1), None), "lm_qkv_attn_h384_f16 generation 1")
-        finally:
-            os.environ.pop("LEANN_MI355X_FUSED_QKV_ATTN")
-        assert np.array_equal(o.view(np.uint16), o1.view(np.uint16)), "generations 1 and 2 of the fused kernel differ"
         # the stand-alone pair on the same operands (Q rounded twice there: fp16-close, not bit-equal)
         qkv16 = np.zeros((tot, 3 * H), np.float16)
         _lib.check(lib.lm_qkv_h384_f16(vp(x), vp(img), vp(b), 3 * H, vp(qkv16), tot, None), "lm_qkv_h384_f16")
@@ -1057,8 +1047,8 @@ def case_encoder_python_wiring():
             mock.patch.object(_lib, "check", new=recording_check):
         with torch.no_grad():
             got = enc16.encode_tokens_packed(ti, tl, 4096)
-    expected = {"lm_pack_tokens": 1, "lm_embed_layernorm_f16": 1, "lm_qkv_attn_h384_f16": cfg.layers, "lm_qkv_h384_f16": 0, "lm_gemm_ws_h384_f16": cfg.layers,
-                "lm_attn_varlen_hd32_f16": 0, "lm_gemm_f16": 2 * cfg.layers, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_meanpool_varlen_f16": 1}
+    expected = {"lm_pack_tokens": 1, "lm_embed_layernorm_f16": 1, "lm_qkv_attn_h384_f16": 0, "lm_qkv_h384_f16": cfg.layers, "lm_gemm_ws_h384_f16": cfg.layers,
+                "lm_attn_varlen_hd32_f16": cfg.layers, "lm_gemm_f16": 2 * cfg.layers, "lm_add_layernorm_f16": 2 * cfg.layers, "lm_meanpool_varlen_f16": 1}
     counts = {k: used.count(k) for k in expected}
     assert counts == expected, (counts, sorted(set(used)))  # no library GEMM, no torch op left
     # mixed configuration: packing kernel + torch pooling (needs the lazily built token -> sequence map) + torch embedding
@@ -1070,10 +1060,10 @@ def case_encoder_python_wiring():
         with torch.no_grad():
             got2 = enc16.encode_tokens_packed(ti, tl, 4096)
     assert float((got2.float() - ref).abs().max()) < 6e-3
-    # the DEFAULT kernel set (QKV projection fused into attention, fused layer tail), then the stand-alone pair behind its switch (weight-streaming
-    # QKV projection, attention), then the weight-stationary projection
-    for ffn, extra, want in ((384, {}, {"lm_qkv_attn_h384_f16": 2, "lm_qkv_h384_f16": 0, "lm_attn_varlen_hd32_f16": 0, "lm_layer_tail_h384_f16": 2}),
-                             (384, {"LEANN_MI355X_FUSED_QKV_ATTN": "0"}, {"lm_qkv_attn_h384_f16": 0, "lm_qkv_h384_f16": 2, "lm_attn_varlen_hd32_f16": 2, "lm_layer_tail_h384_f16": 2}),
+    # the DEFAULT kernel set of a batch of short sequences (weight-streaming QKV projection, attention, fused layer tail), then the QKV projection fused
+    # into attention (the library's choice for long sequences, forced here), then the weight-stationary projection
+    for ffn, extra, want in ((384, {}, {"lm_qkv_attn_h384_f16": 0, "lm_qkv_h384_f16": 2, "lm_attn_varlen_hd32_f16": 2, "lm_layer_tail_h384_f16": 2}),
+                             (384, {"LEANN_MI355X_FUSED_QKV_ATTN": "1"}, {"lm_qkv_attn_h384_f16": 2, "lm_qkv_h384_f16": 0, "lm_attn_varlen_hd32_f16": 0, "lm_layer_tail_h384_f16": 2}),
                              (384, {"LEANN_MI355X_QKV": "0"}, {"lm_gemm_ws_h384_f16": 2, "lm_attn_varlen_hd32_f16": 2, "lm_layer_tail_h384_f16": 2})):
         cfg3 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=ffn, max_pos=64, max_seq_length=48)
         e32 = BertEncoder.random_init(cfg3, 5).eval()
@@ -1098,12 +1088,14 @@ def case_encoder_python_wiring():
     cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=384, max_pos=64, max_seq_length=48)
     e1 = BertEncoder.random_init(cfg1, 5).eval().half()
     outs = {}
-    for onecall, small in (("0", "0"), ("1", "0"), ("0", None), ("1", None)):  # large-forward form, then the small-forward form (general kernels)
+    for onecall, small in (("0", "0"), ("1", "0"), ("0", None), ("1", None), ("0", "fused"), ("1", "fused")):  # large-forward form, small-forward form (general kernels), large form with the fused first half
         used.clear()
         env1 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
         env1["LEANN_MI355X_ONECALL"] = onecall
         if small is not None:
-            env1["LEANN_MI355X_SMALL_TOKENS"] = small
+            env1["LEANN_MI355X_SMALL_TOKENS"] = "0"
+        if small == "fused":
+            env1["LEANN_MI355X_FUSED_QKV_ATTN"] = "1"
         with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
                 mock.patch("torch.cuda.current_stream", new=lambda *a, **k: _Stream()), mock.patch.dict(os.environ, env1, clear=True), \
                 mock.patch.object(_lib, "check", new=recording_check):
@@ -1115,8 +1107,10 @@ def case_encoder_python_wiring():
             assert used.count("lm_gemm_f16") == 4 * cfg1.layers and "lm_layer_tail_h384_f16" not in used, sorted(set(used))
         else:
             assert used.count("lm_layer_tail_h384_f16") == cfg1.layers and "lm_gemm_f16" not in used, sorted(set(used))
+            assert used.count("lm_qkv_attn_h384_f16") == (cfg1.layers if small == "fused" else 0), sorted(set(used))
     print("one-call vs per-kernel: large form max|diff|", float((outs[("0", "0")] - outs[("1", "0")]).abs().max()), "small form", float((outs[("0", None)] - outs[("1", None)]).abs().max()), flush=True)
-    assert torch.equal(outs[("0", "0")], outs[("1", "0")]) and torch.equal(outs[("0", None)], outs[("1", None)])
+    assert torch.equal(outs[("0", "0")], outs[("1", "0")]) and torch.equal(outs[("0", None)], outs[("1", None)]) and torch.equal(outs[("0", "fused")], outs[("1", "fused")])
+    assert float((outs[("1", "fused")].float() - outs[("1", "0")].float()).abs().max()) < 5e-3
     with torch.no_grad():
         ref1 = BertEncoder.random_init(cfg1, 5).eval()(ti, tl).float()
     assert float((outs[("1", None)].float() - ref1).abs().max()) < 6e-3 and float((outs[("1", "0")].float() - ref1).abs().max()) < 6e-3

@@ -161,14 +161,14 @@ def test_fused_qkv_attention_matches_fp32_reference(maxlen, nseq, wscale):
 
     x, lin, cu, mx, ref, grew = _fused_case(torch, maxlen, nseq, wscale)
     assert wscale < 0.2 or maxlen < 64 or grew > 0, "the test data does not reach the rescale branch"
-    o = fused_qkv_attention(x, lin, cu, 12, mx)
+    o = fused_qkv_attention(x, lin, cu, 12, mx, force=True)
     torch.cuda.synchronize()
     assert o is not None and o.shape == ref.shape and not torch.isnan(o).any()
     err = (o.float() - ref).abs().max().item()
     # K and V are rounded to fp16 once (as in the two-kernel form), Q once AFTER the softmax scale; at wscale 0.26 the logits reach +-20 log2 units
     # and a rounding of k moves a probability by up to ~1 %: fp16-level, looser than the pure attention test (whose inputs ARE fp16)
     assert err < (8e-3 if wscale < 0.2 else 2.5e-2), (maxlen, err)
-    again = [fused_qkv_attention(x, lin, cu, 12, mx) for _ in range(3)]
+    again = [fused_qkv_attention(x, lin, cu, 12, mx, force=True) for _ in range(3)]
     torch.cuda.synchronize()
     assert all(torch.equal(o, a) for a in again)
 
@@ -181,7 +181,7 @@ def test_fused_qkv_attention_against_the_pair_it_replaces(monkeypatch):
     from leann_amd.encoder import fused_attention_hd32, fused_linear_h384, fused_qkv_attention
 
     x, lin, cu, mx, ref, _ = _fused_case(torch, 256, 24, 0.1, seed=3)
-    of = fused_qkv_attention(x, lin, cu, 12, mx)
+    of = fused_qkv_attention(x, lin, cu, 12, mx, force=True)
     qkv = fused_linear_h384(x, lin)
     op = fused_attention_hd32(qkv, cu, 12, mx)
     torch.cuda.synchronize()
@@ -189,8 +189,18 @@ def test_fused_qkv_attention_against_the_pair_it_replaces(monkeypatch):
     assert (of.float() - op.float()).abs().max().item() < 6e-3
     ef, ep = (of.float() - ref).abs().max().item(), (op.float() - ref).abs().max().item()
     assert ef < 8e-3 and ep < 8e-3 and ef <= 1.5 * ep, (ef, ep)
+    # the library's own decision: the pair for this batch (mean length ~128), the fused kernel when forced or when the sequences are long
+    assert fused_qkv_attention(x, lin, cu, 12, mx) is None
+    monkeypatch.setenv("LEANN_MI355X_FUSED_QKV_ATTN", "1")
+    assert torch.equal(fused_qkv_attention(x, lin, cu, 12, mx), of)
     monkeypatch.setenv("LEANN_MI355X_FUSED_QKV_ATTN", "0")
-    assert fused_qkv_attention(x, lin, cu, 12, mx) is None  # the switch hands the layer back to the pair
+    assert fused_qkv_attention(x, lin, cu, 12, mx) is None
+    monkeypatch.delenv("LEANN_MI355X_FUSED_QKV_ATTN")
+    xl, linl, cul, mxl, _, _ = _fused_case(torch, 256, 3, 0.1, seed=4)  # lengths 256, 255, 1: mean 170 -> pair
+    assert fused_qkv_attention(xl, linl, cul, 12, mxl) is None
+    cu2 = torch.tensor([0, 256, 512, 740], dtype=torch.int32, device="cuda")  # mean 246.7 -> fused
+    x2 = (torch.randn((740, 384), generator=torch.Generator(device="cpu").manual_seed(1)) * 0.5).half().cuda()
+    assert fused_qkv_attention(x2, linl, cu2, 12, 256) is not None
 
 
 @pytest.mark.parametrize("maxlen", [256, 70, 33])
@@ -200,7 +210,8 @@ def test_head_major_qkv_projection_and_attention_pair(maxlen):
         head-major layout (round 5's timed path; those two entry points are internal), the per-kernel path lm_qkv_h384_f16 ->
         lm_attn_varlen_hd32_f16 over [tokens][1152], whose kernels test_attention_matches_fp32_reference and kbench check against fp32 references:
         the same arithmetic in another layout, so the outputs must be IDENTICAL -- that equality is the head-major pair's kernel-level pin;
-      * fused (the default): both paths run lm_qkv_attn_h384_f16 -> identical; and fp16-close to the pair."""
+      * fused (LEANN_MI355X_FUSED_QKV_ATTN=1; the library's own choice for forwards whose mean length is >= 216): both paths run lm_qkv_attn_h384_f16
+        -> identical; and fp16-close to the pair."""
     import os
 
     import torch
@@ -216,8 +227,8 @@ def test_head_major_qkv_projection_and_attention_pair(maxlen):
     outs = {}
     for name, env in (("onecall_pair", {"LEANN_MI355X_FUSED_QKV_ATTN": "0", "LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
                       ("kernels_pair", {"LEANN_MI355X_FUSED_QKV_ATTN": "0", "LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"}),
-                      ("onecall_fused", {"LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
-                      ("kernels_fused", {"LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"})):
+                      ("onecall_fused", {"LEANN_MI355X_FUSED_QKV_ATTN": "1", "LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
+                      ("kernels_fused", {"LEANN_MI355X_FUSED_QKV_ATTN": "1", "LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
