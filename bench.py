@@ -270,38 +270,40 @@ def _main(args, ap):
     if args.table_roofline and world == 1:
         try:
             idx.set_profiling(True)
-            # 8192 DISTINCT queries of their own (held-out chunks, another seed than the timed queries'): no row gather of this measurement is a
-            # guaranteed re-read of the same query's twin
-            nbig = 8192 if not dry else 16
+            # 32768 DISTINCT queries of their own (held-out chunks, another seed than the timed queries'): no row gather of this measurement is a
+            # guaranteed re-read of the same query's twin.  32768 in flight, not 8192 as until round 5: a stored-embedding search is a chain of
+            # dependent gathers per query, so the kernel's rate is set by the queries resident per CU -- 8192 / 16384 / 32768 in flight: 5.1 / 6.0 /
+            # 6.5 TB/s at beam 1 (profiles/r6_table_mode_queries_in_flight_and_occupancy_sweep.json); the 8192-query rows stay for continuity
+            nbig = 32768 if not dry else 16
             bt, bo, _ = corpus.queries(nbig, seed=97531)
             Qbig = RecomputeProvider(enc, TokenStore(bt, bo, device=lib_dev), provider.dp, dev).embed_ids(torch.arange(nbig, dtype=torch.int32, device=dev)).contiguous()
             bytes_eval = D * 4 + 4
             table_roof = {"queries_in_flight": nbig, "distinct_queries": int(torch.unique(Qbig, dim=0).shape[0])}
             try:  # L2-miss-side bytes of this kernel from its own FETCH_SIZE pass (scripts/pmc_table_mode.sh), as a ratio to the algorithmic bytes
-                pm = json.loads((ROOT / "profiles" / "r6_pmc_table_mode.json").read_text())
+                pm = json.loads((ROOT / "profiles" / "r6_pmc_table_mode_32768_queries.json").read_text())
                 table_roof["traffic"] = {f"beam{c['beam']}": {"l2_miss_side_over_algorithmic": c["l2_miss_side_over_algorithmic"], "l2_miss_side_bytes_per_launch": c["l2_miss_side_bytes"],
                                                               "algorithmic_bytes_per_launch": c["algorithmic_bytes"]} for c in pm["run"]["calls"][-2:]}
-                table_roof["traffic_source"] = ("profiles/r6_pmc_table_mode.json: rocprofv3 --pmc FETCH_SIZE over scripts/pmc_table_mode.py (same index, 8192 distinct queries), calibrated "
+                table_roof["traffic_source"] = ("profiles/r6_pmc_table_mode_32768_queries.json: rocprofv3 --pmc FETCH_SIZE over scripts/pmc_table_mode.py (same index, 32768 distinct queries), calibrated "
                                                 "in-pass on a read of every table row once in the kernel's own access pattern; FETCH_SIZE counts L2 misses (Infinity-Cache hits included)")
             except Exception:  # noqa: BLE001
                 pass
             # interleaved A/B: persistent one-launch kernel (wave / workgroup per query; -1 = the library's own choice) vs lock-step rounds
-            for persistent, wave in ((1, -1), (1, 1), (1, 0), (0, 0)) * 2:
+            for persistent, wave, nq_t in ((1, -1, nbig), (1, 1, nbig), (1, 0, nbig), (1, -1, min(8192, nbig)), (0, 0, min(8192, nbig))) * 2:
                 for beam_t, ef_t in ((4, ef), (1, ef)):
                     idx.set_option("persistent_table", persistent)
                     idx.set_option("persistent_wave", wave)
-                    prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=16384)
-                    idx.search_device(Qbig, 10, prm)
+                    prm = idx.make_params(ef=ef_t, beam=beam_t, recompute=False, max_batch=32768)
+                    idx.search_device(Qbig[:nq_t], 10, prm)
                     st = idx.stats()
                     form = {-1: "auto", 1: "wave_per_query", 0: "workgroup_per_query"}[wave]
-                    key = f"{'k_search_table_persistent_' + form if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}"
+                    key = f"{'k_search_table_persistent_' + form if persistent else 'lockstep_k_update'}_beam{beam_t}_ef{ef_t}" + ("" if nq_t == nbig else f"_{nq_t}_queries")
                     net_ms = max(st["update_span_ms"], 1e-6)
                     r = {"GBps": round(st["ndis"] * bytes_eval / (net_ms * 1e-3) / 1e9, 1), "launches": st["update_launches"],
                          "us_per_launch": round(1e3 * net_ms / max(st["update_launches"], 1), 2),
                          "us_per_launch_event_pair": round(1e3 * st["update_ms"] / max(st["update_launches"], 1), 2),
                          "expand_us_per_launch": round(1e3 * st["expand_ms"] / max(st["update_launches"], 1), 2)}
                     tr_ = (table_roof.get("traffic") or {}).get(f"beam{beam_t}")
-                    if tr_ and persistent:
+                    if tr_ and persistent and nq_t == nbig:
                         r["GBps_l2_miss_side"] = round(r["GBps"] * tr_["l2_miss_side_over_algorithmic"], 1)
                         r["frac_of_8TBps_algorithmic"] = round(r["GBps"] / 8000.0, 4)
                         r["frac_of_8TBps_l2_miss_side"] = round(r["GBps_l2_miss_side"] / 8000.0, 4)
@@ -1156,7 +1158,7 @@ def latency_frontier(idx, Q, recall, first_row, efs=(16, 32, 64), beams=(1, 4), 
         out["batch_256"] = []
         qb = Q[lo + reps + 1 : lo + reps + 1 + 256].contiguous()
         rb = range(lo + reps + 1, lo + reps + 1 + 256)
-        for ef, beam, bs in ((64, 1, 0), (64, 1, 64), (64, 4, 0), (32, 1, 64)):
+        for ef, beam, bs in ((64, 1, 0), (64, 1, 64), (64, 4, 0), (32, 1, 64), (16, 1, 0), (16, 1, 64)):
             if time.perf_counter() - t_all > 1.5 * budget_s:
                 break
             prm = idx.make_params(ef=ef, beam=beam, recompute=True, max_batch=256, batch_size=bs)

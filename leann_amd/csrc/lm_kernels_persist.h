@@ -24,10 +24,11 @@ struct PersistArgs {
 // traversal of a query is a chain of dependent memory round trips -- pop -> neighbour range -> ids -> visited bits -> rows --
 // so throughput is queries in flight / chain latency, and a wave per query puts 4x as many queries on a CU; at beam 1 on a
 // pruned graph (~9 neighbours per hop) a wave's 4 row groups x 2 rows in flight cover a hop's new-list in one pass).
-// OCC = waves per SIMD the register allocation aims at (0: the compiler's own choice -- 112-114 VGPRs at D = 384 fp32: four; 5: <= 96 VGPRs, a few
-// dozen bytes of scratch outside the row loop: option "persistent_occupancy", an A/B at D = 384 fp32 only)
-template <int NCH, bool L2, bool F16, int NT, int OCC = 0>
-__global__ __launch_bounds__(NT, OCC ? OCC : 1) void k_search_table(GraphDev g, WsDev ws, PersistArgs a) {
+// (Round 6 measured a five-waves-per-SIMD register allocation of this kernel -- __launch_bounds__(NT, 5): 96 VGPRs and 20-52 B of scratch instead of the
+// compiler's 112-114 VGPRs = four waves -- against it: slower at every batch size and beam, 4.75-5.03 vs 5.08 TB/s at 8192 queries, 6.21 vs 6.50 at 32768
+// (profiles/r6_table_mode_queries_in_flight_and_occupancy_sweep.json).  What raises the rate is queries in flight: 5.1 / 6.0 / 6.5 TB/s at 8192 / 16384 / 32768.)
+template <int NCH, bool L2, bool F16, int NT>
+__global__ __launch_bounds__(NT) void k_search_table(GraphDev g, WsDev ws, PersistArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint32_t s_off[65];
     __shared__ uint64_t s_b[64];

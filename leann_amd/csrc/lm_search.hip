@@ -106,7 +106,6 @@ struct lm_index {
     int pq_threads = 1024;     // workgroup width of the PQ traversal kernel (option "pq_threads": 256 / 512 / 1024)
     bool pq_rerank_expanded = false;  // option "pq_rerank_expanded": rerank every expanded node (upstream DiskANN's full_retset), not the final list
     int64_t pq_overflow = 0;   // queries (since the option was last set) whose expansions outgrew the record and fell back to the final list
-    int persist_occ = 0;       // option "persistent_occupancy": 0 = the compiler's register allocation (four waves per SIMD at D = 384 fp32), 5 = five (A/B)
     int persistent_wave = -1;  // persistent search: 1 = one wave per query, 0 = one 256-thread workgroup per query, -1 = auto
     int wave_maxnew = 0;     // auto rule threshold on beam x mean level-0 degree; 0 = never: on the 1M-chunk HNSW graph
                              // (max degree 64, mean 9.3) the workgroup form is 1.5x faster (profiles/r1_bench_default_1M_b2048.json
@@ -290,29 +289,8 @@ static int launch_persist_nch(lm_index* ix, const PersistArgs& a, const GraphDev
             hipLaunchKernelGGL((k_search_table<n, L2, F16, 256>), grid, dim3(256), shmem, ix->stream, g, ix->ws, a);      \
         }                                                                                                                \
         break
-        CASEP(1); CASEP(2); CASEP(3); CASEP(4); CASEP(5); CASEP(8); CASEP(12); CASEP(16);
+        CASEP(1); CASEP(2); CASEP(3); CASEP(4); CASEP(5); CASEP(6); CASEP(8); CASEP(12); CASEP(16);
 #undef CASEP
-        case 6:  // D = 384 (MiniLM, bge-small: the benchmarked width): + the five-waves-per-SIMD register allocation behind option "persistent_occupancy"
-            if constexpr (!F16) {
-                if (ix->persist_occ == 5) {
-                    if (wave) {
-                        LM_HIP(hipFuncSetAttribute((const void*)k_search_table<6, L2, F16, 64, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                        hipLaunchKernelGGL((k_search_table<6, L2, F16, 64, 5>), grid, dim3(64), shmem, ix->stream, g, ix->ws, a);
-                    } else {
-                        LM_HIP(hipFuncSetAttribute((const void*)k_search_table<6, L2, F16, 256, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                        hipLaunchKernelGGL((k_search_table<6, L2, F16, 256, 5>), grid, dim3(256), shmem, ix->stream, g, ix->ws, a);
-                    }
-                    break;
-                }
-            }
-            if (wave) {
-                LM_HIP(hipFuncSetAttribute((const void*)k_search_table<6, L2, F16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                hipLaunchKernelGGL((k_search_table<6, L2, F16, 64>), grid, dim3(64), shmem, ix->stream, g, ix->ws, a);
-            } else {
-                LM_HIP(hipFuncSetAttribute((const void*)k_search_table<6, L2, F16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                hipLaunchKernelGGL((k_search_table<6, L2, F16, 256>), grid, dim3(256), shmem, ix->stream, g, ix->ws, a);
-            }
-            break;
         default: LM_FAIL(LM_EINVAL, "unsupported padded dimension (supported: 64..384, 512, 768, 1024)");
     }
     LM_HIP(hipGetLastError());
@@ -920,11 +898,6 @@ int lm_index_set_option(lm_index* ix, const char* name, int64_t value) {
     if (!std::strcmp(name, "persistent_wave")) {
         if (value < -1 || value > 1) LM_FAIL(LM_EINVAL, "persistent_wave must be -1 (auto), 0 or 1");
         ix->persistent_wave = (int)value;
-        return LM_OK;
-    }
-    if (!std::strcmp(name, "persistent_occupancy")) {
-        if (value != 0 && value != 5) LM_FAIL(LM_EINVAL, "persistent_occupancy must be 0 (compiler's choice) or 5");
-        ix->persist_occ = (int)value;
         return LM_OK;
     }
     if (!std::strcmp(name, "wave_maxnew")) {

@@ -45,20 +45,20 @@ for rnd in range(2):
             same = bool(torch.equal(ref[beam][0], d) and torch.equal(ref[beam][1], l))
             out.setdefault(key, []).append({"GBps": round(st["ndis"] * 1540 / ms / 1e6, 1), "ms": round(ms, 3), "ndis_per_query": round(st["ndis"] / 8192, 1),
                                             "identical_results": same})
-# round 6: queries in flight and the register allocation of the persistent kernel (option "persistent_occupancy": 5 waves per SIMD instead of the
-# compiler's 4 at D = 384 fp32) -- beam 1 is a latency chain per query: throughput = queries resident per CU / chain latency
-if "--occupancy-sweep" in sys.argv:
+# round 6: queries in flight -- beam 1 is a latency chain per query: throughput = queries resident per CU / chain latency.  (The same sweep also carried a
+# five-waves-per-SIMD register allocation of the kernel, option "persistent_occupancy": slower everywhere, deleted;
+# profiles/r6_table_mode_queries_in_flight_and_occupancy_sweep.json.)
+if "--occupancy-sweep" in sys.argv or "--queries-in-flight" in sys.argv:
     qt2, qo2, _ = corpus.queries(32768, seed=97531)
     Q2 = RecomputeProvider(enc, TokenStore(qt2, qo2), 384, dev).embed_ids(torch.arange(32768, dtype=torch.int32, device=dev)).contiguous()
     sweep = []
     refs = {}
     for rnd in range(2):
         for nq in (8192, 16384, 32768):
-            for occ in (0, 5):
+            for occ in (0,):
                 for wave in (1, 0):
                     idx.set_option("persistent_table", 1)
                     idx.set_option("persistent_wave", wave)
-                    idx.set_option("persistent_occupancy", occ)
                     for beam in (1, 4):
                         prm = idx.make_params(ef=64, beam=beam, recompute=False, max_batch=32768)
                         d, l = idx.search_device(Q2[:nq], 10, prm)
@@ -69,6 +69,5 @@ if "--occupancy-sweep" in sys.argv:
                             refs[key] = l.clone()
                         sweep.append({"round": rnd, "queries": nq, "waves_per_simd_target": occ or "compiler (4)", "form": "wave" if wave else "workgroup", "beam": beam,
                                       "GBps": round(st["ndis"] * 1540 / ms / 1e6, 1), "ms": round(ms, 3), "identical_labels": bool(torch.equal(refs[key], l))})
-    idx.set_option("persistent_occupancy", 0)
     out["occupancy_sweep"] = sweep
 print(json.dumps(out))
