@@ -78,7 +78,9 @@ def main():
                     "reported as extra_batch_rows -- e.g. 128 = the per-rank batch of C5 (query batch 1024) on 8 GPUs")
     ap.add_argument("--fixed-len", type=int, default=0, help="SURVEY 8(d) variant: every chunk exactly this many tokens (256: 6.06 GFLOP per chunk), instead of len ~ N(180, 50)")
     ap.add_argument("--box-probe-only", action="store_true",
-                    help="run only the box probe's kernel launches (the 262,107-token layer tail x 13) and print its line: what the probe's rocprofv3 --pmc child runs")
+                    help="run only the box probe's kernel launches (the 262,107-token layer tail) and print its line: what the probe's rocprofv3 --pmc child runs")
+    ap.add_argument("--box-survey", action="store_true",
+                    help="the whole box probe alone, L2 / fabric counter pass included (~1 GPU-minute): one JSON line per box, for a table of boxes (DESIGN 6.1)")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the box probe (clock / power sampling, reference launches of the dominant kernel, copy rate)")
     ap.add_argument("--dry-run-emulated", default=None, metavar="LIB",
                     help="TEST ONLY (tests/test_bench_dry_run.py): run this script's control flow -- incl. every world > 1 branch, over gloo -- on the CPU against "
@@ -86,6 +88,8 @@ def main():
     args = ap.parse_args()
     if args.box_probe_only:
         return _box_probe_only()
+    if args.box_survey:
+        return _box_survey()
     if args.dry_run_emulated:
         import contextlib
 
@@ -358,7 +362,7 @@ def _main(args, ap):
     provider.chunks = 0
     barrier()
     kt_close("warmup")
-    sampler = BoxSampler(local_rank).start() if (probe is not None and rank == 0) else None  # a thread reading sysfs once a second (rocm-smi every 5 s where sysfs has no clocks)
+    sampler = BoxSampler(local_rank, period_s=0.25).start() if (probe is not None and rank == 0) else None  # a thread reading sysfs four times a second (rocm-smi every 5 s where sysfs has no clocks)
     t0 = time.perf_counter()
     for s in range(K):
         _, l = ps.search(batches[W + s], 10)
@@ -934,6 +938,27 @@ def _box_probe_only():
     enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2", allow_random=True).to(dev, dtype=torch.float16).eval()
     us = _tail_probe_launches(enc, dev)
     print(json.dumps({"tail_probe_us": [round(x, 1) for x in (us or [])]}), flush=True)
+
+
+def _box_survey():
+    import torch
+
+    from leann_amd import _lib
+    from leann_amd.encoder import BertEncoder
+
+    _lib.require_gpu()
+    dev = torch.device("cuda", 0)
+    enc = BertEncoder.load("sentence-transformers/all-MiniLM-L6-v2", allow_random=True).to(dev, dtype=torch.float16).eval()
+    os.environ["BENCH_FORCE_TCC_PASS"] = "1"
+    out = box_probe(enc, dev, 0)
+    try:
+        out["hostname"] = os.uname().nodename
+        import subprocess
+
+        out["rocm_smi_serial"] = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showserial", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout.strip()[-400:]
+    except Exception:  # noqa: BLE001
+        pass
+    print(json.dumps(out), flush=True)
 
 
 TCC_PASS_COUNTERS = ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_LEVEL_sum", "GRBM_GUI_ACTIVE"]

@@ -49,6 +49,8 @@ int main(void) {
     lm_search_params_default(&prm);
     CHECK(prm.efSearch == 64 && prm.beam_size == 1 && prm.check_relative_distance == 1 && prm.recompute == 1);
     CHECK(strlen(lm_version()) > 0);
+    CHECK(lm_abi_revision() == LM_ABI_REVISION); /* the library speaks the header this host was compiled against */
+    CHECK(prm.batch_size == 0);                  /* dynamic batching off by default (the reference's default, hnsw_backend.py:163) */
 
     lm_index *idx = NULL;
     /* argument validation happens before any device use */
