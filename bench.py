@@ -804,6 +804,28 @@ def _sysfs_cards():
     return sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
 
 
+def _sysfs_card_of_device(index):
+    """The sysfs card of HIP device `index`.  A box shows every GPU of the node under /sys/class/drm while the container sees one of them: match the
+    PCI address (round 6's third survey line sampled an idle neighbour: 158 MHz, 252 W); where that fails, the card that draws the most power."""
+    cards = _sysfs_cards()
+    if not cards:
+        return None
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(index)
+        want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        for c in cards:
+            if os.path.basename(os.path.realpath(c)).lower().startswith(want):
+                return c
+    except Exception:  # noqa: BLE001
+        pass
+    if len(cards) == 1:
+        return cards[0]
+    best = max(cards, key=lambda c: (_sysfs_sample(c).get("power_w") or 0.0))
+    return best
+
+
 def _sysfs_sample(card):
     """{"sclk_mhz", "mclk_mhz", "power_w"} of one card from sysfs (None where a file is missing)"""
     import glob
@@ -849,8 +871,7 @@ class BoxSampler:
     def __init__(self, index=0, period_s=1.0):
         import threading
 
-        cards = _sysfs_cards()
-        self.card = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.card = _sysfs_card_of_device(index)
         self.source = "sysfs" if self.card and _sysfs_sample(self.card)["sclk_mhz"] is not None else "rocm-smi"
         self.period = period_s if self.source == "sysfs" else 5.0
         self.samples = []
@@ -877,7 +898,7 @@ class BoxSampler:
     def stop(self):
         self._stop.set()
         self._th.join(timeout=30)
-        out = {"source": self.source, "n_samples": len(self.samples)}
+        out = {"source": self.source, "n_samples": len(self.samples), "card": os.path.basename(os.path.realpath(self.card)) if self.card else None}
         for k in ("sclk_mhz", "mclk_mhz", "power_w"):
             v = [x[k] for x in self.samples if x.get(k) is not None]
             if v:

@@ -260,6 +260,11 @@ __device__ __forceinline__ void t4_iteration(const T4Addr& c, const float* bs_ne
 }
 
 // ---- attention output projection: one 32-wide k slab (24 dense MFMAs: tile j of o, k-steps u = 0, 1) ---------------------------------
+// (Round 6 measured two changes to this phase -- 1.5 k cycles per slab against a 0.77 k matrix-pipe floor at one wave per SIMD -- and kept neither: the
+// fragment ring 8 deep instead of 4, and on top of it the ring CONTINUOUS over the twelve slabs with the slab's barrier moved in front of slot 16 (no refill
+// bubble per slab, the barrier under fragments in flight): 688.8 / 691.8 / 689.5 us per 262 k tokens for continuous + 8 / 8 / this form, three alternating
+// processes each (profiles/r6_kbench_layer_tail_outprojection_ring_depth_and_continuous_ring_equal.jsonl).  Neither the LDS latency of the fragment
+// reads nor the per-slab refill is what this phase waits for.)
 __device__ __forceinline__ void t4_outproj_slab(const unsigned char* b20, const unsigned char* b21, const half8& a0, const half8& a1,
                                                 float16v (&o)[ML_NJ]) {
     half8 ring[4];

@@ -117,7 +117,7 @@ if os.environ.get("LAT_VARIANTS"):
         idx.set_option("single_query_direct", 1 if "direct" in parts else 0)
         vrow = {"variant": vname}
         for b in tuple(int(v) for v in os.environ.get("LAT_BATCHES", "1,4,16,64,256").split(",")):
-            prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b)
+            prm = idx.make_params(ef=64, beam=1, recompute=True, max_batch=b, batch_size=int(os.environ.get("LAT_BATCH_SIZE", "0")))  # LAT_BATCH_SIZE: dynamic batching target
             reps = 24 if b == 1 else (12 if b <= 16 else 4)
             idx.search_device(Q[0:b].contiguous(), 10, prm)
             lat, labels, p = [], [], b
