@@ -1161,7 +1161,7 @@ def small_batch_latency(idx, Q, prm_of, recall, first_row, batches=(1, 16, 64, 2
     return rows, lo
 
 
-def latency_frontier(idx, Q, recall, first_row, efs=(16, 32, 64), beams=(1, 4), batch_sizes=(0, 32, 64, 128), reps=10, b256=True, budget_s=60.0):
+def latency_frontier(idx, Q, recall, first_row, efs=(16, 32, 64), beams=(1, 4), batch_sizes=(0, 32, 64, 128, 256), reps=16, b256=True, budget_s=75.0):
     """Latency vs recall at B = 1 over the three knobs the reference's search call carries (hnsw_backend.py:203-234): complexity (efSearch),
     beam_width (pops per round) and batch_size (dynamic batching, paper section 4.2: k_expand keeps popping while a round's new-list is
     shorter).  Every cell: `reps` one-query calls on fresh queries (the SAME queries in every cell), p50 latency, recall@10 against the exact

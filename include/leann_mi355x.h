@@ -373,13 +373,23 @@ typedef struct lm_bert_h384_layer {
      * layer tail, whose 128-token workgroup is one ~77 us dependency chain however few tokens it holds (MI355X, 200k-chunk index,
      * B = 1 search: p50 59.7 -> 47.2 ms with the limit at 6144 tokens in round 3; round 4 measured the crossover again -- 6144 /
      * 16384 / 32768 tokens: B = 1 p50 44.9 / 39.3 / 40.0 ms, B = 4 70.1 / 56.5 / 56.7 ms, B = 16 115.2 / 107.9 / 108.6 ms -- and moved
-     * it to 16384).  Same arithmetic up to fp16 rounding of the intermediate activations. */
+     * it to 16384; round 6, with the QKV projection of the next size class on the general GEMM (LM_BERT_QKV_GEMM_TOKENS below) and rounds that
+     * dynamic batching makes 5 - 10 x larger: 4096 / 8192 / 16384 tokens: B = 1 p50 37.8 / 37.9 / 38.2 ms at batch_size 0, 13.1 / 13.0 / 14.0 ms at 64,
+     * 11.9 / 11.8 / 11.9 ms at 128, B = 16 86.4 / 86.6 / 89.1 ms -- moved to 8192: profiles/r6_latency_b1_forward_size_limits_200k.jsonl).  Same
+     * arithmetic up to fp16 rounding of the intermediate activations. */
     const void *wo, *w1, *w2;
     /* Optional: lm_qkv_pack_h384's image of wqkv.  With it the large-forward QKV projection runs on the weight-streaming kernel
      * (lm_qkv_h384_f16: x read once, two waves per SIMD); NULL = the weight-stationary one (lm_gemm_ws_h384_f16 on wqkv). */
     const void *wqkv_img;
 } lm_bert_h384_layer;
-#define LM_BERT_SMALL_TOKENS 16384
+#define LM_BERT_SMALL_TOKENS 8192
+/* Round 6: between the small-forward form and the streaming QKV kernel.  A LARGE-form forward of at most this many tokens takes its QKV projection
+ * from the general GEMM (lm_gemm_f16 on wqkv, then attention over the [tokens][1152] layout) instead of the weight-streaming kernel, whose 256-token
+ * workgroup is a ~45 us chain however few of the 256 CUs the forward fills: 12,288 / 24,576 / 49,152 tokens: 18.6 / 32.2 / 62.4 us against 45.8 /
+ * 53.8 / 65.3 us (profiles/r6_kbench_layer_kernels_at_small_forward_sizes.jsonl) -- the rounds of a small-batch search under dynamic batching
+ * (batch_size 64 ... 128: 12 k ... 35 k tokens).  The fused layer tail stays (64 / 80 us at those sizes against ~100 / ~160 for the five launches it
+ * replaces).  LEANN_MI355X_QKV_GEMM_TOKENS overrides (0 = never; LEANN_MI355X_SMALL_TOKENS=0, "the large-forward kernels at every size", implies 0). */
+#define LM_BERT_QKV_GEMM_TOKENS 45056
 
 typedef struct lm_bert_h384 {
     int32_t n_layers, heads, ffn, normalize;

@@ -44,6 +44,13 @@ extern "C" int lm_h384_first_half_form(int32_t heads, int32_t max_len, int64_t t
     return (int)lm::h384_first_half_form(heads, max_len, total_tokens, n_seqs);
 }
 
+// tokens up to which a LARGE-form forward takes its QKV projection from the general GEMM (include/leann_mi355x.h: LM_BERT_QKV_GEMM_TOKENS)
+static int64_t qkv_gemm_tokens_limit() {
+    if (const char* e = getenv("LEANN_MI355X_QKV_GEMM_TOKENS")) return (int64_t)atoll(e);
+    const char* s = getenv("LEANN_MI355X_SMALL_TOKENS");
+    return s && atoll(s) == 0 ? 0 : (int64_t)LM_BERT_QKV_GEMM_TOKENS;  // SMALL_TOKENS=0: the large-forward kernels at EVERY size (tests, A/B)
+}
+
 extern "C" size_t lm_bert_h384_workspace_bytes(int64_t total_tokens) {
     if (total_tokens <= 0) return 0;
     // x, attention output, y: [T][384]; qkv: [T][1152]; small forwards additionally the feed-forward intermediate [T][ffn <= 2560]; fp16
@@ -73,7 +80,14 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
     bool small = total_tokens <= small_tokens_limit() && m->ffn % 128 == 0;  // (every multiple of 192 in the envelope that is one of 128: 384, 768, 1152, 1536, ...)
     for (int l = 0; small && l < m->n_layers; ++l) small = m->layers[l].wo && m->layers[l].w1 && m->layers[l].w2;
     void* hid = ws + 3 * row + (size_t)total_tokens * 1152 * 2;  // [T][ffn], small forwards only (lm_bert_h384_workspace_bytes)
-    const H384FirstHalf first_half = h384_first_half_form(m->heads, max_len, total_tokens, n_seqs);  // one decision per forward, shared with the Python host's launch path
+    H384FirstHalf first_half = h384_first_half_form(m->heads, max_len, total_tokens, n_seqs);  // one decision per forward, shared with the Python host's launch path
+    bool qkv_gemm = !small && total_tokens <= qkv_gemm_tokens_limit();  // a forward that fills a fraction of the chip: QKV from the general GEMM
+    for (int l = 0; qkv_gemm && l < m->n_layers; ++l) qkv_gemm = m->layers[l].wqkv != nullptr;
+    {
+        const char* f = getenv("LEANN_MI355X_FUSED_QKV_ATTN");
+        if (qkv_gemm && f && f[0] == '1') qkv_gemm = false;  // (the fused kernel forced: it has no stand-alone projection)
+        else if (qkv_gemm) first_half = H384_PAIR_ROW_MAJOR;
+    }
     for (int l = 0; l < m->n_layers; ++l) {
         const lm_bert_h384_layer& L = m->layers[l];
         if (small) {  // every product a grid of small tiles; x -> y (scratch) -> x
@@ -92,8 +106,9 @@ extern "C" int lm_bert_h384_forward_packed(const lm_bert_h384* m, const int32_t*
             if ((rc = lm_qkv_h384_launch(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, 1, stream))) return rc;
             if ((rc = lm_attn_v3_launch_hd32(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, total_tokens, stream))) return rc;
         } else {
-            if ((rc = L.wqkv_img ? lm_qkv_h384_f16(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, stream)
-                                 : lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream)))
+            if ((rc = qkv_gemm      ? lm_gemm_f16(x, L.wqkv, L.bqkv, nullptr, 0, 1152, 384, qkv, total_tokens, stream)
+                      : L.wqkv_img ? lm_qkv_h384_f16(x, L.wqkv_img, L.bqkv, 1152, qkv, total_tokens, stream)
+                                   : lm_gemm_ws_h384_f16(x, L.wqkv, L.bqkv, 1152, qkv, total_tokens, stream)))
                 return rc;
             if ((rc = lm_attn_varlen_hd32_f16(qkv, d_cu_seqlens, n_seqs, m->heads, max_len, a, stream))) return rc;
         }

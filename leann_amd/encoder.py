@@ -208,7 +208,7 @@ def fused_attention_hd32(qkv: torch.Tensor, cu: torch.Tensor, heads: int, max_le
 
 
 GEMM_EPI_GELU, GEMM_EPI_RESIDUAL = 1, 2
-LM_BERT_SMALL_TOKENS = 16384  # include/leann_mi355x.h
+LM_BERT_SMALL_TOKENS = 8192  # include/leann_mi355x.h
 
 
 def small_tokens_limit() -> int:
@@ -216,6 +216,22 @@ def small_tokens_limit() -> int:
     import os
 
     return int(os.environ.get("LEANN_MI355X_SMALL_TOKENS", LM_BERT_SMALL_TOKENS))
+
+
+LM_BERT_QKV_GEMM_TOKENS = 45056  # include/leann_mi355x.h
+
+
+def qkv_gemm_tokens_limit() -> int:
+    """A LARGE-form hidden-384 forward of at most this many tokens takes its QKV projection from the general GEMM (round 6: the streaming kernel's
+    256-token workgroup is a ~45 us chain however few CUs the forward fills; include/leann_mi355x.h: LM_BERT_QKV_GEMM_TOKENS).  Mirrors
+    csrc/lm_encoder_forward.cpp: LEANN_MI355X_QKV_GEMM_TOKENS overrides, LEANN_MI355X_SMALL_TOKENS=0 ("the large-forward kernels at every size") implies 0."""
+    import os
+
+    if "LEANN_MI355X_QKV_GEMM_TOKENS" in os.environ:
+        return int(os.environ["LEANN_MI355X_QKV_GEMM_TOKENS"])
+    if os.environ.get("LEANN_MI355X_SMALL_TOKENS") is not None and int(os.environ["LEANN_MI355X_SMALL_TOKENS"]) == 0:
+        return 0
+    return LM_BERT_QKV_GEMM_TOKENS
 
 
 def fused_gemm(x: torch.Tensor, lin: nn.Linear, epilogue: int = 0, residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -523,10 +539,11 @@ class _Layer(nn.Module):
             if y is not None:
                 return y
         a = None
-        if h == 384 and os.environ.get("LEANN_MI355X_GEMM") != "1" and os.environ.get("LEANN_MI355X_LINEAR", "1") != "0" and os.environ.get("LEANN_MI355X_QKV", "1") == "1":
-            a = fused_qkv_attention(x, self.qkv, cu, self.heads, max_len)  # projection fused into attention (the default of the large forwards)
+        qkv_gemm = h == 384 and tot <= qkv_gemm_tokens_limit() and os.environ.get("LEANN_MI355X_FUSED_QKV_ATTN") != "1"  # (as csrc/lm_encoder_forward.cpp)
+        if h == 384 and not qkv_gemm and os.environ.get("LEANN_MI355X_GEMM") != "1" and os.environ.get("LEANN_MI355X_LINEAR", "1") != "0" and os.environ.get("LEANN_MI355X_QKV", "1") == "1":
+            a = fused_qkv_attention(x, self.qkv, cu, self.heads, max_len)  # projection fused into attention (forwards of long sequences)
         if a is None:
-            qkv2 = (fused_gemm(x, self.qkv) if os.environ.get("LEANN_MI355X_GEMM") == "1" else None) if h == 384 else None
+            qkv2 = (fused_gemm(x, self.qkv) if (qkv_gemm or os.environ.get("LEANN_MI355X_GEMM") == "1") else None) if h == 384 else None
             if qkv2 is None:
                 qkv2 = fused_linear_h384(x, self.qkv)
             if qkv2 is None:

@@ -1088,12 +1088,12 @@ def case_encoder_python_wiring():
     cfg1 = EncoderConfig(vocab_size=500, hidden=384, layers=2, heads=12, ffn=384, max_pos=64, max_seq_length=48)
     e1 = BertEncoder.random_init(cfg1, 5).eval().half()
     outs = {}
-    for onecall, small in (("0", "0"), ("1", "0"), ("0", None), ("1", None), ("0", "fused"), ("1", "fused")):  # large-forward form, small-forward form (general kernels), large form with the fused first half
+    for onecall, small in (("0", "0"), ("1", "0"), ("0", None), ("1", None), ("0", "fused"), ("1", "fused"), ("0", "hybrid"), ("1", "hybrid")):  # large-forward form, small-forward form (general kernels), large form with the fused first half, large form with the QKV projection from the general GEMM
         used.clear()
         env1 = {k: v for k, v in os.environ.items() if not k.startswith("LEANN_MI355X_")}
         env1["LEANN_MI355X_ONECALL"] = onecall
         if small is not None:
-            env1["LEANN_MI355X_SMALL_TOKENS"] = "0"
+            env1["LEANN_MI355X_SMALL_TOKENS"] = "0" if small != "hybrid" else "1"  # hybrid: not a small forward, but below LM_BERT_QKV_GEMM_TOKENS
         if small == "fused":
             env1["LEANN_MI355X_FUSED_QKV_ATTN"] = "1"
         with mock.patch.object(torch.Tensor, "is_cuda", new=property(lambda self: True)), \
@@ -1105,12 +1105,16 @@ def case_encoder_python_wiring():
             assert used.count("lm_bert_h384_forward_packed") == 1 and "lm_gemm_ws_h384_f16" not in used, sorted(set(used))
         elif small is None:
             assert used.count("lm_gemm_f16") == 4 * cfg1.layers and "lm_layer_tail_h384_f16" not in used, sorted(set(used))
+        elif small == "hybrid":  # (round 6) a forward that fills a fraction of the chip: QKV from the general GEMM, attention, the fused tail
+            assert used.count("lm_layer_tail_h384_f16") == cfg1.layers and used.count("lm_gemm_f16") == cfg1.layers and used.count("lm_attn_varlen_hd32_f16") == cfg1.layers
+            assert "lm_qkv_h384_f16" not in used and "lm_qkv_attn_h384_f16" not in used, sorted(set(used))
         else:
             assert used.count("lm_layer_tail_h384_f16") == cfg1.layers and "lm_gemm_f16" not in used, sorted(set(used))
             assert used.count("lm_qkv_attn_h384_f16") == (cfg1.layers if small == "fused" else 0), sorted(set(used))
     print("one-call vs per-kernel: large form max|diff|", float((outs[("0", "0")] - outs[("1", "0")]).abs().max()), "small form", float((outs[("0", None)] - outs[("1", None)]).abs().max()), flush=True)
     assert torch.equal(outs[("0", "0")], outs[("1", "0")]) and torch.equal(outs[("0", None)], outs[("1", None)]) and torch.equal(outs[("0", "fused")], outs[("1", "fused")])
     assert float((outs[("1", "fused")].float() - outs[("1", "0")].float()).abs().max()) < 5e-3
+    assert torch.equal(outs[("0", "hybrid")], outs[("1", "hybrid")]) and float((outs[("1", "hybrid")].float() - outs[("1", "0")].float()).abs().max()) < 5e-3
     with torch.no_grad():
         ref1 = BertEncoder.random_init(cfg1, 5).eval()(ti, tl).float()
     assert float((outs[("1", None)].float() - ref1).abs().max()) < 6e-3 and float((outs[("1", "0")].float() - ref1).abs().max()) < 6e-3

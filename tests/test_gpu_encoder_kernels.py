@@ -228,7 +228,11 @@ def test_head_major_qkv_projection_and_attention_pair(maxlen):
     for name, env in (("onecall_pair", {"LEANN_MI355X_FUSED_QKV_ATTN": "0", "LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
                       ("kernels_pair", {"LEANN_MI355X_FUSED_QKV_ATTN": "0", "LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"}),
                       ("onecall_fused", {"LEANN_MI355X_FUSED_QKV_ATTN": "1", "LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "0"}),
-                      ("kernels_fused", {"LEANN_MI355X_FUSED_QKV_ATTN": "1", "LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"})):
+                      ("kernels_fused", {"LEANN_MI355X_FUSED_QKV_ATTN": "1", "LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "0"}),
+                      # (round 6) the form of a forward that fills a fraction of the chip: not "small" (limit 1 token), below LM_BERT_QKV_GEMM_TOKENS:
+                      # QKV from the general GEMM, attention, the fused layer tail
+                      ("onecall_hybrid", {"LEANN_MI355X_ONECALL": "1", "LEANN_MI355X_SMALL_TOKENS": "1"}),
+                      ("kernels_hybrid", {"LEANN_MI355X_ONECALL": "0", "LEANN_MI355X_SMALL_TOKENS": "1"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -243,6 +247,8 @@ def test_head_major_qkv_projection_and_attention_pair(maxlen):
     assert torch.equal(outs["onecall_pair"][0], outs["kernels_pair"][0])    # head-major pair == row-major pair
     assert torch.equal(outs["onecall_fused"][0], outs["kernels_fused"][0])  # both launch paths run the fused kernel
     assert (outs["onecall_fused"][0] - outs["onecall_pair"][0]).abs().max().item() < 5e-3  # unit vectors: fp16-level agreement of the two forms
+    assert torch.equal(outs["onecall_hybrid"][0], outs["kernels_hybrid"][0])
+    assert (outs["onecall_hybrid"][0] - outs["onecall_pair"][0]).abs().max().item() < 5e-3
 
 
 def test_encoder_forward_with_and_without_the_attention_kernel(monkeypatch):
@@ -666,6 +672,6 @@ def test_sub_batching_does_not_change_the_embeddings():
         assert whole.shape == (120, enc.cfg.hidden) and whole.dtype == torch.float32
         for budget in (7000, 2000, 1):
             part = enc.encode_tokens_packed(ti, tl, budget)
-            # the 384-wide model switches layer form with the sub-batch size (<= 16384 tokens: general kernels): same arithmetic up to fp16
+            # the 384-wide model switches layer form with the sub-batch size (<= 8192 tokens: general kernels; <= 45056: QKV from the general GEMM): same arithmetic up to fp16
             # rounding of intermediate activations
             assert (part - whole).abs().max().item() <= 3e-3, (name, budget)

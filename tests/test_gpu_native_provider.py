@@ -152,7 +152,7 @@ def test_search_over_the_native_provider_equals_python_provider_and_oracle(world
 def test_speculative_prefetch_over_the_native_provider(world):
     """Option "speculate" with the real encoder behind the search: a one-query search asks the built-in provider for more chunks in fewer
     forwards.  With a table-lookup provider the results are those of S = 0 bit for bit (tests/test_gpu_parity.py); with the encoder a
-    chunk's embedding can come from a different launch form (a prefetching round may exceed the small-forward limit of 16384 tokens and
+    chunk's embedding can come from a different launch form (a prefetching round may exceed the small-forward limit of 8192 tokens and
     take the fused kernels): fp16-close distances, and labels that may differ only where two candidates are that close."""
     torch = world["torch"]
     from leann_amd.gpu_graph_build import build_graph_gpu
