@@ -353,7 +353,7 @@ def _main(args, ap):
     # what box is this?  (reference launches of the dominant kernel + a copy rate on the idle chip, before anything is timed)
     probe = None
     if cfg.hidden == 384 and not dry and not args.no_box_probe:
-        probe = box_probe(enc, dev, local_rank)
+        probe = box_probe(enc, dev, local_rank, counter_pass=(rank == 0 and world == 1))  # (the counter pass runs a child process on device 0: single-GPU runs only)
         log("box probe:", json.dumps(probe)[:600])
     kt_close("setup")
     for w in range(W):
@@ -1028,8 +1028,8 @@ def _tcc_pass(timeout_s=240):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def box_probe(enc, dev, local_rank=0):
-    """(ii) and (iii) above.  Never raises."""
+def box_probe(enc, dev, local_rank=0, counter_pass=True):
+    """(ii) and (iii) above.  Never raises.  counter_pass=False (every rank but 0 of a multi-GPU run): no rocprofv3 child process."""
     out = {"what": f"before the timed steps, idle chip: 10 launches of lm_layer_tail_h384_f16 at {TAIL_PROBE_TOKENS} tokens (kbench tail4's size: 675-690 us on the "
                    f"boxes DESIGN 6.1 calls fast, 730+ on the slow ones) and a 1 GiB device-to-device copy; clocks / power sampled during the timed steps"}
     try:
@@ -1045,7 +1045,7 @@ def box_probe(enc, dev, local_rank=0):
         ref = ROOT / "profiles" / "r6_box_probe_tcc_pass_fast_box.json"
         if ref.exists():
             out["tcc_pass_fast_box_reference"] = json.loads(ref.read_text()).get("tcc_pass")
-        if os.environ.get("BENCH_FORCE_TCC_PASS") == "1" or (us and float(np.median(us)) > TAIL_PROBE_SLOW_US and os.environ.get("BENCH_NO_TCC_PASS") != "1"):
+        if counter_pass and (os.environ.get("BENCH_FORCE_TCC_PASS") == "1" or (us and float(np.median(us)) > TAIL_PROBE_SLOW_US and os.environ.get("BENCH_NO_TCC_PASS") != "1")):
             out["tcc_pass"] = _tcc_pass()
             out["tcc_pass_counters"] = ("rocprofv3 --pmc " + " ".join(TCC_PASS_COUNTERS) + " --kernel-trace -- python bench.py --box-probe-only (child process, "
                                         "per-launch means of k_layer_tail_h384; LEVEL / RDREQ = mean fabric read latency in L2 cycles)")

@@ -24,7 +24,7 @@ def _has_gpu() -> bool:
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _has_gpu(), reason="needs an MI355X")]
 
 
-def test_diskann_searcher_plugin_against_the_pq_oracle(tmp_path, built_libs):
+def test_diskann_searcher_plugin_against_the_pq_oracle(tmp_path, built_libs, monkeypatch):
     import torch
 
     from leann_amd import csr_format as cf
@@ -50,7 +50,12 @@ def test_diskann_searcher_plugin_against_the_pq_oracle(tmp_path, built_libs):
     assert np.array_equal(r["distances"].view(np.uint32), od.view(np.uint32))
     assert np.all(np.diff(r["distances"], axis=1) >= 0)  # squared L2, best first
     s.cleanup()
-    # (2) recompute: pruned index (no vectors), PQ traversal + ONE deferred exact rerank through the in-process encoder
+    # (2) recompute: pruned index (no vectors), PQ traversal + ONE deferred exact rerank through the in-process encoder.
+    # The strict comparison (same order, bit for bit the order the oracle gets from the build-time embeddings) needs the build-time forward (600
+    # chunks, ~10 k tokens) and the rerank's forward (a few hundred chunks) to run the SAME kernels: the forward has three size classes since round 6
+    # (include/leann_mi355x.h: LM_BERT_SMALL_TOKENS / LM_BERT_QKV_GEMM_TOKENS) whose fp16 results differ in the last bits, and this random-weight
+    # encoder puts all chunks within 1e-3 of each other in similarity.  So: pinned to one class -> strict; library defaults -> equal up to near ties.
+    monkeypatch.setenv("LEANN_MI355X_SMALL_TOKENS", str(1 << 30))
     enc = BertEncoder.load(model, allow_random=True).to("cuda", dtype=torch.float16)
     p2 = str(tmp_path / "pruned.leann")
     tok = load_tokenizer(model, 256, p2, texts, enc.cfg.vocab_size, allow_stand_in=enc.weights_source == "random")
@@ -75,6 +80,17 @@ def test_diskann_searcher_plugin_against_the_pq_oracle(tmp_path, built_libs):
     assert np.allclose(r2["distances"], od2, atol=5e-3)                    # GPU fp16 encoder vs the embeddings it produced at build time
     assert np.all(np.diff(r2["distances"], axis=1) <= 0)                   # +IP, best first
     assert s2.last_stats()["nunique"] == ost["n_rerank_unique"]            # one deferred fetch of the unique candidates
+    # library defaults: the rerank's forward is a "small" one, the build-time forward was not -- same candidates up to near ties of the exact scores
+    monkeypatch.delenv("LEANN_MI355X_SMALL_TOKENS")
+    r3 = s2.search(emb[:9], 4, complexity=48, beam_width=8, recompute_embeddings=True, zmq_port=5557)
+    tie = 2e-3
+    for qi, (row, dist) in enumerate(zip(r3["labels"], r3["distances"])):
+        exact = emb[[int(v) for v in row]] @ emb[qi]                       # the oracle's score of what the library returned
+        assert row[0] == str(qi)
+        assert np.all(exact >= od2[qi, -1] - tie), (qi, row, oi2[qi])      # nothing returned that the oracle ranks clearly below its own k-th
+        assert np.all(np.diff(exact) <= tie), (qi, row, exact)             # in the oracle's order up to near ties
+        assert np.allclose(dist, exact, atol=5e-3)
+    assert s2.last_stats()["nunique"] == ost["n_rerank_unique"]
     s2.cleanup()
 
 
