@@ -22,6 +22,7 @@
 //     eight row pairs have eight different (row >> 1) & 7, the two rows of a pair sit in different halves of the 256-byte bank row;
 //   * one barrier per K-tile: wait own DMA (vmcnt(0)) -> barrier -> 32 MFMAs with the next K-tile's DMA pieces issued behind the first
 //     two fragment requests (measured best placement: profiles/r3_session3_gemm_loop_variants.txt);
+//     (round 6: the residual epilogues run a rotated form of this loop -- see GM_LOOP_FOR below -- because its registers hold a tile's residual rows ahead of time);
 //   * PERSISTENT: one workgroup per CU walks a list of output tiles.  s_memtime stamps of the one-tile-per-workgroup form (QKV
 //     shape, 12 K-tiles): 3.4 k cycles until the first K-tile has landed + 34.0 k main loop + 5.6 k epilogue + 0.5 k store drain,
 //     and a workgroup swap on top.  Here the NEXT tile's first K-tile is requested before the epilogue starts (it lands under the
@@ -47,6 +48,8 @@ namespace lm {
 #define GM_WAIT_VM0() ((void)0)
 #define GM_WAIT_VM(n) ((void)0)
 #define GM_WAIT_LGKM0() ((void)0)
+#define GM_WAIT_LGKM0_SEEN() ((void)0)
+#define GM_WAIT_VM0_SEEN() ((void)0)
 #define GM_BARRIER() __syncthreads()
 #define GM_UNIFORM(v) (v)
 #else
@@ -54,6 +57,10 @@ namespace lm {
 #define GM_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define GM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define GM_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// the same wait as an instruction the compiler's own wait-count bookkeeping SEES (gfx9 encoding: vmcnt 63, expcnt 7, lgkmcnt 0): behind it the fragments requested
+// earlier count as landed, so MFMAs that use them are not made to wait for LDS reads issued later (an asm wait is invisible to that bookkeeping)
+#define GM_WAIT_LGKM0_SEEN() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define GM_WAIT_VM0_SEEN() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt 0, expcnt 7, lgkmcnt 15
 #define GM_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
 
@@ -96,6 +103,17 @@ using GemmSmall = GemmShape<2, 2, 2, 2>;  // 128 x 128, 256 threads, 64 accumula
 // Launch shape (diagnosis: LEANN_MI355X_GEMM_GRID=tiles): the persistent grid is one workgroup per CU; a grid of one workgroup per
 // tile runs the same code with tile lists of length one (the round-3 session-2..4 form, for A/B).
 constexpr int GM_VAR_DEFAULT = 0;
+// LOOP (round 6): 0 = the round-5 tile loop (barrier in front of a K-tile's first fragment reads; bias slice staged in LDS and added in the epilogue; a residual
+// row loaded where it is added).  3 = the ROTATED loop (barrier in front of a K-tile's LAST k-step; the accumulators start at the bias) + all residual rows of a tile
+// requested ahead with one wait.  Measured on the encoder's shapes at 65,536 tokens, three interleaved rounds (GPU session 15): the rotation by itself is worth nothing
+// (QKV of a 768-wide model 241-244 us in form 0, 250-251 in form 3; first feed-forward product + GELU 361 / 367-372; MiniLM QKV 82-84 / 86-95) -- the barrier release and
+// the first LDS round trip of a K-tile were NOT what the 8-wave shape loses against the vendor library's bare product (204 / 272 us); the residual rows ahead are worth
+// 3-7 % (out-projection + residual 111-115 -> 104-106 us, second feed-forward product + residual 302-303 -> 291-294): every residual load of form 0 sits in the branch of
+// its store behind its own s_waitcnt vmcnt(0) -- 16 serial round trips per 256 x 256 tile.  Form 0's registers do not hold the rows of form 3's epilogue (30 VGPRs of
+// scratch), so: the residual epilogues run form 3, the others form 0.  Also built, measured there and deleted: the next K-tile's DMA pieces spread one behind each MFMA
+// of the last k-step (equal), and a four-wave shape of 128 x 128 per wave (one wave per SIMD, a third less LDS read traffic: 20-60 % SLOWER -- a wave alone on its
+// SIMD hides neither its own DMA issue nor the barrier).
+#define GM_LOOP_FOR(EPI) (((EPI) & 2) != 0 ? 3 : 0)
 
 #if defined(LM_DIAG) && !defined(LM_EMULATED_DEVICE)
 #define GM_STAMP(t)                                     \
@@ -114,7 +132,7 @@ constexpr int GM_VAR_DEFAULT = 0;
 // walks its tiles i = 0, 1, ... as (rb = (i / NC) * 8 + x, column tile i % NC): the NC tiles of a row block are neighbours in time on
 // ONE XCD, so x is fetched from HBM once and re-read from that XCD's L2.  Workgroup b = (slot = b / 8, x = b % 8) takes the tiles
 // i = slot, slot + gridDim.x / 8, ... of its XCD.
-template <class S, int EPI, int VAR>
+template <class S, int EPI, int VAR, int LOOP>
 __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
     const __half* __restrict__ x, const __half* __restrict__ w, const float* __restrict__ bias, const __half* __restrict__ resid,
     __half* __restrict__ out, int T, int N, int K) {
@@ -204,13 +222,89 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
 #pragma unroll
     for (int i = 0; i < S::PIECES; ++i) issue_piece(0, 0, i);
     for (;;) {
+        if constexpr ((LOOP & 1) != 0) {
+            // the accumulators START at the bias (register 4 q + e of tile (i, j) <-> feature 32 i + 8 q + 4 g + e of the wave's slice, whatever the token):
+            // no bias slice in LDS, no add in the epilogue (as the hidden-384 kernels do it: the bias is the first MFMA's C operand)
+            const int fb = n0 + wf * S::TF * 32 + 4 * g;
 #pragma unroll
-        for (int i = 0; i < S::TF; ++i)
+            for (int i = 0; i < S::TF; ++i)
 #pragma unroll
-            for (int j = 0; j < S::TT; ++j)
+                for (int q = 0; q < 4; ++q) {
+                    const int f = fb + 32 * i + 8 * q;
+                    const float4v bv = *(const float4v*)(bias + (f < N ? f : N - 4));  // (features past N -- a partial last column tile -- are never stored)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int j = 0; j < S::TT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bv[e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+                for (int j = 0; j < S::TT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
         [[maybe_unused]] unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+        if constexpr ((LOOP & 1) != 0) {
+            // ROTATED main loop (round 6).  The barrier of a K-tile sits in front of its LAST k-step's MFMAs instead of in front of its first fragment
+            // reads: when a wave reaches it, that step's fragments are already in registers (lgkmcnt(0): the wave is done reading the stage) and its pieces
+            // of the next K-tile have landed (vmcnt(0)).  Behind the barrier the next K-tile's first fragments are requested from the other stage and the
+            // K-tile after that is requested into the stage that just fell free -- both UNDER the last step's MFMAs: the matrix pipe no longer idles through
+            // a barrier release + an LDS round trip once per K-tile (the form above: wait, barrier, then the first fragment reads with nothing to issue).
+            half8 af[2][S::TF], bf[2][S::TT];
+            auto rd = [&](const unsigned char* sb, int kk, half8 (&a)[S::TF], half8 (&b)[S::TT]) {
+#pragma unroll
+                for (int i = 0; i < S::TF; ++i) a[i] = *(const half8*)(sb + a_base + i * 4096 + fo[kk]);
+#pragma unroll
+                for (int j = 0; j < S::TT; ++j) b[j] = *(const half8*)(sb + b_base + j * 4096 + fo[kk]);
+            };
+            auto mm = [&](const half8 (&a)[S::TF], const half8 (&b)[S::TT]) {
+#pragma unroll
+                for (int i = 0; i < S::TF; ++i)
+#pragma unroll
+                    for (int j = 0; j < S::TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            };
+            GM_WAIT_VM0_SEEN();  // this wave's pieces of the tile's first K-tile have landed (its stores of the previous tile's epilogue are out, the bias values are in) ...
+            GM_BARRIER();        // ... and everybody else's; all waves are done with the previous tile's epilogue (output tiles = stage 1's memory)
+            GM_STAMP(tm0);
+            if (ntile == 0) ts1 = tm0;
+            rd(smem, 0, af[0], bf[0]);
+#pragma unroll
+            for (int p = 0; p < S::PIECES; ++p) issue_piece(1, 1, p);  // (nk >= 2)
+            for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {  // K-tile kt + h out of stage h
+                    const unsigned char* sb = smem + h * S::STAGE;
+                    const unsigned char* so = smem + (h ^ 1) * S::STAGE;
+                    rd(sb, 1, af[1], bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(af[0], bf[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd(sb, 2, af[0], bf[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(af[1], bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd(sb, 3, af[1], bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(af[0], bf[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    GM_WAIT_LGKM0_SEEN();  // step 3's fragments are in registers: this wave's last read of stage h is complete
+                    GM_WAIT_VM0();    // this wave's pieces of K-tile kt + h + 1 have landed
+                    GM_BARRIER();     // everybody's: stage h ^ 1 is complete, stage h is free
+                    const bool more_k = kt + h + 1 < nk;
+                    if (more_k) rd(so, 0, af[0], bf[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + h + 2 < nk) {
+#pragma unroll
+                        for (int p = 0; p < S::PIECES; ++p) issue_piece(kt + h + 2, h, p);
+                    }
+                    mm(af[1], bf[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // (the loop's last barrier: every wave is done with both stages)
+        } else {
         for (int kt = 0; kt < nk; kt += 2) {
             GM_WAIT_VM0();   // this wave's pieces of K-tile kt have landed (and its stores of the previous tile's epilogue are out) ...
             GM_BARRIER();    // ... and so have everybody else's; all waves are done with stage 1 (K-tile kt - 1 / the previous output tiles)
@@ -232,6 +326,7 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
             GM_WAIT_LGKM0();
         }
         GM_BARRIER();  // every wave is done with both stages
+        }
         GM_STAMP(tm1);
         // ---- the NEXT tile's first K-tile goes into stage 0 now: it lands while this tile's epilogue runs ----
         const int ti_next = ti + nslot;
@@ -252,6 +347,24 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
         constexpr int LPR = S::TF * 4, RPI = 64 / LPR;
         const int lr = lane / LPR, lc = lane % LPR;
         const int64_t col = n0_cur + wf * S::TF * 32 + lc * 8;
+        // Residual rows (LOOP & 2, round 6): ALL of the tile's rows requested up front with CLAMPED addresses (behind the next tile's prefetch), ONE wait for them
+        // behind the first column block's LDS writes -- instead of a load inside the `if (tok < T && col < N)` of the store loop, where every one of the
+        // 32 / RPI * TT loads got its own s_waitcnt vmcnt(0): 16 serial round trips per 256 x 256 tile, each of them also waiting for the previous row's
+        // store (the out-projection of a 768-wide model: 116 us against the vendor library's 75 us per 65 k tokens).  The wait is one the compiler's
+        // bookkeeping sees: the stores that follow (conditional, hence "maybe outstanding" to that bookkeeping) then never stand between a load and its use.
+        constexpr int NIT = 32 / RPI;
+        typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+        [[maybe_unused]] gm_u32x4 rr[S::TT][NIT];
+        if constexpr ((EPI & GM_EPI_RESID) != 0 && (LOOP & 2) != 0) {
+            const int64_t colc = col < N ? col : (int64_t)N - 8;
+#pragma unroll
+            for (int j = 0; j < S::TT; ++j)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int tok = t0_cur + wt * S::TT * 32 + 32 * j + it * RPI + lr;
+                    rr[j][it] = *(const gm_u32x4*)((const _Float16*)resid + (int64_t)(tok < T ? tok : T - 1) * N + colc);
+                }
+        }
 #pragma unroll
         for (int j = 0; j < S::TT; ++j) {
             GM_STAMP(tm2);
@@ -259,21 +372,53 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
             for (int i = 0; i < S::TF; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4v bb = *(const float4v*)(bl + 32 * i + 8 * q);
+                    float4v bb = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr ((LOOP & 1) == 0) bb = *(const float4v*)(bl + 32 * i + 8 * q);
                     half4 h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][4 * q + e] + bb[e];
+                        float v = acc[i][j][4 * q + e];
+                        if constexpr ((LOOP & 1) == 0) v += bb[e];
                         if constexpr ((EPI & GM_EPI_GELU) != 0) v = gm_gelu(v);
                         h[e] = (_Float16)v;
                     }
                     *(half4*)(ot + r31 * S::RS + (32 * i + 8 * q + 4 * g) * 2) = h;
                 }
+            if constexpr ((EPI & GM_EPI_RESID) != 0 && (LOOP & 2) != 0) {
+                if (j == 0) {
+                    GM_WAIT_VM0_SEEN();  // the residual rows (and the next tile's first K-tile, requested before them) are in
+#ifndef LM_EMULATED_DEVICE
+#pragma unroll
+                    for (int j2 = 0; j2 < S::TT; ++j2)
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rr[j2][it]));  // (opaque from here on: no load may sink below this point into a store branch)
+#endif
+                }
+            }
             LM_WAVE_SYNC();  // the tile is read back by the wave that wrote it: no workgroup barrier
             GM_STAMP(tm3);
             if constexpr (VAR == 7) tacc[2] += tm3 - tm2;
+            if constexpr ((LOOP & 2) != 0) {  // all rows of the block read back first, then the stores: one LDS wait per block instead of one per row
+                half8 y[NIT];
 #pragma unroll
-            for (int it = 0; it < 32 / RPI; ++it) {
+                for (int it = 0; it < NIT; ++it) {
+                    const unsigned char* src = ot + (it * RPI + lr) * S::RS + lc * 16;  // 8-byte aligned (RS = 8 mod 16): two ds_read_b64
+                    const half4 lo = *(const half4*)src, hi = *(const half4*)(src + 8);
+                    y[it] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int tok = t0_cur + wt * S::TT * 32 + 32 * j + it * RPI + lr;
+                    if constexpr ((EPI & GM_EPI_RESID) != 0) {
+                        const half8 rv = __builtin_bit_cast(half8, rr[j][it]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[it][e] = (_Float16)((float)y[it][e] + (float)rv[e]);
+                    }
+                    if (tok < T && col < N) *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y[it];
+                }
+            } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
                 const int row = it * RPI + lr;
                 const int tok = t0_cur + wt * S::TT * 32 + 32 * j + row;
                 const unsigned char* src = ot + row * S::RS + lc * 16;  // 8-byte aligned (RS = 8 mod 16): two ds_read_b64
@@ -281,12 +426,13 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
                 half8 y = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 if (tok < T && col < N) {
                     if constexpr ((EPI & GM_EPI_RESID) != 0) {
-                        const half8 rr = *(const half8*)((const _Float16*)resid + (int64_t)tok * N + col);
+                        const half8 rv = *(const half8*)((const _Float16*)resid + (int64_t)tok * N + col);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)y[e] + (float)rr[e]);
+                        for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)y[e] + (float)rv[e]);
                     }
                     *(half8*)((_Float16*)out + (int64_t)tok * N + col) = y;
                 }
+            }
             }
             LM_WAVE_SYNC();  // the read-back is done before the next column block overwrites the tile
             GM_STAMP(tm2);
@@ -314,7 +460,7 @@ __global__ __launch_bounds__(S::THREADS) LM_TWO_WAVES_PER_SIMD void k_gemm_f16(
 #endif
 }
 
-template <class S, int EPI, int VAR>
+template <class S, int EPI, int VAR, int LOOP>
 static int gemm_launch_var(const void* d_x, const void* d_w, const float* d_bias, const void* d_resid, void* d_out, int64_t tokens, int32_t n_out,
                            int32_t k_in, hipStream_t st) {
     const int64_t rbs = (tokens + S::BM - 1) / S::BM;
@@ -340,8 +486,8 @@ static int gemm_launch_var(const void* d_x, const void* d_w, const float* d_bias
     if (one_per_tile) slots = per_xcd;
 #endif
     static DynLdsAttr attr;
-    LM_HIP(ensure_dyn_lds(attr, (const void*)k_gemm_f16<S, EPI, VAR>, S::LDS));
-    hipLaunchKernelGGL((k_gemm_f16<S, EPI, VAR>), dim3((unsigned)(8 * slots)), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
+    LM_HIP(ensure_dyn_lds(attr, (const void*)k_gemm_f16<S, EPI, VAR, LOOP>, S::LDS));
+    hipLaunchKernelGGL((k_gemm_f16<S, EPI, VAR, LOOP>), dim3((unsigned)(8 * slots)), dim3(S::THREADS), S::LDS, st, (const __half*)d_x, (const __half*)d_w, d_bias,
                        (const __half*)d_resid, (__half*)d_out, (int)tokens, n_out, k_in);
     LM_HIP(hipGetLastError());
     return LM_OK;
@@ -352,9 +498,10 @@ static int gemm_launch(const void* d_x, const void* d_w, const float* d_bias, co
                        int32_t k_in, hipStream_t st) {
 #ifdef LM_DIAG
     static const int var = [] { const char* v = getenv("LEANN_MI355X_GEMM_VARIANT"); return v ? atoi(v) : GM_VAR_DEFAULT; }();
-    if (var == 7) return gemm_launch_var<S, EPI, 7>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
+    if (var == 7) return gemm_launch_var<S, EPI, 7, 0>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
 #endif
-    return gemm_launch_var<S, EPI, GM_VAR_DEFAULT>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
+    // which form of the tile loop an epilogue runs (GM_LOOP_FOR above): measured, profiles/r6_kbench_gemm_f16_forms_*.jsonl
+    return gemm_launch_var<S, EPI, GM_VAR_DEFAULT, GM_LOOP_FOR(EPI)>(d_x, d_w, d_bias, d_resid, d_out, tokens, n_out, k_in, st);
 }
 
 }  // namespace lm

@@ -892,6 +892,8 @@ def case_gemm_f16():
     run(100, 256, 128, 2)            # short launch: small tiles although N % 256 == 0
     run(1200, 128, 128, 1)           # ten row blocks of 128: the last group of eight is padded
     run(300, 1152, 128, 2)           # 256-wide tiles with a half-empty last column tile (the QKV width of the 384-wide models)
+    run(700, 768, 768, 2)            # twelve K-tiles, three column tiles, tile lists of several tiles per workgroup (the out-projection of a 768-wide model)
+    run(200, 384, 384, 3)            # six K-tiles on the 128 x 128 shape
     try:
         lib.lm_gemm_f16.restype = C.c_int
         x = np.zeros((4, 100), np.float16)
