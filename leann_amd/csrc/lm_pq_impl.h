@@ -78,27 +78,57 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
     // fetched as 16-byte pieces (m % 16 == 0) or dwords.  Round 2 spread one vector over 4 lanes (every lane re-loading all m / 4
     // dwords): 64 vectors per workgroup pass and 100-byte gathers one dword at a time made the kernel latency bound (2 % of the HBM
     // rate); one lane per vector puts 256 independent gathers in flight per pass and needs no cross-lane reduction.
+    auto word = [&](float& p0, float& p1, float& p2, float& p3, int i, uint32_t w) {
+        const float* l4 = lut + ((4 * i) << 8);
+        p0 = p0 + l4[w & 255u];
+        p1 = p1 + l4[256 + ((w >> 8) & 255u)];
+        p2 = p2 + l4[512 + ((w >> 16) & 255u)];
+        p3 = p3 + l4[768 + (w >> 24)];
+    };
+    // (round 6) the row's NQ 16-byte pieces are ALL requested before the first lookup, NQ a compile-time constant of the call: the loop form below was compiled to
+    // load / s_waitcnt vmcnt(0) / 16 lookups per piece -- six DEPENDENT global round trips per evaluation at m = 96, the longest chain of a hop.  Same additions in the
+    // same order: bit-identical distances.
+    typedef unsigned pq_u32x4 __attribute__((ext_vector_type(4)));
+    auto adc_pieces = [&](auto NQ, int32_t v) -> float {
+        constexpr int nq = decltype(NQ)::value;
+        const pq_u32x4* c4 = (const pq_u32x4*)(pq.codes + (size_t)v * pq.m);
+        pq_u32x4 c[nq];
+#pragma unroll
+        for (int i = 0; i < nq; ++i) c[i] = c4[i];
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < nq; ++i) {
+            word(p0, p1, p2, p3, 4 * i, c[i][0]);
+            word(p0, p1, p2, p3, 4 * i + 1, c[i][1]);
+            word(p0, p1, p2, p3, 4 * i + 2, c[i][2]);
+            word(p0, p1, p2, p3, 4 * i + 3, c[i][3]);
+        }
+        return (p0 + p1) + (p2 + p3);
+    };
     auto adc1 = [&](int32_t v) -> float {
+        using std::integral_constant;
+        switch (pq.m) {  // (wave uniform)
+            case 16: return adc_pieces(integral_constant<int, 1>{}, v);
+            case 32: return adc_pieces(integral_constant<int, 2>{}, v);
+            case 48: return adc_pieces(integral_constant<int, 3>{}, v);
+            case 64: return adc_pieces(integral_constant<int, 4>{}, v);
+            case 96: return adc_pieces(integral_constant<int, 6>{}, v);
+            case 128: return adc_pieces(integral_constant<int, 8>{}, v);
+            default: break;
+        }
         const uint32_t* cw = (const uint32_t*)(pq.codes + (size_t)v * pq.m);
         float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
-        auto word = [&](int i, uint32_t w) {
-            const float* l4 = lut + ((4 * i) << 8);
-            p0 = p0 + l4[w & 255u];
-            p1 = p1 + l4[256 + ((w >> 8) & 255u)];
-            p2 = p2 + l4[512 + ((w >> 16) & 255u)];
-            p3 = p3 + l4[768 + (w >> 24)];
-        };
         if ((pq.m & 15) == 0) {
             const uint4* c4 = (const uint4*)cw;
             for (int i = 0; i < (mw >> 2); ++i) {
                 const uint4 w4 = c4[i];
-                word(4 * i, w4.x);
-                word(4 * i + 1, w4.y);
-                word(4 * i + 2, w4.z);
-                word(4 * i + 3, w4.w);
+                word(p0, p1, p2, p3, 4 * i, w4.x);
+                word(p0, p1, p2, p3, 4 * i + 1, w4.y);
+                word(p0, p1, p2, p3, 4 * i + 2, w4.z);
+                word(p0, p1, p2, p3, 4 * i + 3, w4.w);
             }
         } else {
-            for (int i = 0; i < mw; ++i) word(i, cw[i]);
+            for (int i = 0; i < mw; ++i) word(p0, p1, p2, p3, i, cw[i]);
         }
         return (p0 + p1) + (p2 + p3);
     };
@@ -147,32 +177,50 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
         nexp += np;
         const uint32_t totalc = s_off[np];
         // ---- flattened expansion over the workgroup, visited test-and-set, ordered compaction ----
+        // (round 6) EP passes of the workgroup in flight at a time: their neighbour ids are requested together (clamped indices: unconditional loads), then their
+        // test-and-sets (a lane past the end ORs a zero into a word of its own), then the ordered compactions -- one global round trip per EP * NTH
+        // neighbours for each of the two, where the pass-at-a-time form paid both per NTH.  Which of two duplicates of a node counts as the fresh one may differ
+        // from that form; the SET of fresh nodes, hence every key the hop produces, does not.
         int total = 0;
-        for (uint32_t f0 = 0; f0 < totalc; f0 += NTH) {
-            const uint32_t f = f0 + tid;
-            bool fresh = false;
-            int32_t v = -1;
-            if (f < totalc) {
+        constexpr int EP = 4;
+        for (uint32_t f0 = 0; f0 < totalc; f0 += EP * NTH) {
+            int32_t vv[EP];
+            uint32_t bitp[EP], oldw[EP];
+#pragma unroll
+            for (int p = 0; p < EP; ++p) {
+                const uint32_t f = f0 + p * NTH + tid;
+                const bool valid = f < totalc;
+                const uint32_t fc = valid ? f : totalc - 1;
                 int lo = 0, hi = np - 1;
                 while (lo < hi) {
                     int mid = (lo + hi + 1) >> 1;
-                    if (s_off[mid] <= f) lo = mid;
+                    if (s_off[mid] <= fc) lo = mid;
                     else hi = mid - 1;
                 }
-                v = g.neighbors[s_b[lo] + (f - s_off[lo])];
-                uint32_t bit = 1u << (v & 31);
-                uint32_t old = atomicOr(&vis[v >> 5], bit);
-                fresh = !(old & bit);
+                vv[p] = g.neighbors[s_b[lo] + (fc - s_off[lo])];
+                bitp[p] = valid ? 1u : 0u;
             }
-            unsigned long long m = __ballot(fresh);
-            if (lane == 0) s_wcnt[wv] = __popcll(m);
-            __syncthreads();
-            int woff = 0;
-            for (int i = 0; i < wv; ++i) woff += s_wcnt[i];
-            if (fresh) s_new[total + woff + __popcll(m & ((1ull << lane) - 1ull))] = v;
 #pragma unroll
-            for (int w2 = 0; w2 < NWV; ++w2) total += s_wcnt[w2];
-            __syncthreads();
+            for (int p = 0; p < EP; ++p) {  // a lane past the end ORs a zero into a word of its own (tid mod nw): the same word for all of them would serialise in the L2
+                const bool valid = bitp[p] != 0u;
+                bitp[p] <<= (vv[p] & 31);
+                oldw[p] = atomicOr(&vis[valid ? (uint32_t)(vv[p] >> 5) : (uint32_t)tid % (uint32_t)ws.nw], bitp[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < EP; ++p) {
+                if (f0 + p * NTH < totalc) {  // (workgroup uniform)
+                    const bool fresh = bitp[p] != 0u && !(oldw[p] & bitp[p]);
+                    unsigned long long m = __ballot(fresh);
+                    if (lane == 0) s_wcnt[wv] = __popcll(m);
+                    __syncthreads();
+                    int woff = 0;
+                    for (int i = 0; i < wv; ++i) woff += s_wcnt[i];
+                    if (fresh) s_new[total + woff + __popcll(m & ((1ull << lane) - 1ull))] = vv[p];
+#pragma unroll
+                    for (int w2 = 0; w2 < NWV; ++w2) total += s_wcnt[w2];
+                    __syncthreads();
+                }
+            }
         }
         const int n = total;
         n_adc += (unsigned long long)n;
