@@ -110,6 +110,33 @@ __device__ __forceinline__ void rank_merge(const uint64_t* lpool, int npool0, co
     __syncthreads();
 }
 
+// ---- the same merge WITHOUT sorting newk first: a key's place in the merged list = (new keys below it) + (pool entries below it); the first count by
+//      scanning all n new keys (every lane of a wave reads the same LDS word: a broadcast, no bank conflict), the second by binary search in the sorted pool
+//      (new key) or its own index (pool entry).  One barrier instead of the bitonic sort's log2(P) (log2(P) + 1) / 2: for a few hundred survivors per hop
+//      the sort's barriers were most of a hop of k_pq_traverse.  Same output as sort_keys + rank_merge (keys are unique).  Ends with a barrier. ----
+template <int NT>
+__device__ __forceinline__ void rank_merge_unsorted(const uint64_t* lpool, int npool0, const uint64_t* newk, int n, uint64_t* out, int ef, int tid) {
+    for (int it = tid; it < n + npool0; it += NT) {
+        const bool is_new = it < n;
+        const uint64_t key = is_new ? newk[it] : lpool[it - n];
+        const uint64_t kk = key >> 1;
+        int below = 0;
+        for (int x = 0; x < n; ++x) below += (newk[x] >> 1) < kk ? 1 : 0;
+        int lo = it - n;  // a pool entry's own index
+        if (is_new) {
+            lo = 0;
+            int hi = npool0;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if ((lpool[mid] >> 1) < kk) lo = mid + 1;
+                else hi = mid;
+            }
+        }
+        if (below + lo < ef) out[below + lo] = key;
+    }
+    __syncthreads();
+}
+
 // ---- next pops: the W smallest unexpanded pool entries, by ONE wave (lane = 0..63; every lane of the wave calls it and gets
 //      the same count back).  Both faiss stop rules (search_from_candidates; pinned by oracle/lm_oracle_faiss.c):
 //        check_relative_distance: v0 = pop_min(); if (count_below(d0) >= efSearch) break;   -- count_below(d0) is the

@@ -37,6 +37,9 @@ struct PqArgs {
 // NTH = threads per workgroup = per query.  The lookup table alone is m x 1 KB of LDS (96 KB at m = 96): one workgroup per CU, so the
 // workgroup's own width is all the latency hiding the CU gets.  Round 2 ran 256 threads (ONE wave per SIMD; 2 % of the HBM rate); with
 // 1024 threads (four waves per SIMD) a hop's visited tests, code-row gathers, compactions and the bitonic sort all run four times wider.
+#ifndef PQ_RANK_SORT_MAX
+#define PQ_RANK_SORT_MAX 512  // survivors of a hop up to which their places in the list are counted instead of sorted (k_pq_traverse)
+#endif
 template <int NTH>
 __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev ws, PqArgs a) {
     constexpr int NWV = NTH / 64;
@@ -54,21 +57,85 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* qv = a.Q + (size_t)q * a.Dp;
     // ---- lookup table (canonical: sequential fmaf over the sub-vector) ----
-    for (int e = tid; e < pq.m * 256; e += NTH) {
-        const int j = e >> 8, lo = pq.chunk_off[j], len = pq.chunk_off[j + 1] - lo;
-        const float* cb = pq.codebooks + (size_t)256 * lo + (size_t)(e & 255) * len;
-        const float* qs = qv + lo;
+    // (round 6) The element-at-a-time loop was compiled to two loads + s_waitcnt vmcnt(0) per element: at m = 96, d = 384 every thread paid 24 entries x 4 elements
+    // = 96 dependent round trips before the query's first hop.  Now the loads of FOUR elements (and, for 4-element sub-vectors, of four entries) are requested before
+    // the first of them is used; the fmaf chain runs over the elements in the same order: bit-identical table.
+    auto lut_value = [&](const float* qs, const float* cb, int len) -> float {
         float acc = 0.0f;
+        int t = 0;
         if (a.metric == LM_METRIC_L2) {
-            for (int t = 0; t < len; ++t) {
+            for (; t + 4 <= len; t += 4) {
+                const float q0 = qs[t], q1 = qs[t + 1], q2 = qs[t + 2], q3 = qs[t + 3], c0 = cb[t], c1 = cb[t + 1], c2 = cb[t + 2], c3 = cb[t + 3];
+                const float d0 = q0 - c0, d1 = q1 - c1, d2 = q2 - c2, d3 = q3 - c3;
+                acc = __builtin_fmaf(d0, d0, acc);
+                acc = __builtin_fmaf(d1, d1, acc);
+                acc = __builtin_fmaf(d2, d2, acc);
+                acc = __builtin_fmaf(d3, d3, acc);
+            }
+            for (; t < len; ++t) {
                 float d = qs[t] - cb[t];
                 acc = __builtin_fmaf(d, d, acc);
             }
-        } else {
-            for (int t = 0; t < len; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
-            acc = -acc;
+            return acc;
         }
-        lut[e] = acc;
+        for (; t + 4 <= len; t += 4) {
+            const float q0 = qs[t], q1 = qs[t + 1], q2 = qs[t + 2], q3 = qs[t + 3], c0 = cb[t], c1 = cb[t + 1], c2 = cb[t + 2], c3 = cb[t + 3];
+            acc = __builtin_fmaf(q0, c0, acc);
+            acc = __builtin_fmaf(q1, c1, acc);
+            acc = __builtin_fmaf(q2, c2, acc);
+            acc = __builtin_fmaf(q3, c3, acc);
+        }
+        for (; t < len; ++t) acc = __builtin_fmaf(qs[t], cb[t], acc);
+        return -acc;
+    };
+    {
+        const int ne = pq.m * 256;
+        constexpr int EU = 4;
+        for (int e0 = tid; e0 < ne; e0 += EU * NTH) {
+            int lov[EU], lenv[EU];
+            bool four = true;
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const int e = min(e0 + u * NTH, ne - 1);  // (clamped: the tail group recomputes the last entry, stores are guarded)
+                lov[u] = pq.chunk_off[e >> 8];
+                lenv[u] = pq.chunk_off[(e >> 8) + 1] - lov[u];
+                four = four && lenv[u] == 4;
+            }
+            if (four) {  // the common shape (d = 4 m): sixteen centroid and sixteen query elements in flight per thread
+                float qe[EU][4], ce[EU][4];
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int e = min(e0 + u * NTH, ne - 1);
+                    const float* cb = pq.codebooks + (size_t)256 * lov[u] + (size_t)(e & 255) * 4;
+                    const float* qs = qv + lov[u];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        qe[u][t] = qs[t];
+                        ce[u][t] = cb[t];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (a.metric == LM_METRIC_L2) {
+                            const float d = qe[u][t] - ce[u][t];
+                            acc = __builtin_fmaf(d, d, acc);
+                        } else {
+                            acc = __builtin_fmaf(qe[u][t], ce[u][t], acc);
+                        }
+                    }
+                    if (e0 + u * NTH < ne) lut[e0 + u * NTH] = a.metric == LM_METRIC_L2 ? acc : -acc;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int e = e0 + u * NTH;
+                    if (e < ne) lut[e] = lut_value(qv + lov[u], pq.codebooks + (size_t)256 * lov[u] + (size_t)(e & 255) * lenv[u], lenv[u]);
+                }
+            }
+        }
     }
     __syncthreads();
     uint32_t* vis = ws.visited + (size_t)q * ws.nw;
@@ -247,11 +314,16 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
             for (int w2 = 0; w2 < NWV; ++w2) kept += s_wcnt[w2];
             __syncthreads();
         }
-        int Pn = 1;
-        while (Pn < kept) Pn <<= 1;
-        for (int i = kept + tid; i < Pn; i += NTH) newk[i] = KEY_NONE;
-        __syncthreads();
-        if (kept > 0) {
+        if (kept > 0 && kept <= PQ_RANK_SORT_MAX) {  // (round 6) few survivors -- the steady state: their places by counting, one barrier (lm_beam_common.h)
+            rank_merge_unsorted<NTH>(lpool, npool, newk, kept, outp, a.L, tid);
+            npool = min(a.L, npool + kept);
+            for (int i = tid; i < npool; i += NTH) lpool[i] = outp[i];
+            __syncthreads();
+        } else if (kept > 0) {
+            int Pn = 1;
+            while (Pn < kept) Pn <<= 1;
+            for (int i = kept + tid; i < Pn; i += NTH) newk[i] = KEY_NONE;
+            __syncthreads();
             sort_keys<NTH>(newk, Pn, tid);
             rank_merge<NTH>(lpool, npool, newk, kept, outp, a.L, tid);
             npool = min(a.L, npool + kept);
