@@ -114,6 +114,11 @@ __device__ __forceinline__ void rank_merge(const uint64_t* lpool, int npool0, co
 //      scanning all n new keys (every lane of a wave reads the same LDS word: a broadcast, no bank conflict), the second by binary search in the sorted pool
 //      (new key) or its own index (pool entry).  One barrier instead of the bitonic sort's log2(P) (log2(P) + 1) / 2: for a few hundred survivors per hop
 //      the sort's barriers were most of a hop of k_pq_traverse.  Same output as sort_keys + rank_merge (keys are unique).  Ends with a barrier. ----
+// when counting beats sorting: every thread's scan is n broadcast reads per item it owns; the bitonic sort is log2(P)(log2(P) + 1) / 2 barrier-separated steps
+template <int NT>
+__device__ __forceinline__ bool rank_merge_unsorted_pays(int npool0, int n) {
+    return n * ((n + npool0 + NT - 1) / NT) <= 256;
+}
 template <int NT>
 __device__ __forceinline__ void rank_merge_unsorted(const uint64_t* lpool, int npool0, const uint64_t* newk, int n, uint64_t* out, int ef, int tid) {
     for (int it = tid; it < n + npool0; it += NT) {

@@ -162,11 +162,17 @@ __global__ __launch_bounds__(NT) void k_search_table(GraphDev g, WsDev ws, Persi
         int Pn = 1;
         while (Pn < n) Pn <<= 1;
         eval_new(n);
-        for (int i = n + tid; i < Pn; i += NT) newk[i] = KEY_NONE;
+        const bool by_count = rank_merge_unsorted_pays<NT>(npool, n);  // (round 6) a hop's few new keys: places by counting, one barrier instead of the sort's
+        if (!by_count)
+            for (int i = n + tid; i < Pn; i += NT) newk[i] = KEY_NONE;
         __syncthreads();
         if (n > 0) {
-            sort_keys<NT>(newk, Pn, tid);
-            rank_merge<NT>(lpool, npool, newk, n, outp, ef, tid);
+            if (by_count) {
+                rank_merge_unsorted<NT>(lpool, npool, newk, n, outp, ef, tid);
+            } else {
+                sort_keys<NT>(newk, Pn, tid);
+                rank_merge<NT>(lpool, npool, newk, n, outp, ef, tid);
+            }
             npool = min(ef, npool + n);
             for (int i = tid; i < npool; i += NT) lpool[i] = outp[i];
             __syncthreads();

@@ -102,8 +102,12 @@ __device__ __forceinline__ void update_body(const WsDev& ws, const UpdateArgs& a
     const int npool1 = min(ef, npool0 + n);
     uint64_t* fin = lpool;  // where the merged pool lives
     if (n > 0) {
-        sort_keys<NT>(newk, Pn, tid);
-        rank_merge<NT>(lpool, npool0, newk, n, out, ef, tid);
+        if (rank_merge_unsorted_pays<NT>(npool0, n)) {  // (round 6) the usual round: a handful of new keys -- no sort (the padding of newk is then unused)
+            rank_merge_unsorted<NT>(lpool, npool0, newk, n, out, ef, tid);
+        } else {
+            sort_keys<NT>(newk, Pn, tid);
+            rank_merge<NT>(lpool, npool0, newk, n, out, ef, tid);
+        }
         fin = out;
     }
     if (tid < 64) {
