@@ -114,10 +114,24 @@ __device__ __forceinline__ void rank_merge(const uint64_t* lpool, int npool0, co
 //      scanning all n new keys (every lane of a wave reads the same LDS word: a broadcast, no bank conflict), the second by binary search in the sorted pool
 //      (new key) or its own index (pool entry).  One barrier instead of the bitonic sort's log2(P) (log2(P) + 1) / 2: for a few hundred survivors per hop
 //      the sort's barriers were most of a hop of k_pq_traverse.  Same output as sort_keys + rank_merge (keys are unique).  Ends with a barrier. ----
+// The limit up to which keys are placed by counting.  On the device: the caller's constant.  In the host emulation (tests/hip_emul) LM_EMUL_COUNTING_MERGE_LIMIT
+// overrides it, so that the CPU suite walks BOTH branches of every caller (the small graphs of the emulated cases would never reach the bitonic sort otherwise:
+// tests/test_emulated_search.py::test_sort_and_counting_merge_agree).
+__device__ __forceinline__ int counting_merge_limit(int dflt) {
+#ifdef LM_EMULATED_DEVICE
+    static const int v = [] {
+        const char* e = getenv("LM_EMUL_COUNTING_MERGE_LIMIT");
+        return e ? atoi(e) : -1;
+    }();
+    return v >= 0 ? v : dflt;
+#else
+    return dflt;
+#endif
+}
 // when counting beats sorting: every thread's scan is n broadcast reads per item it owns; the bitonic sort is log2(P)(log2(P) + 1) / 2 barrier-separated steps
 template <int NT>
 __device__ __forceinline__ bool rank_merge_unsorted_pays(int npool0, int n) {
-    return n * ((n + npool0 + NT - 1) / NT) <= 256;
+    return n * ((n + npool0 + NT - 1) / NT) <= counting_merge_limit(256);
 }
 template <int NT>
 __device__ __forceinline__ void rank_merge_unsorted(const uint64_t* lpool, int npool0, const uint64_t* newk, int n, uint64_t* out, int ef, int tid) {

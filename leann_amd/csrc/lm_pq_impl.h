@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NTH) void k_pq_traverse(GraphDev g, PqDev pq, WsDev
             for (int w2 = 0; w2 < NWV; ++w2) kept += s_wcnt[w2];
             __syncthreads();
         }
-        if (kept > 0 && kept <= PQ_RANK_SORT_MAX) {  // (round 6) few survivors -- the steady state: their places by counting, one barrier (lm_beam_common.h)
+        if (kept > 0 && kept <= counting_merge_limit(PQ_RANK_SORT_MAX)) {  // (round 6) few survivors -- the steady state: their places by counting, one barrier (lm_beam_common.h)
             rank_merge_unsorted<NTH>(lpool, npool, newk, kept, outp, a.L, tid);
             npool = min(a.L, npool + kept);
             for (int i = tid; i < npool; i += NTH) lpool[i] = outp[i];

@@ -113,6 +113,21 @@ def test_search_kernels_have_no_unmarked_lane_races(emul_dir):
     assert not races, "\n".join(races[:10]) + out[-3000:]
 
 
+def test_sort_and_counting_merge_agree(emul_dir):
+    """A hop's new keys get their places in the candidate list either by a bitonic sort + rank merge or -- when they are few (round 6) -- by counting
+    (csrc/lm_beam_common.h: rank_merge_unsorted; callers k_update, k_search_table, k_pq_traverse).  The emulated cases' small graphs always take the counting
+    branch at the library's limits; LM_EMUL_COUNTING_MERGE_LIMIT (host emulation only) moves the limit so that the same oracle comparisons walk the sort
+    (0: never count) and an in-between mix (12)."""
+    import build_emul_lib
+
+    lib = build_emul_lib.build(emul_dir)
+    cases = ["table_mips", "table_l2_d100", "recompute_memo", "recompute_wave_variant", "pq_deferred", "pq_table", "two_level", "dynamic_batching"]
+    for limit in ("0", "12"):
+        env = dict(os.environ, LM_EMUL_COUNTING_MERGE_LIMIT=limit)
+        r = subprocess.run([sys.executable, "-m", "tests.emulated_search_cases", str(lib), *cases], cwd=str(ROOT), capture_output=True, text=True, timeout=1500, env=env)
+        assert r.returncode == 0 and "ALL CASES OK" in r.stdout and "MISMATCH" not in r.stdout, f"limit {limit}:\n" + r.stdout[-3000:] + r.stderr[-3000:]
+
+
 @pytest.mark.skipif(os.environ.get("LEANN_EMUL_ASAN") != "1", reason="opt-in (adds ~1.5 min): LEANN_EMUL_ASAN=1")
 def test_search_kernels_stay_in_bounds_under_address_sanitizer(emul_dir):
     """Device allocations of the emulated runtime are exact-size heap blocks: any read or write past a graph / pool /
