@@ -659,8 +659,9 @@ def _main(args, ap):
         mlp_tf = mlp["work"] / (mlp["ms"] * 1e-3) / 1e12
         tpl = mlp["work"] / fpt / max(mlp["launches"], 1) if fpt else None  # tokens per launch
         ktraffic = ktraffic_src = None
-        try:  # HBM-side bytes per launch: the separate PMC passes of this kernel (profiles/r4_pmc_layer_tail.json), per token x this run's launch size
-            pmc_t = json.loads((ROOT / "profiles" / "r4_pmc_layer_tail.json").read_text())
+        try:  # HBM-side bytes per launch: the separate PMC passes of this kernel (profiles/r6_pmc_layer_tail.json: re-taken on round 6's final tree; round 4's as a fallback), per token x this run's launch size
+            pmc_file_t = next(f for f in ("r6_pmc_layer_tail.json", "r4_pmc_layer_tail.json") if (ROOT / "profiles" / f).exists())
+            pmc_t = json.loads((ROOT / "profiles" / pmc_file_t).read_text())
             if kt_dominant == _lib.KT_LAYER_TAIL:
                 ktraffic = round(pmc_t["k_layer_tail_h384"]["hbm_bytes_per_token"] * tpl)
                 ktraffic_src = pmc_t["k_layer_tail_h384"].get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over scripts/kbench.cpp (profiles/r4_pmc_layer_tail.json), scaled by tokens/launch")
