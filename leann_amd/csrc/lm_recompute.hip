@@ -22,6 +22,7 @@
 // (lm_recompute_create_general).  fp16 weights.  A model outside both keeps the Python provider (a GPU path as well, not a fallback).
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include "lm_device_types.h"
@@ -280,6 +281,8 @@ static int rc_finish_create(lm_recompute* rc, const lm_tokens* tokens, int32_t m
     rc->tokens = tokens;
     rc->T = max_seq_len;
     rc->max_tokens = max_tokens;
+    if (const char* ft = getenv("LEANN_MI355X_FORWARD_TOKENS"))  // A/B: a forward's token budget whatever the caller asked for (scripts/sessions/r6_29.sh)
+        if (atoll(ft) > 0) rc->max_tokens = atoll(ft);
     hipError_t e;
     if ((e = hipMalloc((void**)&rc->d_meta, 16)) != hipSuccess || (e = hipHostMalloc((void**)&rc->h_meta, 16)) != hipSuccess) {
         set_error(std::string("lm_recompute_create: ") + hipGetErrorString(e));
