@@ -681,6 +681,15 @@ def _main(args, ap):
                     "timing": "library-side: HIP event pairs recorded by the library around every launch of this kernel in the timed region, on the launch stream "
                               "(csrc/lm_timing.cpp); the timed region is the product default path (library-side recompute provider, one-call forwards)",
                     "instrumentation": f"the timed region contains these {mlp['launches']} event pairs (2 records per launch of this kernel, nothing else)"}
+        try:  # context, not the roofline's `peak`: what a register-only MFMA loop sustains on this part under its power cap (scripts/mfma_sustained.cpp, measured once)
+            sus = json.loads((ROOT / "profiles" / "r6_mfma_sustained_register_only_ceiling_under_the_power_cap.jsonl").read_text().splitlines()[0])
+            roofline["sustained_mfma_ceiling"] = {
+                "TFLOPs": sus["TFLOPs"], "achieved_over_it": round(mlp_tf / sus["TFLOPs"], 4), "power_w": (sus.get("power_w") or {}).get("median"),
+                "what": "v_mfma_f32_32x32x16_f16 back to back on every SIMD, operands (random fp16 bits) and accumulators in registers, nothing else, for seconds: the rate the "
+                        "socket's power cap leaves of the 2.5 PFLOP/s figure `peak` quotes (profiles/r6_mfma_sustained_register_only_ceiling_under_the_power_cap.jsonl; another "
+                        "box than this run's).  `frac` stays achieved / peak"}
+        except Exception:  # noqa: BLE001
+            pass
     else:  # encoder without the fused block (hidden != 384): fall back to the distance kernel's line
         roofline = roofline_dist
     result = {
