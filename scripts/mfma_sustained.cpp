@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, 4) void k_mfma(float* out, int iters, unsigned
 //   DMA:     one global_load_lds_dwordx4 per four MFMAs and wave (256 B per MFMA: the tail's 48 KB of W1 / W2 slabs per 192 MFMAs of a workgroup) from a 2.6 MB buffer
 //            every CU walks in the same order (L2 hits, as the weight stream)
 //   VALU:    three v_fma_f32 per MFMA (the GELU micro-operations between the tail's MFMAs)
-template <int LDSREAD, int DMA, int VALU>
+//   REUSE:   2 = every LDS fragment feeds TWO MFMAs and the DMA stream runs at half the rate: what a kernel with two token blocks per wave would see (it does not fit
+//            the register file with fp32 accumulators at hidden 384: DESIGN 8) -- the worth of halving the operand bytes per flop
+template <int LDSREAD, int DMA, int VALU, int REUSE = 1>
 __global__ __launch_bounds__(256, 1) void k_mix(float* out, const unsigned char* __restrict__ wbuf, unsigned wbytes, int iters, unsigned seed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [0, 64 K): fragments; [64 K, 80 K): DMA landing area
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -97,9 +99,12 @@ __global__ __launch_bounds__(256, 1) void k_mix(float* out, const unsigned char*
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(LDSREAD ? frag[i & 3] : x[i & 1], y[(i >> 1) & 1], acc[i & 3], 0, 0, 0);
-            if constexpr (LDSREAD) frag[i & 3] = *(const h8*)(lds + ((roff + 1024 * i) & 0xffffu) + 16 * lane);
+            if constexpr (LDSREAD) {
+                if (REUSE == 1 || (i & 1)) frag[i & 3] = *(const h8*)(lds + ((roff + 1024 * i) & 0xffffu) + 16 * lane);
+                else frag[i & 3] = frag[(i + 3) & 3];  // (REUSE 2: the fragment read one slot earlier serves a second MFMA: a register move the compiler folds into the operand choice)
+            }
             if constexpr (DMA) {
-                if ((i & 3) == 0) {
+                if ((i & (4 * REUSE - 1)) == 0) {
                     const unsigned m0v = __builtin_amdgcn_readfirstlane(65536u + (unsigned)wave * 4096u + (unsigned)(i >> 2) * 1024u);
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(goff), "s"(wbuf), "s"(m0v) : "memory", "m0");
                     goff += 4096;
@@ -140,7 +145,8 @@ int main(int argc, char** argv) {
                                 {"zero operands, back to back", 0, 1, 1},   {"random operands, s_nop 10 behind every MFMA", 2, 0, 1},    {"random operands, s_nop 15 behind every MFMA", 1, 0, 1},
                                 {"mix: MFMA only (the mixing kernel's own baseline)", 0, 0, 1, 1}, {"mix: + A operand from LDS (ds_read_b128 per MFMA)", 0, 0, 1, 2},
                                 {"mix: + A from LDS + LDS-DMA stream from L2 (256 B per MFMA and wave)", 0, 0, 1, 3}, {"mix: + three v_fma_f32 per MFMA", 0, 0, 1, 4},
-                                {"mix: + A from LDS + LDS-DMA stream + three v_fma_f32 per MFMA", 0, 0, 1, 5}};
+                                {"mix: + A from LDS + LDS-DMA stream + three v_fma_f32 per MFMA", 0, 0, 1, 5},
+                                {"mix: all three, every LDS fragment and DMA byte serving TWO MFMAs", 0, 0, 1, 6}};
     const unsigned wbytes = 2654208;  // 648 x 4096 B: the layer tail's W_o + W1 + W2 images
     unsigned char* d_w;
     CK(hipMalloc(&d_w, wbytes + 8192));
@@ -151,6 +157,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)k_mix<1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_lds));
     CK(hipFuncSetAttribute((const void*)k_mix<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_lds));
     CK(hipFuncSetAttribute((const void*)k_mix<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_lds));
+    CK(hipFuncSetAttribute((const void*)k_mix<1, 1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mix_lds));
     const int only = argc > 2 ? atoi(argv[2]) : -1;  // one setting per process (scripts/mfma_sustained.py samples clocks / power per setting)
     int index = -1;
     for (const Setting& st : settings) {
@@ -163,6 +170,7 @@ int main(int argc, char** argv) {
             else if (st.mix == 3) hipLaunchKernelGGL((k_mix<1, 1, 0>), dim3(blocks), dim3(256), mix_lds, 0, d_out, d_w, wbytes, iters, 12345u);
             else if (st.mix == 4) hipLaunchKernelGGL((k_mix<0, 0, 1>), dim3(blocks), dim3(256), mix_lds, 0, d_out, d_w, wbytes, iters, 12345u);
             else if (st.mix == 5) hipLaunchKernelGGL((k_mix<1, 1, 1>), dim3(blocks), dim3(256), mix_lds, 0, d_out, d_w, wbytes, iters, 12345u);
+            else if (st.mix == 6) hipLaunchKernelGGL((k_mix<1, 1, 1, 2>), dim3(blocks), dim3(256), mix_lds, 0, d_out, d_w, wbytes, iters, 12345u);
             else if (st.pad == 0) hipLaunchKernelGGL(k_mfma<0>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 12345u, st.zeros);
             else if (st.pad == 1) hipLaunchKernelGGL(k_mfma<1>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 12345u, st.zeros);
             else hipLaunchKernelGGL(k_mfma<2>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 12345u, st.zeros);

@@ -15,7 +15,7 @@ exe = ROOT / "leann_amd" / "lib" / "bin" / "mfma_sustained"
 if not exe.exists():
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", str(ROOT / "scripts" / "mfma_sustained.cpp"), "-o", str(exe)], check=True)
 seconds = sys.argv[1] if len(sys.argv) > 1 else "4"
-for i in range(11):
+for i in range(12):
     smp = B.BoxSampler(0, period_s=0.2).start()
     r = subprocess.run([str(exe), seconds, str(i)], capture_output=True, text=True, timeout=120)
     box = smp.stop()
